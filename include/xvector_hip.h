@@ -1,0 +1,236 @@
+/*
+ * xvector_hip.h - C-ABI of the MI355X (gfx950) x-vector training/extraction hot path.
+ *
+ * The reference (mycrazycracy/tf-kaldi-speaker) has NO native/FFI interface on this
+ * path: its hot path is a TF1 graph built by model/tdnn.py:33-191, model/pooling.py:9-34,
+ * model/loss.py:9-355 and run by model/trainer.py:505-508 (sess.run(train_op)).  This
+ * header is therefore the boundary that the drop-in Python `Trainer`
+ * (tf_kaldi_speaker_amd/model/trainer.py) binds through ctypes; every entry point names
+ * the reference call site(s) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.  All data pointers are DEVICE
+ *     pointers (HBM) unless the name starts with h_.  All tensors are fp32 row-major,
+ *     labels int32.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Every call
+ *     only ENQUEUES work; nothing synchronises unless stated.
+ *   - return 0 on success, non-zero on error; xv_last_error() gives the message of the
+ *     last failing call on the calling thread.
+ *   - an engine handle is single-threaded (one TF session per Trainer, trainer.py:24).
+ *
+ * "Spliced view": a frame-level activation tensor x[B][T][C] is consumed by a layer with
+ * context width k as the matrix whose row (b,t) is the contiguous span x[b][t..t+k-1][:]
+ * (k*C floats) - rows overlap in memory, nothing is materialised (no im2col).  k = 1 is a
+ * plain dense layer.
+ */
+#ifndef XVECTOR_HIP_H
+#define XVECTOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XV_ABI_VERSION 1
+
+const char* xv_last_error(void);
+int xv_abi_version(void);
+/* number of visible HIP devices (0 when none / driver missing); never throws */
+int xv_device_count(void);
+
+/* dst[r][0..cols) = src[r][0..cols) for r < rows (device to device, pitches in floats). */
+int xv_copy_2d(void* stream, float* dst, size_t ldd, const float* src, size_t lds, int rows, int cols);
+
+/* ---------------------------------------------------------------------------------
+ * Op level (each is one or two kernel launches; used by the parity tests and the engine)
+ * --------------------------------------------------------------------------------- */
+
+/* Bytes of scratch an op-level call may need (upper bound for any op below at these sizes). */
+size_t xv_op_workspace_bytes(int rows, int cols_in, int cols_out);
+
+/* Zero-pad the channel axis: dst[r][0..c_dst) = src[r][0..c_src), 0 beyond.  Used to bring
+ * the 30-dim MFCC rows (dataset feed of trainer.py:491) to a 16-byte-aligned pitch. */
+int xv_pad_channels(void* stream, const float* src, int rows, int c_src, float* dst, int c_dst);
+
+/* Kernel-layout weights for xv_affine_forward: wt[o][j*c_pad + c] = kernel[j][c][o]
+ * (TF layout [k][C][O] of tdnn/tdnnX_{conv,dense}/kernel, tdnn.py:39,57,75,96,115,147,166);
+ * columns c in [C, c_pad) are zero. */
+int xv_prep_weight_fwd(void* stream, const float* kernel, int k, int c, int o, float* wt, int c_pad);
+/* Kernel-layout weights for xv_affine_dgrad: wf[c][(k-1-j)*O + o] = kernel[j][c][o]. */
+int xv_prep_weight_dgrad(void* stream, const float* kernel, int k, int c, int o, float* wf);
+
+/* z[(b,t)][o] = bias[o] + sum_{j<k} sum_c x[b][t+j][c] * kernel[j][c][o]
+ *   == tf.layers.conv2d(.., (1,k)) VALID, tdnn.py:39-44,57-62,75-80 and tf.layers.dense,
+ *   tdnn.py:96-100,115-119,147-151,166-170 (k = 1, segs = rows, t_in = 1).
+ * x: [segs][t_in][c_pad] spliced view, wt from xv_prep_weight_fwd, z: [segs*(t_in-k+1)][ldz].
+ * If bn_part != NULL it receives per-128-row-tile column statistics of z (sum and centred
+ * sum of squares, layout [2][tiles_m][o]) for xv_bn_finalize - the batch statistics of
+ * tf.layers.batch_normalization(training=True), tdnn.py:46.  `ws` is scratch
+ * (xv_op_workspace_bytes) used when the launcher splits the reduction. */
+int xv_affine_forward(void* stream, const float* x, int segs, int t_in, int c_pad, int k,
+                      const float* wt, const float* bias, float* z, int o, int ldz,
+                      float* bn_part, void* ws, size_t ws_bytes);
+
+/* dx[(b,s)][c] = sum_j sum_o dz[b][s-j][o] * kernel[j][c][o]  (gradient of the above w.r.t. x).
+ * dz_pad: [segs][t_out + 2(k-1)][o] with k-1 ZERO rows before and after each segment
+ * (written by xv_bn_backward_apply); wf from xv_prep_weight_dgrad ([c][k*o]); dx: [segs*(t_out+k-1)][c]. */
+int xv_affine_dgrad(void* stream, const float* dz_pad, int segs, int t_out, int o, int k,
+                    const float* wf, float* dx, int c, void* ws, size_t ws_bytes);
+
+/* dkernel[j][c][o] = sum_{b,t} x[b][t+j][c] * dz[b][t][o]  (+ l2_scale * kernel[j][c][o],
+ *   the gradient of tf.contrib.layers.l2_regularizer, tdnn.py:43 / trainer.py:357-358).
+ * x: spliced view [segs][t_in][c_pad]; dz rows live in a buffer with `dz_seg_pitch` rows per
+ * segment starting at row `dz_row0` (so the padded dz of xv_affine_dgrad can be used directly).
+ * Output in TF layout [k][c][o] (padded channels dropped). */
+int xv_affine_wgrad(void* stream, const float* x, int segs, int t_in, int c_pad, int k, int c,
+                    const float* dz, int dz_seg_pitch, int dz_row0, int o,
+                    const float* kernel, float l2_scale, float* dkernel,
+                    void* ws, size_t ws_bytes);
+
+/* out[n] = sum_r a[r][n]  (bias gradient, tf.layers bias_add grad). a: [rows][lda]. */
+int xv_colsum(void* stream, const float* a, int rows, int n, int lda, float* out, void* ws, size_t ws_bytes);
+/* Per-tile column statistics in the xv_affine_forward bn_part layout, for tensors that were
+ * produced by a split reduction (segment-level layers). */
+int xv_col_stats(void* stream, const float* z, int rows, int n, int ldz, float* bn_part);
+
+/* tf.layers.batch_normalization(training=True) statistics, tdnn.py:46,64,82,102,121,153,177:
+ * combine bn_part -> mean, biased var; scale = gamma*rsqrt(var+eps), shift = beta-mean*scale;
+ * moving <- moving*momentum + batch*(1-momentum) (unbiased var if unbiased_moving != 0).
+ * Outputs: mean[n], invstd[n], scale[n], shift[n]. */
+int xv_bn_finalize(void* stream, const float* bn_part, int rows, int n,
+                   const float* gamma, const float* beta, float eps, float momentum, int unbiased_moving,
+                   float* moving_mean, float* moving_var,
+                   float* mean, float* invstd, float* scale, float* shift);
+/* Inference statistics (training=False): scale/shift from the moving averages. */
+int xv_bn_inference_scale(void* stream, int n, const float* gamma, const float* beta,
+                          const float* moving_mean, const float* moving_var, float eps,
+                          float* scale, float* shift);
+/* a = relu?(z*scale + shift)   (tdnn.py:46-52: BN then tf.nn.relu). relu != 0 applies ReLU. */
+int xv_bn_apply(void* stream, const float* z, int rows, int n, int ldz, const float* scale, const float* shift,
+                int relu, float* a, int lda);
+/* Backward of ReLU(BN(z)) given da (both dense [segs*t][n]): dy = da * (y>0); dgamma = sum dy*xhat; dbeta = sum dy;
+ * dz = gamma*invstd*(dy - dbeta/rows - xhat*dgamma/rows) written into a segment-padded buffer
+ * dz_pad [segs][t + 2*pad][n] (pad rows zeroed).  relu != 0 means a ReLU follows the BN. */
+int xv_bn_relu_backward(void* stream, const float* da, const float* z, int segs, int t, int n,
+                        const float* gamma, const float* mean, const float* invstd,
+                        const float* scale, const float* shift, int relu, int pad,
+                        float* dz_pad, float* dgamma, float* dbeta, void* ws, size_t ws_bytes);
+/* Backward of a bare ReLU (no BN in front): dz = da * (a > 0). */
+int xv_relu_backward(void* stream, const float* da, const float* a, size_t count, float* dz);
+
+/* statistics_pooling, pooling.py:9-34: out[b] = concat(mean_t x, sqrt(max-masked var_t x)). */
+int xv_stat_pool_forward(void* stream, const float* x, int b, int t, int c, float* out);
+int xv_stat_pool_backward(void* stream, const float* x, const float* out, const float* dout,
+                          int b, int t, int c, float* dx);
+
+/* l2_scaling, common.py:45-58 (feature_norm:true, trainer.py:183-186). */
+int xv_l2_scaling_forward(void* stream, const float* x, int rows, int n, float factor, float* y);
+int xv_l2_scaling_backward(void* stream, const float* x, const float* dy, int rows, int n, float factor, float* dx);
+
+/* Loss family, loss.py:9-355. */
+enum { XV_LOSS_SOFTMAX = 0, XV_LOSS_ASOFTMAX = 1, XV_LOSS_AMSOFTMAX = 2, XV_LOSS_ARCSOFTMAX = 3 };
+/* tf.nn.l2_normalize(w, dim=0), loss.py:104: inv_norm[n], wn[c][ldn] = w*inv, wnt[n][c] = wn^T.
+ * normalize == 0 copies unnormalised (plain softmax, loss.py:30). */
+int xv_loss_prep_weight(void* stream, const float* w, int c, int n, int normalize,
+                        float* inv_norm, float* wn, int ldn, float* wnt);
+/* Given logits = x . wn (+bias) [rows][ldl]: margin transform of the target logit, lambda
+ * blend (fa = 1/(1+lambda)), mean sparse softmax cross entropy, and the gradients
+ * dlogits [rows][ldl] (pad columns zeroed) and dnorm[rows] (= dL/d||x||, 0 for softmax).
+ * loss_out: one float (mean over rows).  asoftmax: m in {1,2,4}. */
+int xv_margin_softmax_rows(void* stream, int kind, const float* logits, int rows, int n, int ldl,
+                           const float* x, int c, const int32_t* labels, float m, float lambda,
+                           float* dlogits, float* dnorm, float* row_loss, float* loss_out);
+/* dx[r][:] += dnorm[r] * x[r][:] / ||x[r]||  (the ||x|| paths of loss.py:122,147). */
+int xv_add_norm_grad(void* stream, const float* x, const float* dnorm, int rows, int c, float* dx);
+/* Gradient through l2_normalize: dw = inv*(dwn - wn*colsum(dwn*wn)) + l2_scale*w. */
+int xv_loss_weight_backward(void* stream, const float* dwn, int lddwn, const float* wn, int ldn,
+                            const float* inv_norm, const float* w, int c, int n, int normalize,
+                            float l2_scale, float* dw, void* ws, size_t ws_bytes);
+
+/* sum over a flat range of 0.5*scale*w^2 accumulated into *out (regularization_loss). */
+int xv_l2_reg_loss(void* stream, const float* w, size_t count, float scale, float* out_accum);
+
+/* Optimisers, trainer.py:332-346.  g is scaled by grad_scale first (1/world for DP). */
+int xv_sgd_update(void* stream, float* p, const float* g, size_t count, float lr, float grad_scale);
+int xv_momentum_update(void* stream, float* p, const float* g, float* acc, size_t count,
+                       float lr, float momentum, int nesterov, float grad_scale);
+int xv_adam_update(void* stream, float* p, const float* g, float* m, float* v, size_t count,
+                   float lr, float beta1, float beta2, float eps, int t, float grad_scale);
+/* sum of squares of a flat range accumulated into *out (for tf.clip_by_global_norm). */
+int xv_sumsq(void* stream, const float* g, size_t count, float* out_accum);
+
+/* ---------------------------------------------------------------------------------
+ * Engine level: the whole tdnn + loss graph of Trainer.build / sess.run(train_op)
+ * --------------------------------------------------------------------------------- */
+typedef struct xv_engine xv_engine;
+
+typedef struct xv_config {
+    int32_t feat_dim;                 /* dim, train.py:71 */
+    int32_t num_speakers;             /* train.py:74 (0 => no loss head, predict only) */
+    int32_t num_nodes_pooling_layer;  /* tdnn.py:111-113, default 1500 */
+    int32_t num_nodes_last_layer;     /* tdnn.py:162-164, default 512 */
+    int32_t last_layer_no_bn;         /* tdnn.py:173-174 */
+    int32_t last_layer_linear;        /* tdnn.py:183-184 */
+    int32_t feature_norm;             /* trainer.py:183 */
+    float feature_scaling_factor;
+    int32_t loss_kind;                /* XV_LOSS_* (trainer.py:234-250) */
+    float margin_m;                   /* asoftmax_m / amsoftmax_m / arcsoftmax_m */
+    float lambda_min, lambda_base, lambda_gamma, lambda_power; /* loss.py:144-145 */
+    float weight_l2_regularizer;      /* tdnn.py:43 */
+    float output_weight_l2_regularizer; /* loss.py:26-28; < 0 => use weight_l2_regularizer */
+    float batchnorm_momentum;         /* tdnn.py:47 */
+    float bn_epsilon;                 /* [TF] 1e-3 */
+    int32_t fused_bn_unbiased_moving_var; /* SURVEY N4 switch (layers 1-3) */
+    int32_t optimizer;                /* 0 sgd, 1 momentum, 2 adam (trainer.py:332-346) */
+    float momentum;
+    int32_t use_nesterov;
+    float clip_gradient_norm;         /* trainer.py:408-410; <= 0 => clip_gradient:false */
+    int32_t max_batch;                /* capacity: chunks per step */
+    int32_t max_frames;               /* capacity: frames per chunk */
+} xv_config;
+
+int xv_engine_create(const xv_config* cfg, xv_engine** out);
+void xv_engine_destroy(xv_engine* e);
+
+/* Variable table (TF names/shapes in graph order, e.g. "tdnn/tdnn1_conv/kernel" [1,5,D,512]). */
+int xv_engine_num_variables(const xv_engine* e);
+/* name: pointer to a static string; shape: up to 4 dims written, returns rank via *rank;
+ * offset in floats into the variables buffer; trainable flag. */
+int xv_engine_variable_info(const xv_engine* e, int index, const char** name, int32_t shape[4],
+                            int32_t* rank, size_t* offset, int32_t* trainable);
+/* Flat sizes in floats: all variables (trainable first, then BN moving statistics),
+ * trainable only (= gradient buffer), optimiser state. */
+size_t xv_engine_variables_count(const xv_engine* e);
+size_t xv_engine_trainable_count(const xv_engine* e);
+size_t xv_engine_optimizer_state_count(const xv_engine* e);
+/* Caller-owned device buffers (e.g. torch tensors): variables, gradients, optimiser state. */
+int xv_engine_bind(xv_engine* e, float* variables, float* grads, float* opt_state);
+
+/* tdnn(features) (+ entire_network's l2_scaling).  features: [b][t][feat_dim].
+ * training != 0: batch statistics + moving-average update (is_training=True). */
+int xv_engine_forward(xv_engine* e, void* stream, const float* features, int b, int t, int training);
+/* loss_network(features, labels) + gradients of loss + regulariser w.r.t. every trainable
+ * variable into the bound gradient buffer.  global_step feeds the lambda schedule
+ * (trainer.py:505-508).  stage: -1 = everything; 0..XV_BWD_STAGES-1 = that slice only (lets the
+ * host overlap the gradient all-reduce of finished slices with the rest of the backward). */
+#define XV_BWD_STAGES 4
+int xv_engine_loss_forward(xv_engine* e, void* stream, const int32_t* labels, int global_step, int with_margin);
+int xv_engine_backward(xv_engine* e, void* stream, int stage);
+/* [begin,end) float range of the gradient buffer completed by backward stage `stage`. */
+int xv_engine_stage_grad_range(const xv_engine* e, int stage, size_t* begin, size_t* end);
+/* optimiser step on the bound buffers (after the gradient all-reduce). t = 1-based update count. */
+int xv_engine_apply(xv_engine* e, void* stream, float lr, float grad_scale, int t);
+/* scalars of the last step, device pointers to 1 float each: raw loss, regularisation loss */
+int xv_engine_loss_ptrs(xv_engine* e, float** raw_loss, float** reg_loss);
+/* endpoint by reference name ("tdnn1_conv", ..., "pooling", "tdnn6_dense", "output", "logits"):
+ * device pointer, rows, cols, leading dimension of the most recent forward. */
+int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, int32_t* rows, int32_t* cols, int32_t* ld);
+/* Mark kernel-layout weight copies stale (call after writing the variables buffer directly). */
+int xv_engine_invalidate_weights(xv_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XVECTOR_HIP_H */

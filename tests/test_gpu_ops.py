@@ -1,0 +1,288 @@
+"""Per-kernel parity on a real MI355X: every op-level C-ABI entry point against the CPU
+oracle (oracle/xvector_oracle.py, float64 as ground truth) on the same seeded inputs.
+
+Tolerances (fp32 arithmetic, north_star: embeddings within 1e-4 relative):
+  GEMM-backed ops: ||gpu - ref||_F / ||ref||_F <= 5e-6  and  max|gpu-ref| <= 2e-5 * max|ref|
+  (v_mfma_f32_32x32x2_f32 is an exact-fp32 fma chain; the error is accumulation order only).
+  elementwise / reductions: 2e-5 relative to the tensor scale.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import xvector_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(a, dtype=np.float32):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(DEV)
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def assert_close(got, ref, rel_f=5e-6, rel_max=2e-5, name=""):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert np.all(np.isfinite(got)), name
+    scale = max(np.abs(ref).max(), 1e-30)
+    fro = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+    mx = np.abs(got - ref).max() / scale
+    assert fro <= rel_f and mx <= rel_max, "%s: rel_fro=%.3e (<=%.1e) rel_max=%.3e (<=%.1e)" % (name, fro, rel_f, mx, rel_max)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tf_kaldi_speaker_amd import ops as m
+    return m
+
+
+# (segs, t_in, c, k, o)  - ragged M/N/K tails, the feature layer (c=30 -> pad 32), dense k=1
+AFFINE_CASES = [
+    (3, 40, 30, 5, 512),      # tdnn1 shape: K = 160 after padding, M = 108 (< one tile)
+    (5, 61, 512, 5, 512),     # tdnn2: M = 285 (ragged), K = 2560
+    (4, 50, 512, 7, 512),     # tdnn3: K = 3584
+    (1, 333, 512, 1, 1500),   # tdnn5 dense: N = 1500 (ragged N), one segment
+    (7, 16, 64, 7, 96),       # tiny: t_out = 10 < K-step, N < tile
+    (130, 1, 3000, 1, 512),   # tdnn6: segment-level, K = 3000 (ragged K), split path
+]
+
+
+@pytest.mark.parametrize("segs,t_in,c,k,o", AFFINE_CASES)
+def test_affine_forward_and_bn_stats(ops, segs, t_in, c, k, o):
+    rs = np.random.RandomState(segs * 1000 + t_in)
+    x = rs.randn(segs, t_in, c).astype(np.float32)
+    kern = (rs.randn(k, c, o) / np.sqrt(k * c)).astype(np.float32)
+    bias = rs.randn(o).astype(np.float32)
+    c_pad = (c + 3) // 4 * 4
+    xp = ops.pad_channels(dev(x.reshape(-1, c)), c_pad).view(segs, t_in, c_pad)
+    wt = ops.prep_weight_fwd(dev(kern), c_pad)
+    ref = O.conv1d_valid_fwd(x.astype(np.float64), kern.astype(np.float64), bias.astype(np.float64)).reshape(-1, o)
+    z = ops.affine_forward(xp, k, wt, dev(bias), o)
+    assert_close(host(z), ref, name="affine_forward")
+    rows = ref.shape[0]
+    if rows >= 2:
+        z2, part = ops.affine_forward(xp, k, wt, dev(bias), o, with_stats=True)
+        assert_close(host(z2), ref, name="affine_forward(stats)")
+        gamma, beta = rs.rand(o).astype(np.float32) + 0.5, rs.randn(o).astype(np.float32)
+        mm, mv = dev(np.zeros(o)), dev(np.ones(o))
+        mean, invstd, scale, shift = ops.bn_finalize(part, rows, dev(gamma), dev(beta), 1e-3, 0.99, True, mm, mv)
+        rmean, rvar = ref.mean(0), ref.var(0)
+        assert_close(host(mean), rmean, 2e-5, 1e-4, "bn mean")
+        assert_close(host(invstd), 1 / np.sqrt(rvar + 1e-3), 2e-5, 1e-4, "bn invstd")
+        assert_close(host(mm), 0.01 * rmean, 2e-5, 1e-4, "moving mean")
+        assert_close(host(mv), 0.99 + 0.01 * rvar * rows / (rows - 1), 2e-5, 1e-4, "moving var (unbiased, N4)")
+        a = ops.bn_apply(z2, scale, shift, True)
+        yref, _ = O.batchnorm_train_fwd(ref, gamma.astype(np.float64), beta.astype(np.float64))
+        assert_close(host(a), np.maximum(yref, 0), 2e-5, 1e-4, "bn_apply+relu")
+
+
+@pytest.mark.parametrize("segs,t_in,c,k,o", AFFINE_CASES[:5])
+def test_affine_dgrad_wgrad(ops, segs, t_in, c, k, o):
+    rs = np.random.RandomState(segs * 77 + k)
+    t_out = t_in - k + 1
+    x = rs.randn(segs, t_in, c).astype(np.float32)
+    kern = (rs.randn(k, c, o) / np.sqrt(k * c)).astype(np.float32)
+    dz = rs.randn(segs, t_out, o).astype(np.float32)
+    dx_ref, dk_ref, db_ref = O.conv1d_valid_bwd(x.astype(np.float64), kern.astype(np.float64), dz.astype(np.float64))
+    pad = k - 1
+    dzp = np.zeros((segs, t_out + 2 * pad, o), np.float32)
+    dzp[:, pad:pad + t_out] = dz
+    d_dzp = dev(dzp.reshape(-1, o))
+    c_pad = (c + 3) // 4 * 4
+    if c % 4 == 0:
+        wf = ops.prep_weight_dgrad(dev(kern))
+        dx = ops.affine_dgrad(d_dzp, segs, t_out, o, k, wf, c)
+        assert_close(host(dx), dx_ref.reshape(-1, c), name="affine_dgrad")
+    xp = ops.pad_channels(dev(x.reshape(-1, c)), c_pad).view(segs, t_in, c_pad)
+    l2 = 1e-2
+    dk = ops.affine_wgrad(xp, k, c, d_dzp, t_out + 2 * pad, pad, o, dev(kern), l2)
+    assert_close(host(dk), dk_ref + l2 * kern.astype(np.float64), name="affine_wgrad")
+    assert_close(host(ops.colsum(d_dzp)), db_ref, 2e-5, 1e-4, "colsum (bias grad)")
+
+
+def test_gemm_identity_asymmetric(ops):
+    """A = I check with an ASYMMETRIC B (catches swapped row/col maps of the MFMA C/D layout)."""
+    n = 256
+    x = np.eye(n, dtype=np.float32)[None]                       # [1, n, n] dense rows
+    kern = (np.arange(n)[:, None] * 1000 + np.arange(n)[None, :]).astype(np.float32)[None]   # [1, n, n]
+    wt = ops.prep_weight_fwd(dev(kern), n)
+    z = ops.affine_forward(dev(x).view(n, 1, n), 1, wt, dev(np.zeros(n)), n)
+    assert np.array_equal(host(z), kern[0].astype(np.float64))
+
+
+@pytest.mark.parametrize("relu,pad", [(1, 0), (1, 6), (0, 0)])
+def test_bn_relu_backward(ops, relu, pad):
+    rs = np.random.RandomState(5 + pad)
+    segs, t, n = 6, 37, 512
+    z = (rs.randn(segs * t, n) * 2 + 0.5).astype(np.float32)
+    da = rs.randn(segs * t, n).astype(np.float32)
+    gamma, beta = (rs.rand(n) + 0.5).astype(np.float32), (0.3 * rs.randn(n)).astype(np.float32)
+    y, cache = O.batchnorm_train_fwd(z.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64))
+    dy = da.astype(np.float64) * (y > 0) if relu else da.astype(np.float64)
+    dz_ref, dg_ref, db_ref = O.batchnorm_train_bwd(dy, cache, gamma.astype(np.float64))
+    part = ops.col_stats(dev(z))
+    mean, invstd, scale, shift = ops.bn_finalize(part, segs * t, dev(gamma), dev(beta), 1e-3, 0.99, False, None, None)
+    dz, dg, db = ops.bn_relu_backward(dev(da), dev(z), segs, t, dev(gamma), mean, invstd, scale, shift, relu, pad)
+    dzh = host(dz).reshape(segs, t + 2 * pad, n)
+    if pad:
+        assert np.all(dzh[:, :pad] == 0) and np.all(dzh[:, pad + t:] == 0)
+    assert_close(dzh[:, pad:pad + t].reshape(-1, n), dz_ref, 2e-5, 2e-4, "bn dz")
+    assert_close(host(dg), dg_ref, 2e-5, 1e-4, "dgamma")
+    assert_close(host(db), db_ref, 2e-5, 1e-4, "dbeta")
+
+
+def test_statistics_pooling_adversarial(ops):
+    """Rows from the reference's pooling self-test (pooling.py:478-510 style): tiny, zero, huge, constant."""
+    rs = np.random.RandomState(9)
+    b, t, c = 6, 186, 1500
+    x = rs.rand(b, t, c).astype(np.float32)
+    x[0] *= 1e-8
+    x[1] = 0
+    x[2] *= 100
+    x[3] = 100.0
+    ref, cache = O.statistics_pooling_fwd(x.astype(np.float64))
+    out = ops.stat_pool_forward(dev(x))
+    got = host(out)
+    assert_close(got[:, :c], ref[:, :c], 2e-6, 1e-5, "pool mean")
+    # std of the constant / zero rows is exactly sqrt(1e-12); elsewhere relative agreement
+    assert np.allclose(got[[1, 3], c:], 1e-6, rtol=1e-5)
+    assert_close(got[[0, 2, 4, 5], c:], ref[[0, 2, 4, 5], c:], 1e-5, 1e-4, "pool std")
+    dout = rs.randn(b, 2 * c).astype(np.float32)
+    dref = O.statistics_pooling_bwd(x.astype(np.float64), cache, dout.astype(np.float64))
+    dx = host(ops.stat_pool_backward(dev(x), out, dev(dout)))
+    assert np.all(np.isfinite(dx)), "Gradient should not be nan"
+    for i in (2, 4, 5):
+        assert_close(dx[i], dref[i], 2e-5, 2e-4, "pool dx row %d" % i)
+    # clamped-variance rows: only the mean path carries gradient
+    assert_close(dx[1], np.broadcast_to(dout[1, None, :c] / t, (t, c)), 1e-6, 1e-5, "pool dx zero row")
+
+
+@pytest.mark.parametrize("t", [1, 7, 15, 186, 401])
+def test_statistics_pooling_lengths(ops, t):
+    rs = np.random.RandomState(t)
+    x = (rs.randn(3, t, 1500) * 3 + 5).astype(np.float32)
+    ref, _ = O.statistics_pooling_fwd(x.astype(np.float64))
+    got = host(ops.stat_pool_forward(dev(x)))
+    assert_close(got, ref, 5e-6, 5e-5, "pool T=%d" % t)
+
+
+def test_l2_scaling(ops):
+    rs = np.random.RandomState(3)
+    x = rs.randn(100, 512).astype(np.float32)
+    x[2] *= 1e-8
+    x[3] *= 100
+    y_ref, cache = O.l2_scaling_fwd(x.astype(np.float64), 30.0)
+    y = host(ops.l2_scaling_forward(dev(x), 30.0))
+    assert_close(y, y_ref, 2e-6, 1e-5, "l2_scaling")
+    assert np.allclose(np.linalg.norm(y[3:], axis=1), 30.0, rtol=1e-5)   # the reference's own check, tdnn.py:246-247
+    dy = rs.randn(100, 512).astype(np.float32)
+    dx_ref = O.l2_scaling_bwd(x.astype(np.float64), cache, dy.astype(np.float64), 30.0)
+    dx = host(ops.l2_scaling_backward(dev(x), dev(dy), 30.0))
+    for r in (0, 1, 3, 50):
+        assert_close(dx[r], dx_ref[r], 2e-5, 2e-4, "l2_scaling bwd row %d" % r)
+
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_golden.npz"))
+KIND_ID = {"asoftmax": 1, "additive_margin_softmax": 2, "additive_angular_margin_softmax": 3}
+
+
+def test_loss_family_against_reference_golden_vectors(ops):
+    """HIP loss path (normalise W -> MFMA logits -> margin/xent rows) against the reference's own
+    NumPy oracle outputs (tests/golden/loss_golden.npz), tolerance = the reference's np.allclose
+    bar scaled for fp32 (rtol 2e-5 + atol 1e-6), and gradients against the pinned oracle."""
+    n_cases = len(G["loss"])
+    worst = 0.0
+    for i in range(n_cases):
+        kind = str(G["kind"][i])
+        m = float(G["m"][i])
+        emb, w, labels = G["emb"][i], G["w"][i], G["labels"][i]
+        lam = O.margin_lambda(*G["sched"][i], int(G["step"][i]))
+        e64 = emb.astype(np.float64)
+        x = dev(emb)
+        if G["feature_norm"][i]:
+            x = ops.l2_scaling_forward(x, 0.1)
+            e64, _ = O.l2_scaling_fwd(e64, 0.1)
+        inv, wn, wnt = ops.loss_prep_weight(dev(w), True)
+        c, n = w.shape
+        ldl = wn.shape[1]
+        xp = x.view(x.shape[0], 1, c)
+        logits = torch.zeros((x.shape[0], ldl), dtype=torch.float32, device=DEV)
+        logits[:, :n] = ops.affine_forward(xp, 1, wnt, None, n)
+        loss, dlogits, dnorm, _ = ops.margin_softmax_rows(KIND_ID[kind], logits, n, x, dev(labels, np.int32), m, lam)
+        got = float(host(loss)[0])
+        ref = float(G["loss"][i])
+        assert abs(got - ref) <= 1e-6 + 2e-5 * abs(ref), (i, kind, m, got, ref)
+        worst = max(worst, abs(got - ref) / max(abs(ref), 1e-9))
+        # gradients vs the pinned oracle (float64)
+        mm = int(m) if kind == "asoftmax" else m
+        _, lg_ref, (df_ref, dk_ref) = O.margin_softmax_loss(kind, e64, labels, w.astype(np.float64), mm, lam)
+        assert_close(host(logits)[:, :n], lg_ref, 5e-6, 2e-5, "logits")
+        assert np.all(host(dlogits)[:, n:] == 0)
+        wf = wn[:, :ldl]
+        dx = ops.affine_forward(dlogits.view(dlogits.shape[0], 1, ldl), 1, wf, None, c)
+        dx = ops.add_norm_grad(x, dnorm, dx)
+        gscale = max(np.abs(df_ref).max(), 1e-12)
+        assert np.all(np.isfinite(host(dx))), "Gradient should not be nan (tdnn.py:282)"
+        assert np.abs(host(dx) - df_ref).max() <= 2e-4 * gscale + 1e-7, (i, kind, m)
+    assert worst < 5e-5
+
+
+def test_loss_weight_backward_and_softmax_kind(ops):
+    rs = np.random.RandomState(21)
+    rows, c, n = 32, 512, 1001     # odd N: logits pitch padded to 1004
+    x = rs.randn(rows, c).astype(np.float32)
+    w = (rs.randn(c, n) * 0.05).astype(np.float32)
+    b = (rs.randn(n) * 0.1).astype(np.float32)
+    labels = rs.randint(0, n, rows).astype(np.int32)
+    for kind, name, m in ((0, "softmax", 0.0), (2, "additive_margin_softmax", 0.2), (3, "additive_angular_margin_softmax", 0.3),
+                          (1, "asoftmax", 4)):
+        normalize = kind != 0
+        inv, wn, wnt = ops.loss_prep_weight(dev(w), normalize)
+        ldl = wn.shape[1]
+        logits = torch.zeros((rows, ldl), dtype=torch.float32, device=DEV)
+        logits[:, :n] = ops.affine_forward(dev(x).view(rows, 1, c), 1, wnt, dev(b) if kind == 0 else None, n)
+        lam = 0.5
+        loss, dlogits, dnorm, _ = ops.margin_softmax_rows(kind, logits, n, dev(x), dev(labels, np.int32), m, lam)
+        if kind == 0:
+            lref, _, (df_ref, dk_ref, db_ref) = O.softmax_loss(x.astype(np.float64), labels, w.astype(np.float64), b.astype(np.float64))
+            assert_close(host(ops.colsum(dlogits[:, :n])), db_ref, 2e-5, 1e-4, "softmax bias grad")
+        else:
+            lref, _, (df_ref, dk_ref) = O.margin_softmax_loss(name, x.astype(np.float64), labels, w.astype(np.float64), m, lam)
+        assert abs(float(host(loss)[0]) - lref) <= 2e-5 * abs(lref) + 1e-6, name
+        # d wn = x^T dlogits through the weight-gradient GEMM, then through l2_normalize
+        dwn = ops.affine_wgrad(dev(x).view(rows, 1, c), 1, c, dlogits, 1, 0, ldl, None, 0.0)[0]      # [c, ldl]
+        dw = ops.loss_weight_backward(dwn, wn, inv, dev(w), normalize, 1e-2)
+        assert_close(host(dw), dk_ref + 1e-2 * w.astype(np.float64), 2e-5, 2e-4, "loss dW " + name)
+
+
+def test_optimizers_and_reductions(ops):
+    rs = np.random.RandomState(1)
+    n = 100003
+    p0, g = rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32)
+    p = dev(p0)
+    ops.sgd_update(p, dev(g), 0.1, 0.5)
+    assert_close(host(p), O.sgd_update(p0.astype(np.float64), 0.5 * g.astype(np.float64), 0.1), 1e-6, 1e-6, "sgd")
+    for nesterov in (False, True):
+        p, acc = dev(p0), dev(np.zeros(n))
+        pr, ar = p0.astype(np.float64), np.zeros(n)
+        for _ in range(3):
+            ops.momentum_update(p, dev(g), acc, 0.01, 0.9, nesterov)
+            pr, ar = O.momentum_update(pr, g.astype(np.float64), ar, 0.01, 0.9, nesterov)
+        assert_close(host(p), pr, 1e-6, 1e-6, "momentum")
+    p, m, v = dev(p0), dev(np.zeros(n)), dev(np.zeros(n))
+    pr, mr, vr = p0.astype(np.float64), np.zeros(n), np.zeros(n)
+    for t in (1, 2, 3):
+        ops.adam_update(p, dev(g), m, v, 0.001, t)
+        pr, mr, vr = O.adam_update(pr, g.astype(np.float64), mr, vr, t, 0.001)
+    assert_close(host(p), pr, 1e-6, 1e-5, "adam")
+    acc = dev(np.zeros(1))
+    ops.l2_reg_loss(dev(g), 1e-2, acc)
+    assert abs(float(host(acc)[0]) - 0.005 * float((g.astype(np.float64) ** 2).sum())) < 1e-4 * 0.005 * n

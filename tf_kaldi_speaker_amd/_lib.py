@@ -1,0 +1,149 @@
+"""ctypes binding of the C-ABI declared in include/xvector_hip.h.
+
+The shared library is the product; there is NO CPU fallback.  If it is missing
+or an entry point fails, this module raises - it never routes to NumPy/torch.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxvector_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class XvError(RuntimeError):
+    pass
+
+
+class XvConfig(C.Structure):
+    """Mirror of `struct xv_config` (include/xvector_hip.h)."""
+    _fields_ = [
+        ("feat_dim", C.c_int32),
+        ("num_speakers", C.c_int32),
+        ("num_nodes_pooling_layer", C.c_int32),
+        ("num_nodes_last_layer", C.c_int32),
+        ("last_layer_no_bn", C.c_int32),
+        ("last_layer_linear", C.c_int32),
+        ("feature_norm", C.c_int32),
+        ("feature_scaling_factor", C.c_float),
+        ("loss_kind", C.c_int32),
+        ("margin_m", C.c_float),
+        ("lambda_min", C.c_float),
+        ("lambda_base", C.c_float),
+        ("lambda_gamma", C.c_float),
+        ("lambda_power", C.c_float),
+        ("weight_l2_regularizer", C.c_float),
+        ("output_weight_l2_regularizer", C.c_float),
+        ("batchnorm_momentum", C.c_float),
+        ("bn_epsilon", C.c_float),
+        ("fused_bn_unbiased_moving_var", C.c_int32),
+        ("optimizer", C.c_int32),
+        ("momentum", C.c_float),
+        ("use_nesterov", C.c_int32),
+        ("clip_gradient_norm", C.c_float),
+        ("max_batch", C.c_int32),
+        ("max_frames", C.c_int32),
+    ]
+
+
+LOSS_KINDS = {
+    "softmax": 0,
+    "asoftmax": 1,
+    "additive_margin_softmax": 2,
+    "additive_angular_margin_softmax": 3,
+}
+OPTIMIZERS = {"sgd": 0, "momentum": 1, "adam": 2}
+
+_VP = C.c_void_p
+_SZ = C.c_size_t
+_I = C.c_int
+_F = C.c_float
+
+# name -> (restype, argtypes).  Kept in header order; tests/test_abi.py checks that every
+# prototype of include/xvector_hip.h is listed here and exported by the .so.
+SIGNATURES = {
+    "xv_last_error": (C.c_char_p, []),
+    "xv_abi_version": (_I, []),
+    "xv_device_count": (_I, []),
+    "xv_copy_2d": (_I, [_VP, _VP, _SZ, _VP, _SZ, _I, _I]),
+    "xv_op_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "xv_pad_channels": (_I, [_VP, _VP, _I, _I, _VP, _I]),
+    "xv_prep_weight_fwd": (_I, [_VP, _VP, _I, _I, _I, _VP, _I]),
+    "xv_prep_weight_dgrad": (_I, [_VP, _VP, _I, _I, _I, _VP]),
+    "xv_affine_forward": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _VP, _SZ]),
+    "xv_affine_dgrad": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _I, _VP, _SZ]),
+    "xv_affine_wgrad": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _I, _VP, _F, _VP, _VP, _SZ]),
+    "xv_colsum": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ]),
+    "xv_col_stats": (_I, [_VP, _VP, _I, _I, _I, _VP]),
+    "xv_bn_finalize": (_I, [_VP, _VP, _I, _I, _VP, _VP, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "xv_bn_inference_scale": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _F, _VP, _VP]),
+    "xv_bn_apply": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP, _I]),
+    "xv_bn_relu_backward": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _SZ]),
+    "xv_relu_backward": (_I, [_VP, _VP, _VP, _SZ, _VP]),
+    "xv_stat_pool_forward": (_I, [_VP, _VP, _I, _I, _I, _VP]),
+    "xv_stat_pool_backward": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "xv_l2_scaling_forward": (_I, [_VP, _VP, _I, _I, _F, _VP]),
+    "xv_l2_scaling_backward": (_I, [_VP, _VP, _VP, _I, _I, _F, _VP]),
+    "xv_loss_prep_weight": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP]),
+    "xv_margin_softmax_rows": (_I, [_VP, _I, _VP, _I, _I, _I, _VP, _I, _VP, _F, _F, _VP, _VP, _VP, _VP]),
+    "xv_add_norm_grad": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
+    "xv_loss_weight_backward": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _SZ]),
+    "xv_l2_reg_loss": (_I, [_VP, _VP, _SZ, _F, _VP]),
+    "xv_sgd_update": (_I, [_VP, _VP, _VP, _SZ, _F, _F]),
+    "xv_momentum_update": (_I, [_VP, _VP, _VP, _VP, _SZ, _F, _F, _I, _F]),
+    "xv_adam_update": (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _F, _F, _F, _F, _I, _F]),
+    "xv_sumsq": (_I, [_VP, _VP, _SZ, _VP]),
+    "xv_engine_create": (_I, [C.POINTER(XvConfig), C.POINTER(_VP)]),
+    "xv_engine_destroy": (None, [_VP]),
+    "xv_engine_num_variables": (_I, [_VP]),
+    "xv_engine_variable_info": (_I, [_VP, _I, C.POINTER(C.c_char_p), c_int32_p, c_int32_p, C.POINTER(_SZ), c_int32_p]),
+    "xv_engine_variables_count": (_SZ, [_VP]),
+    "xv_engine_trainable_count": (_SZ, [_VP]),
+    "xv_engine_optimizer_state_count": (_SZ, [_VP]),
+    "xv_engine_bind": (_I, [_VP, _VP, _VP, _VP]),
+    "xv_engine_forward": (_I, [_VP, _VP, _VP, _I, _I, _I]),
+    "xv_engine_loss_forward": (_I, [_VP, _VP, _VP, _I, _I]),
+    "xv_engine_backward": (_I, [_VP, _VP, _I]),
+    "xv_engine_stage_grad_range": (_I, [_VP, _I, C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "xv_engine_apply": (_I, [_VP, _VP, _F, _F, _I]),
+    "xv_engine_loss_ptrs": (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),
+    "xv_engine_endpoint": (_I, [_VP, C.c_char_p, C.POINTER(_VP), c_int32_p, c_int32_p, c_int32_p]),
+    "xv_engine_invalidate_weights": (_I, [_VP]),
+}
+
+XV_BWD_STAGES = 4
+_lib = None
+
+
+def load():
+    """Load libxvector_hip.so (built in-tree by `make -C tf_kaldi_speaker_amd/csrc`,
+    or `python -c 'import __graft_entry__ as g; g.build()'`).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise XvError(
+            "HIP extension %s is missing - build it with `make -C %s` (hipcc, gfx950). "
+            "There is no CPU fallback." % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here == ABI mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.xv_abi_version() != 1:
+        raise XvError("ABI version mismatch: library reports %d" % lib.xv_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().xv_last_error()
+        raise XvError("%s failed (rc=%d): %s" % (what or "xv call", rc, msg.decode() if msg else "?"))
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise XvError on failure."""
+    check(getattr(load(), name)(*args), name)

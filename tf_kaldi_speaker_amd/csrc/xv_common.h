@@ -1,0 +1,77 @@
+// Internal helpers shared by the HIP translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "xvector_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define XV_WAVE 64
+
+void xv_set_error(const char* fmt, ...);
+
+#define XV_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            xv_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                   \
+        }                                                                               \
+    } while (0)
+
+#define XV_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            xv_set_error(__VA_ARGS__);   \
+            return 2;                    \
+        }                                \
+    } while (0)
+
+#define XV_LAUNCH_CHECK()                                                               \
+    do {                                                                                \
+        hipError_t _e = hipGetLastError();                                              \
+        if (_e != hipSuccess) {                                                         \
+            xv_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                   \
+        }                                                                               \
+    } while (0)
+
+static inline int xv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t xv_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- GEMM geometry shared between launchers and the engine -------------------------
+#define XV_TILE_M 128
+#define XV_TILE_N 128
+#define XV_TILE_K 32
+
+// Internal GEMM launchers (xv_gemm.hip).
+// C[m][n] (+)= sum_k A[rowmap(m)][k] * Bt[n][k]   ("NT", both operands k-contiguous)
+// rowmap(m) = (m / a_rps) * a_pitch + (m % a_rps) rows of lda floats.
+struct XvGemmNT {
+    const float* A; long lda; int a_rps; int a_pitch;
+    const float* Bt; long ldb;
+    float* C; long ldc;
+    int M, N, K;
+    const float* bias;      // optional, [N]
+    float* bn_part;         // optional, [2][tiles_m][N]
+    void* ws; size_t ws_bytes;
+};
+int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g);
+
+// P[z][m][n] = sum_{r in chunk z} A[amap(r)][m] * B[bmap(r)][n]   ("TN", reduction over rows)
+struct XvGemmTN {
+    const float* A; long lda; int a_rps; int a_pitch;   // [R] rows mapped, M columns used
+    const float* B; long ldb; int b_rps; int b_pitch;   // [R] rows mapped, N columns used
+    int M, N, R;
+    float* P;            // slabs [splits][M][N]
+    int splits;          // chosen by xv_tn_splits
+};
+int xv_tn_splits(int M, int N, int R);
+int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g);
+int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int C, int c_pad, int n_in, int n_out, const float* w,
+                           long ldw, float l2, float* out, long ldo);

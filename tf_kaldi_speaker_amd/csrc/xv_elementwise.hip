@@ -1,0 +1,615 @@
+// HBM-bound kernels of the TDNN hot path: layout prep, BatchNorm (statistics finalise, apply,
+// backward), ReLU, statistics pooling, l2_scaling, bias gradients, optimisers.  gfx950 only.
+// All tensors fp32 row-major with the channel axis contiguous, so threads always run along
+// channels (16 B per lane where the pitch allows) and reductions over rows are per-thread
+// serial + wave shuffle / LDS combine.  No atomics on any path that feeds a gradient.
+#include <stdarg.h>
+
+#include "xv_common.h"
+
+// ------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void xv_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* xv_last_error(void) { return g_err; }
+extern "C" int xv_abi_version(void) { return XV_ABI_VERSION; }
+extern "C" int xv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static inline int grid_for(long total, int block, int cap = 4096) {
+    long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int xv_copy_2d(void* stream, float* dst, size_t ldd, const float* src, size_t lds, int rows, int cols) {
+    XV_REQUIRE(dst && src && rows > 0 && cols > 0 && ldd >= (size_t)cols && lds >= (size_t)cols, "copy_2d: bad arguments");
+    XV_CHECK_HIP(hipMemcpy2DAsync(dst, ldd * sizeof(float), src, lds * sizeof(float), (size_t)cols * sizeof(float), rows,
+                                  hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// layout prep
+// ------------------------------------------------------------------------------------
+__global__ void pad_channels_kernel(const float* __restrict__ src, long rows, int c_src, float* __restrict__ dst, int c_dst) {
+    long total = rows * c_dst;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / c_dst;
+        int c = (int)(i - r * c_dst);
+        dst[i] = c < c_src ? src[r * c_src + c] : 0.f;
+    }
+}
+
+extern "C" int xv_pad_channels(void* stream, const float* src, int rows, int c_src, float* dst, int c_dst) {
+    XV_REQUIRE(rows > 0 && c_src > 0 && c_dst >= c_src, "pad_channels: bad shape rows=%d c_src=%d c_dst=%d", rows, c_src, c_dst);
+    long total = (long)rows * c_dst;
+    hipLaunchKernelGGL(pad_channels_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, (long)rows, c_src, dst, c_dst);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// wt[o][j*c_pad + c] = kernel[(j*C + c)*O + o], zero for c >= C.  32x32 LDS-tiled transpose:
+// reads run along o (contiguous in kernel), writes run along the padded k axis (contiguous in wt).
+__global__ void prep_weight_fwd_kernel(const float* __restrict__ w, int k, int C, int O, float* __restrict__ wt, int c_pad) {
+    __shared__ float tile[32][33];
+    const int kp = k * c_pad;
+    const int kk0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        int kk = kk0 + r, o = o0 + tx;
+        float v = 0.f;
+        if (kk < kp && o < O) {
+            int j = kk / c_pad, c = kk - j * c_pad;
+            if (c < C) v = w[((long)j * C + c) * O + o];
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int o = o0 + r, kk = kk0 + tx;
+        if (o < O && kk < kp) wt[(long)o * kp + kk] = tile[tx][r];
+    }
+}
+
+extern "C" int xv_prep_weight_fwd(void* stream, const float* kernel, int k, int c, int o, float* wt, int c_pad) {
+    XV_REQUIRE(k > 0 && c > 0 && o > 0 && c_pad >= c, "prep_weight_fwd: bad shape");
+    dim3 grid(xv_cdiv((long)k * c_pad, 32), xv_cdiv(o, 32));
+    hipLaunchKernelGGL(prep_weight_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, kernel, k, c, o, wt, c_pad);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void prep_weight_dgrad_kernel(const float* __restrict__ w, int k, int C, int O, float* __restrict__ wf) {
+    long total = (long)k * C * O;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int o = (int)(i % O);
+        long jc = i / O;
+        int c = (int)(jc % C), j = (int)(jc / C);
+        wf[(long)c * k * O + (long)(k - 1 - j) * O + o] = w[i];
+    }
+}
+
+extern "C" int xv_prep_weight_dgrad(void* stream, const float* kernel, int k, int c, int o, float* wf) {
+    XV_REQUIRE(k > 0 && c > 0 && o > 0, "prep_weight_dgrad: bad shape");
+    long total = (long)k * c * o;
+    hipLaunchKernelGGL(prep_weight_dgrad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, kernel, k, c, o, wf);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// column sums / column statistics (row-chunk partials, then a fixed-order combine)
+// ------------------------------------------------------------------------------------
+#define CS_ROWS 128
+__global__ void colsum_partial_kernel(const float* __restrict__ a, int rows, int n, long lda, float* __restrict__ part) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    int r0 = blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+    if (col >= n) return;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += a[(long)r * lda + col];
+    part[(long)blockIdx.y * n + col] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ out) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(long)c * n + col];
+    out[col] = s;
+}
+
+extern "C" int xv_colsum(void* stream, const float* a, int rows, int n, int lda, float* out, void* ws, size_t ws_bytes) {
+    XV_REQUIRE(rows > 0 && n > 0 && lda >= n, "colsum: bad shape");
+    int chunks = xv_cdiv(rows, CS_ROWS);
+    XV_REQUIRE((size_t)chunks * n * sizeof(float) <= ws_bytes, "colsum: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(xv_cdiv(n, 256), chunks), dim3(256), 0, s, a, rows, n, (long)lda, (float*)ws);
+    XV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(xv_cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, chunks, n, out);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// bn_part layout: [2][tiles][n] with tiles = ceil(rows / XV_TILE_M): sum, then centred sum of squares.
+__global__ void col_stats_kernel(const float* __restrict__ z, int rows, int n, long ldz, float* __restrict__ part, int tiles) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    int tile = blockIdx.y;
+    int r0 = tile * XV_TILE_M, r1 = min(rows, r0 + XV_TILE_M);
+    if (col >= n) return;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += z[(long)r * ldz + col];
+    float mean = s / (float)(r1 - r0);
+    float q = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        float d = z[(long)r * ldz + col] - mean;
+        q += d * d;
+    }
+    part[(long)tile * n + col] = s;
+    part[((long)tiles + tile) * n + col] = q;
+}
+
+extern "C" int xv_col_stats(void* stream, const float* z, int rows, int n, int ldz, float* bn_part) {
+    XV_REQUIRE(rows > 0 && n > 0 && ldz >= n, "col_stats: bad shape");
+    int tiles = xv_cdiv(rows, XV_TILE_M);
+    hipLaunchKernelGGL(col_stats_kernel, dim3(xv_cdiv(n, 128), tiles), dim3(128), 0, (hipStream_t)stream, z, rows, n, (long)ldz, bn_part, tiles);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// BatchNorm
+// ------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int rows, int n, int tiles,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, int unbiased, float* __restrict__ mmean, float* __restrict__ mvar,
+                                   float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                   float* __restrict__ scale_o, float* __restrict__ shift_o) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    // Chan et al. pairwise combine of per-tile (count, sum, M2) in double (<= a few hundred terms)
+    double total = 0.0;
+    for (int t = 0; t < tiles; ++t) total += (double)part[(long)t * n + c];
+    double mean = total / (double)rows;
+    double m2 = 0.0;
+    for (int t = 0; t < tiles; ++t) {
+        int cnt = min(XV_TILE_M, rows - t * XV_TILE_M);
+        double tm = (double)(part[(long)t * n + c] / (float)cnt);   // same tile mean the producer centred on
+        double d = tm - mean;
+        m2 += (double)part[((long)tiles + t) * n + c] + d * d * (double)cnt;
+    }
+    float var = (float)(m2 / (double)rows);
+    float meanf = (float)mean;
+    float invstd = 1.0f / sqrtf(var + eps);
+    float sc = gamma[c] * invstd;
+    mean_o[c] = meanf;
+    invstd_o[c] = invstd;
+    scale_o[c] = sc;
+    shift_o[c] = beta[c] - meanf * sc;
+    if (mmean) {
+        float v = (unbiased && rows > 1) ? var * ((float)rows / (float)(rows - 1)) : var;
+        mmean[c] = mmean[c] * momentum + meanf * (1.0f - momentum);
+        mvar[c] = mvar[c] * momentum + v * (1.0f - momentum);
+    }
+}
+
+extern "C" int xv_bn_finalize(void* stream, const float* bn_part, int rows, int n, const float* gamma, const float* beta,
+                              float eps, float momentum, int unbiased_moving, float* moving_mean, float* moving_var,
+                              float* mean, float* invstd, float* scale, float* shift) {
+    XV_REQUIRE(rows > 0 && n > 0, "bn_finalize: bad shape");
+    int tiles = xv_cdiv(rows, XV_TILE_M);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(xv_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, bn_part, rows, n, tiles,
+                       gamma, beta, eps, momentum, unbiased_moving, moving_mean, moving_var, mean, invstd, scale, shift);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void bn_inference_scale_kernel(int n, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          const float* __restrict__ mmean, const float* __restrict__ mvar, float eps,
+                                          float* __restrict__ scale, float* __restrict__ shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float sc = gamma[c] * (1.0f / sqrtf(mvar[c] + eps));
+    scale[c] = sc;
+    shift[c] = beta[c] - mmean[c] * sc;
+}
+
+extern "C" int xv_bn_inference_scale(void* stream, int n, const float* gamma, const float* beta, const float* moving_mean,
+                                     const float* moving_var, float eps, float* scale, float* shift) {
+    XV_REQUIRE(n > 0, "bn_inference_scale: bad shape");
+    hipLaunchKernelGGL(bn_inference_scale_kernel, dim3(xv_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, n, gamma, beta,
+                       moving_mean, moving_var, eps, scale, shift);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// a = relu?(z*scale+shift), 16 B per lane along channels
+__global__ void bn_apply_kernel(const float* __restrict__ z, long rows, int nq, long ldz, const float* __restrict__ scale,
+                                const float* __restrict__ shift, int relu, float* __restrict__ a, long lda) {
+    long total = rows * nq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / nq;
+        int q = (int)(i - r * nq);
+        f32x4 v = *(const f32x4*)(z + r * ldz + 4 * q);
+        f32x4 sc = *(const f32x4*)(scale + 4 * q);
+        f32x4 sh = *(const f32x4*)(shift + 4 * q);
+        v = v * sc + sh;
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *(f32x4*)(a + r * lda + 4 * q) = v;
+    }
+}
+
+extern "C" int xv_bn_apply(void* stream, const float* z, int rows, int n, int ldz, const float* scale, const float* shift,
+                           int relu, float* a, int lda) {
+    XV_REQUIRE(rows > 0 && n > 0 && n % 4 == 0 && ldz % 4 == 0 && lda % 4 == 0, "bn_apply: n/ld must be multiples of 4 (n=%d)", n);
+    long total = (long)rows * (n / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, z, (long)rows, n / 4,
+                       (long)ldz, scale, shift, relu, a, (long)lda);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward pass 1: per (64-row chunk, 256-column block) partial sums of dy and dy*xhat.
+// block = 256 threads = 64 column-quads x 4 row lanes.
+#define BB_ROWS 64
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ z, int rows,
+                                                            int n, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu,
+                                                            float* __restrict__ part /* [chunks][2][n] */) {
+    __shared__ f32x4 red[2][4][64];
+    const int qx = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + qx) * 4;
+    const int r0 = blockIdx.y * BB_ROWS, r1 = min(rows, r0 + BB_ROWS);
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (col < n) {
+        f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
+        f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
+        for (int r = r0 + rl; r < r1; r += 4) {
+            f32x4 zz = *(const f32x4*)(z + (long)r * n + col);
+            f32x4 dd = *(const f32x4*)(da + (long)r * n + col);
+            if (relu) {
+                f32x4 y = zz * sc + sh;
+                dd.x = y.x > 0.f ? dd.x : 0.f; dd.y = y.y > 0.f ? dd.y : 0.f;
+                dd.z = y.z > 0.f ? dd.z : 0.f; dd.w = y.w > 0.f ? dd.w : 0.f;
+            }
+            f32x4 xh = (zz - mu) * is;
+            s1 += dd;
+            s2 += dd * xh;
+        }
+    }
+    red[0][rl][qx] = s1;
+    red[1][rl][qx] = s2;
+    __syncthreads();
+    if (rl == 0 && col < n) {
+        f32x4 t1 = (red[0][0][qx] + red[0][1][qx]) + (red[0][2][qx] + red[0][3][qx]);
+        f32x4 t2 = (red[1][0][qx] + red[1][1][qx]) + (red[1][2][qx] + red[1][3][qx]);
+        *(f32x4*)(part + ((long)blockIdx.y * 2 + 0) * n + col) = t1;
+        *(f32x4*)(part + ((long)blockIdx.y * 2 + 1) * n + col) = t2;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int n, int rows,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef /* [2][n] */) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < chunks; ++k) {
+        s1 += part[((long)k * 2 + 0) * n + c];
+        s2 += part[((long)k * 2 + 1) * n + c];
+    }
+    dbeta[c] = s1;
+    dgamma[c] = s2;
+    coef[c] = s1 / (float)rows;
+    coef[n + c] = s2 / (float)rows;
+}
+
+// Backward pass 2: dz = gamma*invstd*(dy - c1 - xhat*c2) into the segment-padded layout.
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ z, int segs, int t, int nq,
+                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, const float* __restrict__ coef, int relu, int pad,
+                                    float* __restrict__ dz) {
+    const int tp = t + 2 * pad, n = nq * 4;
+    long total = (long)segs * tp * nq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long dr = i / nq;
+        int col = (int)(i - dr * nq) * 4;
+        int seg = (int)(dr / tp), u = (int)(dr - (long)seg * tp) - pad;
+        f32x4 out = {0, 0, 0, 0};
+        if (u >= 0 && u < t) {
+            long r = (long)seg * t + u;
+            f32x4 zz = *(const f32x4*)(z + r * n + col);
+            f32x4 dd = *(const f32x4*)(da + r * n + col);
+            f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
+            if (relu) {
+                f32x4 y = zz * *(const f32x4*)(scale + col) + *(const f32x4*)(shift + col);
+                dd.x = y.x > 0.f ? dd.x : 0.f; dd.y = y.y > 0.f ? dd.y : 0.f;
+                dd.z = y.z > 0.f ? dd.z : 0.f; dd.w = y.w > 0.f ? dd.w : 0.f;
+            }
+            f32x4 xh = (zz - mu) * is;
+            f32x4 c1 = *(const f32x4*)(coef + col), c2 = *(const f32x4*)(coef + n + col);
+            out = (*(const f32x4*)(gamma + col) * is) * (dd - c1 - xh * c2);
+        }
+        *(f32x4*)(dz + dr * n + col) = out;
+    }
+}
+
+extern "C" int xv_bn_relu_backward(void* stream, const float* da, const float* z, int segs, int t, int n, const float* gamma,
+                                   const float* mean, const float* invstd, const float* scale, const float* shift, int relu,
+                                   int pad, float* dz_pad, float* dgamma, float* dbeta, void* ws, size_t ws_bytes) {
+    XV_REQUIRE(segs > 0 && t > 0 && n > 0 && n % 4 == 0 && pad >= 0, "bn_relu_backward: bad shape (n=%d must be a multiple of 4)", n);
+    const int rows = segs * t;
+    const int chunks = xv_cdiv(rows, BB_ROWS);
+    size_t need = ((size_t)chunks * 2 * n + 2 * n) * sizeof(float);
+    XV_REQUIRE(need <= ws_bytes, "bn_relu_backward: workspace too small (%zu > %zu)", need, ws_bytes);
+    float* part = (float*)ws;
+    float* coef = part + (size_t)chunks * 2 * n;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s, da, z, rows, n, mean, invstd,
+                       scale, shift, relu, part);
+    XV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, 128)), dim3(128), 0, s, (const float*)part, chunks, n, rows,
+                       dgamma, dbeta, coef);
+    XV_LAUNCH_CHECK();
+    long total = (long)segs * (t + 2 * pad) * (n / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, da, z, segs, t, n / 4, gamma, mean,
+                       invstd, scale, shift, (const float*)coef, relu, pad, dz_pad);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ a, size_t count, float* __restrict__ dz) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        dz[i] = a[i] > 0.f ? da[i] : 0.f;
+}
+extern "C" int xv_relu_backward(void* stream, const float* da, const float* a, size_t count, float* dz) {
+    XV_REQUIRE(count > 0, "relu_backward: empty");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for((long)count, 256)), dim3(256), 0, (hipStream_t)stream, da, a, count, dz);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// statistics pooling (pooling.py:9-34)
+// wave = 32 channel-quads x 2 frame lanes (lane ^ 32 partner), block = 4 waves = 8 frame lanes.
+// Each lane runs Welford over its frames for 4 channels; lanes are merged with Chan's formula:
+// across the two halves of a wave by __shfl_xor, across waves through LDS.
+// ------------------------------------------------------------------------------------
+struct Wf4 { f32x4 mean, m2; float n; };
+__device__ __forceinline__ void wf_merge(f32x4& mean, f32x4& m2, float& n, const f32x4& mean_b, const f32x4& m2_b, float n_b) {
+    float nn = n + n_b;
+    if (nn > 0.f) {
+        f32x4 d = mean_b - mean;
+        float w = n_b / nn;
+        mean = mean + d * w;
+        m2 = m2 + m2_b + d * d * (n * w);
+    }
+    n = nn;
+}
+
+__global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restrict__ x, int T, int C, float* __restrict__ out) {
+    __shared__ f32x4 s_mean[4][32], s_m2[4][32];
+    __shared__ float s_n[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qx = lane & 31, half = lane >> 5;
+    const int col = (blockIdx.x * 32 + qx) * 4;
+    const int b = blockIdx.y;
+    const int fl = wave * 2 + half;          // frame lane 0..7
+    const bool cv = col < C;
+    const float* xp = x + (long)b * T * C + (cv ? col : 0);
+    f32x4 mean = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+    float n = 0.f;
+    int t = fl;
+    // 4 loads in flight per lane
+    for (; t + 24 < T; t += 32) {
+        f32x4 v0 = *(const f32x4*)(xp + (long)t * C);
+        f32x4 v1 = *(const f32x4*)(xp + (long)(t + 8) * C);
+        f32x4 v2 = *(const f32x4*)(xp + (long)(t + 16) * C);
+        f32x4 v3 = *(const f32x4*)(xp + (long)(t + 24) * C);
+        f32x4 d;
+        n += 1.f; d = v0 - mean; mean += d * (1.f / n); m2 += d * (v0 - mean);
+        n += 1.f; d = v1 - mean; mean += d * (1.f / n); m2 += d * (v1 - mean);
+        n += 1.f; d = v2 - mean; mean += d * (1.f / n); m2 += d * (v2 - mean);
+        n += 1.f; d = v3 - mean; mean += d * (1.f / n); m2 += d * (v3 - mean);
+    }
+    for (; t < T; t += 8) {
+        f32x4 v = *(const f32x4*)(xp + (long)t * C);
+        n += 1.f;
+        f32x4 d = v - mean;
+        mean += d * (1.f / n);
+        m2 += d * (v - mean);
+    }
+    // merge the two frame lanes of this wave
+    f32x4 mean_b, m2_b;
+    mean_b.x = __shfl_xor(mean.x, 32); mean_b.y = __shfl_xor(mean.y, 32);
+    mean_b.z = __shfl_xor(mean.z, 32); mean_b.w = __shfl_xor(mean.w, 32);
+    m2_b.x = __shfl_xor(m2.x, 32); m2_b.y = __shfl_xor(m2.y, 32);
+    m2_b.z = __shfl_xor(m2.z, 32); m2_b.w = __shfl_xor(m2.w, 32);
+    float n_b = __shfl_xor(n, 32);
+    if (half == 0) {
+        wf_merge(mean, m2, n, mean_b, m2_b, n_b);
+        s_mean[wave][qx] = mean;
+        s_m2[wave][qx] = m2;
+        if (qx == 0) s_n[wave] = n;
+    }
+    __syncthreads();
+    if (wave == 0 && half == 0 && cv) {
+        mean = s_mean[0][qx]; m2 = s_m2[0][qx]; n = s_n[0];
+        for (int w = 1; w < 4; ++w) wf_merge(mean, m2, n, s_mean[w][qx], s_m2[w][qx], s_n[w]);
+        f32x4 var = m2 * (1.f / (float)T);
+        const float eps = 1e-12f;
+        f32x4 sd;
+        sd.x = sqrtf(var.x <= eps ? eps : var.x); sd.y = sqrtf(var.y <= eps ? eps : var.y);
+        sd.z = sqrtf(var.z <= eps ? eps : var.z); sd.w = sqrtf(var.w <= eps ? eps : var.w);
+        *(f32x4*)(out + (long)b * 2 * C + col) = mean;
+        *(f32x4*)(out + (long)b * 2 * C + C + col) = sd;
+    }
+}
+
+extern "C" int xv_stat_pool_forward(void* stream, const float* x, int b, int t, int c, float* out) {
+    XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0, "stat_pool_forward: bad shape (c=%d must be a multiple of 4)", c);
+    hipLaunchKernelGGL(stat_pool_fwd_kernel, dim3(xv_cdiv(c / 4, 32), b), dim3(256), 0, (hipStream_t)stream, x, t, c, out);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void stat_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ out, const float* __restrict__ dout,
+                                     int T, int cq, float* __restrict__ dx, long total) {
+    const int C = cq * 4;
+    const float invT = 1.f / (float)T;
+    const float sd_eps = sqrtf(1e-12f);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long row = i / cq;
+        int col = (int)(i - row * cq) * 4;
+        int b = (int)(row / T);
+        const float* o = out + (long)b * 2 * C;
+        const float* g = dout + (long)b * 2 * C;
+        f32x4 mean = *(const f32x4*)(o + col), sd = *(const f32x4*)(o + C + col);
+        f32x4 dm = *(const f32x4*)(g + col), ds = *(const f32x4*)(g + C + col);
+        f32x4 v = *(const f32x4*)(x + row * C + col);
+        f32x4 k;   // dstd * (1/std) / T, zero where the variance was clamped (pooling.py:28-29)
+        k.x = sd.x <= sd_eps ? 0.f : ds.x / sd.x * invT; k.y = sd.y <= sd_eps ? 0.f : ds.y / sd.y * invT;
+        k.z = sd.z <= sd_eps ? 0.f : ds.z / sd.z * invT; k.w = sd.w <= sd_eps ? 0.f : ds.w / sd.w * invT;
+        *(f32x4*)(dx + row * C + col) = dm * invT + k * (v - mean);
+    }
+}
+
+extern "C" int xv_stat_pool_backward(void* stream, const float* x, const float* out, const float* dout, int b, int t, int c, float* dx) {
+    XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0, "stat_pool_backward: bad shape");
+    long total = (long)b * t * (c / 4);
+    hipLaunchKernelGGL(stat_pool_bwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, out, dout, t,
+                       c / 4, dx, total);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// l2_scaling (common.py:45-58): one wave per row
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ void l2_scaling_fwd_kernel(const float* __restrict__ x, int rows, int n, float factor, float* __restrict__ y) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (long)row * n;
+    float ss = 0.f;
+    for (int c = lane; c < n; c += 64) ss += xr[c] * xr[c];
+    ss = wave_sum(ss);
+    float inv = rsqrtf(fmaxf(ss, 1e-12f)) * factor;
+    for (int c = lane; c < n; c += 64) y[(long)row * n + c] = xr[c] * inv;
+}
+__global__ void l2_scaling_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int rows, int n, float factor,
+                                      float* __restrict__ dx) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (long)row * n;
+    const float* gr = dy + (long)row * n;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < n; c += 64) { ss += xr[c] * xr[c]; dot += xr[c] * gr[c]; }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    float inv = rsqrtf(fmaxf(ss, 1e-12f)) * factor;
+    float k = ss >= 1e-12f ? inv / ss * dot : 0.f;
+    for (int c = lane; c < n; c += 64) dx[(long)row * n + c] = gr[c] * inv - xr[c] * k;
+}
+extern "C" int xv_l2_scaling_forward(void* stream, const float* x, int rows, int n, float factor, float* y) {
+    XV_REQUIRE(rows > 0 && n > 0, "l2_scaling_forward: bad shape");
+    hipLaunchKernelGGL(l2_scaling_fwd_kernel, dim3(xv_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, n, factor, y);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xv_l2_scaling_backward(void* stream, const float* x, const float* dy, int rows, int n, float factor, float* dx) {
+    XV_REQUIRE(rows > 0 && n > 0, "l2_scaling_backward: bad shape");
+    hipLaunchKernelGGL(l2_scaling_bwd_kernel, dim3(xv_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, dy, rows, n, factor, dx);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// scalar reductions (reporting / clip-by-global-norm only) and optimisers
+// ------------------------------------------------------------------------------------
+__global__ void sumsq_kernel(const float* __restrict__ w, size_t count, float scale, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) s += w[i] * w[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, scale * ((red[0] + red[1]) + (red[2] + red[3])));
+}
+extern "C" int xv_l2_reg_loss(void* stream, const float* w, size_t count, float scale, float* out_accum) {
+    XV_REQUIRE(count > 0, "l2_reg_loss: empty");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for((long)count, 256, 512)), dim3(256), 0, (hipStream_t)stream, w, count, 0.5f * scale, out_accum);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xv_sumsq(void* stream, const float* g, size_t count, float* out_accum) {
+    XV_REQUIRE(count > 0, "sumsq: empty");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for((long)count, 256, 512)), dim3(256), 0, (hipStream_t)stream, g, count, 1.0f, out_accum);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, size_t count, float lr, float gs) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = p[i] - lr * (g[i] * gs);
+}
+__global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc, size_t count, float lr,
+                                float mom, int nesterov, float gs) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * gs;
+        float a = mom * acc[i] + gi;
+        acc[i] = a;
+        p[i] = nesterov ? p[i] - lr * (gi + mom * a) : p[i] - lr * a;
+    }
+}
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t count, float lr_t, float b1, float b2, float eps, float gs) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * gs;
+        float mi = b1 * m[i] + (1.f - b1) * gi;
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+extern "C" int xv_sgd_update(void* stream, float* p, const float* g, size_t count, float lr, float grad_scale) {
+    XV_REQUIRE(count > 0, "sgd_update: empty");
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for((long)count, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, count, lr, grad_scale);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xv_momentum_update(void* stream, float* p, const float* g, float* acc, size_t count, float lr, float momentum,
+                                  int nesterov, float grad_scale) {
+    XV_REQUIRE(count > 0, "momentum_update: empty");
+    hipLaunchKernelGGL(momentum_kernel, dim3(grid_for((long)count, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, acc, count, lr,
+                       momentum, nesterov, grad_scale);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xv_adam_update(void* stream, float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
+                              float beta2, float eps, int t, float grad_scale) {
+    XV_REQUIRE(count > 0 && t >= 1, "adam_update: bad arguments");
+    double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((long)count, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, count,
+                       (float)lr_t, beta1, beta2, eps, grad_scale);
+    XV_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,635 @@
+// Engine: the whole tdnn (model/tdnn.py:33-191) + entire_network (model/trainer.py:168-188) +
+// loss (model/loss.py) + regulariser/optimiser (model/trainer.py:332-436) graph as a fixed
+// sequence of kernel launches on one HIP stream.  This is the native counterpart of what the
+// TF1 runtime does under sess.run(train_op); the Python Trainer only feeds pointers.
+//
+// HBM layout (all fp32, channel axis contiguous):
+//   variables  : caller-owned flat buffer, TF variable order, trainable first then BN moving
+//                statistics; every variable starts on a 16-byte boundary.  Gradients mirror the
+//                trainable section, so backward "stages" finish contiguous tail slices of the
+//                gradient buffer and the host can all-reduce them while earlier layers still run.
+//   activations: per frame layer z_l (pre-BN) and a_l (post BN+ReLU), [chunks*frames_l][C_l].
+//   backward   : one da buffer and one dz buffer, ping-ponged down the stack; dz is stored with
+//                k-1 zero frames around each chunk so the data gradient is the SAME spliced-view
+//                GEMM as the forward pass (xv_gemm.hip).
+//   weights    : kernel-layout copies (transposed / tap-flipped / channel-padded) rebuilt once
+//                per optimiser step.
+#include <string>
+#include <vector>
+
+#include "xv_common.h"
+
+namespace {
+
+struct Var {
+    std::string name;
+    int32_t shape[4];
+    int32_t rank;
+    size_t offset;   // floats, into the variables buffer
+    size_t count;    // floats
+    bool trainable;
+};
+
+struct Affine {   // one conv/dense layer (+ optional BN, ReLU)
+    std::string prefix;    // "tdnn1"
+    std::string kind;      // "conv" | "dense"
+    int k, c_in, c_pad, c_out;
+    bool has_bn, has_relu, fused_bn;
+    int v_kernel, v_bias, v_gamma, v_beta, v_mmean, v_mvar;
+    float *wt, *wf;                       // kernel-layout weights (wf only when k > 1)
+    float *z, *a;                         // activations
+    float *bn_part, *mean, *invstd, *scale, *shift;
+    int rows;                             // rows of the most recent forward
+};
+
+}  // namespace
+
+struct xv_engine {
+    xv_config cfg;
+    std::vector<Var> vars;
+    size_t n_train = 0, n_all = 0, n_opt = 0;
+    float *V = nullptr, *G = nullptr, *S = nullptr;   // bound buffers
+    Affine L[7];
+    int v_loss_kernel = -1, v_loss_bias = -1;
+    int c_pad0 = 0;
+    int P = 0, Lout = 0, N = 0, ldl = 0;
+    // device arena
+    char* arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    float *xpad = nullptr, *pool = nullptr, *h7 = nullptr, *out = nullptr;
+    float *logits = nullptr, *dlogits = nullptr, *dnorm = nullptr, *row_loss = nullptr;
+    float *inv_norm = nullptr, *wn = nullptr, *wnt = nullptr, *dwn = nullptr;
+    float *bufD = nullptr, *bufZ = nullptr, *d_small0 = nullptr, *d_small1 = nullptr;
+    float *scalars = nullptr;   // [0] raw loss, [1] reg loss, [2] grad sumsq
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    int32_t* labels_dev = nullptr;   // caller's pointer of the current step
+    bool weights_dirty = true;
+    // state of the most recent forward
+    int B = 0, T = 0, training = 0;
+    int Tl[6] = {0, 0, 0, 0, 0, 0};   // frames after each frame layer (index 0 = input)
+    float lambda = 0.f;
+    int with_margin = 1;
+    hipStream_t last_stream = nullptr;
+    size_t stage_begin[XV_BWD_STAGES], stage_end[XV_BWD_STAGES];
+};
+
+namespace {
+
+float* carve(xv_engine* e, size_t floats) {
+    size_t bytes = xv_align(floats * sizeof(float), 256);
+    if (e->arena_used + bytes > e->arena_bytes) return nullptr;
+    float* p = (float*)(e->arena + e->arena_used);
+    e->arena_used += bytes;
+    return p;
+}
+
+int add_var(xv_engine* e, const std::string& name, std::initializer_list<int> shape, bool trainable) {
+    Var v;
+    v.name = name;
+    v.rank = (int32_t)shape.size();
+    v.count = 1;
+    int i = 0;
+    for (int s : shape) { v.shape[i++] = s; v.count *= (size_t)s; }
+    for (; i < 4; ++i) v.shape[i] = 1;
+    v.offset = 0;
+    v.trainable = trainable;
+    e->vars.push_back(v);
+    return (int)e->vars.size() - 1;
+}
+
+float* vptr(xv_engine* e, int idx) { return e->V + e->vars[idx].offset; }
+float* gptr(xv_engine* e, int idx) { return e->G + e->vars[idx].offset; }
+
+void build_variables(xv_engine* e) {
+    const xv_config& c = e->cfg;
+    const int D = c.feat_dim;
+    e->P = c.num_nodes_pooling_layer;
+    e->Lout = c.num_nodes_last_layer;
+    e->N = c.num_speakers;
+    struct Spec { const char* prefix; const char* kind; int k, cin, cout; bool bn, relu, fused; };
+    const Spec specs[7] = {
+        {"tdnn1", "conv", 5, D, 512, true, true, true},
+        {"tdnn2", "conv", 5, 512, 512, true, true, true},
+        {"tdnn3", "conv", 7, 512, 512, true, true, true},
+        {"tdnn4", "dense", 1, 512, 512, true, true, false},
+        {"tdnn5", "dense", 1, 512, e->P, true, true, false},
+        {"tdnn6", "dense", 1, 2 * e->P, 512, true, true, false},
+        {"tdnn7", "dense", 1, 512, e->Lout, !c.last_layer_no_bn, !c.last_layer_linear, false},
+    };
+    for (int i = 0; i < 7; ++i) {
+        Affine& a = e->L[i];
+        const Spec& s = specs[i];
+        a.prefix = s.prefix; a.kind = s.kind;
+        a.k = s.k; a.c_in = s.cin; a.c_out = s.cout;
+        a.c_pad = (int)xv_align(s.cin, 4);   // == c_in except for the feature layer (30 -> 32)
+        a.has_bn = s.bn; a.has_relu = s.relu; a.fused_bn = s.fused;
+        std::string base = std::string("tdnn/") + s.prefix + "_" + s.kind;
+        if (s.k > 1) a.v_kernel = add_var(e, base + "/kernel", {1, s.k, s.cin, s.cout}, true);
+        else a.v_kernel = add_var(e, base + "/kernel", {s.cin, s.cout}, true);
+        a.v_bias = add_var(e, base + "/bias", {s.cout}, true);
+        a.v_gamma = a.v_beta = a.v_mmean = a.v_mvar = -1;
+        if (s.bn) {
+            std::string bn = std::string("tdnn/") + s.prefix + "_bn";
+            a.v_gamma = add_var(e, bn + "/gamma", {s.cout}, true);
+            a.v_beta = add_var(e, bn + "/beta", {s.cout}, true);
+            a.v_mmean = add_var(e, bn + "/moving_mean", {s.cout}, false);
+            a.v_mvar = add_var(e, bn + "/moving_variance", {s.cout}, false);
+        }
+    }
+    e->c_pad0 = e->L[0].c_pad;
+    if (e->N > 0) {
+        e->v_loss_kernel = add_var(e, "softmax/output/kernel", {e->Lout, e->N}, true);
+        if (c.loss_kind == XV_LOSS_SOFTMAX) e->v_loss_bias = add_var(e, "softmax/output/bias", {e->N}, true);
+    }
+    // offsets: trainable section first (graph order), then non-trainable; 16-byte aligned starts
+    size_t off = 0;
+    for (auto& v : e->vars) if (v.trainable) { v.offset = off; off += xv_align(v.count, 4); }
+    e->n_train = off;
+    for (auto& v : e->vars) if (!v.trainable) { v.offset = off; off += xv_align(v.count, 4); }
+    e->n_all = off;
+    e->n_opt = c.optimizer == 0 ? 0 : (c.optimizer == 1 ? e->n_train : 2 * e->n_train);
+
+    // backward stages -> contiguous gradient ranges (stage 0 finishes the tail of the buffer)
+    auto first_off = [&](int layer) { return e->vars[e->L[layer].v_kernel].offset; };
+    e->stage_begin[0] = first_off(5); e->stage_end[0] = e->n_train;   // tdnn6, tdnn7, loss
+    e->stage_begin[1] = first_off(3); e->stage_end[1] = first_off(5); // tdnn4, tdnn5
+    e->stage_begin[2] = first_off(2); e->stage_end[2] = first_off(3); // tdnn3
+    e->stage_begin[3] = 0;            e->stage_end[3] = first_off(2); // tdnn1, tdnn2
+}
+
+int alloc_buffers(xv_engine* e) {
+    const xv_config& c = e->cfg;
+    const size_t B = c.max_batch, T = c.max_frames;
+    XV_REQUIRE(B >= 1 && T >= 15, "engine: max_batch >= 1 and max_frames >= 15 required (receptive field of tdnn1-3)");
+    size_t rows[6];
+    rows[0] = B * T; rows[1] = B * (T - 4); rows[2] = B * (T - 8); rows[3] = rows[4] = rows[5] = B * (T - 14);
+    e->ldl = e->N > 0 ? (int)xv_align(e->N, 4) : 0;
+    // --- size pass
+    size_t need = 0;
+    auto want = [&](size_t floats) { need += xv_align(floats * sizeof(float), 256); };
+    want(rows[0] * e->c_pad0);
+    for (int i = 0; i < 7; ++i) {
+        Affine& a = e->L[i];
+        size_t r = i < 5 ? rows[i + 1] : B;
+        want((size_t)a.c_out * a.k * a.c_pad);                 // wt
+        if (a.k > 1) want((size_t)a.c_in * a.k * a.c_out);     // wf
+        want(r * a.c_out); want(r * a.c_out);                  // z, a
+        want(2 * (size_t)xv_cdiv(r, XV_TILE_M) * a.c_out);     // bn_part
+        for (int j = 0; j < 4; ++j) want(a.c_out);
+    }
+    want(B * 2 * e->P); want(B * e->Lout); want(B * e->Lout);
+    if (e->N > 0) {
+        want(B * e->ldl); want(B * e->ldl); want(B); want(B);
+        want(e->N); want((size_t)e->Lout * e->ldl); want((size_t)e->N * e->Lout); want((size_t)e->Lout * e->ldl);
+    }
+    size_t maxc = e->P > 512 ? e->P : 512;
+    size_t bufd = rows[1] * 512;
+    if (rows[5] * maxc > bufd) bufd = rows[5] * maxc;
+    size_t bufz = B * (T - 8 + 8) * 512;                        // tdnn2: (T2 + 2*4) frames
+    if (B * (T - 14 + 12) * 512 > bufz) bufz = B * (T - 14 + 12) * 512;
+    if (rows[5] * maxc > bufz) bufz = rows[5] * maxc;
+    if (rows[1] * 512 > bufz) bufz = rows[1] * 512;
+    want(bufd); want(bufz);
+    want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512)); want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512));
+    want(16);
+    // GEMM split slabs: weight-gradient partials dominate
+    size_t ws = 0;
+    for (int i = 0; i < 7; ++i) {
+        Affine& a = e->L[i];
+        size_t r = i < 5 ? rows[i + 1] : B;
+        int M = a.k * a.c_pad, Nn = a.c_out;
+        size_t s = (size_t)xv_tn_splits(M, Nn, (int)r) * M * Nn * sizeof(float);
+        if (s > ws) ws = s;
+    }
+    if (e->N > 0) {
+        size_t s = (size_t)xv_tn_splits(e->Lout, e->ldl, (int)B) * e->Lout * e->ldl * sizeof(float);
+        if (s > ws) ws = s;
+        s = (size_t)16 * B * e->ldl * sizeof(float);
+        if (s > ws) ws = s;
+    }
+    size_t opws = xv_op_workspace_bytes((int)rows[1], 2 * e->P, 2 * e->P);
+    if (opws > ws) ws = opws;
+    ws = xv_align(ws, 256);
+    need += ws + 4096;
+    XV_CHECK_HIP(hipMalloc((void**)&e->arena, need));
+    XV_CHECK_HIP(hipMemset(e->arena, 0, need));
+    e->arena_bytes = need;
+    e->arena_used = 0;
+    // --- carve pass
+    e->xpad = carve(e, rows[0] * e->c_pad0);
+    for (int i = 0; i < 7; ++i) {
+        Affine& a = e->L[i];
+        size_t r = i < 5 ? rows[i + 1] : B;
+        a.wt = carve(e, (size_t)a.c_out * a.k * a.c_pad);
+        a.wf = a.k > 1 ? carve(e, (size_t)a.c_in * a.k * a.c_out) : nullptr;
+        a.z = carve(e, r * a.c_out);
+        a.a = carve(e, r * a.c_out);
+        a.bn_part = carve(e, 2 * (size_t)xv_cdiv(r, XV_TILE_M) * a.c_out);
+        a.mean = carve(e, a.c_out); a.invstd = carve(e, a.c_out);
+        a.scale = carve(e, a.c_out); a.shift = carve(e, a.c_out);
+        a.rows = 0;
+    }
+    e->pool = carve(e, B * 2 * e->P);
+    e->h7 = carve(e, B * e->Lout);
+    e->out = carve(e, B * e->Lout);
+    if (e->N > 0) {
+        e->logits = carve(e, B * e->ldl); e->dlogits = carve(e, B * e->ldl);
+        e->dnorm = carve(e, B); e->row_loss = carve(e, B);
+        e->inv_norm = carve(e, e->N);
+        e->wn = carve(e, (size_t)e->Lout * e->ldl);
+        e->wnt = carve(e, (size_t)e->N * e->Lout);
+        e->dwn = carve(e, (size_t)e->Lout * e->ldl);
+    }
+    e->bufD = carve(e, bufd);
+    e->bufZ = carve(e, bufz);
+    size_t small = B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512);
+    e->d_small0 = carve(e, small);
+    e->d_small1 = carve(e, small);
+    e->scalars = carve(e, 16);
+    e->ws = carve(e, ws / sizeof(float));
+    e->ws_bytes = ws;
+    XV_REQUIRE(e->ws != nullptr && e->scalars != nullptr, "engine: internal arena accounting error");
+    return 0;
+}
+
+int ensure_weights(xv_engine* e, hipStream_t s) {
+    if (!e->weights_dirty) return 0;
+    for (int i = 0; i < 7; ++i) {
+        Affine& a = e->L[i];
+        int rc = xv_prep_weight_fwd(s, vptr(e, a.v_kernel), a.k, a.c_in, a.c_out, a.wt, a.c_pad);
+        if (rc) return rc;
+        if (a.k > 1 && i > 0) {
+            rc = xv_prep_weight_dgrad(s, vptr(e, a.v_kernel), a.k, a.c_in, a.c_out, a.wf);
+            if (rc) return rc;
+        }
+    }
+    if (e->N > 0) {
+        int rc = xv_loss_prep_weight(s, vptr(e, e->v_loss_kernel), e->Lout, e->N, e->cfg.loss_kind != XV_LOSS_SOFTMAX, e->inv_norm,
+                                     e->wn, e->ldl, e->wnt);
+        if (rc) return rc;
+    }
+    e->weights_dirty = false;
+    return 0;
+}
+
+// BN (+ReLU) forward of one layer given z
+int bn_forward(xv_engine* e, hipStream_t s, Affine& a, int rows, bool stats_from_gemm, float* dst_a) {
+    const xv_config& c = e->cfg;
+    int rc;
+    if (e->training) {
+        if (!stats_from_gemm) {
+            rc = xv_col_stats(s, a.z, rows, a.c_out, a.c_out, a.bn_part);
+            if (rc) return rc;
+        }
+        rc = xv_bn_finalize(s, a.bn_part, rows, a.c_out, vptr(e, a.v_gamma), vptr(e, a.v_beta), c.bn_epsilon, c.batchnorm_momentum,
+                            a.fused_bn && c.fused_bn_unbiased_moving_var, vptr(e, a.v_mmean), vptr(e, a.v_mvar), a.mean, a.invstd,
+                            a.scale, a.shift);
+    } else {
+        rc = xv_bn_inference_scale(s, a.c_out, vptr(e, a.v_gamma), vptr(e, a.v_beta), vptr(e, a.v_mmean), vptr(e, a.v_mvar),
+                                   c.bn_epsilon, a.scale, a.shift);
+    }
+    if (rc) return rc;
+    return xv_bn_apply(s, a.z, rows, a.c_out, a.c_out, a.scale, a.shift, a.has_relu ? 1 : 0, dst_a, a.c_out);
+}
+
+}  // namespace
+
+extern "C" int xv_engine_create(const xv_config* cfg, xv_engine** out) {
+    XV_REQUIRE(cfg && out, "engine_create: null argument");
+    XV_REQUIRE(cfg->feat_dim > 0, "engine_create: feat_dim must be positive");
+    XV_REQUIRE(cfg->num_nodes_pooling_layer > 0 && cfg->num_nodes_pooling_layer % 4 == 0,
+               "engine_create: num_nodes_pooling_layer must be a positive multiple of 4 (got %d)", cfg->num_nodes_pooling_layer);
+    XV_REQUIRE(cfg->num_nodes_last_layer > 0 && cfg->num_nodes_last_layer % 4 == 0,
+               "engine_create: num_nodes_last_layer must be a positive multiple of 4 (got %d)", cfg->num_nodes_last_layer);
+    XV_REQUIRE(cfg->loss_kind >= XV_LOSS_SOFTMAX && cfg->loss_kind <= XV_LOSS_ARCSOFTMAX, "Not implement loss kind %d", cfg->loss_kind);
+    XV_REQUIRE(cfg->optimizer >= 0 && cfg->optimizer <= 2, "Optimizer %d is not supported.", cfg->optimizer);
+    if (cfg->loss_kind == XV_LOSS_ASOFTMAX && cfg->num_speakers > 0)
+        XV_REQUIRE(cfg->margin_m == 1.f || cfg->margin_m == 2.f || cfg->margin_m == 4.f, "[ERROR] m=%d is not unsupported.", (int)cfg->margin_m);
+    XV_REQUIRE(!cfg->feature_norm || cfg->feature_scaling_factor > 0.f, "If feature normalization is applied, scaling factor is necessary.");
+    xv_engine* e = new xv_engine();
+    e->cfg = *cfg;
+    build_variables(e);
+    int rc = alloc_buffers(e);
+    if (rc) { xv_engine_destroy(e); return rc; }
+    *out = e;
+    return 0;
+}
+
+extern "C" void xv_engine_destroy(xv_engine* e) {
+    if (!e) return;
+    if (e->arena) (void)hipFree(e->arena);
+    delete e;
+}
+
+extern "C" int xv_engine_num_variables(const xv_engine* e) { return e ? (int)e->vars.size() : 0; }
+
+extern "C" int xv_engine_variable_info(const xv_engine* e, int index, const char** name, int32_t shape[4], int32_t* rank, size_t* offset,
+                                       int32_t* trainable) {
+    XV_REQUIRE(e && index >= 0 && index < (int)e->vars.size(), "variable_info: index out of range");
+    const Var& v = e->vars[index];
+    if (name) *name = v.name.c_str();
+    if (shape) for (int i = 0; i < 4; ++i) shape[i] = v.shape[i];
+    if (rank) *rank = v.rank;
+    if (offset) *offset = v.offset;
+    if (trainable) *trainable = v.trainable ? 1 : 0;
+    return 0;
+}
+
+extern "C" size_t xv_engine_variables_count(const xv_engine* e) { return e ? e->n_all : 0; }
+extern "C" size_t xv_engine_trainable_count(const xv_engine* e) { return e ? e->n_train : 0; }
+extern "C" size_t xv_engine_optimizer_state_count(const xv_engine* e) { return e ? e->n_opt : 0; }
+
+extern "C" int xv_engine_bind(xv_engine* e, float* variables, float* grads, float* opt_state) {
+    XV_REQUIRE(e && variables, "engine_bind: variables buffer required");
+    XV_REQUIRE(((uintptr_t)variables % 16) == 0 && ((uintptr_t)grads % 16) == 0, "engine_bind: buffers must be 16-byte aligned");
+    e->V = variables; e->G = grads; e->S = opt_state;
+    e->weights_dirty = true;
+    return 0;
+}
+
+extern "C" int xv_engine_invalidate_weights(xv_engine* e) {
+    XV_REQUIRE(e, "null engine");
+    e->weights_dirty = true;
+    return 0;
+}
+
+extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* features, int b, int t, int training) {
+    XV_REQUIRE(e && e->V, "engine_forward: engine not bound");
+    XV_REQUIRE(b >= 1 && b <= e->cfg.max_batch, "engine_forward: batch %d exceeds capacity %d", b, e->cfg.max_batch);
+    XV_REQUIRE(t >= 15 && t <= e->cfg.max_frames, "engine_forward: %d frames outside [15, %d]", t, e->cfg.max_frames);
+    hipStream_t s = (hipStream_t)stream;
+    e->last_stream = s;
+    e->B = b; e->T = t; e->training = training;
+    int rc = ensure_weights(e, s);
+    if (rc) return rc;
+    rc = xv_pad_channels(s, features, b * t, e->cfg.feat_dim, e->xpad, e->c_pad0);
+    if (rc) return rc;
+    const float* cur = e->xpad;
+    int cur_t = t;
+    e->Tl[0] = t;
+    for (int i = 0; i < 5; ++i) {
+        Affine& a = e->L[i];
+        int t_out = cur_t - a.k + 1;
+        int rows = b * t_out;
+        rc = xv_affine_forward(s, cur, b, cur_t, a.c_pad, a.k, a.wt, vptr(e, a.v_bias), a.z, a.c_out, a.c_out,
+                               training ? a.bn_part : nullptr, e->ws, e->ws_bytes);
+        if (rc) return rc;
+        rc = bn_forward(e, s, a, rows, true, a.a);
+        if (rc) return rc;
+        a.rows = rows;
+        cur = a.a; cur_t = t_out;
+        e->Tl[i + 1] = t_out;
+    }
+    rc = xv_stat_pool_forward(s, e->L[4].a, b, cur_t, e->P, e->pool);
+    if (rc) return rc;
+    // segment-level layers
+    Affine& l6 = e->L[5];
+    rc = xv_affine_forward(s, e->pool, b, 1, l6.c_pad, 1, l6.wt, vptr(e, l6.v_bias), l6.z, l6.c_out, l6.c_out, nullptr, e->ws, e->ws_bytes);
+    if (rc) return rc;
+    rc = bn_forward(e, s, l6, b, false, l6.a);
+    if (rc) return rc;
+    l6.rows = b;
+    Affine& l7 = e->L[6];
+    rc = xv_affine_forward(s, l6.a, b, 1, l7.c_pad, 1, l7.wt, vptr(e, l7.v_bias), l7.z, l7.c_out, l7.c_out, nullptr, e->ws, e->ws_bytes);
+    if (rc) return rc;
+    l7.rows = b;
+    const size_t bytes7 = (size_t)b * l7.c_out * sizeof(float);
+    if (l7.has_bn) {
+        rc = bn_forward(e, s, l7, b, false, e->h7);
+        if (rc) return rc;
+    } else if (l7.has_relu) {
+        // relu(z) = bn_apply with scale 1 / shift 0 is overkill; reuse l2-free path: copy then clamp
+        XV_CHECK_HIP(hipMemcpyAsync(e->h7, l7.z, bytes7, hipMemcpyDeviceToDevice, s));
+        rc = xv_relu_backward(s, e->h7, e->h7, (size_t)b * l7.c_out, e->h7);   // x>0 ? x : 0
+        if (rc) return rc;
+    } else {
+        XV_CHECK_HIP(hipMemcpyAsync(e->h7, l7.z, bytes7, hipMemcpyDeviceToDevice, s));
+    }
+    if (e->cfg.feature_norm) {
+        rc = xv_l2_scaling_forward(s, e->h7, b, l7.c_out, e->cfg.feature_scaling_factor, e->out);
+        if (rc) return rc;
+    } else {
+        XV_CHECK_HIP(hipMemcpyAsync(e->out, e->h7, bytes7, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+extern "C" int xv_engine_loss_forward(xv_engine* e, void* stream, const int32_t* labels, int global_step, int with_margin) {
+    XV_REQUIRE(e && e->V && e->N > 0, "engine_loss_forward: engine has no loss head");
+    XV_REQUIRE(e->B > 0, "engine_loss_forward: run forward first");
+    hipStream_t s = (hipStream_t)stream;
+    const xv_config& c = e->cfg;
+    const int b = e->B;
+    e->labels_dev = (int32_t*)labels;
+    e->with_margin = with_margin;
+    int rc = ensure_weights(e, s);
+    if (rc) return rc;
+    XvGemmNT g = {};
+    g.A = e->out; g.lda = e->Lout; g.a_rps = 1; g.a_pitch = 1;
+    g.Bt = e->wnt; g.ldb = e->Lout;
+    g.C = e->logits; g.ldc = e->ldl;
+    g.M = b; g.N = e->N; g.K = e->Lout;
+    g.bias = e->v_loss_bias >= 0 ? vptr(e, e->v_loss_bias) : nullptr;
+    g.ws = e->ws; g.ws_bytes = e->ws_bytes;
+    rc = xv_launch_gemm_nt(s, g);
+    if (rc) return rc;
+    // lambda schedule, loss.py:144-145 (host side: global_step is a fed placeholder, trainer.py:507)
+    double lam = (double)c.lambda_base * pow(1.0 + (double)c.lambda_gamma * (double)global_step, -(double)c.lambda_power);
+    if (lam < (double)c.lambda_min) lam = (double)c.lambda_min;
+    e->lambda = (float)lam;
+    int kind = c.loss_kind;
+    float m = c.margin_m;
+    if (!with_margin && kind != XV_LOSS_SOFTMAX) { kind = XV_LOSS_ASOFTMAX; m = 1.0f; }   // trainer.py:261-271
+    rc = xv_margin_softmax_rows(s, kind, e->logits, b, e->N, e->ldl, e->out, e->Lout, labels, m, e->lambda, e->dlogits, e->dnorm,
+                                e->row_loss, e->scalars + 0);
+    if (rc) return rc;
+    // regularization_loss, trainer.py:357-358
+    XV_CHECK_HIP(hipMemsetAsync(e->scalars + 1, 0, sizeof(float), s));
+    for (int i = 0; i < 7; ++i) {
+        rc = xv_l2_reg_loss(s, vptr(e, e->L[i].v_kernel), e->vars[e->L[i].v_kernel].count, c.weight_l2_regularizer, e->scalars + 1);
+        if (rc) return rc;
+    }
+    float ol2 = c.output_weight_l2_regularizer >= 0.f ? c.output_weight_l2_regularizer : c.weight_l2_regularizer;
+    return xv_l2_reg_loss(s, vptr(e, e->v_loss_kernel), e->vars[e->v_loss_kernel].count, ol2, e->scalars + 1);
+}
+
+namespace {
+
+// backward of one affine(+BN+ReLU) layer.  da: gradient w.r.t. the layer OUTPUT (after BN/ReLU),
+// dense [segs*t_out][c_out].  x/t_in: the layer input view.  Writes parameter gradients and, if
+// dx != nullptr, the gradient w.r.t. the layer input ([segs*t_in][c_in]).
+int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, const float* x, int segs, int t_in, float* dx,
+                   const float* act_out) {
+    const xv_config& c = e->cfg;
+    const int t_out = t_in - a.k + 1;
+    const int pad = (dx && a.k > 1) ? a.k - 1 : 0;
+    int rc;
+    const float* dz = nullptr;
+    if (a.has_bn) {
+        rc = xv_bn_relu_backward(s, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift,
+                                 a.has_relu ? 1 : 0, pad, e->bufZ, gptr(e, a.v_gamma), gptr(e, a.v_beta), e->ws, e->ws_bytes);
+        if (rc) return rc;
+        dz = e->bufZ;
+    } else if (a.has_relu) {
+        rc = xv_relu_backward(s, da, act_out, (size_t)segs * t_out * a.c_out, e->bufZ);
+        if (rc) return rc;
+        dz = e->bufZ;
+    } else {
+        dz = da;
+    }
+    const int seg_pitch = t_out + 2 * pad;
+    rc = xv_affine_wgrad(s, x, segs, t_in, a.c_pad, a.k, a.c_in, dz, seg_pitch, pad, a.c_out, vptr(e, a.v_kernel),
+                         c.weight_l2_regularizer, gptr(e, a.v_kernel), e->ws, e->ws_bytes);
+    if (rc) return rc;
+    rc = xv_colsum(s, dz, segs * seg_pitch, a.c_out, a.c_out, gptr(e, a.v_bias), e->ws, e->ws_bytes);
+    if (rc) return rc;
+    if (dx) {
+        const float* wf = a.k > 1 ? a.wf : vptr(e, a.v_kernel);
+        rc = xv_affine_dgrad(s, dz, segs, t_out, a.c_out, a.k, wf, dx, a.c_in, e->ws, e->ws_bytes);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
+    XV_REQUIRE(e && e->V && e->G, "engine_backward: gradient buffer not bound");
+    XV_REQUIRE(e->training && e->labels_dev, "engine_backward: needs a training forward + loss_forward first");
+    XV_REQUIRE(stage >= -1 && stage < XV_BWD_STAGES, "engine_backward: bad stage %d", stage);
+    hipStream_t s = (hipStream_t)stream;
+    const xv_config& c = e->cfg;
+    const int b = e->B;
+    int rc;
+    if (stage == -1 || stage == 0) {
+        // d out = dlogits . wn^T   (pad column of both is zero, so K = ldl is exact)
+        XvGemmNT g = {};
+        g.A = e->dlogits; g.lda = e->ldl; g.a_rps = 1; g.a_pitch = 1;
+        g.Bt = e->wn; g.ldb = e->ldl;
+        g.C = e->d_small0; g.ldc = e->Lout;
+        g.M = b; g.N = e->Lout; g.K = e->ldl;
+        g.ws = e->ws; g.ws_bytes = e->ws_bytes;
+        rc = xv_launch_gemm_nt(s, g);
+        if (rc) return rc;
+        rc = xv_add_norm_grad(s, e->out, e->dnorm, b, e->Lout, e->d_small0);
+        if (rc) return rc;
+        // d wn = out^T . dlogits
+        XvGemmTN w = {};
+        w.A = e->out; w.lda = e->Lout; w.a_rps = b; w.a_pitch = b;
+        w.B = e->dlogits; w.ldb = e->ldl; w.b_rps = b; w.b_pitch = b;
+        w.M = e->Lout; w.N = e->ldl; w.R = b;
+        w.splits = xv_tn_splits(w.M, w.N, w.R);
+        XV_REQUIRE((size_t)w.splits * w.M * w.N * sizeof(float) <= e->ws_bytes, "engine_backward: workspace too small for the loss weight gradient");
+        w.P = (float*)e->ws;
+        rc = xv_launch_gemm_tn(s, w);
+        if (rc) return rc;
+        rc = xv_launch_wgrad_reduce(s, w.P, w.splits, 1, e->Lout, e->Lout, e->ldl, e->ldl, nullptr, 0, 0.f, e->dwn, e->ldl);
+        if (rc) return rc;
+        float ol2 = c.output_weight_l2_regularizer >= 0.f ? c.output_weight_l2_regularizer : c.weight_l2_regularizer;
+        rc = xv_loss_weight_backward(s, e->dwn, e->ldl, e->wn, e->ldl, e->inv_norm, vptr(e, e->v_loss_kernel), e->Lout, e->N,
+                                     c.loss_kind != XV_LOSS_SOFTMAX, ol2, gptr(e, e->v_loss_kernel), e->ws, e->ws_bytes);
+        if (rc) return rc;
+        if (e->v_loss_bias >= 0) {
+            rc = xv_colsum(s, e->dlogits, b, e->N, e->ldl, gptr(e, e->v_loss_bias), e->ws, e->ws_bytes);
+            if (rc) return rc;
+        }
+        const float* d = e->d_small0;
+        if (c.feature_norm) {
+            rc = xv_l2_scaling_backward(s, e->h7, d, b, e->Lout, c.feature_scaling_factor, e->d_small1);
+            if (rc) return rc;
+            d = e->d_small1;
+        }
+        // tdnn7 -> d a6 (into bufD), tdnn6 -> d pool (into d_small0), pooling -> d a5 (into bufD)
+        rc = layer_backward(e, s, e->L[6], d, e->L[5].a, b, 1, e->bufD, e->h7);
+        if (rc) return rc;
+        rc = layer_backward(e, s, e->L[5], e->bufD, e->pool, b, 1, e->d_small0, nullptr);
+        if (rc) return rc;
+        rc = xv_stat_pool_backward(s, e->L[4].a, e->pool, e->d_small0, b, e->Tl[5], e->P, e->bufD);
+        if (rc) return rc;
+    }
+    if (stage == -1 || stage == 1) {
+        rc = layer_backward(e, s, e->L[4], e->bufD, e->L[3].a, b * e->Tl[5], 1, e->bufD, nullptr);   // tdnn5: da4 overwrites da5
+        if (rc) return rc;
+        rc = layer_backward(e, s, e->L[3], e->bufD, e->L[2].a, b * e->Tl[4], 1, e->bufD, nullptr);   // tdnn4
+        if (rc) return rc;
+    }
+    if (stage == -1 || stage == 2) {
+        rc = layer_backward(e, s, e->L[2], e->bufD, e->L[1].a, b, e->Tl[2], e->bufD, nullptr);        // tdnn3 -> d a2
+        if (rc) return rc;
+    }
+    if (stage == -1 || stage == 3) {
+        rc = layer_backward(e, s, e->L[1], e->bufD, e->L[0].a, b, e->Tl[1], e->bufD, nullptr);        // tdnn2 -> d a1
+        if (rc) return rc;
+        rc = layer_backward(e, s, e->L[0], e->bufD, e->xpad, b, e->Tl[0], nullptr, nullptr);           // tdnn1
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int xv_engine_stage_grad_range(const xv_engine* e, int stage, size_t* begin, size_t* end) {
+    XV_REQUIRE(e && stage >= 0 && stage < XV_BWD_STAGES && begin && end, "stage_grad_range: bad arguments");
+    *begin = e->stage_begin[stage];
+    *end = e->stage_end[stage];
+    return 0;
+}
+
+__global__ void clip_scale_kernel(float* __restrict__ g, size_t count, const float* __restrict__ sumsq, float grad_scale, float clip) {
+    // tf.clip_by_global_norm: g * clip / max(norm, clip)
+    float norm = sqrtf(*sumsq) * grad_scale;
+    float k = grad_scale * (clip / fmaxf(norm, clip));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) g[i] *= k;
+}
+
+extern "C" int xv_engine_apply(xv_engine* e, void* stream, float lr, float grad_scale, int t) {
+    XV_REQUIRE(e && e->V && e->G, "engine_apply: buffers not bound");
+    XV_REQUIRE(e->cfg.optimizer == 0 || e->S, "engine_apply: optimiser state buffer not bound");
+    hipStream_t s = (hipStream_t)stream;
+    const xv_config& c = e->cfg;
+    if (c.clip_gradient_norm > 0.f) {
+        XV_CHECK_HIP(hipMemsetAsync(e->scalars + 2, 0, sizeof(float), s));
+        int rc = xv_sumsq(s, e->G, e->n_train, e->scalars + 2);
+        if (rc) return rc;
+        hipLaunchKernelGGL(clip_scale_kernel, dim3(2048), dim3(256), 0, s, e->G, e->n_train, (const float*)(e->scalars + 2), grad_scale,
+                           c.clip_gradient_norm);
+        XV_LAUNCH_CHECK();
+        grad_scale = 1.0f;
+    }
+    int rc;
+    if (c.optimizer == 0) rc = xv_sgd_update(s, e->V, e->G, e->n_train, lr, grad_scale);
+    else if (c.optimizer == 1) rc = xv_momentum_update(s, e->V, e->G, e->S, e->n_train, lr, c.momentum, c.use_nesterov, grad_scale);
+    else rc = xv_adam_update(s, e->V, e->G, e->S, e->S + e->n_train, e->n_train, lr, 0.9f, 0.999f, 1e-8f, t, grad_scale);
+    e->weights_dirty = true;
+    return rc;
+}
+
+extern "C" int xv_engine_loss_ptrs(xv_engine* e, float** raw_loss, float** reg_loss) {
+    XV_REQUIRE(e, "null engine");
+    if (raw_loss) *raw_loss = e->scalars + 0;
+    if (reg_loss) *reg_loss = e->scalars + 1;
+    return 0;
+}
+
+extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, int32_t* rows, int32_t* cols, int32_t* ld) {
+    XV_REQUIRE(e && name && ptr && rows && cols && ld, "engine_endpoint: null argument");
+    XV_REQUIRE(e->B > 0, "engine_endpoint: run forward first");
+    std::string n(name);
+    auto set = [&](float* p, int r, int c, int l) { *ptr = p; *rows = r; *cols = c; *ld = l; return 0; };
+    for (int i = 0; i < 7; ++i) {
+        Affine& a = e->L[i];
+        if (n == a.prefix + "_" + a.kind) return set(a.z, a.rows, a.c_out, a.c_out);
+        if (n == a.prefix + "_relu" && a.has_relu) return set(i == 6 ? e->h7 : a.a, a.rows, a.c_out, a.c_out);
+        if (n == a.prefix + "_bn" && a.has_bn) {
+            if (!a.has_relu) return set(i == 6 ? e->h7 : a.a, a.rows, a.c_out, a.c_out);
+            // BN output is never materialised on the hot path (fused with ReLU): rebuild on demand
+            int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 0, e->bufZ, a.c_out);
+            if (rc) return rc;
+            return set(e->bufZ, a.rows, a.c_out, a.c_out);
+        }
+    }
+    if (n == "pooling") return set(e->pool, e->B, 2 * e->P, 2 * e->P);
+    if (n == "output") return set(e->out, e->B, e->Lout, e->Lout);
+    if (n == "logits" && e->N > 0) return set(e->logits, e->B, e->N, e->ldl);
+    xv_set_error("engine_endpoint: unknown endpoint '%s'", name);
+    return 3;
+}

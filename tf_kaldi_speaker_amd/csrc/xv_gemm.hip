@@ -1,0 +1,504 @@
+// fp32 MFMA GEMM kernels for the TDNN hot path (gfx950 / CDNA4 only).
+//
+// Two shapes cover every contraction of tdnn.py / loss.py:
+//
+//  NT  C[m][n] = sum_k A[rowmap(m)][k] * Bt[n][k]
+//      forward conv/dense (A = spliced activation view, Bt = kernel^T), data gradients
+//      (A = zero-padded dz view, Bt = tap-flipped kernel), logits.
+//  TN  P[m][n] = sum_r A[amap(r)][m] * B[bmap(r)][n]
+//      weight gradients (reduction over the ~25k (chunk,frame) rows), split over r.
+//
+// The "spliced view" makes the context window free: row (b,t) of a layer with context k is
+// the contiguous span x[b][t..t+k-1][:], so rowmap(m) = (m / rps) * pitch + (m % rps) with
+// leading dimension C < K.  Rows overlap in memory; the 128-row A tile of one workgroup
+// therefore re-reads the same (128+k-1) x C window k times from L2, never from HBM.
+//
+// Both kernels: 128x128 output tile, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile
+// as 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 acc VGPRs), K-step 32, register-staged
+// double-buffered LDS, one barrier per K-step, 2 workgroups per CU.
+//
+// MFMA operand maps (cdna_hip_programming.md section 3): lane l supplies A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]; D register r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), column l&31.
+// The contraction is order-insensitive in k as long as A and B agree, so the NT kernel lets
+// lane-half h own 4 CONSECUTIVE k of every 8 (one ds_read_b128 feeds 4 MFMAs).
+#include "xv_common.h"
+
+#define BM XV_TILE_M
+#define BN XV_TILE_N
+#define BK XV_TILE_K
+#define NT_PITCH 36   // floats; 36/4 = 9 is odd => ds_read_b128 of 16 distinct rows hits 16 distinct 16-B slots
+
+struct NTArgs {
+    const float* A; long lda; int a_rps; int a_pitch;
+    const float* Bt; long ldb;
+    float* C; long ldc; long c_split_stride;
+    int M, N, K, k_chunk;
+    int tiles_m, tiles_n;
+    const float* bias;
+    float* part_sum; float* part_m2;
+};
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+    // blocks b and b+8 share an XCD (round-robin dispatch): hand each XCD a contiguous run of
+    // tiles so the n-tiles of one m-tile (same A rows) and neighbouring m-tiles (overlapping
+    // context windows) hit the same L2.  Bijective for any nwg.
+    int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void xv_gemm_nt_kernel(NTArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * NT_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int t = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int k_begin = blockIdx.z * p.k_chunk;
+    const int k_end = min(p.K, k_begin + p.k_chunk);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+
+    // ---- global -> register staging: thread owns rows lrow+32i, 4 consecutive k at lk
+    const int lrow = tid >> 3, lk = (tid & 7) * 4;
+    const float* ap[4];
+    const float* bp[4];
+    bool av[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + lrow + 32 * i;
+        av[i] = m < p.M;
+        int mm = av[i] ? m : 0;
+        int seg = mm / p.a_rps, tt = mm - seg * p.a_rps;
+        ap[i] = p.A + ((long)seg * p.a_pitch + tt) * p.lda;
+        int n = n0 + lrow + 32 * i;
+        bv[i] = n < p.N;
+        bp[i] = p.Bt + (long)(bv[i] ? n : 0) * p.ldb;
+    }
+    f32x4 ra[4], rb[4];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int kt) {
+        int k = k_begin + kt * BK + lk;
+        bool kv = k < k_end;
+        int kc = kv ? k : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 va = *(const f32x4*)(ap[i] + kc);
+            f32x4 vb = *(const f32x4*)(bp[i] + kc);
+            ra[i] = (kv && av[i]) ? va : zero4;
+            rb[i] = (kv && bv[i]) ? vb : zero4;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* sa = smem + buf * (2 * BM * NT_PITCH);
+        float* sb = sa + BM * NT_PITCH;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(f32x4*)(sa + (lrow + 32 * i) * NT_PITCH + lk) = ra[i];
+            *(f32x4*)(sb + (lrow + 32 * i) * NT_PITCH + lk) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (nk > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+
+    const int a_off = (wr * 64 + li) * NT_PITCH + 4 * lh;
+    const int b_off = (wc * 64 + li) * NT_PITCH + 4 * lh;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* sa = smem + buf * (2 * BM * NT_PITCH);
+        const float* sb = sa + BM * NT_PITCH;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            f32x4 af[2], bf[2];
+            af[0] = *(const f32x4*)(sa + a_off + 8 * q);
+            af[1] = *(const f32x4*)(sa + a_off + 32 * NT_PITCH + 8 * q);
+            bf[0] = *(const f32x4*)(sb + b_off + 8 * q);
+            bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[0][e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[1][e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[0][e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[1][e], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    float* C = p.C + (long)blockIdx.z * p.c_split_stride;
+    float bias_v[2] = {0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            int n = n0 + wc * 64 + b * 32 + li;
+            bias_v[b] = n < p.N ? p.bias[n] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            int n = n0 + wc * 64 + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[a][b][r] + bias_v[b];
+                acc[a][b][r] = v;
+                if (m < p.M && n < p.N) C[(long)m * p.ldc + n] = v;
+            }
+        }
+
+    if (STATS) {
+        // Per-tile column statistics for BatchNorm: sum and sum of squares centred on the TILE
+        // mean (Chan-combinable, no E[x^2]-E[x]^2 cancellation).  Deterministic, no atomics.
+        float* red = smem;             // [2][128] sums per wave-row
+        float* red2 = smem + 256;      // [2][128] centred squares
+        const int cnt = min(BM, p.M - m0);
+        float s[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float v = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    v += (m < p.M) ? acc[a][b][r] : 0.f;
+                }
+            v += __shfl_xor(v, 32);
+            s[b] = v;
+            if (lh == 0) red[wr * 128 + wc * 64 + b * 32 + li] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            int col = wc * 64 + b * 32 + li;
+            float mean = (red[col] + red[128 + col]) / (float)cnt;
+            float v = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float d = acc[a][b][r] - mean;
+                    v += (m < p.M) ? d * d : 0.f;
+                }
+            v += __shfl_xor(v, 32);
+            if (lh == 0) red2[wr * 128 + col] = v;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            int n = n0 + tid;
+            if (n < p.N) {
+                p.part_sum[(long)tile_m * p.N + n] = red[tid] + red[128 + tid];
+                p.part_m2[(long)tile_m * p.N + n] = red2[tid] + red2[128 + tid];
+            }
+        }
+    }
+}
+
+// out[m][n] = sum_z slab[z][m][n] (+ bias[n])
+__global__ void xv_splitk_reduce_kernel(const float* __restrict__ slab, int splits, long split_stride, int M, int N,
+                                        int lds, const float* __restrict__ bias, float* __restrict__ out, long ldo) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)M * N;
+    for (; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int m = (int)(idx / N), n = (int)(idx - (long)m * N);
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += slab[z * split_stride + (long)m * lds + n];
+        if (bias) v += bias[n];
+        out[(long)m * ldo + n] = v;
+    }
+}
+
+int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
+    XV_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm_nt: K/lda/ldb must be multiples of 4 (K=%d lda=%ld ldb=%ld)", g.K, g.lda, g.ldb);
+    XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0, "gemm_nt: operands must be 16-byte aligned");
+    XV_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.a_rps > 0, "gemm_nt: empty problem");
+    NTArgs p;
+    p.A = g.A; p.lda = g.lda; p.a_rps = g.a_rps; p.a_pitch = g.a_pitch;
+    p.Bt = g.Bt; p.ldb = g.ldb;
+    p.M = g.M; p.N = g.N; p.K = g.K;
+    p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
+    p.bias = g.bias; p.part_sum = nullptr; p.part_m2 = nullptr;
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int ksteps = xv_cdiv(g.K, BK);
+    int splits = 1;
+    if (!g.bn_part && tiles < 192 && ksteps >= 8) {
+        splits = xv_cdiv(512, tiles);
+        if (splits > ksteps / 4) splits = ksteps / 4;
+        if (splits < 1) splits = 1;
+        const long np = (long)xv_align(g.N, 4);
+        while (splits > 1 && (size_t)splits * g.M * np * sizeof(float) > g.ws_bytes) --splits;
+    }
+    if (splits == 1) {
+        p.C = g.C; p.ldc = g.ldc; p.c_split_stride = 0; p.k_chunk = ksteps * BK;
+        dim3 grid(tiles, 1, 1);
+        if (g.bn_part) {
+            p.part_sum = g.bn_part;
+            p.part_m2 = g.bn_part + (long)p.tiles_m * g.N;
+            hipLaunchKernelGGL(xv_gemm_nt_kernel<true>, grid, dim3(256), 0, s, p);
+        } else {
+            hipLaunchKernelGGL(xv_gemm_nt_kernel<false>, grid, dim3(256), 0, s, p);
+        }
+        XV_LAUNCH_CHECK();
+        return 0;
+    }
+    XV_REQUIRE(!g.bn_part, "gemm_nt: bn statistics are not available on the split path");
+    const long np = (long)xv_align(g.N, 4);
+    XV_REQUIRE((size_t)splits * g.M * np * sizeof(float) <= g.ws_bytes, "gemm_nt: workspace too small (%zu bytes)", g.ws_bytes);
+    p.C = (float*)g.ws; p.ldc = np; p.c_split_stride = (long)g.M * np;
+    p.k_chunk = xv_cdiv(ksteps, splits) * BK;
+    splits = xv_cdiv(g.K, p.k_chunk);
+    p.bias = nullptr;
+    dim3 grid(tiles, 1, splits);
+    hipLaunchKernelGGL(xv_gemm_nt_kernel<false>, grid, dim3(256), 0, s, p);
+    XV_LAUNCH_CHECK();
+    long total = (long)g.M * g.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(xv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)g.ws, splits,
+                       (long)g.M * np, g.M, g.N, (int)np, g.bias, g.C, g.ldc);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------
+// TN: weight gradients
+// -------------------------------------------------------------------------------------
+struct TNArgs {
+    const float* A; long lda; int a_rps; int a_pitch;
+    const float* B; long ldb; int b_rps; int b_pitch;
+    float* P;
+    int M, N, R, r_chunk;
+    int tiles_m, tiles_n;
+};
+
+__global__ __launch_bounds__(256, 2) void xv_gemm_tn_kernel(TNArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * BM];   // [buf][A|B][32][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int t = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int r_begin = blockIdx.z * p.r_chunk;
+    const int r_end = min(p.R, r_begin + p.r_chunk);
+    const int nk = (r_end - r_begin + BK - 1) / BK;
+
+    // thread owns reduction rows lr+8i of each K-step, 4 consecutive output columns at lc
+    const int lr = tid >> 5, lc = (tid & 31) * 4;
+    const bool a_cv = (m0 + lc) < p.M, b_cv = (n0 + lc) < p.N;
+    const int a_col = a_cv ? m0 + lc : 0, b_col = b_cv ? n0 + lc : 0;
+    // incremental row maps (no division in the loop)
+    int a_seg[4], a_t[4], b_seg[4], b_t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = r_begin + lr + 8 * i;
+        a_seg[i] = r / p.a_rps; a_t[i] = r - a_seg[i] * p.a_rps;
+        b_seg[i] = r / p.b_rps; b_t[i] = r - b_seg[i] * p.b_rps;
+    }
+    f32x4 ra[4], rb[4];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = r_begin + kt * BK + lr + 8 * i;
+            bool rv = r < r_end;
+            long arow = rv ? ((long)a_seg[i] * p.a_pitch + a_t[i]) : 0;
+            long brow = rv ? ((long)b_seg[i] * p.b_pitch + b_t[i]) : 0;
+            f32x4 va = *(const f32x4*)(p.A + arow * p.lda + a_col);
+            f32x4 vb = *(const f32x4*)(p.B + brow * p.ldb + b_col);
+            ra[i] = (rv && a_cv) ? va : zero4;
+            rb[i] = (rv && b_cv) ? vb : zero4;
+            a_t[i] += BK;
+            while (a_t[i] >= p.a_rps) { a_t[i] -= p.a_rps; ++a_seg[i]; }
+            b_t[i] += BK;
+            while (b_t[i] >= p.b_rps) { b_t[i] -= p.b_rps; ++b_seg[i]; }
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* sa = smem + buf * (2 * BK * BM);
+        float* sb = sa + BK * BM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(f32x4*)(sa + (lr + 8 * i) * BM + lc) = ra[i];
+            *(f32x4*)(sb + (lr + 8 * i) * BN + lc) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (nk > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    const int a_off = lh * BM + wr * 64 + li;
+    const int b_off = lh * BN + wc * 64 + li;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* sa = smem + buf * (2 * BK * BM);
+        const float* sb = sa + BK * BM;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            float a0 = sa[a_off + 2 * ks * BM], a1 = sa[a_off + 2 * ks * BM + 32];
+            float b0 = sb[b_off + 2 * ks * BN], b1 = sb[b_off + 2 * ks * BN + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* P = p.P + (long)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            int n = n0 + wc * 64 + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M && n < p.N) P[(long)m * p.N + n] = acc[a][b][r];
+            }
+        }
+}
+
+int xv_tn_splits(int M, int N, int R) {
+    int tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
+    int ksteps = xv_cdiv(R, BK);
+    int splits = xv_cdiv(512, tiles);
+    if (splits > ksteps / 2) splits = ksteps / 2;
+    if (splits < 1) splits = 1;
+    int chunk = xv_cdiv(ksteps, splits) * BK;
+    return xv_cdiv(R, chunk);
+}
+
+int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
+    XV_REQUIRE(g.M % 4 == 0 && g.N % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0,
+               "gemm_tn: M/N/lda/ldb must be multiples of 4 (M=%d N=%d lda=%ld ldb=%ld)", g.M, g.N, g.lda, g.ldb);
+    XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm_tn: operands must be 16-byte aligned");
+    XV_REQUIRE(g.M > 0 && g.N > 0 && g.R > 0 && g.splits >= 1, "gemm_tn: empty problem");
+    TNArgs p;
+    p.A = g.A; p.lda = g.lda; p.a_rps = g.a_rps; p.a_pitch = g.a_pitch;
+    p.B = g.B; p.ldb = g.ldb; p.b_rps = g.b_rps; p.b_pitch = g.b_pitch;
+    p.P = g.P; p.M = g.M; p.N = g.N; p.R = g.R;
+    p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
+    int ksteps = xv_cdiv(g.R, BK);
+    p.r_chunk = xv_cdiv(ksteps, g.splits) * BK;
+    int splits = xv_cdiv(g.R, p.r_chunk);
+    XV_REQUIRE(splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", splits, g.splits);
+    dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
+    hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------
+// Public op-level wrappers around the two GEMMs
+// -------------------------------------------------------------------------------------
+extern "C" size_t xv_op_workspace_bytes(int rows, int cols_in, int cols_out) {
+    // split slabs: at most ~512 workgroup tiles of 128x128 floats, plus column partials
+    size_t slabs = (size_t)640 * BM * BN * sizeof(float);
+    size_t wg = (size_t)xv_align(cols_in, BM) * xv_align(cols_out, BN) * sizeof(float) * 8;
+    size_t part = ((size_t)xv_cdiv(rows > 0 ? rows : 1, 64) * 2 + 2) * (size_t)(cols_out > cols_in ? cols_out : cols_in) * sizeof(float);
+    size_t m = slabs > wg ? slabs : wg;
+    return xv_align((m > part ? m : part) + 4096, 256);
+}
+
+extern "C" int xv_affine_forward(void* stream, const float* x, int segs, int t_in, int c_pad, int k, const float* wt,
+                                 const float* bias, float* z, int o, int ldz, float* bn_part, void* ws, size_t ws_bytes) {
+    XV_REQUIRE(segs > 0 && k >= 1 && t_in >= k && c_pad > 0 && o > 0 && ldz >= o, "affine_forward: bad shape (t_in=%d k=%d)", t_in, k);
+    XvGemmNT g = {};
+    g.A = x; g.lda = c_pad; g.a_rps = t_in - k + 1; g.a_pitch = t_in;
+    g.Bt = wt; g.ldb = (long)k * c_pad;
+    g.C = z; g.ldc = ldz;
+    g.M = segs * (t_in - k + 1); g.N = o; g.K = k * c_pad;
+    g.bias = bias; g.bn_part = bn_part; g.ws = ws; g.ws_bytes = ws_bytes;
+    return xv_launch_gemm_nt((hipStream_t)stream, g);
+}
+
+extern "C" int xv_affine_dgrad(void* stream, const float* dz_pad, int segs, int t_out, int o, int k, const float* wf, float* dx,
+                               int c, void* ws, size_t ws_bytes) {
+    XV_REQUIRE(segs > 0 && k >= 1 && t_out >= 1 && o > 0 && c > 0, "affine_dgrad: bad shape");
+    XvGemmNT g = {};
+    g.A = dz_pad; g.lda = o; g.a_rps = t_out + k - 1; g.a_pitch = t_out + 2 * (k - 1);
+    g.Bt = wf; g.ldb = (long)k * o;
+    g.C = dx; g.ldc = c;
+    g.M = segs * (t_out + k - 1); g.N = c; g.K = k * o;
+    g.ws = ws; g.ws_bytes = ws_bytes;
+    return xv_launch_gemm_nt((hipStream_t)stream, g);
+}
+
+// out[(j*C + c)][n] = sum_z P[z][j*c_pad + c][n] (+ l2 * w[(j*C + c)][n])
+__global__ void xv_wgrad_reduce_kernel(const float* __restrict__ P, int splits, long slab, int k, int C, int c_pad, int n_in,
+                                       int n_out, const float* __restrict__ w, long ldw, float l2, float* __restrict__ out, long ldo) {
+    long total = (long)k * C * n_out;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long row = i / n_out;
+        int n = (int)(i - row * n_out);
+        int j = (int)(row / C), c = (int)(row - (long)j * C);
+        long m = (long)j * c_pad + c;
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += P[z * slab + m * n_in + n];
+        if (w) v += l2 * w[row * ldw + n];
+        out[row * ldo + n] = v;
+    }
+}
+
+int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int C, int c_pad, int n_in, int n_out, const float* w,
+                           long ldw, float l2, float* out, long ldo) {
+    long total = (long)k * C * n_out;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(xv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, P, splits, (long)k * c_pad * n_in, k, C, c_pad, n_in,
+                       n_out, w, ldw, l2, out, ldo);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xv_affine_wgrad(void* stream, const float* x, int segs, int t_in, int c_pad, int k, int c, const float* dz,
+                               int dz_seg_pitch, int dz_row0, int o, const float* kernel, float l2_scale, float* dkernel, void* ws,
+                               size_t ws_bytes) {
+    XV_REQUIRE(segs > 0 && k >= 1 && t_in >= k && c_pad >= c && o > 0 && o % 4 == 0, "affine_wgrad: bad shape (o=%d must be a multiple of 4)", o);
+    const int t_out = t_in - k + 1;
+    XvGemmTN g = {};
+    g.A = x; g.lda = c_pad; g.a_rps = t_out; g.a_pitch = t_in;
+    g.B = dz + (long)dz_row0 * o; g.ldb = o; g.b_rps = t_out; g.b_pitch = dz_seg_pitch;
+    g.M = k * c_pad; g.N = o; g.R = segs * t_out;
+    g.splits = xv_tn_splits(g.M, g.N, g.R);
+    XV_REQUIRE((size_t)g.splits * g.M * g.N * sizeof(float) <= ws_bytes, "affine_wgrad: workspace too small (%zu needed)",
+               (size_t)g.splits * g.M * g.N * sizeof(float));
+    g.P = (float*)ws;
+    int rc = xv_launch_gemm_tn((hipStream_t)stream, g);
+    if (rc) return rc;
+    return xv_launch_wgrad_reduce((hipStream_t)stream, g.P, g.splits, k, c, c_pad, o, o, l2_scale != 0.f ? kernel : nullptr, o,
+                                  l2_scale, dkernel, o);
+}

@@ -1,0 +1,265 @@
+// Softmax loss family of model/loss.py:9-355 on gfx950: weight normalisation, the per-chunk
+// margin transform + annealing blend + mean sparse cross entropy with its gradients, and the
+// gradient through tf.nn.l2_normalize.  The [rows x N] logits GEMMs themselves run on the MFMA
+// kernels of xv_gemm.hip; everything here is HBM/L2-bound row or column work.
+#include "xv_common.h"
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// block-wide (256 threads) reductions through 4 LDS slots
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum_f(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max_f(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// inv_norm[n] = rsqrt(max(sum_c w[c][n]^2, 1e-12))   (tf.nn.l2_normalize(w, dim=0), loss.py:104)
+__global__ void col_inv_norm_kernel(const float* __restrict__ w, int C, int N, int normalize, float* __restrict__ inv) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    if (!normalize) { inv[n] = 1.f; return; }
+    float ss = 0.f;
+    for (int c = 0; c < C; ++c) { float v = w[(long)c * N + n]; ss += v * v; }
+    inv[n] = rsqrtf(fmaxf(ss, 1e-12f));
+}
+
+// wn[c][ldn] = w[c][n]*inv[n] (pad columns zero), wnt[n][C] = wn^T through a 32x32 LDS tile
+__global__ void loss_prep_weight_kernel(const float* __restrict__ w, int C, int N, const float* __restrict__ inv,
+                                        float* __restrict__ wn, int ldn, float* __restrict__ wnt) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        int c = c0 + r, n = n0 + tx;
+        float v = 0.f;
+        if (c < C && n < N) v = w[(long)c * N + n] * inv[n];
+        if (c < C && n < ldn) wn[(long)c * ldn + n] = v;
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int n = n0 + r, c = c0 + tx;
+        if (n < N && c < C) wnt[(long)n * C + c] = tile[tx][r];
+    }
+}
+
+extern "C" int xv_loss_prep_weight(void* stream, const float* w, int c, int n, int normalize, float* inv_norm, float* wn, int ldn,
+                                   float* wnt) {
+    XV_REQUIRE(c > 0 && n > 0 && ldn >= n, "loss_prep_weight: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(col_inv_norm_kernel, dim3(xv_cdiv(n, 256)), dim3(256), 0, s, w, c, n, normalize, inv_norm);
+    XV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_prep_weight_kernel, dim3(xv_cdiv(ldn, 32), xv_cdiv(c, 32)), dim3(256), 0, s, w, c, n,
+                       (const float*)inv_norm, wn, ldn, wnt);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// One workgroup per chunk (row).  phi / dphi follow loss.py:129-139 (A-Softmax sign-polynomial
+// form), :225 (AM), :314-323 (ArcFace with the sqrt(max(1-c^2,1e-12)) guard).
+__global__ __launch_bounds__(256) void margin_softmax_rows_kernel(int kind, const float* __restrict__ logits, int rows, int N,
+                                                                  long ldl, const float* __restrict__ x, int C,
+                                                                  const int* __restrict__ labels, float m, float lambda,
+                                                                  float* __restrict__ dlogits, float* __restrict__ dnorm,
+                                                                  float* __restrict__ row_loss) {
+    __shared__ float red[4];
+    __shared__ float s_upd, s_dsel, s_dn;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* lr = logits + (long)r * ldl;
+    float* gr = dlogits + (long)r * ldl;
+    const int y = labels[r];
+    const bool margin = (kind != XV_LOSS_SOFTMAX) && !(kind == XV_LOSS_ASOFTMAX && m == 1.0f);
+    float fa = 0.f, fs = 1.f;
+    float ss = 0.f;
+    if (margin) {
+        for (int c = tid; c < C; c += 256) { float v = x[(long)r * C + c]; ss += v * v; }
+        ss = block_sum(ss, red);
+        fa = 1.0f / (1.0f + lambda);
+        fs = 1.0f - fa;
+        if (tid == 0) {
+            const float eps = 1e-12f;
+            float sel = lr[y];
+            float rawn = sqrtf(ss);
+            float fn = fmaxf(rawn, eps);
+            float craw = sel / fn;
+            float lo = -1.0f + eps, hi = 1.0f - eps;          // == -1, 1 in fp32 (loss.py:125)
+            float c = fminf(fmaxf(craw, lo), hi);
+            float cm = (craw >= lo && craw <= hi) ? 1.f : 0.f;
+            float phi, dphi;
+            if (kind == XV_LOSS_ASOFTMAX) {
+                float sg = (c > 0.f) - (c < 0.f);
+                if (m == 2.0f) {
+                    phi = 2.f * sg * c * c - 1.f;
+                    dphi = 4.f * fabsf(c);
+                } else {
+                    float c2 = c * c, c4 = c2 * c2;
+                    float t = 2.f * c2 - 1.f;
+                    float s3 = ((t > 0.f) - (t < 0.f)) * sg;
+                    float s4 = 2.f * sg + s3 - 3.f;
+                    phi = s3 * (8.f * c4 - 8.f * c2 + 1.f) + s4;
+                    dphi = s3 * (32.f * c2 * c - 16.f * c);
+                }
+            } else if (kind == XV_LOSS_AMSOFTMAX) {
+                phi = c - m;
+                dphi = 1.f;
+            } else {
+                float sin_sq = 1.f - c * c;
+                bool live = sin_sq >= 1e-12f;
+                float sn = sqrtf(fmaxf(sin_sq, 1e-12f));
+                float cosm = cosf(m), sinm = sinf(m);
+                float cpm = c * cosm - sn * sinm;
+                float dcpm = cosm + (live ? c / sn : 0.f) * sinm;
+                bool first = c > cosf(3.14159265358979323846f - m);
+                phi = first ? cpm : -cpm - 2.f;
+                dphi = first ? dcpm : -dcpm;
+            }
+            float scaled = phi * fn;
+            // updated = fs*logits + fa*(logits + scatter(scaled - sel))      (loss.py:146-152)
+            s_upd = fs * sel + fa * (sel + (scaled - sel));
+            s_dsel = fa * (dphi * cm - 1.f);
+            // d/d||x||: fa * (phi - dphi*cm*craw), routed to x only where ||x|| >= eps
+            s_dn = (rawn >= eps) ? fa * (phi - dphi * cm * craw) : 0.f;
+        }
+        __syncthreads();
+    }
+    // log-sum-exp over the updated logits
+    float mx = -INFINITY;
+    for (int j = tid; j < N; j += 256) {
+        float l = lr[j];
+        float u = margin ? (j == y ? s_upd : fs * l + fa * l) : l;
+        mx = fmaxf(mx, u);
+    }
+    mx = block_max(mx, red);
+    float se = 0.f;
+    for (int j = tid; j < N; j += 256) {
+        float l = lr[j];
+        float u = margin ? (j == y ? s_upd : fs * l + fa * l) : l;
+        se += expf(u - mx);
+    }
+    se = block_sum(se, red);
+    const float lse = logf(se) + mx;
+    const float inv_rows = 1.0f / (float)rows;
+    const float uy = margin ? s_upd : lr[y];
+    for (int j = tid; j < (int)ldl; j += 256) {
+        float g = 0.f;
+        if (j < N) {
+            float l = lr[j];
+            float u = margin ? (j == y ? s_upd : fs * l + fa * l) : l;
+            float p = expf(u - lse);
+            float gj = (p - (j == y ? 1.f : 0.f)) * inv_rows;
+            g = margin ? (fs + fa) * gj : gj;
+            if (margin && j == y) g += s_dsel * gj;
+        }
+        gr[j] = g;
+    }
+    if (tid == 0) {
+        row_loss[r] = lse - uy;
+        float py = expf(uy - lse);
+        dnorm[r] = margin ? s_dn * (py - 1.f) * inv_rows : 0.f;
+    }
+}
+
+__global__ void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *out = s / (float)n;
+}
+
+extern "C" int xv_margin_softmax_rows(void* stream, int kind, const float* logits, int rows, int n, int ldl, const float* x, int c,
+                                      const int32_t* labels, float m, float lambda, float* dlogits, float* dnorm, float* row_loss,
+                                      float* loss_out) {
+    XV_REQUIRE(rows > 0 && n > 0 && ldl >= n && c > 0, "margin_softmax_rows: bad shape");
+    XV_REQUIRE(kind >= XV_LOSS_SOFTMAX && kind <= XV_LOSS_ARCSOFTMAX, "Not implement loss kind %d", kind);
+    if (kind == XV_LOSS_ASOFTMAX)
+        XV_REQUIRE(m == 1.0f || m == 2.0f || m == 4.0f, "[ERROR] m=%d is not unsupported.", (int)m);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(margin_softmax_rows_kernel, dim3(rows), dim3(256), 0, s, kind, logits, rows, n, (long)ldl, x, c,
+                       (const int*)labels, m, lambda, dlogits, dnorm, row_loss);
+    XV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, (const float*)row_loss, rows, loss_out);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx[r][:] += dnorm[r] * x[r][:] / ||x[r]||
+__global__ void add_norm_grad_kernel(const float* __restrict__ x, const float* __restrict__ dnorm, int rows, int C,
+                                     float* __restrict__ dx) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (long)row * C;
+    float ss = 0.f;
+    for (int c = lane; c < C; c += 64) ss += xr[c] * xr[c];
+    ss = wave_sum_f(ss);
+    float nrm = sqrtf(ss);
+    float k = nrm > 0.f ? dnorm[row] / nrm : 0.f;
+    for (int c = lane; c < C; c += 64) dx[(long)row * C + c] += k * xr[c];
+}
+extern "C" int xv_add_norm_grad(void* stream, const float* x, const float* dnorm, int rows, int c, float* dx) {
+    XV_REQUIRE(rows > 0 && c > 0, "add_norm_grad: bad shape");
+    hipLaunchKernelGGL(add_norm_grad_kernel, dim3(xv_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, dnorm, rows, c, dx);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// dot[n] = sum_c dwn[c][n] * wn[c][n]
+__global__ void col_dot_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb, int C, int N,
+                               float* __restrict__ dot) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += a[(long)c * lda + n] * b[(long)c * ldb + n];
+    dot[n] = s;
+}
+__global__ void loss_weight_bwd_kernel(const float* __restrict__ dwn, long lddwn, const float* __restrict__ wn, long ldn,
+                                       const float* __restrict__ inv, const float* __restrict__ dot, const float* __restrict__ w,
+                                       int C, int N, int normalize, float l2, float* __restrict__ dw) {
+    long total = (long)C * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i / N), n = (int)(i - (long)c * N);
+        float g = dwn[(long)c * lddwn + n];
+        if (normalize) {
+            // ss < eps columns are frozen by the maximum() of l2_normalize: only the scale term survives
+            float ss_live = inv[n] < 0.99e6f ? 1.f : 0.f;   // inv == rsqrt(1e-12) ~ 1e6 when clamped
+            g = inv[n] * (g - ss_live * wn[(long)c * ldn + n] * dot[n]);
+        }
+        dw[i] = g + l2 * w[i];
+    }
+}
+extern "C" int xv_loss_weight_backward(void* stream, const float* dwn, int lddwn, const float* wn, int ldn, const float* inv_norm,
+                                       const float* w, int c, int n, int normalize, float l2_scale, float* dw, void* ws,
+                                       size_t ws_bytes) {
+    XV_REQUIRE(c > 0 && n > 0 && lddwn >= n && ldn >= n, "loss_weight_backward: bad shape");
+    XV_REQUIRE(!normalize || (size_t)n * sizeof(float) <= ws_bytes, "loss_weight_backward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* dot_buf = (float*)ws;
+    if (normalize) {
+        hipLaunchKernelGGL(col_dot_kernel, dim3(xv_cdiv(n, 256)), dim3(256), 0, s, dwn, (long)lddwn, wn, (long)ldn, c, n, dot_buf);
+        XV_LAUNCH_CHECK();
+    }
+    long total = (long)c * n;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(loss_weight_bwd_kernel, dim3(blocks), dim3(256), 0, s, dwn, (long)lddwn, wn, (long)ldn, inv_norm,
+                       (const float*)dot_buf, w, c, n, normalize, l2_scale, dw);
+    XV_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,228 @@
+"""Host-side handle on the native engine (csrc/xv_engine.hip).
+
+torch is used here for exactly three things: owning device memory (the flat
+variables / gradient / optimiser-state buffers), naming the HIP stream, and
+(in `parallel`) the RCCL all-reduce.  All arithmetic happens in the C-ABI.
+"""
+from collections import OrderedDict
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, XV_BWD_STAGES
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lambda_min=0.0, lambda_base=1000.0,
+                lambda_gamma=1e-4, lambda_power=5.0, num_nodes_pooling_layer=1500, num_nodes_last_layer=512,
+                last_layer_no_bn=False, last_layer_linear=False, feature_norm=False, feature_scaling_factor=1.0,
+                weight_l2_regularizer=1e-2, output_weight_l2_regularizer=None, batchnorm_momentum=0.99,
+                bn_epsilon=1e-3, fused_bn_unbiased_moving_var=True, optimizer="sgd", momentum=0.9, use_nesterov=False,
+                clip_gradient_norm=0.0, max_batch=128, max_frames=400):
+    if loss_func not in LOSS_KINDS:
+        raise NotImplementedError("Not implement %s loss" % loss_func)
+    if optimizer not in OPTIMIZERS:
+        raise SystemExit("Optimizer %s is not supported." % optimizer)
+    c = XvConfig()
+    c.feat_dim = int(feat_dim)
+    c.num_speakers = int(num_speakers or 0)
+    c.num_nodes_pooling_layer = int(num_nodes_pooling_layer)
+    c.num_nodes_last_layer = int(num_nodes_last_layer)
+    c.last_layer_no_bn = int(bool(last_layer_no_bn))
+    c.last_layer_linear = int(bool(last_layer_linear))
+    c.feature_norm = int(bool(feature_norm))
+    c.feature_scaling_factor = float(feature_scaling_factor)
+    c.loss_kind = LOSS_KINDS[loss_func]
+    c.margin_m = float(margin_m)
+    c.lambda_min, c.lambda_base = float(lambda_min), float(lambda_base)
+    c.lambda_gamma, c.lambda_power = float(lambda_gamma), float(lambda_power)
+    c.weight_l2_regularizer = float(weight_l2_regularizer)
+    c.output_weight_l2_regularizer = -1.0 if output_weight_l2_regularizer is None else float(output_weight_l2_regularizer)
+    c.batchnorm_momentum = float(batchnorm_momentum)
+    c.bn_epsilon = float(bn_epsilon)
+    c.fused_bn_unbiased_moving_var = int(bool(fused_bn_unbiased_moving_var))
+    c.optimizer = OPTIMIZERS[optimizer]
+    c.momentum = float(momentum)
+    c.use_nesterov = int(bool(use_nesterov))
+    c.clip_gradient_norm = float(clip_gradient_norm)
+    c.max_batch = int(max_batch)
+    c.max_frames = int(max_frames)
+    return c
+
+
+class Engine(object):
+    """One TDNN x-vector graph resident on one GPU."""
+
+    def __init__(self, config, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise XvError("No HIP device visible: the x-vector engine only runs on MI355X (no CPU fallback).")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.config = config
+        h = C.c_void_p()
+        _lib.check(self.lib.xv_engine_create(C.byref(config), C.byref(h)), "xv_engine_create")
+        self.h = h
+        self.n_all = self.lib.xv_engine_variables_count(h)
+        self.n_train = self.lib.xv_engine_trainable_count(h)
+        self.n_opt = self.lib.xv_engine_optimizer_state_count(h)
+        self.variables = torch.zeros(self.n_all, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.n_train, dtype=torch.float32, device=self.device)
+        self.opt_state = torch.zeros(max(self.n_opt, 4), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.xv_engine_bind(h, _ptr(self.variables), _ptr(self.grads), _ptr(self.opt_state)), "xv_engine_bind")
+        self.table = OrderedDict()   # name -> (shape, offset, trainable)
+        for i in range(self.lib.xv_engine_num_variables(h)):
+            name = C.c_char_p()
+            shape = (C.c_int32 * 4)()
+            rank, trainable = C.c_int32(), C.c_int32()
+            off = C.c_size_t()
+            _lib.check(self.lib.xv_engine_variable_info(h, i, C.byref(name), shape, C.byref(rank), C.byref(off),
+                                                        C.byref(trainable)), "xv_engine_variable_info")
+            self.table[name.value.decode()] = (tuple(shape[:rank.value]), off.value, bool(trainable.value))
+        self.update_count = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            torch.cuda.synchronize(self.device)
+            self.lib.xv_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- variables ----------------------------------------------------------------
+    def set_variables(self, values):
+        """values: dict name -> array in the TF shape.  Missing names keep their value."""
+        host = self.variables.cpu().numpy()
+        for name, v in values.items():
+            if name not in self.table:
+                raise KeyError("unknown variable %s" % name)
+            shape, off, _ = self.table[name]
+            a = np.asarray(v, np.float32)
+            if a.shape != shape:
+                raise ValueError("variable %s: shape %s, expected %s" % (name, a.shape, shape))
+            host[off:off + a.size] = a.reshape(-1)
+        self.variables.copy_(torch.from_numpy(host))
+        _lib.check(self.lib.xv_engine_invalidate_weights(self.h))
+
+    def get_variables(self):
+        host = self.variables.cpu().numpy()
+        out = OrderedDict()
+        for name, (shape, off, _) in self.table.items():
+            n = int(np.prod(shape))
+            out[name] = host[off:off + n].reshape(shape).copy()
+        return out
+
+    def get_gradients(self):
+        host = self.grads.cpu().numpy()
+        out = OrderedDict()
+        for name, (shape, off, trainable) in self.table.items():
+            if trainable:
+                n = int(np.prod(shape))
+                out[name] = host[off:off + n].reshape(shape).copy()
+        return out
+
+    def init_variables(self, seed=0):
+        """Glorot-uniform kernels, zero biases, gamma=1, beta=0, moving_mean=0, moving_variance=1
+        ([TF] defaults of tf.layers.conv2d/dense/batch_normalization and xavier_initializer, loss.py:100-102)."""
+        rs = np.random.RandomState(seed)
+        vals = {}
+        for name, (shape, _, _) in self.table.items():
+            leaf = name.rsplit("/", 1)[1]
+            if leaf == "kernel":
+                if len(shape) == 4:
+                    fan_in, fan_out = shape[1] * shape[2], shape[1] * shape[3]
+                else:
+                    fan_in, fan_out = shape
+                lim = np.sqrt(6.0 / (fan_in + fan_out))
+                vals[name] = rs.uniform(-lim, lim, size=shape).astype(np.float32)
+            elif leaf in ("gamma", "moving_variance"):
+                vals[name] = np.ones(shape, np.float32)
+            else:
+                vals[name] = np.zeros(shape, np.float32)
+        self.set_variables(vals)
+
+    # ---- graph execution ------------------------------------------------------------
+    def _dev(self, a, dtype):
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=dtype).contiguous()
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32 if dtype == torch.float32 else np.int32)).to(self.device)
+        return t
+
+    def forward(self, features, training):
+        x = self._dev(features, torch.float32)
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        b, t, d = x.shape
+        if d != self.config.feat_dim:
+            raise ValueError("feature dim %d != %d" % (d, self.config.feat_dim))
+        self._keep = [x]
+        _lib.check(self.lib.xv_engine_forward(self.h, _stream(), _ptr(x), int(b), int(t), int(bool(training))),
+                   "xv_engine_forward")
+
+    def loss(self, labels, global_step, with_margin=True):
+        y = self._dev(labels, torch.int32)
+        self._keep.append(y)
+        _lib.check(self.lib.xv_engine_loss_forward(self.h, _stream(), _ptr(y), int(global_step), int(bool(with_margin))),
+                   "xv_engine_loss_forward")
+
+    def backward(self, stage=-1):
+        _lib.check(self.lib.xv_engine_backward(self.h, _stream(), int(stage)), "xv_engine_backward")
+
+    def stage_grad_range(self, stage):
+        b, e = C.c_size_t(), C.c_size_t()
+        _lib.check(self.lib.xv_engine_stage_grad_range(self.h, int(stage), C.byref(b), C.byref(e)))
+        return b.value, e.value
+
+    def apply(self, lr, grad_scale=1.0):
+        self.update_count += 1
+        _lib.check(self.lib.xv_engine_apply(self.h, _stream(), float(lr), float(grad_scale), int(self.update_count)),
+                   "xv_engine_apply")
+
+    def losses(self):
+        """(raw_loss, regularization_loss) of the last loss() call - synchronises."""
+        raw, reg = C.c_void_p(), C.c_void_p()
+        _lib.check(self.lib.xv_engine_loss_ptrs(self.h, C.byref(raw), C.byref(reg)))
+        out = torch.empty(2, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.xv_copy_2d(_stream(), _ptr(out), 2, raw, 2, 1, 2), "xv_copy_2d")
+        v = out.cpu().numpy()
+        return float(v[0]), float(v[1])
+
+    def endpoint(self, name):
+        """Copy of an endpoint of the most recent forward as a torch tensor [rows, cols]."""
+        p = C.c_void_p()
+        rows, cols, ld = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self.lib.xv_engine_endpoint(self.h, name.encode(), C.byref(p), C.byref(rows), C.byref(cols), C.byref(ld)),
+                   "xv_engine_endpoint(%s)" % name)
+        out = torch.empty((rows.value, cols.value), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.xv_copy_2d(_stream(), _ptr(out), cols.value, p, ld.value, rows.value, cols.value), "xv_copy_2d")
+        return out
+
+    def train_step(self, features, labels, lr, global_step, allreduce=None):
+        """One sess.run(train_op) (trainer.py:505-508).  `allreduce(tensor_slice)` - if given - is
+        called after each backward stage on the finished slice of the flat gradient buffer."""
+        self.forward(features, True)
+        self.loss(labels, global_step, True)
+        if allreduce is None:
+            self.backward(-1)
+            self.apply(lr, 1.0)
+        else:
+            for st in range(XV_BWD_STAGES):
+                self.backward(st)
+                b, e = self.stage_grad_range(st)
+                allreduce(self.grads[b:e])
+            self.apply(lr, allreduce.grad_scale)

@@ -1,0 +1,225 @@
+"""Op-level Python wrappers over the C-ABI (include/xvector_hip.h, "Op level").
+
+Inputs/outputs are torch CUDA tensors used purely as device buffers; every
+function enqueues HIP kernels on torch's current stream.  No arithmetic is done
+by torch here.  These are what the per-kernel parity tests call.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+TILE_M = 128
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+_WS = {}
+
+
+def workspace(device, nbytes=256 << 20):
+    key = (str(device), nbytes)
+    if key not in _WS:
+        _WS[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    return _WS[key]
+
+
+def _ws(t):
+    w = workspace(t.device)
+    return _p(w), C.c_size_t(w.numel() * 4)
+
+
+def pad_channels(x2d, c_dst):
+    rows, c = x2d.shape
+    out = _f32((rows, c_dst), x2d)
+    _lib.call("xv_pad_channels", _s(), _p(x2d), rows, c, _p(out), c_dst)
+    return out
+
+
+def prep_weight_fwd(kernel, c_pad):
+    """kernel: [k, C, O] -> [O, k*c_pad]"""
+    k, c, o = kernel.shape
+    wt = _f32((o, k * c_pad), kernel)
+    _lib.call("xv_prep_weight_fwd", _s(), _p(kernel), k, c, o, _p(wt), c_pad)
+    return wt
+
+
+def prep_weight_dgrad(kernel):
+    """kernel: [k, C, O] -> [C, k*O] (taps flipped)"""
+    k, c, o = kernel.shape
+    wf = _f32((c, k * o), kernel)
+    _lib.call("xv_prep_weight_dgrad", _s(), _p(kernel), k, c, o, _p(wf))
+    return wf
+
+
+def affine_forward(x, k, wt, bias, o, with_stats=False):
+    """x: [segs, t_in, c_pad] -> z [segs*(t_in-k+1), o] (+ bn_part)."""
+    segs, t_in, c_pad = x.shape
+    rows = segs * (t_in - k + 1)
+    z = _f32((rows, o), x)
+    part = _f32((2, (rows + TILE_M - 1) // TILE_M, o), x) if with_stats else None
+    wp, wb = _ws(x)
+    _lib.call("xv_affine_forward", _s(), _p(x), segs, t_in, c_pad, k, _p(wt), _p(bias), _p(z), o, o, _p(part), wp, wb)
+    return (z, part) if with_stats else z
+
+
+def affine_dgrad(dz_pad, segs, t_out, o, k, wf, c):
+    dx = _f32((segs * (t_out + k - 1), c), dz_pad)
+    wp, wb = _ws(dz_pad)
+    _lib.call("xv_affine_dgrad", _s(), _p(dz_pad), segs, t_out, o, k, _p(wf), _p(dx), c, wp, wb)
+    return dx
+
+
+def affine_wgrad(x, k, c, dz, dz_seg_pitch, dz_row0, o, kernel, l2_scale):
+    segs, t_in, c_pad = x.shape
+    dk = _f32((k, c, o), x)
+    wp, wb = _ws(x)
+    _lib.call("xv_affine_wgrad", _s(), _p(x), segs, t_in, c_pad, k, c, _p(dz), dz_seg_pitch, dz_row0, o, _p(kernel),
+              float(l2_scale), _p(dk), wp, wb)
+    return dk
+
+
+def colsum(a):
+    rows, n = a.shape
+    out = _f32((n,), a)
+    wp, wb = _ws(a)
+    _lib.call("xv_colsum", _s(), _p(a), rows, n, a.stride(0), _p(out), wp, wb)
+    return out
+
+
+def col_stats(z):
+    rows, n = z.shape
+    part = _f32((2, (rows + TILE_M - 1) // TILE_M, n), z)
+    _lib.call("xv_col_stats", _s(), _p(z), rows, n, z.stride(0), _p(part))
+    return part
+
+
+def bn_finalize(part, rows, gamma, beta, eps, momentum, unbiased, moving_mean, moving_var):
+    n = gamma.numel()
+    mean, invstd, scale, shift = (_f32((n,), gamma) for _ in range(4))
+    _lib.call("xv_bn_finalize", _s(), _p(part), rows, n, _p(gamma), _p(beta), float(eps), float(momentum), int(unbiased),
+              _p(moving_mean), _p(moving_var), _p(mean), _p(invstd), _p(scale), _p(shift))
+    return mean, invstd, scale, shift
+
+
+def bn_inference_scale(gamma, beta, moving_mean, moving_var, eps):
+    n = gamma.numel()
+    scale, shift = _f32((n,), gamma), _f32((n,), gamma)
+    _lib.call("xv_bn_inference_scale", _s(), n, _p(gamma), _p(beta), _p(moving_mean), _p(moving_var), float(eps), _p(scale), _p(shift))
+    return scale, shift
+
+
+def bn_apply(z, scale, shift, relu):
+    rows, n = z.shape
+    a = _f32((rows, n), z)
+    _lib.call("xv_bn_apply", _s(), _p(z), rows, n, n, _p(scale), _p(shift), int(relu), _p(a), n)
+    return a
+
+
+def bn_relu_backward(da, z, segs, t, gamma, mean, invstd, scale, shift, relu, pad):
+    n = z.shape[1]
+    dz = _f32((segs * (t + 2 * pad), n), z)
+    dgamma, dbeta = _f32((n,), z), _f32((n,), z)
+    wp, wb = _ws(z)
+    _lib.call("xv_bn_relu_backward", _s(), _p(da), _p(z), segs, t, n, _p(gamma), _p(mean), _p(invstd), _p(scale), _p(shift),
+              int(relu), int(pad), _p(dz), _p(dgamma), _p(dbeta), wp, wb)
+    return dz, dgamma, dbeta
+
+
+def relu_backward(da, a):
+    dz = torch.empty_like(da)
+    _lib.call("xv_relu_backward", _s(), _p(da), _p(a), C.c_size_t(da.numel()), _p(dz))
+    return dz
+
+
+def stat_pool_forward(x):
+    b, t, c = x.shape
+    out = _f32((b, 2 * c), x)
+    _lib.call("xv_stat_pool_forward", _s(), _p(x), b, t, c, _p(out))
+    return out
+
+
+def stat_pool_backward(x, out, dout):
+    b, t, c = x.shape
+    dx = torch.empty_like(x)
+    _lib.call("xv_stat_pool_backward", _s(), _p(x), _p(out), _p(dout), b, t, c, _p(dx))
+    return dx
+
+
+def l2_scaling_forward(x, factor):
+    y = torch.empty_like(x)
+    _lib.call("xv_l2_scaling_forward", _s(), _p(x), x.shape[0], x.shape[1], float(factor), _p(y))
+    return y
+
+
+def l2_scaling_backward(x, dy, factor):
+    dx = torch.empty_like(x)
+    _lib.call("xv_l2_scaling_backward", _s(), _p(x), _p(dy), x.shape[0], x.shape[1], float(factor), _p(dx))
+    return dx
+
+
+def loss_prep_weight(w, normalize):
+    c, n = w.shape
+    ldn = (n + 3) // 4 * 4
+    inv = _f32((n,), w)
+    wn = _f32((c, ldn), w)
+    wnt = _f32((n, c), w)
+    _lib.call("xv_loss_prep_weight", _s(), _p(w), c, n, int(normalize), _p(inv), _p(wn), ldn, _p(wnt))
+    return inv, wn, wnt
+
+
+def margin_softmax_rows(kind, logits, n, x, labels, m, lam):
+    """logits: [rows, ldl] (ldl >= n).  Returns loss (1-elem tensor), dlogits, dnorm, row_loss."""
+    rows, ldl = logits.shape
+    dlogits = torch.empty_like(logits)
+    dnorm, row_loss, loss = _f32((rows,), logits), _f32((rows,), logits), _f32((1,), logits)
+    _lib.call("xv_margin_softmax_rows", _s(), int(kind), _p(logits), rows, n, ldl, _p(x), x.shape[1], _p(labels), float(m),
+              float(lam), _p(dlogits), _p(dnorm), _p(row_loss), _p(loss))
+    return loss, dlogits, dnorm, row_loss
+
+
+def add_norm_grad(x, dnorm, dx):
+    _lib.call("xv_add_norm_grad", _s(), _p(x), _p(dnorm), x.shape[0], x.shape[1], _p(dx))
+    return dx
+
+
+def loss_weight_backward(dwn, wn, inv, w, normalize, l2_scale):
+    c, n = w.shape
+    dw = torch.empty_like(w)
+    wp, wb = _ws(w)
+    _lib.call("xv_loss_weight_backward", _s(), _p(dwn), dwn.stride(0), _p(wn), wn.stride(0), _p(inv), _p(w), c, n, int(normalize),
+              float(l2_scale), _p(dw), wp, wb)
+    return dw
+
+
+def l2_reg_loss(w, scale, accum):
+    _lib.call("xv_l2_reg_loss", _s(), _p(w), C.c_size_t(w.numel()), float(scale), _p(accum))
+
+
+def sumsq(g, accum):
+    _lib.call("xv_sumsq", _s(), _p(g), C.c_size_t(g.numel()), _p(accum))
+
+
+def sgd_update(p, g, lr, grad_scale=1.0):
+    _lib.call("xv_sgd_update", _s(), _p(p), _p(g), C.c_size_t(p.numel()), float(lr), float(grad_scale))
+
+
+def momentum_update(p, g, acc, lr, momentum, nesterov, grad_scale=1.0):
+    _lib.call("xv_momentum_update", _s(), _p(p), _p(g), _p(acc), C.c_size_t(p.numel()), float(lr), float(momentum), int(nesterov),
+              float(grad_scale))
+
+
+def adam_update(p, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _lib.call("xv_adam_update", _s(), _p(p), _p(g), _p(m), _p(v), C.c_size_t(p.numel()), float(lr), float(beta1), float(beta2),
+              float(eps), int(t), float(grad_scale))
