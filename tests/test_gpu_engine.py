@@ -1,9 +1,10 @@
 """Whole-graph parity on a real MI355X: the native engine (one C call per phase) against the
 CPU oracle's train_step on the same seeded variables / features / labels.
 
-Tolerances: endpoints (incl. the tdnn6_dense embedding) within 1e-4 relative of the float64
-oracle - the bar north_star states for embeddings; gradients within 1e-3 of the largest entry of
-each variable (two GEMM levels deeper than the embeddings, fp32 accumulation)."""
+Tolerances: endpoints (incl. the tdnn6_dense embedding) within 5e-5 relative of the float64
+oracle (north_star asks 1e-4 for embeddings; measured 1e-6..2e-5); gradients within 1e-4 of the
+largest entry of each variable, evaluated on the GPU's ReLU on/off pattern (see
+oracle_step_with_gpu_relu_pattern); updated variables within 2e-5."""
 import numpy as np
 import pytest
 import torch
@@ -70,6 +71,61 @@ def test_variable_table_matches_reference_names():
     eng.close()
 
 
+RELU_LAYERS = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5", "tdnn6", "tdnn7")
+
+
+def oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x, labels, lr, step, opt_state):
+    """Oracle train step whose ReLU on/off pattern is taken from the GPU forward.
+
+    ReLU makes the gradient a discontinuous function of the forward values: a pre-activation
+    that is -3e-6 in float64 and +4e-8 in fp32 flips one mask bit, and with only ~200 rows per
+    BatchNorm in these unit-test shapes one flipped bit moves a per-channel gradient by ~1 %.
+    That is rounding, not arithmetic, so the test (1) asserts that the GPU pattern differs from
+    the float64 pattern only where the float64 pre-activation is within 2e-5 of zero and in
+    fewer than 1e-4 of the positions, then (2) checks all gradients at 1e-4 against the oracle
+    evaluated on the GPU's pattern."""
+    bn_new = {}
+    feats, ep, caches = O.tdnn_forward(V, x, cfg_o, True, bn_new)
+    ep_gpu = dict(ep)
+    for prefix in RELU_LAYERS:
+        key = prefix + "_relu"
+        if key not in ep:
+            continue
+        got = eng.endpoint(key).cpu().numpy().reshape(ep[key].shape)
+        flips = (got > 0) != (ep[key] > 0)
+        assert flips.mean() < 1e-4, (key, flips.mean())
+        pre = ep[prefix + "_bn"]
+        assert np.all(np.abs(pre[flips]) < 2e-5 * max(1.0, np.abs(pre).max())), key
+        ep_gpu[key] = got.astype(np.float64)
+    raw_loss, logits, dfeat, Gl = O.loss_forward_backward(V, cfg_o, feats, labels, step)
+    reg, Gr = O.regularization(V, cfg_o)
+    G = O.tdnn_backward(V, cfg_o, ep_gpu, caches, dfeat)
+    G.update(Gl)
+    for k, g in Gr.items():
+        G[k] = G[k] + g
+    ep["logits"] = logits
+    # optimiser on the oracle side (same code path as O.train_step)
+    newV, new_state = {}, {}
+    t = opt_state.get("__t__", 0) + 1
+    for name, p in V.items():
+        if not O.is_trainable(name):
+            newV[name] = bn_new.get(name, p)
+            continue
+        g = G[name].reshape(p.shape)
+        if cfg_o.optimizer == "sgd":
+            newV[name] = O.sgd_update(p, g, lr)
+        elif cfg_o.optimizer == "momentum":
+            newV[name], new_state[name] = O.momentum_update(p, g, opt_state.get(name, np.zeros_like(p)), lr, cfg_o.momentum,
+                                                            cfg_o.use_nesterov)
+        else:
+            m, v = opt_state.get(name, (np.zeros_like(p), np.zeros_like(p)))
+            pn, m, v = O.adam_update(p, g, m, v, t, lr)
+            newV[name], new_state[name] = pn, (m, v)
+    new_state["__t__"] = t
+    info = {"raw_loss": raw_loss, "reg_loss": reg, "grads": G, "endpoints": ep}
+    return newV, new_state, info
+
+
 @pytest.mark.parametrize("kw", CASES, ids=lambda d: "-".join("%s" % v for v in d.values()))
 def test_train_step_matches_oracle(kw):
     B, T = 6, 40
@@ -78,20 +134,20 @@ def test_train_step_matches_oracle(kw):
     x = rs.randn(B, T, 30).astype(np.float32)
     labels = rs.randint(0, cfg_o.num_speakers, B).astype(np.int32)
     step, lr = 1234, 0.05
-    opt_state = {}
-    newV, opt_state, info = O.train_step(V, opt_state, cfg_o, x.astype(np.float64), labels, lr, step)
 
     eng.forward(x, True)
     eng.loss(labels, step, True)
     eng.backward(-1)
+    newV, _, info = oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x.astype(np.float64), labels, lr, step, {})
     raw, reg = eng.losses()
-    assert abs(raw - info["raw_loss"]) <= 1e-4 * abs(info["raw_loss"]) + 1e-6
-    assert abs(reg - info["reg_loss"]) <= 1e-4 * abs(info["reg_loss"])
+    assert abs(raw - info["raw_loss"]) <= 2e-5 * abs(info["raw_loss"]) + 1e-6
+    assert abs(reg - info["reg_loss"]) <= 2e-5 * abs(info["reg_loss"])
     for name in ("tdnn1_conv", "tdnn1_relu", "tdnn2_conv", "tdnn3_conv", "tdnn3_relu", "tdnn4_dense", "tdnn5_dense",
                  "tdnn5_bn", "tdnn5_relu", "pooling", "tdnn6_dense", "tdnn6_relu", "tdnn7_dense", "output", "logits"):
         ref = info["endpoints"][name]
         got = eng.endpoint(name).cpu().numpy()
-        assert rel_err(got, ref.reshape(got.shape)) <= 1e-4, (name, rel_err(got, ref.reshape(got.shape)))
+        # north_star: embeddings within 1e-4 relative; measured ~1e-6..2e-5
+        assert rel_err(got, ref.reshape(got.shape)) <= 5e-5, (name, rel_err(got, ref.reshape(got.shape)))
     grads = eng.get_gradients()
     for name, g in grads.items():
         ref = info["grads"][name].reshape(g.shape)
@@ -100,7 +156,7 @@ def test_train_step_matches_oracle(kw):
             assert np.abs(g).max() <= 1e-4 * max(1.0, np.abs(info["grads"][name.replace("/bias", "/kernel")]).max())
             continue
         assert np.all(np.isfinite(g)), name
-        assert rel_err(g, ref) <= 1e-3, (name, rel_err(g, ref))
+        assert rel_err(g, ref) <= 1e-4, (name, rel_err(g, ref))
     # optimiser + BN moving averages
     eng.apply(lr, 1.0)
     after = eng.get_variables()
@@ -109,7 +165,14 @@ def test_train_step_matches_oracle(kw):
         if name.endswith("/bias") and not name.startswith("softmax"):
             continue
         denom = max(np.abs(ref).max(), 1e-12)
-        assert np.abs(v - ref).max() / denom <= 2e-4, (name, np.abs(v - ref).max() / denom)
+        diff = np.abs(v - ref)
+        if cfg_o.optimizer == "adam" and name in info["grads"]:
+            # Adam's first step is lr*g/(|g|+1e-8): entries whose gradient is rounding noise (|g| << 1e-8-ish
+            # relative to the tensor) get a step whose sign is noise on both sides; the kernel itself is
+            # pinned on identical inputs in test_gpu_ops.py::test_optimizers_and_reductions.
+            gref = np.abs(info["grads"][name].reshape(v.shape))
+            diff = diff[gref >= 1e-3 * gref.max()]
+        assert diff.max() / denom <= 2e-5, (name, diff.max() / denom)
     eng.close()
 
 
@@ -124,10 +187,10 @@ def test_second_step_uses_updated_weights_and_staged_backward():
     for it in range(2):
         x = rs.randn(B, T, 30).astype(np.float32)
         labels = rs.randint(0, cfg_o.num_speakers, B).astype(np.int32)
-        V, opt, info = O.train_step(V, opt, cfg_o, x.astype(np.float64), labels, 0.1, it)
         eng.forward(x, True)
         eng.loss(labels, it, True)
         eng.backward(-1)
+        V, opt, info = oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x.astype(np.float64), labels, 0.1, it, opt)
         g_all = eng.grads.clone()
         eng.grads.zero_()
         covered = 0
@@ -141,7 +204,7 @@ def test_second_step_uses_updated_weights_and_staged_backward():
     after = eng.get_variables()
     for name in ("tdnn/tdnn2_conv/kernel", "tdnn/tdnn5_dense/kernel", "softmax/output/kernel", "tdnn/tdnn3_bn/moving_variance"):
         ref = V[name]
-        assert np.abs(after[name] - ref).max() / np.abs(ref).max() <= 5e-4, name
+        assert np.abs(after[name] - ref).max() / np.abs(ref).max() <= 1e-4, name
     eng.close()
 
 

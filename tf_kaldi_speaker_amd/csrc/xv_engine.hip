@@ -627,6 +627,9 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
             return set(e->bufZ, a.rows, a.c_out, a.c_out);
         }
     }
+    // debug views of the backward scratch (valid right after backward stage 0)
+    if (n == "debug:da5") return set(e->bufD, e->B * e->Tl[5], e->P, e->P);
+    if (n == "debug:dpool") return set(e->d_small0, e->B, 2 * e->P, 2 * e->P);
     if (n == "pooling") return set(e->pool, e->B, 2 * e->P, 2 * e->P);
     if (n == "output") return set(e->out, e->B, e->Lout, e->Lout);
     if (n == "logits" && e->N > 0) return set(e->logits, e->B, e->N, e->ldl);
