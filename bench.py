@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterance-chunks/sec of full x-vector optimiser steps on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d shape S1): standard 5-layer TDNN
+x-vector + AM-Softmax (m = 0.2), 128 chunks x 200 frames x 30-dim MFCC per GPU, 7351 speakers,
+fp32, plain SGD + L2 - one "step" = forward + loss + backward (+ gradient all-reduce for N > 1)
++ update on synthetic features already resident in HBM.  Weak scaling: 128 chunks per GPU.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
+dominant kernel (live hipEvent timing of every MFMA GEMM launch inside the timed region) and, at
+N = 1, `cpu_baseline` = the NumPy oracle's train_step timed on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+# algorithmic work of shape S1 (per 128-chunk step)
+B, T, D, NSPK = 128, 200, 30, 7351
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32-input MFMA peak
+KIND_NAMES = ["xv_gemm_nt_kernel<true> (forward conv/dense + BN stats)",
+              "xv_gemm_nt_kernel<false> (data gradients / logits)",
+              "xv_gemm_tn_kernel (weight gradients)"]
+
+
+def step_flops(b, t, d, n):
+    """2*M*K*N per contraction, backward = 2x forward."""
+    t1, t2, t3 = t - 4, t - 8, t - 14
+    fwd = 2.0 * b * (t1 * 5 * d * 512 + t2 * 2560 * 512 + t3 * 3584 * 512 + t3 * 512 * 512 + t3 * 512 * 1500)
+    fwd += 2.0 * b * (3000 * 512 + 512 * 512 + 512 * n)
+    return fwd, 3.0 * fwd
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (a NumPy port of the reference arithmetic, NOT TensorFlow) on the host cores."""
+    from oracle import xvector_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    cb = 16
+    cfg = O.Config(feat_dim=D, num_speakers=NSPK, loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True)
+    V = O.init_variables(cfg, seed=0, dtype=np.float32)
+    rs = np.random.RandomState(0)
+    x = rs.randn(cb, T, D).astype(np.float32)
+    y = rs.randint(0, NSPK, cb)
+    state = {}
+    V, state, _ = O.train_step(V, state, cfg, x, y, 0.01, 0)      # warm-up (BLAS thread pool, page faults)
+    t0 = time.time()
+    n = 0
+    while True:
+        V, state, _ = O.train_step(V, state, cfg, x, y, 0.01, n + 1)
+        n += 1
+        if time.time() - t0 > seconds_budget * 0.5 or n >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": round(cb * n / dt, 2), "unit": "chunks/s", "cores": int(threads), "kind": "port",
+            "sample": "oracle (NumPy/OpenBLAS fp32 port, this repo) train_step, %d chunks x %d frames x %d-dim, %d speakers, %d steps in %.1f s"
+                      % (cb, T, D, NSPK, n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from tf_kaldi_speaker_amd import _lib, engine as E
+    from tf_kaldi_speaker_amd.parallel import GradAllReduce
+    lib = _lib.load()
+
+    cfg = E.make_config(D, NSPK, loss_func="additive_margin_softmax", margin_m=0.2, lambda_min=0.0, lambda_base=1000.0,
+                        lambda_gamma=1e-4, lambda_power=5.0, last_layer_linear=True, weight_l2_regularizer=1e-2,
+                        batchnorm_momentum=0.99, optimizer="sgd", max_batch=B, max_frames=T)
+    eng = E.Engine(cfg, device=str(dev))
+    eng.init_variables(seed=0)       # identical replicas on every rank
+    rs = np.random.RandomState(1000 + rank)
+    nb = 4                           # rotate a few resident batches
+    xs = [torch.from_numpy(rs.randn(B, T, D).astype(np.float32)).to(dev) for _ in range(nb)]
+    ys = [torch.from_numpy(rs.randint(0, NSPK, B).astype(np.int32)).to(dev) for _ in range(nb)]
+    allreduce = GradAllReduce(dist, world) if world > 1 else None
+    lr = 0.01
+
+    def one_step(i):
+        eng.train_step(xs[i % nb], ys[i % nb], lr, i, allreduce=allreduce)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    launches_per_step = 64
+    _lib.check(lib.xv_profile_begin(int(args.steps * launches_per_step)), "xv_profile_begin")
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    cnt = (C.c_int64 * 3)()
+    ms = (C.c_double * 3)()
+    fl = (C.c_double * 3)()
+    _lib.check(lib.xv_profile_end(cnt, ms, fl), "xv_profile_end")
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    raw, reg = eng.losses()
+    if not np.isfinite(raw):
+        sys.exit("bench.py: loss is not finite (%r)" % raw)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        fwd_flops, total_flops = step_flops(B, T, D, NSPK)
+        dom = int(np.argmax([ms[k] for k in range(3)]))
+        kernels = []
+        for k in range(3):
+            if cnt[k]:
+                kernels.append({"kernel": KIND_NAMES[k], "launches": int(cnt[k]), "avg_ms": ms[k] / cnt[k],
+                                "tflops": fl[k] / (ms[k] * 1e-3) / 1e12, "share_of_step": ms[k] / args.steps / ms_per_step})
+        achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12
+        out = {
+            "metric": "utterance-chunks/sec (200-frame x 30-dim)",
+            "value": round(value, 1),
+            "unit": "chunks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "TDNN x-vector (tdnn.py 5 frame + 2 segment layers, stat pooling) + AM-Softmax m=0.2, "
+                                   "full optimiser step (fwd+bwd+L2+SGD%s), %d chunks/GPU x %d frames x %d-dim, %d speakers"
+                                   % ("+RCCL all-reduce" if world > 1 else "", B, T, D, NSPK),
+                       "chunks_per_gpu": B, "frames": T, "feat_dim": D, "num_speakers": NSPK,
+                       "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(ms[dom] / cnt[dom], 4), "launches": int(cnt[dom]),
+                         "algorithmic_flops_per_launch": fl[dom] / cnt[dom]},
+            "step_flops": {"algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
+                           "whole_step_tflops": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
+                           "whole_step_frac_of_f32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "kernels": kernels,
+            "loss": round(raw, 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,16 @@ int xv_abi_version(void);
 /* number of visible HIP devices (0 when none / driver missing); never throws */
 int xv_device_count(void);
 
+/* Live kernel timing for bench.py's roofline leg: while enabled, every launch of the three MFMA
+ * GEMM kernels is bracketed by hipEvents on the stream it is launched on.
+ *   kind 0 = xv_gemm_nt_kernel<true>  (forward conv/dense + BN-statistics epilogue)
+ *   kind 1 = xv_gemm_nt_kernel<false> (data gradients, logits, split launches)
+ *   kind 2 = xv_gemm_tn_kernel        (weight gradients)
+ * xv_profile_end synchronises the recorded events and returns, per kind, the number of launches,
+ * their summed duration in ms and their summed algorithmic FLOPs (2*M*N*K each). */
+int xv_profile_begin(int max_launches);
+int xv_profile_end(int64_t launches[3], double ms[3], double flops[3]);
+
 /* dst[r][0..cols) = src[r][0..cols) for r < rows (device to device, pitches in floats). */
 int xv_copy_2d(void* stream, float* dst, size_t ldd, const float* src, size_t lds, int rows, int cols);
 

@@ -1,0 +1,57 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the gradient all-reduce wrapper used by
+Engine.train_step (the engine itself needs a GPU; the collective wiring does not)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tf_kaldi_speaker_amd.parallel import GradAllReduce, average_bn_statistics, broadcast_variables
+    rs = np.random.RandomState(rank)
+    n_train, n_all = 1003, 1100
+    grads = torch.from_numpy(rs.randn(n_train).astype(np.float32))
+    variables = torch.from_numpy(rs.randn(n_all).astype(np.float32))
+    broadcast_variables(dist, variables, 0)
+    variables[n_train:] += rank            # diverging BN statistics
+    ar = GradAllReduce(dist, world)
+    # stage ranges as the engine reports them: contiguous, tail first
+    ranges = [(700, 1003), (400, 700), (100, 400), (0, 100)]
+    for b, e in ranges:
+        ar(grads[b:e])
+    ar.wait()
+    average_bn_statistics(dist, variables, n_train, world)
+    q.put((rank, grads.numpy().copy(), variables.numpy().copy(), ar.grad_scale))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    world, port = 2, 29517 + os.getpid() % 1000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g_expected = sum(np.random.RandomState(r).randn(1003).astype(np.float32) for r in range(world))
+    rs0 = np.random.RandomState(0)
+    rs0.randn(1003)                                   # rank 0 draws its gradients first
+    v0 = rs0.randn(1100).astype(np.float32)
+    for rank, g, v, scale in res:
+        assert np.allclose(g, g_expected, rtol=1e-6, atol=1e-6)
+        assert scale == 0.5
+        assert np.allclose(v[:1003], v0[:1003])                     # trainable part: rank 0's broadcast
+        assert np.allclose(v[1003:], v0[1003:] + 0.5, atol=1e-6)    # BN statistics: mean over ranks

@@ -67,6 +67,8 @@ SIGNATURES = {
     "xv_last_error": (C.c_char_p, []),
     "xv_abi_version": (_I, []),
     "xv_device_count": (_I, []),
+    "xv_profile_begin": (_I, [_I]),
+    "xv_profile_end": (_I, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "xv_copy_2d": (_I, [_VP, _VP, _SZ, _VP, _SZ, _I, _I]),
     "xv_op_workspace_bytes": (_SZ, [_I, _I, _I]),
     "xv_pad_channels": (_I, [_VP, _VP, _I, _I, _VP, _I]),

@@ -227,6 +227,53 @@ __global__ void xv_splitk_reduce_kernel(const float* __restrict__ slab, int spli
     }
 }
 
+// ---- live launch timing (bench.py roofline leg) ----------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+size_t g_prof_cap = 0;
+std::vector<hipEvent_t> g_prof_events;   // pool, two per record slot
+struct ProfScope {
+    hipStream_t s; int idx;
+    ProfScope(hipStream_t st, int kind, double flops) : s(st), idx(-1) {
+        if (!g_prof_on || g_prof.size() >= g_prof_cap) return;
+        idx = (int)g_prof.size();
+        ProfRec r = {g_prof_events[2 * idx], g_prof_events[2 * idx + 1], kind, flops};
+        g_prof.push_back(r);
+        (void)hipEventRecord(r.a, s);
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, s); }
+};
+}  // namespace
+
+extern "C" int xv_profile_begin(int max_launches) {
+    XV_REQUIRE(max_launches > 0, "profile_begin: max_launches must be positive");
+    while (g_prof_events.size() < (size_t)2 * max_launches) {
+        hipEvent_t ev;
+        XV_CHECK_HIP(hipEventCreate(&ev));
+        g_prof_events.push_back(ev);
+    }
+    g_prof.clear();
+    g_prof_cap = (size_t)max_launches;
+    g_prof_on = true;
+    return 0;
+}
+
+extern "C" int xv_profile_end(int64_t launches[3], double ms[3], double flops[3]) {
+    g_prof_on = false;
+    for (int k = 0; k < 3; ++k) { launches[k] = 0; ms[k] = 0.0; flops[k] = 0.0; }
+    for (auto& r : g_prof) {
+        XV_CHECK_HIP(hipEventSynchronize(r.b));
+        float t = 0.f;
+        XV_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        launches[r.kind] += 1; ms[r.kind] += (double)t; flops[r.kind] += r.flops;
+    }
+    g_prof.clear();
+    return 0;
+}
+
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     XV_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm_nt: K/lda/ldb must be multiples of 4 (K=%d lda=%ld ldb=%ld)", g.K, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0, "gemm_nt: operands must be 16-byte aligned");
@@ -250,6 +297,7 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     if (splits == 1) {
         p.C = g.C; p.ldc = g.ldc; p.c_split_stride = 0; p.k_chunk = ksteps * BK;
         dim3 grid(tiles, 1, 1);
+        ProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
         if (g.bn_part) {
             p.part_sum = g.bn_part;
             p.part_m2 = g.bn_part + (long)p.tiles_m * g.N;
@@ -268,7 +316,10 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     splits = xv_cdiv(g.K, p.k_chunk);
     p.bias = nullptr;
     dim3 grid(tiles, 1, splits);
-    hipLaunchKernelGGL(xv_gemm_nt_kernel<false>, grid, dim3(256), 0, s, p);
+    {
+        ProfScope prof(s, 1, 2.0 * g.M * g.N * g.K);
+        hipLaunchKernelGGL(xv_gemm_nt_kernel<false>, grid, dim3(256), 0, s, p);
+    }
     XV_LAUNCH_CHECK();
     long total = (long)g.M * g.N;
     int blocks = (int)((total + 255) / 256);
@@ -416,7 +467,10 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     int splits = xv_cdiv(g.R, p.r_chunk);
     XV_REQUIRE(splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", splits, g.splits);
     dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-    hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
+    {
+        ProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
+        hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
+    }
     XV_LAUNCH_CHECK();
     return 0;
 }

@@ -225,4 +225,5 @@ class Engine(object):
                 self.backward(st)
                 b, e = self.stage_grad_range(st)
                 allreduce(self.grads[b:e])
+            allreduce.wait()
             self.apply(lr, allreduce.grad_scale)
