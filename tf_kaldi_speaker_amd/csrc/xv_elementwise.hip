@@ -112,20 +112,43 @@ extern "C" int xv_prep_weight_dgrad(void* stream, const float* kernel, int k, in
 // column sums / column statistics (row-chunk partials, then a fixed-order combine)
 // ------------------------------------------------------------------------------------
 #define CS_ROWS 128
-__global__ void colsum_partial_kernel(const float* __restrict__ a, int rows, int n, long lda, float* __restrict__ part) {
-    int col = blockIdx.x * blockDim.x + threadIdx.x;
-    int r0 = blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
-    if (col >= n) return;
+// block = 256 threads = 64 columns x 4 row lanes; row lanes are combined in a fixed order
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, int rows, int n, long lda,
+                                                             float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += a[(long)r * lda + col];
-    part[(long)blockIdx.y * n + col] = s;
+    if (col < n) {
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            float v0 = a[(long)r * lda + col], v1 = a[(long)(r + 4) * lda + col];
+            float v2 = a[(long)(r + 8) * lda + col], v3 = a[(long)(r + 12) * lda + col];
+            s += (v0 + v1) + (v2 + v3);
+        }
+        for (; r < r1; r += 4) s += a[(long)r * lda + col];
+    }
+    red[rl][cx] = s;
+    __syncthreads();
+    if (rl == 0 && col < n) part[(long)blockIdx.y * n + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ out) {
-    int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= n) return;
+// block = 256 threads = 32 columns x 8 chunk lanes
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ out) {
+    __shared__ float red[8][32];
+    const int cx = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cx;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(long)c * n + col];
-    out[col] = s;
+    if (col < n)
+        for (int c = cl; c < chunks; c += 8) s += part[(long)c * n + col];
+    red[cl][cx] = s;
+    __syncthreads();
+    if (cl == 0 && col < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cx];
+        out[col] = t;
+    }
 }
 
 extern "C" int xv_colsum(void* stream, const float* a, int rows, int n, int lda, float* out, void* ws, size_t ws_bytes) {
@@ -133,9 +156,9 @@ extern "C" int xv_colsum(void* stream, const float* a, int rows, int n, int lda,
     int chunks = xv_cdiv(rows, CS_ROWS);
     XV_REQUIRE((size_t)chunks * n * sizeof(float) <= ws_bytes, "colsum: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(xv_cdiv(n, 256), chunks), dim3(256), 0, s, a, rows, n, (long)lda, (float*)ws);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(xv_cdiv(n, 64), chunks), dim3(256), 0, s, a, rows, n, (long)lda, (float*)ws);
     XV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(xv_cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, chunks, n, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(xv_cdiv(n, 32)), dim3(256), 0, s, (const float*)ws, chunks, n, out);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -169,23 +192,40 @@ extern "C" int xv_col_stats(void* stream, const float* z, int rows, int n, int l
 // ------------------------------------------------------------------------------------
 // BatchNorm
 // ------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int rows, int n, int tiles,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, int unbiased, float* __restrict__ mmean, float* __restrict__ mvar,
-                                   float* __restrict__ mean_o, float* __restrict__ invstd_o,
-                                   float* __restrict__ scale_o, float* __restrict__ shift_o) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    // Chan et al. pairwise combine of per-tile (count, sum, M2) in double (<= a few hundred terms)
-    double total = 0.0;
-    for (int t = 0; t < tiles; ++t) total += (double)part[(long)t * n + c];
-    double mean = total / (double)rows;
-    double m2 = 0.0;
-    for (int t = 0; t < tiles; ++t) {
-        int cnt = min(XV_TILE_M, rows - t * XV_TILE_M);
-        double tm = (double)(part[(long)t * n + c] / (float)cnt);   // same tile mean the producer centred on
-        double d = tm - mean;
-        m2 += (double)part[((long)tiles + t) * n + c] + d * d * (double)cnt;
+// block = 256 threads = 32 channels x 8 tile lanes.  Each lane folds its tiles' (count, mean, M2)
+// with Chan's pairwise formula in double, lanes are then folded in lane order (deterministic).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int n, int tiles,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          float momentum, int unbiased, float* __restrict__ mmean,
+                                                          float* __restrict__ mvar, float* __restrict__ mean_o,
+                                                          float* __restrict__ invstd_o, float* __restrict__ scale_o,
+                                                          float* __restrict__ shift_o) {
+    __shared__ double s_cnt[8][32], s_mean[8][32], s_m2[8][32];
+    const int cx = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    double cnt = 0.0, mean = 0.0, m2 = 0.0;
+    if (c < n) {
+        for (int t = tl; t < tiles; t += 8) {
+            int tc = min(XV_TILE_M, rows - t * XV_TILE_M);
+            double tm = (double)(part[(long)t * n + c] / (float)tc);   // the tile mean the producer centred on
+            double tq = (double)part[((long)tiles + t) * n + c];
+            double nn = cnt + (double)tc, d = tm - mean;
+            mean += d * ((double)tc / nn);
+            m2 += tq + d * d * (cnt * (double)tc / nn);
+            cnt = nn;
+        }
+    }
+    s_cnt[tl][cx] = cnt; s_mean[tl][cx] = mean; s_m2[tl][cx] = m2;
+    __syncthreads();
+    if (tl != 0 || c >= n) return;
+    for (int k = 1; k < 8; ++k) {
+        double cb = s_cnt[k][cx];
+        if (cb > 0.0) {
+            double nn = cnt + cb, d = s_mean[k][cx] - mean;
+            mean += d * (cb / nn);
+            m2 += s_m2[k][cx] + d * d * (cnt * cb / nn);
+            cnt = nn;
+        }
     }
     float var = (float)(m2 / (double)rows);
     float meanf = (float)mean;
@@ -207,7 +247,7 @@ extern "C" int xv_bn_finalize(void* stream, const float* bn_part, int rows, int 
                               float* mean, float* invstd, float* scale, float* shift) {
     XV_REQUIRE(rows > 0 && n > 0, "bn_finalize: bad shape");
     int tiles = xv_cdiv(rows, XV_TILE_M);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(xv_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, bn_part, rows, n, tiles,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(xv_cdiv(n, 32)), dim3(256), 0, (hipStream_t)stream, bn_part, rows, n, tiles,
                        gamma, beta, eps, momentum, unbiased_moving, moving_mean, moving_var, mean, invstd, scale, shift);
     XV_LAUNCH_CHECK();
     return 0;
@@ -300,15 +340,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int n, int rows,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef /* [2][n] */) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
+// block = 256 threads = 32 channels x 8 chunk lanes, fixed-order combine
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int n, int rows,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef /* [2][n] */) {
+    __shared__ float r1[8][32], r2[8][32];
+    const int cx = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < chunks; ++k) {
-        s1 += part[((long)k * 2 + 0) * n + c];
-        s2 += part[((long)k * 2 + 1) * n + c];
-    }
+    if (c < n)
+        for (int k = cl; k < chunks; k += 8) {
+            s1 += part[((long)k * 2 + 0) * n + c];
+            s2 += part[((long)k * 2 + 1) * n + c];
+        }
+    r1[cl][cx] = s1; r2[cl][cx] = s2;
+    __syncthreads();
+    if (cl != 0 || c >= n) return;
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; }
     dbeta[c] = s1;
     dgamma[c] = s2;
     coef[c] = s1 / (float)rows;
@@ -360,7 +410,7 @@ extern "C" int xv_bn_relu_backward(void* stream, const float* da, const float* z
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s, da, z, rows, n, mean, invstd,
                        scale, shift, relu, part);
     XV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, 128)), dim3(128), 0, s, (const float*)part, chunks, n, rows,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, 32)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
                        dgamma, dbeta, coef);
     XV_LAUNCH_CHECK();
     long total = (long)segs * (t + 2 * pad) * (n / 4);

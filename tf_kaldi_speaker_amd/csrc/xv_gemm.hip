@@ -36,7 +36,23 @@ struct NTArgs {
     int tiles_m, tiles_n;
     const float* bias;
     float* part_sum; float* part_m2;
+    const float* zero;
 };
+
+// Out-of-range rows / k read this 16-byte zero page instead of being masked after the load: the
+// select is on the ADDRESS, so every global_load is unconditional and hipcc neither branches
+// around it nor drains vmcnt right behind it (the first build waited vmcnt(0) four times per
+// K-step at the top of the loop: profiles/r01_first_bench.json, 53 % of the MFMA roof).
+// The page is ordinary hipMalloc'd global memory handed in through the kernel arguments (a
+// __device__ constant made the selected pointer generic -> flat_load, which also counts on
+// lgkmcnt and so serialised the LDS fragment reads behind the global loads).
+static float* g_zero_page = nullptr;
+static int ensure_zero_page() {
+    if (g_zero_page) return 0;
+    XV_CHECK_HIP(hipMalloc((void**)&g_zero_page, 256));
+    XV_CHECK_HIP(hipMemset(g_zero_page, 0, 256));
+    return 0;
+}
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     // blocks b and b+8 share an XCD (round-robin dispatch): hand each XCD a contiguous run of
@@ -77,17 +93,16 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_nt_kernel(NTArgs p) {
         bp[i] = p.Bt + (long)(bv[i] ? n : 0) * p.ldb;
     }
     f32x4 ra[4], rb[4];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ zp = p.zero;
     auto gload = [&](int kt) {
         int k = k_begin + kt * BK + lk;
         bool kv = k < k_end;
-        int kc = kv ? k : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f32x4 va = *(const f32x4*)(ap[i] + kc);
-            f32x4 vb = *(const f32x4*)(bp[i] + kc);
-            ra[i] = (kv && av[i]) ? va : zero4;
-            rb[i] = (kv && bv[i]) ? vb : zero4;
+            const float* pa = (kv && av[i]) ? ap[i] + k : zp;
+            const float* pb = (kv && bv[i]) ? bp[i] + k : zp;
+            ra[i] = *(const f32x4*)pa;
+            rb[i] = *(const f32x4*)pb;
         }
     };
     auto lstore = [&](int buf) {
@@ -278,7 +293,9 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     XV_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm_nt: K/lda/ldb must be multiples of 4 (K=%d lda=%ld ldb=%ld)", g.K, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0, "gemm_nt: operands must be 16-byte aligned");
     XV_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.a_rps > 0, "gemm_nt: empty problem");
+    if (ensure_zero_page()) return 1;
     NTArgs p;
+    p.zero = g_zero_page;
     p.A = g.A; p.lda = g.lda; p.a_rps = g.a_rps; p.a_pitch = g.a_pitch;
     p.Bt = g.Bt; p.ldb = g.ldb;
     p.M = g.M; p.N = g.N; p.K = g.K;
@@ -288,7 +305,7 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     const int ksteps = xv_cdiv(g.K, BK);
     int splits = 1;
     if (!g.bn_part && tiles < 192 && ksteps >= 8) {
-        splits = xv_cdiv(512, tiles);
+        splits = 512 / tiles;
         if (splits > ksteps / 4) splits = ksteps / 4;
         if (splits < 1) splits = 1;
         const long np = (long)xv_align(g.N, 4);
@@ -334,13 +351,22 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
 // TN: weight gradients
 // -------------------------------------------------------------------------------------
 struct TNArgs {
-    const float* A; long lda; int a_rps; int a_pitch;
-    const float* B; long ldb; int b_rps; int b_pitch;
+    const float* A; long lda; int a_pitch;
+    const float* B; long ldb; int b_pitch;
+    int rps; float inv_rps;
     float* P;
     int M, N, R, r_chunk;
     int tiles_m, tiles_n;
+    const float* zero;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// LDS image [r][128] (output index contiguous, exactly as it sits in HBM: no transpose).
+// Fragment reads are ds_read_b64: lane i of a lane-half takes output rows 2i and 2i+1 of the
+// wave's 64 at reduction row r = 2*ks + half, which feed the two 32x32 accumulators in that
+// direction (the MFMA only needs A and B to agree on r).  So accumulator (a,b) register reg of
+// lane l holds  m = m0 + wr*64 + 2*row(reg,l) + a,  n = n0 + wc*64 + 2*(l&31) + b.
 __global__ __launch_bounds__(256, 2) void xv_gemm_tn_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * BM];   // [buf][A|B][32][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -357,32 +383,24 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_tn_kernel(TNArgs p) {
     // thread owns reduction rows lr+8i of each K-step, 4 consecutive output columns at lc
     const int lr = tid >> 5, lc = (tid & 31) * 4;
     const bool a_cv = (m0 + lc) < p.M, b_cv = (n0 + lc) < p.N;
-    const int a_col = a_cv ? m0 + lc : 0, b_col = b_cv ? n0 + lc : 0;
-    // incremental row maps (no division in the loop)
-    int a_seg[4], a_t[4], b_seg[4], b_t[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int r = r_begin + lr + 8 * i;
-        a_seg[i] = r / p.a_rps; a_t[i] = r - a_seg[i] * p.a_rps;
-        b_seg[i] = r / p.b_rps; b_t[i] = r - b_seg[i] * p.b_rps;
-    }
+    const float* __restrict__ zp = p.zero;
+    const float* abase = p.A + (a_cv ? m0 + lc : 0);
+    const float* bbase = p.B + (b_cv ? n0 + lc : 0);
     f32x4 ra[4], rb[4];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int r = r_begin + kt * BK + lr + 8 * i;
             bool rv = r < r_end;
-            long arow = rv ? ((long)a_seg[i] * p.a_pitch + a_t[i]) : 0;
-            long brow = rv ? ((long)b_seg[i] * p.b_pitch + b_t[i]) : 0;
-            f32x4 va = *(const f32x4*)(p.A + arow * p.lda + a_col);
-            f32x4 vb = *(const f32x4*)(p.B + brow * p.ldb + b_col);
-            ra[i] = (rv && a_cv) ? va : zero4;
-            rb[i] = (rv && b_cv) ? vb : zero4;
-            a_t[i] += BK;
-            while (a_t[i] >= p.a_rps) { a_t[i] -= p.a_rps; ++a_seg[i]; }
-            b_t[i] += BK;
-            while (b_t[i] >= p.b_rps) { b_t[i] -= p.b_rps; ++b_seg[i]; }
+            // seg = r / rps without an integer divide (r < 2^24, so the float quotient is off by <= 1)
+            int seg = (int)((float)r * p.inv_rps);
+            int tt = r - seg * p.rps;
+            seg += (tt >= p.rps) - (tt < 0);
+            tt = r - seg * p.rps;
+            const float* pa = (rv && a_cv) ? abase + ((long)seg * p.a_pitch + tt) * p.lda : zp;
+            const float* pb = (rv && b_cv) ? bbase + ((long)seg * p.b_pitch + tt) * p.ldb : zp;
+            ra[i] = *(const f32x4*)pa;
+            rb[i] = *(const f32x4*)pb;
         }
     };
     auto lstore = [&](int buf) {
@@ -408,36 +426,57 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_tn_kernel(TNArgs p) {
         lstore(0);
     }
     __syncthreads();
-    const int a_off = lh * BM + wr * 64 + li;
-    const int b_off = lh * BN + wc * 64 + li;
+    const int a_off = lh * BM + wr * 64 + 2 * li;
+    const int b_off = lh * BN + wc * 64 + 2 * li;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
-        const float* sa = smem + buf * (2 * BK * BM);
-        const float* sb = sa + BK * BM;
+        const float* sa = smem + buf * (2 * BK * BM) + a_off;
+        const float* sb = smem + buf * (2 * BK * BM) + BK * BM + b_off;
+        // Software pipeline over the two halves of the K-step: the second half's 16 fragment reads
+        // are issued BEFORE the first half's 32 MFMAs.  sched_barrier pins that order - hipcc's
+        // scheduler otherwise sinks every ds_read to just in front of its use and exposes the LDS
+        // latency once per 8 MFMAs.
+        f32x2 af[BK / 4], bf[BK / 4], an[BK / 4], bn[BK / 4];
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            float a0 = sa[a_off + 2 * ks * BM], a1 = sa[a_off + 2 * ks * BM + 32];
-            float b0 = sb[b_off + 2 * ks * BN], b1 = sb[b_off + 2 * ks * BN + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int j = 0; j < BK / 4; ++j) {
+            af[j] = *(const f32x2*)(sa + 2 * j * BM);
+            bf[j] = *(const f32x2*)(sb + 2 * j * BN);
+        }
+#pragma unroll
+        for (int j = 0; j < BK / 4; ++j) {
+            an[j] = *(const f32x2*)(sa + 2 * (BK / 4 + j) * BM);
+            bn[j] = *(const f32x2*)(sb + 2 * (BK / 4 + j) * BN);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < BK / 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BK / 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].y, acc[1][1], 0, 0, 0);
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
     float* P = p.P + (long)blockIdx.z * p.M * p.N;
+    const int n = n0 + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            int n = n0 + wc * 64 + b * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M && n < p.N) P[(long)m * p.N + n] = acc[a][b][r];
+        for (int r = 0; r < 16; ++r) {
+            int m = m0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;
+            if (m < p.M && n < p.N) {
+                f32x2 v = {acc[a][0][r], acc[a][1][r]};
+                *(f32x2*)(P + (long)m * p.N + n) = v;
             }
         }
 }
@@ -445,7 +484,10 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_tn_kernel(TNArgs p) {
 int xv_tn_splits(int M, int N, int R) {
     int tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
     int ksteps = xv_cdiv(R, BK);
-    int splits = xv_cdiv(512, tiles);
+    // 2 workgroups are resident per CU (LDS 64 KB each): keep tiles*splits <= 512 so the whole
+    // grid is ONE co-resident round.  (560 workgroups = 512 + a 48-workgroup second round cost
+    // 2x on the first build: 61 TF on tdnn2/3, 24 TF on tdnn5.)
+    int splits = 512 / tiles;
     if (splits > ksteps / 2) splits = ksteps / 2;
     if (splits < 1) splits = 1;
     int chunk = xv_cdiv(ksteps, splits) * BK;
@@ -457,9 +499,14 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
                "gemm_tn: M/N/lda/ldb must be multiples of 4 (M=%d N=%d lda=%ld ldb=%ld)", g.M, g.N, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm_tn: operands must be 16-byte aligned");
     XV_REQUIRE(g.M > 0 && g.N > 0 && g.R > 0 && g.splits >= 1, "gemm_tn: empty problem");
+    if (ensure_zero_page()) return 1;
     TNArgs p;
-    p.A = g.A; p.lda = g.lda; p.a_rps = g.a_rps; p.a_pitch = g.a_pitch;
-    p.B = g.B; p.ldb = g.ldb; p.b_rps = g.b_rps; p.b_pitch = g.b_pitch;
+    p.zero = g_zero_page;
+    XV_REQUIRE(g.a_rps == g.b_rps && g.a_rps > 0, "gemm_tn: both operands must share the rows-per-segment");
+    XV_REQUIRE(g.R < (1 << 24), "gemm_tn: at most 2^24 reduction rows");
+    p.A = g.A; p.lda = g.lda; p.a_pitch = g.a_pitch;
+    p.B = g.B; p.ldb = g.ldb; p.b_pitch = g.b_pitch;
+    p.rps = g.a_rps; p.inv_rps = 1.0f / (float)g.a_rps;
     p.P = g.P; p.M = g.M; p.N = g.N; p.R = g.R;
     p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
     int ksteps = xv_cdiv(g.R, BK);

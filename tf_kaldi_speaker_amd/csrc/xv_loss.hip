@@ -31,12 +31,22 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // inv_norm[n] = rsqrt(max(sum_c w[c][n]^2, 1e-12))   (tf.nn.l2_normalize(w, dim=0), loss.py:104)
-__global__ void col_inv_norm_kernel(const float* __restrict__ w, int C, int N, int normalize, float* __restrict__ inv) {
-    int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    if (!normalize) { inv[n] = 1.f; return; }
+// block = 256 threads = 32 columns x 8 row lanes (rows c = lane, lane+8, ...), fixed-order combine
+__global__ __launch_bounds__(256) void col_inv_norm_kernel(const float* __restrict__ w, int C, int N, int normalize,
+                                                           float* __restrict__ inv) {
+    __shared__ float red[8][32];
+    const int cx = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + cx;
     float ss = 0.f;
-    for (int c = 0; c < C; ++c) { float v = w[(long)c * N + n]; ss += v * v; }
+    if (n < N && normalize)
+        for (int c = rl; c < C; c += 8) { float v = w[(long)c * N + n]; ss += v * v; }
+    red[rl][cx] = ss;
+    __syncthreads();
+    if (rl != 0 || n >= N) return;
+    if (!normalize) { inv[n] = 1.f; return; }
+    ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ss += red[k][cx];
     inv[n] = rsqrtf(fmaxf(ss, 1e-12f));
 }
 
@@ -64,7 +74,7 @@ extern "C" int xv_loss_prep_weight(void* stream, const float* w, int c, int n, i
                                    float* wnt) {
     XV_REQUIRE(c > 0 && n > 0 && ldn >= n, "loss_prep_weight: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(col_inv_norm_kernel, dim3(xv_cdiv(n, 256)), dim3(256), 0, s, w, c, n, normalize, inv_norm);
+    hipLaunchKernelGGL(col_inv_norm_kernel, dim3(xv_cdiv(n, 32)), dim3(256), 0, s, w, c, n, normalize, inv_norm);
     XV_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_prep_weight_kernel, dim3(xv_cdiv(ldn, 32), xv_cdiv(c, 32)), dim3(256), 0, s, w, c, n,
                        (const float*)inv_norm, wn, ldn, wnt);
@@ -220,13 +230,21 @@ extern "C" int xv_add_norm_grad(void* stream, const float* x, const float* dnorm
     return 0;
 }
 
-// dot[n] = sum_c dwn[c][n] * wn[c][n]
-__global__ void col_dot_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb, int C, int N,
-                               float* __restrict__ dot) {
-    int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// dot[n] = sum_c dwn[c][n] * wn[c][n]      (32 columns x 8 row lanes per block)
+__global__ __launch_bounds__(256) void col_dot_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                      int C, int N, float* __restrict__ dot) {
+    __shared__ float red[8][32];
+    const int cx = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + cx;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += a[(long)c * lda + n] * b[(long)c * ldb + n];
+    if (n < N)
+        for (int c = rl; c < C; c += 8) s += a[(long)c * lda + n] * b[(long)c * ldb + n];
+    red[rl][cx] = s;
+    __syncthreads();
+    if (rl != 0 || n >= N) return;
+    s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][cx];
     dot[n] = s;
 }
 __global__ void loss_weight_bwd_kernel(const float* __restrict__ dwn, long lddwn, const float* __restrict__ wn, long ldn,
@@ -252,7 +270,7 @@ extern "C" int xv_loss_weight_backward(void* stream, const float* dwn, int lddwn
     hipStream_t s = (hipStream_t)stream;
     float* dot_buf = (float*)ws;
     if (normalize) {
-        hipLaunchKernelGGL(col_dot_kernel, dim3(xv_cdiv(n, 256)), dim3(256), 0, s, dwn, (long)lddwn, wn, (long)ldn, c, n, dot_buf);
+        hipLaunchKernelGGL(col_dot_kernel, dim3(xv_cdiv(n, 32)), dim3(256), 0, s, dwn, (long)lddwn, wn, (long)ldn, c, n, dot_buf);
         XV_LAUNCH_CHECK();
     }
     long total = (long)c * n;
