@@ -47,7 +47,15 @@ static inline size_t xv_align(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // ---- GEMM geometry shared between launchers and the engine -------------------------
 #define XV_TILE_M 128
 #define XV_TILE_N 128
-#define XV_TILE_K 32
+#ifndef XV_TILE_K
+#define XV_TILE_K 16
+#endif
+// workgroups of 256 threads that are resident per CU (== waves per SIMD); LDS and VGPR budgets of
+// both GEMM kernels are sized for it, and the split policies aim at one co-resident round.
+#ifndef XV_WGS_PER_CU
+#define XV_WGS_PER_CU (XV_TILE_K == 16 ? 4 : 2)
+#endif
+#define XV_RESIDENT_WGS (256 * XV_WGS_PER_CU)
 
 // Internal GEMM launchers (xv_gemm.hip).
 // C[m][n] (+)= sum_k A[rowmap(m)][k] * Bt[n][k]   ("NT", both operands k-contiguous)

@@ -26,7 +26,12 @@
 #define BM XV_TILE_M
 #define BN XV_TILE_N
 #define BK XV_TILE_K
-#define NT_PITCH 36   // floats; 36/4 = 9 is odd => ds_read_b128 of 16 distinct rows hits 16 distinct 16-B slots
+#define NT_PITCH (BK + 4)   // floats; (BK+4)/4 is odd (9 or 5) => ds_read_b128 of 16 distinct rows hits 16 distinct 16-B slots
+static_assert(BK == 16 || BK == 32, "K-step must be 16 or 32");
+#define NT_KQ (BK / 4)               // float4 per tile row
+#define NT_RPT (BM * NT_KQ / 256)    // tile rows staged per thread (2 or 4)
+#define NT_RSTRIDE (256 / NT_KQ)     // row distance between a thread's staged rows
+#define TN_RPT (BK / 8)              // reduction rows staged per thread (2 or 4)
 
 struct NTArgs {
     const float* A; long lda; int a_rps; int a_pitch;
@@ -63,7 +68,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(256, 2) void xv_gemm_nt_kernel(NTArgs p) {
+__global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * NT_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -77,28 +82,28 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_nt_kernel(NTArgs p) {
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
     // ---- global -> register staging: thread owns rows lrow+32i, 4 consecutive k at lk
-    const int lrow = tid >> 3, lk = (tid & 7) * 4;
-    const float* ap[4];
-    const float* bp[4];
-    bool av[4], bv[4];
+    const int lrow = tid / NT_KQ, lk = (tid % NT_KQ) * 4;
+    const float* ap[NT_RPT];
+    const float* bp[NT_RPT];
+    bool av[NT_RPT], bv[NT_RPT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = m0 + lrow + 32 * i;
+    for (int i = 0; i < NT_RPT; ++i) {
+        int m = m0 + lrow + NT_RSTRIDE * i;
         av[i] = m < p.M;
         int mm = av[i] ? m : 0;
         int seg = mm / p.a_rps, tt = mm - seg * p.a_rps;
         ap[i] = p.A + ((long)seg * p.a_pitch + tt) * p.lda;
-        int n = n0 + lrow + 32 * i;
+        int n = n0 + lrow + NT_RSTRIDE * i;
         bv[i] = n < p.N;
         bp[i] = p.Bt + (long)(bv[i] ? n : 0) * p.ldb;
     }
-    f32x4 ra[4], rb[4];
+    f32x4 ra[NT_RPT], rb[NT_RPT];
     const float* __restrict__ zp = p.zero;
     auto gload = [&](int kt) {
         int k = k_begin + kt * BK + lk;
         bool kv = k < k_end;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NT_RPT; ++i) {
             const float* pa = (kv && av[i]) ? ap[i] + k : zp;
             const float* pb = (kv && bv[i]) ? bp[i] + k : zp;
             ra[i] = *(const f32x4*)pa;
@@ -109,9 +114,9 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_nt_kernel(NTArgs p) {
         float* sa = smem + buf * (2 * BM * NT_PITCH);
         float* sb = sa + BM * NT_PITCH;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(f32x4*)(sa + (lrow + 32 * i) * NT_PITCH + lk) = ra[i];
-            *(f32x4*)(sb + (lrow + 32 * i) * NT_PITCH + lk) = rb[i];
+        for (int i = 0; i < NT_RPT; ++i) {
+            *(f32x4*)(sa + (lrow + NT_RSTRIDE * i) * NT_PITCH + lk) = ra[i];
+            *(f32x4*)(sb + (lrow + NT_RSTRIDE * i) * NT_PITCH + lk) = rb[i];
         }
     };
 
@@ -304,8 +309,8 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     const int tiles = p.tiles_m * p.tiles_n;
     const int ksteps = xv_cdiv(g.K, BK);
     int splits = 1;
-    if (!g.bn_part && tiles < 192 && ksteps >= 8) {
-        splits = 512 / tiles;
+    if (!g.bn_part && tiles < XV_RESIDENT_WGS / 2 && ksteps >= 8) {
+        splits = XV_RESIDENT_WGS / tiles;
         if (splits > ksteps / 4) splits = ksteps / 4;
         if (splits < 1) splits = 1;
         const long np = (long)xv_align(g.N, 4);
@@ -367,7 +372,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // wave's 64 at reduction row r = 2*ks + half, which feed the two 32x32 accumulators in that
 // direction (the MFMA only needs A and B to agree on r).  So accumulator (a,b) register reg of
 // lane l holds  m = m0 + wr*64 + 2*row(reg,l) + a,  n = n0 + wc*64 + 2*(l&31) + b.
-__global__ __launch_bounds__(256, 2) void xv_gemm_tn_kernel(TNArgs p) {
+__global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * BM];   // [buf][A|B][32][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -386,10 +391,10 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_tn_kernel(TNArgs p) {
     const float* __restrict__ zp = p.zero;
     const float* abase = p.A + (a_cv ? m0 + lc : 0);
     const float* bbase = p.B + (b_cv ? n0 + lc : 0);
-    f32x4 ra[4], rb[4];
+    f32x4 ra[TN_RPT], rb[TN_RPT];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TN_RPT; ++i) {
             int r = r_begin + kt * BK + lr + 8 * i;
             bool rv = r < r_end;
             // seg = r / rps without an integer divide (r < 2^24, so the float quotient is off by <= 1)
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_tn_kernel(TNArgs p) {
         float* sa = smem + buf * (2 * BK * BM);
         float* sb = sa + BK * BM;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TN_RPT; ++i) {
             *(f32x4*)(sa + (lr + 8 * i) * BM + lc) = ra[i];
             *(f32x4*)(sb + (lr + 8 * i) * BN + lc) = rb[i];
         }
@@ -487,7 +492,7 @@ int xv_tn_splits(int M, int N, int R) {
     // 2 workgroups are resident per CU (LDS 64 KB each): keep tiles*splits <= 512 so the whole
     // grid is ONE co-resident round.  (560 workgroups = 512 + a 48-workgroup second round cost
     // 2x on the first build: 61 TF on tdnn2/3, 24 TF on tdnn5.)
-    int splits = 512 / tiles;
+    int splits = XV_RESIDENT_WGS / tiles;
     if (splits > ksteps / 2) splits = ksteps / 2;
     if (splits < 1) splits = 1;
     int chunk = xv_cdiv(ksteps, splits) * BK;
