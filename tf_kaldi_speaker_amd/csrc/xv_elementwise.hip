@@ -164,27 +164,51 @@ extern "C" int xv_colsum(void* stream, const float* a, int rows, int n, int lda,
 }
 
 // bn_part layout: [2][tiles][n] with tiles = ceil(rows / XV_TILE_M): sum, then centred sum of squares.
-__global__ void col_stats_kernel(const float* __restrict__ z, int rows, int n, long ldz, float* __restrict__ part, int tiles) {
-    int col = blockIdx.x * blockDim.x + threadIdx.x;
-    int tile = blockIdx.y;
-    int r0 = tile * XV_TILE_M, r1 = min(rows, r0 + XV_TILE_M);
-    if (col >= n) return;
+// block = 256 threads = 32 columns x 8 row lanes over one 128-row tile; two passes (sum, then
+// squares centred on the tile mean) with fixed-order combines through LDS.
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ z, int rows, int n, long ldz,
+                                                        float* __restrict__ part, int tiles) {
+    __shared__ float red[8][32];
+    __shared__ float s_mean[32];
+    const int cx = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cx;
+    const int tile = blockIdx.y;
+    const int r0 = tile * XV_TILE_M, r1 = min(rows, r0 + XV_TILE_M);
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += z[(long)r * ldz + col];
-    float mean = s / (float)(r1 - r0);
-    float q = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        float d = z[(long)r * ldz + col] - mean;
-        q += d * d;
+    if (col < n)
+        for (int r = r0 + rl; r < r1; r += 8) s += z[(long)r * ldz + col];
+    red[rl][cx] = s;
+    __syncthreads();
+    if (rl == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cx];
+        if (col < n) part[(long)tile * n + col] = t;
+        s_mean[cx] = t / (float)(r1 - r0);
     }
-    part[(long)tile * n + col] = s;
-    part[((long)tiles + tile) * n + col] = q;
+    __syncthreads();
+    const float mean = s_mean[cx];
+    float q = 0.f;
+    if (col < n)
+        for (int r = r0 + rl; r < r1; r += 8) {
+            float d = z[(long)r * ldz + col] - mean;
+            q += d * d;
+        }
+    __syncthreads();
+    red[rl][cx] = q;
+    __syncthreads();
+    if (rl == 0 && col < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cx];
+        part[((long)tiles + tile) * n + col] = t;
+    }
 }
 
 extern "C" int xv_col_stats(void* stream, const float* z, int rows, int n, int ldz, float* bn_part) {
     XV_REQUIRE(rows > 0 && n > 0 && ldz >= n, "col_stats: bad shape");
     int tiles = xv_cdiv(rows, XV_TILE_M);
-    hipLaunchKernelGGL(col_stats_kernel, dim3(xv_cdiv(n, 128), tiles), dim3(128), 0, (hipStream_t)stream, z, rows, n, (long)ldz, bn_part, tiles);
+    hipLaunchKernelGGL(col_stats_kernel, dim3(xv_cdiv(n, 32), tiles), dim3(256), 0, (hipStream_t)stream, z, rows, n, (long)ldz, bn_part, tiles);
     XV_LAUNCH_CHECK();
     return 0;
 }

@@ -56,7 +56,8 @@ struct xv_engine {
     // device arena
     char* arena = nullptr;
     size_t arena_bytes = 0, arena_used = 0;
-    float *xpad = nullptr, *pool = nullptr, *h7 = nullptr, *out = nullptr;
+    float *xpad = nullptr, *pool = nullptr, *h7_buf = nullptr, *out_buf = nullptr;
+    float *h7 = nullptr, *out = nullptr;   // views of the most recent forward (may alias tdnn7's z / h7)
     float *logits = nullptr, *dlogits = nullptr, *dnorm = nullptr, *row_loss = nullptr;
     float *inv_norm = nullptr, *wn = nullptr, *wnt = nullptr, *dwn = nullptr;
     float *bufD = nullptr, *bufZ = nullptr, *d_small0 = nullptr, *d_small1 = nullptr;
@@ -65,6 +66,7 @@ struct xv_engine {
     size_t ws_bytes = 0;
     int32_t* labels_dev = nullptr;   // caller's pointer of the current step
     bool weights_dirty = true;
+    bool reg_valid = false;
     // state of the most recent forward
     int B = 0, T = 0, training = 0;
     int Tl[6] = {0, 0, 0, 0, 0, 0};   // frames after each frame layer (index 0 = input)
@@ -231,8 +233,8 @@ int alloc_buffers(xv_engine* e) {
         a.rows = 0;
     }
     e->pool = carve(e, B * 2 * e->P);
-    e->h7 = carve(e, B * e->Lout);
-    e->out = carve(e, B * e->Lout);
+    e->h7_buf = carve(e, B * e->Lout);
+    e->out_buf = carve(e, B * e->Lout);
     if (e->N > 0) {
         e->logits = carve(e, B * e->ldl); e->dlogits = carve(e, B * e->ldl);
         e->dnorm = carve(e, B); e->row_loss = carve(e, B);
@@ -394,23 +396,23 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
     rc = xv_affine_forward(s, l6.a, b, 1, l7.c_pad, 1, l7.wt, vptr(e, l7.v_bias), l7.z, l7.c_out, l7.c_out, nullptr, e->ws, e->ws_bytes);
     if (rc) return rc;
     l7.rows = b;
-    const size_t bytes7 = (size_t)b * l7.c_out * sizeof(float);
     if (l7.has_bn) {
-        rc = bn_forward(e, s, l7, b, false, e->h7);
+        rc = bn_forward(e, s, l7, b, false, e->h7_buf);
         if (rc) return rc;
+        e->h7 = e->h7_buf;
     } else if (l7.has_relu) {
-        // relu(z) = bn_apply with scale 1 / shift 0 is overkill; reuse l2-free path: copy then clamp
-        XV_CHECK_HIP(hipMemcpyAsync(e->h7, l7.z, bytes7, hipMemcpyDeviceToDevice, s));
-        rc = xv_relu_backward(s, e->h7, e->h7, (size_t)b * l7.c_out, e->h7);   // x>0 ? x : 0
+        rc = xv_relu_backward(s, l7.z, l7.z, (size_t)b * l7.c_out, e->h7_buf);   // z > 0 ? z : 0
         if (rc) return rc;
+        e->h7 = e->h7_buf;
     } else {
-        XV_CHECK_HIP(hipMemcpyAsync(e->h7, l7.z, bytes7, hipMemcpyDeviceToDevice, s));
+        e->h7 = l7.z;
     }
     if (e->cfg.feature_norm) {
-        rc = xv_l2_scaling_forward(s, e->h7, b, l7.c_out, e->cfg.feature_scaling_factor, e->out);
+        rc = xv_l2_scaling_forward(s, e->h7, b, l7.c_out, e->cfg.feature_scaling_factor, e->out_buf);
         if (rc) return rc;
+        e->out = e->out_buf;
     } else {
-        XV_CHECK_HIP(hipMemcpyAsync(e->out, e->h7, bytes7, hipMemcpyDeviceToDevice, s));
+        e->out = e->h7;
     }
     return 0;
 }
@@ -444,14 +446,27 @@ extern "C" int xv_engine_loss_forward(xv_engine* e, void* stream, const int32_t*
     rc = xv_margin_softmax_rows(s, kind, e->logits, b, e->N, e->ldl, e->out, e->Lout, labels, m, e->lambda, e->dlogits, e->dnorm,
                                 e->row_loss, e->scalars + 0);
     if (rc) return rc;
-    // regularization_loss, trainer.py:357-358
+    e->reg_valid = false;
+    return 0;
+}
+
+// regularization_loss, trainer.py:357-358.  It does not feed any gradient (the L2 term is added
+// analytically in the weight-gradient reduce), so it is only evaluated when the host asks for it
+// (the reference fetches it on logging steps only, trainer.py:485-499).
+static int compute_reg_loss(xv_engine* e, hipStream_t s) {
+    const xv_config& c = e->cfg;
     XV_CHECK_HIP(hipMemsetAsync(e->scalars + 1, 0, sizeof(float), s));
     for (int i = 0; i < 7; ++i) {
-        rc = xv_l2_reg_loss(s, vptr(e, e->L[i].v_kernel), e->vars[e->L[i].v_kernel].count, c.weight_l2_regularizer, e->scalars + 1);
+        int rc = xv_l2_reg_loss(s, vptr(e, e->L[i].v_kernel), e->vars[e->L[i].v_kernel].count, c.weight_l2_regularizer, e->scalars + 1);
         if (rc) return rc;
     }
-    float ol2 = c.output_weight_l2_regularizer >= 0.f ? c.output_weight_l2_regularizer : c.weight_l2_regularizer;
-    return xv_l2_reg_loss(s, vptr(e, e->v_loss_kernel), e->vars[e->v_loss_kernel].count, ol2, e->scalars + 1);
+    if (e->N > 0) {
+        float ol2 = c.output_weight_l2_regularizer >= 0.f ? c.output_weight_l2_regularizer : c.weight_l2_regularizer;
+        int rc = xv_l2_reg_loss(s, vptr(e, e->v_loss_kernel), e->vars[e->v_loss_kernel].count, ol2, e->scalars + 1);
+        if (rc) return rc;
+    }
+    e->reg_valid = true;
+    return 0;
 }
 
 namespace {
@@ -600,11 +615,16 @@ extern "C" int xv_engine_apply(xv_engine* e, void* stream, float lr, float grad_
     else if (c.optimizer == 1) rc = xv_momentum_update(s, e->V, e->G, e->S, e->n_train, lr, c.momentum, c.use_nesterov, grad_scale);
     else rc = xv_adam_update(s, e->V, e->G, e->S, e->S + e->n_train, e->n_train, lr, 0.9f, 0.999f, 1e-8f, t, grad_scale);
     e->weights_dirty = true;
+    e->reg_valid = false;
     return rc;
 }
 
 extern "C" int xv_engine_loss_ptrs(xv_engine* e, float** raw_loss, float** reg_loss) {
-    XV_REQUIRE(e, "null engine");
+    XV_REQUIRE(e && e->V, "loss_ptrs: engine not bound");
+    if (reg_loss && !e->reg_valid) {
+        int rc = compute_reg_loss(e, e->last_stream);
+        if (rc) return rc;
+    }
     if (raw_loss) *raw_loss = e->scalars + 0;
     if (reg_loss) *reg_loss = e->scalars + 1;
     return 0;

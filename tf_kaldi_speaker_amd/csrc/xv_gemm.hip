@@ -26,7 +26,14 @@
 #define BM XV_TILE_M
 #define BN XV_TILE_N
 #define BK XV_TILE_K
-#define NT_PITCH (BK + 4)   // floats; (BK+4)/4 is odd (9 or 5) => ds_read_b128 of 16 distinct rows hits 16 distinct 16-B slots
+// NT LDS image: [128 rows][BK floats], no padding, 16-byte chunk c of row r stored at chunk
+// c ^ f(r) with f(r) = (r >> NT_SW_SHIFT) & (NT_KQ-1).  ds_read_b128 (banks = 16 slots of 16 B,
+// 16-lane groups reading 16 different rows at one chunk index) sees 16 distinct slots, and
+// ds_write_b128 (8-lane groups = 2 rows x 4 chunks at BK=16) sees 8 distinct slots: the padded
+// image of the first build had 2-way write conflicts at BK=16 (SQ_LDS_BANK_CONFLICT, profiles/).
+#define NT_PITCH BK
+#define NT_SW_SHIFT (BK == 16 ? 2 : 1)
+#define NT_SWZ(row) ((((row) >> NT_SW_SHIFT) & (BK / 4 - 1)))
 static_assert(BK == 16 || BK == 32, "K-step must be 16 or 32");
 #define NT_KQ (BK / 4)               // float4 per tile row
 #define NT_RPT (BM * NT_KQ / 256)    // tile rows staged per thread (2 or 4)
@@ -115,8 +122,10 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
         float* sb = sa + BM * NT_PITCH;
 #pragma unroll
         for (int i = 0; i < NT_RPT; ++i) {
-            *(f32x4*)(sa + (lrow + NT_RSTRIDE * i) * NT_PITCH + lk) = ra[i];
-            *(f32x4*)(sb + (lrow + NT_RSTRIDE * i) * NT_PITCH + lk) = rb[i];
+            const int row = lrow + NT_RSTRIDE * i;
+            const int pos = (((lk >> 2) ^ NT_SWZ(row)) << 2);
+            *(f32x4*)(sa + row * NT_PITCH + pos) = ra[i];
+            *(f32x4*)(sb + row * NT_PITCH + pos) = rb[i];
         }
     };
 
@@ -134,8 +143,9 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
     }
     __syncthreads();
 
-    const int a_off = (wr * 64 + li) * NT_PITCH + 4 * lh;
-    const int b_off = (wc * 64 + li) * NT_PITCH + 4 * lh;
+    const int a_off = (wr * 64 + li) * NT_PITCH;
+    const int b_off = (wc * 64 + li) * NT_PITCH;
+    const int fsw = NT_SWZ(li);     // rows wr*64 + a*32 + li share f(li): the offsets are multiples of 16
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
@@ -144,10 +154,11 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 af[2], bf[2];
-            af[0] = *(const f32x4*)(sa + a_off + 8 * q);
-            af[1] = *(const f32x4*)(sa + a_off + 32 * NT_PITCH + 8 * q);
-            bf[0] = *(const f32x4*)(sb + b_off + 8 * q);
-            bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + 8 * q);
+            const int pos = (((2 * q + lh) ^ fsw) << 2);
+            af[0] = *(const f32x4*)(sa + a_off + pos);
+            af[1] = *(const f32x4*)(sa + a_off + 32 * NT_PITCH + pos);
+            bf[0] = *(const f32x4*)(sb + b_off + pos);
+            bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[0][e], acc[0][0], 0, 0, 0);
@@ -378,10 +389,15 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int t = xcd_swizzle(blockIdx.x, gridDim.x);
+    // 1-D grid over (split, tile): after the XCD swizzle every XCD owns a contiguous run, i.e. whole
+    // reduction chunks, so the rows of A and B that one chunk touches are fetched into ONE L2
+    // (the (tiles, splits) grid of the first build spread every chunk over all 8 XCDs: 51 % hits).
+    const int v = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int split = v / tiles, t = v - split * tiles;
     const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int r_begin = blockIdx.z * p.r_chunk;
+    const int r_begin = split * p.r_chunk;
     const int r_end = min(p.R, r_begin + p.r_chunk);
     const int nk = (r_end - r_begin + BK - 1) / BK;
 
@@ -472,7 +488,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p
         __syncthreads();
     }
 
-    float* P = p.P + (long)blockIdx.z * p.M * p.N;
+    float* P = p.P + (long)split * p.M * p.N;
     const int n = n0 + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -518,7 +534,7 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     p.r_chunk = xv_cdiv(ksteps, g.splits) * BK;
     int splits = xv_cdiv(g.R, p.r_chunk);
     XV_REQUIRE(splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", splits, g.splits);
-    dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
+    dim3 grid(p.tiles_m * p.tiles_n * splits, 1, 1);
     {
         ProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
         hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
