@@ -35,6 +35,27 @@ KIND_NAMES = ["xv_gemm_nt_kernel<true> (forward conv/dense + BN stats)",
               "xv_gemm_tn_kernel (weight gradients)"]
 
 
+KIND_SYMBOLS = ["xv_gemm_nt_kernel<true>", "xv_gemm_nt_kernel<false>", "xv_gemm_tn_kernel"]
+
+
+def pmc_traffic(kind):
+    """HBM-side bytes per launch of the dominant kernel, from the most recent committed rocprofv3 PMC
+    passes (profiles/rNN_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
+    passes).  bench.py cannot run the PMC passes itself, so this is null when no file is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        for name, v in d["kernels"].items():
+            if KIND_SYMBOLS[kind] in name:
+                return int(v["bytes_per_launch_corrected"])
+    except Exception:
+        return None
+    return None
+
+
 def step_flops(b, t, d, n):
     """2*M*K*N per contraction, backward = 2x forward."""
     t1, t2, t3 = t - 4, t - 8, t - 14
@@ -173,7 +194,8 @@ def main():
                        "chunks_per_gpu": B, "frames": T, "feat_dim": D, "num_speakers": NSPK,
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                         "traffic_unit": "bytes/launch past L2 (rocprofv3 PMC, profiles/)",
                          "avg_launch_ms": round(ms[dom] / cnt[dom], 4), "launches": int(cnt[dom]),
                          "algorithmic_flops_per_launch": fl[dom] / cnt[dom]},
             "step_flops": {"algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
