@@ -1,0 +1,129 @@
+"""Drop-in boundary on a real MI355X: the reference's Trainer API surface (build / train / valid /
+predict / save / load) and the train.py / extract.py / make_checkpoint.py drivers on a synthetic Kaldi
+data directory, with embeddings checked against the oracle in inference mode."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import xvector_oracle as O
+from tests.kaldi_fixture import make_data_dir
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "tf_kaldi_speaker_amd")
+
+CONFIG = {
+    "Note": "shape of egs/voxceleb/v1/nnet_conf/tdnn_amsoftmax_m0.20_linear_bn_1e-2.json, shrunk loop counts",
+    "seed": 0, "network_type": "tdnn", "last_layer_no_bn": False, "last_layer_linear": True, "feature_norm": False,
+    "loss_func": "additive_margin_softmax", "amsoftmax_m": 0.20, "amsoftmax_lambda_min": 0, "amsoftmax_lambda_base": 1000,
+    "amsoftmax_lambda_gamma": 0.0001, "amsoftmax_lambda_power": 5,
+    "batch_type": "softmax", "pooling_type": "statistics_pooling", "embedding_node": "tdnn6_dense",
+    "learning_rate": 0.01, "use_nesterov": False, "clip_gradient": False, "clip_gradient_norm": 3,
+    "weight_l2_regularizer": 1e-2, "batchnorm_momentum": 0.99,
+    "num_epochs": 2, "num_steps_per_epoch": 6, "reduce_lr_epochs": 4, "show_training_progress": 2, "keep_checkpoint_max": 100,
+    "save_summary_steps": 10000, "save_checkpoints_steps": 30000, "valid_max_iterations": 1000,
+    "num_parallel_datasets": 2, "max_queue_size": 4, "num_speakers_per_batch": 4, "num_segments_per_speaker": 1,
+    "min_segment_len": 30, "max_segment_len": 50, "early_stop_epochs": 10, "min_learning_rate": 1e-6,
+}
+
+
+def _oracle_cfg(num_speakers):
+    return O.Config(feat_dim=30, num_speakers=num_speakers, loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True)
+
+
+def test_trainer_api_roundtrip(tmp_path):
+    from tf_kaldi_speaker_amd.misc.utils import Params
+    from tf_kaldi_speaker_amd.model.trainer import Trainer
+    data, spklist, mats = make_data_dir(str(tmp_path / "train"), num_spk=6, utts_per_spk=3, min_frames=60, max_frames=110)
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps(CONFIG))
+    params = Params(str(cfg_path))
+    model = str(tmp_path / "exp")
+    os.makedirs(os.path.join(model, "nnet"))
+    tr = Trainer(params, model)
+    with pytest.raises(NotImplementedError):
+        tr.build("train", dim=30, loss_type="no_such_loss", num_speakers=6)
+    tr.build("train", dim=30, loss_type=params.loss_func, num_speakers=6)
+    tr.build("valid", dim=30, loss_type=params.loss_func, num_speakers=6)
+    assert params.dict["num_nodes_pooling_layer"] == 1500 and params.dict["num_nodes_last_layer"] == 512   # defaults inserted
+    before = tr.engine.get_variables()
+    tr.train(data, spklist, 0.01)
+    after = tr.engine.get_variables()
+    assert np.abs(after["tdnn/tdnn3_conv/kernel"] - before["tdnn/tdnn3_conv/kernel"]).max() > 0
+    assert not np.allclose(after["tdnn/tdnn2_bn/moving_mean"], 0)                # UPDATE_OPS ran
+    assert os.path.isfile(os.path.join(model, "nnet", "checkpoint")) and os.path.isfile(os.path.join(model, "nnet", "model-6.npz"))
+    assert 'model_checkpoint_path: "' in open(os.path.join(model, "nnet", "checkpoint")).read()
+    loss, emb, labels = tr.valid(data, spklist, batch_type="softmax", output_embeddings=True)
+    assert np.isfinite(loss) and emb.shape[1] == 512 and emb.shape[0] == labels.shape[0] and emb.shape[0] >= 16
+    tr.train(data, spklist, 0.005)                                                   # second epoch resumes from step 6
+    assert os.path.isfile(os.path.join(model, "nnet", "model-12.npz"))
+    # predict in a fresh Trainer that only builds the predict graph (extract.py:54-58)
+    p2 = Params(str(cfg_path))
+    tr2 = Trainer(p2, model, single_cpu=True)
+    tr2.build("predict", dim=30)
+    feat = next(iter(mats.values()))
+    e1 = tr2.predict(feat)
+    assert e1.shape == (512,)
+    e3 = tr2.predict(np.stack([feat[:40], feat[10:50]]))
+    assert e3.shape == (2, 512)
+    # oracle, inference mode, same variables
+    V = {k: v.astype(np.float64) for k, v in tr.engine.get_variables().items()}
+    _, ep, _ = O.tdnn_forward(V, feat[None].astype(np.float64), _oracle_cfg(6), False)
+    ref = ep["tdnn6_dense"][0]
+    assert np.abs(e1 - ref).max() / np.abs(ref).max() < 1e-4         # north_star: embeddings within 1e-4 relative
+    p2.embedding_node = "output"
+    assert tr2.predict(feat).shape == (512,)
+    tr.close()
+    tr2.close()
+
+
+def test_drivers_as_run_sh_calls_them(tmp_path):
+    """python nnet/lib/train.py ... ; make_checkpoint.py ; extract.py with PYTHONPATH=$TF_KALDI_ROOT (run_train_nnet.sh:30,64)."""
+    data, spklist, mats = make_data_dir(str(tmp_path / "train"), num_spk=6, utts_per_spk=3, min_frames=60, max_frames=110)
+    vdata, vspk, _ = make_data_dir(str(tmp_path / "valid"), num_spk=6, utts_per_spk=2, min_frames=60, max_frames=110, seed=5)
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps(CONFIG))
+    model = str(tmp_path / "exp")
+    os.makedirs(model)
+    env = dict(os.environ, TF_KALDI_ROOT=PKG, PYTHONPATH=PKG)
+    lib = os.path.join(PKG, "nnet", "lib")
+    r = subprocess.run([sys.executable, os.path.join(lib, "train.py"), "--config", str(cfg_path), data, spklist, vdata, vspk, model],
+                       env=env, cwd=PKG, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    nnet = os.path.join(model, "nnet")
+    assert open(os.path.join(nnet, "feature_dim")).read().strip() == "30"
+    lr_lines = open(os.path.join(nnet, "learning_rate")).read().strip().split("\n")
+    vl_lines = open(os.path.join(nnet, "valid_loss")).read().strip().split("\n")
+    assert len(lr_lines) == 3 and lr_lines[0].startswith("0 0.0100") and len(vl_lines) == 2 and len(vl_lines[0].split(" ")) == 3
+    assert os.path.isdir(os.path.join(model, "codes", "model")) and os.path.isfile(os.path.join(nnet, "config.json"))
+    r = subprocess.run([sys.executable, os.path.join(lib, "make_checkpoint.py"), "--checkpoint", "last", model], env=env, cwd=PKG,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "model-12" in r.stdout, r.stderr[-2000:]
+    # extraction: ark in, float-vector ark out; a 130-frame utterance with --chunk-size 60 exercises the split/average path
+    from tf_kaldi_speaker_amd.dataset import kaldi_io
+    ark_in, ark_out = str(tmp_path / "in.ark"), str(tmp_path / "xvector.ark")
+    long_utt = np.concatenate(list(mats.values())[:2])[:130]
+    with open(ark_in, "wb") as f:
+        kaldi_io.write_mat(f, long_utt, key="long")
+        kaldi_io.write_mat(f, list(mats.values())[2], key="short")
+        kaldi_io.write_mat(f, long_utt[:20], key="tiny")           # < --min-chunk-size: skipped
+    r = subprocess.run([sys.executable, os.path.join(lib, "extract.py"), "--node", "tdnn6_dense", "--chunk-size", "60", "--min-chunk-size", "25",
+                        model, "ark:" + ark_in, "ark:" + ark_out], env=env, cwd=PKG, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = dict(kaldi_io.read_vec_flt_ark(ark_out))
+    assert sorted(out) == ["long", "short"] and out["long"].shape == (512,) and out["long"].dtype == np.float32
+    # oracle re-derivation of the chunked embedding from the saved variables
+    ck = np.load(os.path.join(nnet, "model-12.npz"))
+    V = {k: ck[k].astype(np.float64) for k in ck.files if not k.startswith("__")}
+    cfg_o = _oracle_cfg(6)
+    embs, lens = [], []
+    for s, n in [(0, 60), (30, 60), (60, 60), (90, 40)]:
+        _, ep, _ = O.tdnn_forward(V, long_utt[None, s:s + n].astype(np.float64), cfg_o, False)
+        embs.append(ep["tdnn6_dense"][0]); lens.append(n)
+    ref = (np.array(embs) * np.array(lens)[:, None]).sum(0) / sum(lens)
+    assert np.abs(out["long"] - ref).max() / np.abs(ref).max() < 1e-4

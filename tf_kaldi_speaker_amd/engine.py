@@ -10,8 +10,12 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib
-from ._lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, XV_BWD_STAGES
+try:
+    from . import _lib
+    from ._lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, XV_BWD_STAGES
+except ImportError:      # drop-in layout: PYTHONPATH=$TF_KALDI_ROOT makes these top-level modules
+    import _lib
+    from _lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, XV_BWD_STAGES
 
 
 def _ptr(t):
@@ -202,6 +206,14 @@ class Engine(object):
         v = out.cpu().numpy()
         return float(v[0]), float(v[1])
 
+    def raw_loss(self):
+        """Mean loss of the last loss() call (synchronises); does not evaluate the regulariser."""
+        raw = C.c_void_p()
+        _lib.check(self.lib.xv_engine_loss_ptrs(self.h, C.byref(raw), None))
+        out = torch.empty(1, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.xv_copy_2d(_stream(), _ptr(out), 1, raw, 1, 1, 1), "xv_copy_2d")
+        return float(out.cpu().numpy()[0])
+
     def endpoint(self, name):
         """Copy of an endpoint of the most recent forward as a torch tensor [rows, cols]."""
         p = C.c_void_p()
@@ -212,18 +224,23 @@ class Engine(object):
         _lib.check(self.lib.xv_copy_2d(_stream(), _ptr(out), cols.value, p, ld.value, rows.value, cols.value), "xv_copy_2d")
         return out
 
-    def train_step(self, features, labels, lr, global_step, allreduce=None):
+    def train_step(self, features, labels, lr, global_step, allreduce=None, fetch_losses=False):
         """One sess.run(train_op) (trainer.py:505-508).  `allreduce(tensor_slice)` - if given - is
-        called after each backward stage on the finished slice of the flat gradient buffer."""
+        called after each backward stage on the finished slice of the flat gradient buffer.
+        fetch_losses: also return (raw_loss, regularization_loss) evaluated on the PRE-update
+        weights, as the reference's logging fetch does (trainer.py:485-499); this synchronises."""
         self.forward(features, True)
         self.loss(labels, global_step, True)
         if allreduce is None:
             self.backward(-1)
-            self.apply(lr, 1.0)
+            grad_scale = 1.0
         else:
             for st in range(XV_BWD_STAGES):
                 self.backward(st)
                 b, e = self.stage_grad_range(st)
                 allreduce(self.grads[b:e])
             allreduce.wait()
-            self.apply(lr, allreduce.grad_scale)
+            grad_scale = allreduce.grad_scale
+        out = self.losses() if fetch_losses else None
+        self.apply(lr, grad_scale)
+        return out

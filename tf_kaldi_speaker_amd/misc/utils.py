@@ -1,0 +1,263 @@
+"""Config / checkpoint-selection / EER helpers with the reference's misc/utils.py API
+(Params :13, save_codes_and_config :64, load_lr :193, load_valid_loss :203, get_checkpoint :217,
+compute_cos_pairwise_eer :273).  No TensorFlow: the checkpoint *index* file keeps TF's text format
+(`model_checkpoint_path: "..."`), the payload is this repo's own .npz (model/trainer.py)."""
+import json
+import logging
+import os
+import re
+import shutil
+import sys
+
+import numpy as np
+
+log = logging.getLogger("tf_kaldi_speaker_amd")
+
+
+class Params(object):
+    """Hyper-parameters loaded from a JSON file; attribute and `.dict[...]` access.
+    Unknown / comment keys ("Note": ...) are legal (tdnn_softmax_1e-2.json:2,13)."""
+
+    def __init__(self, json_path):
+        self.update(json_path)
+
+    def save(self, json_path):
+        with open(json_path, "w") as f:
+            json.dump({k: v for k, v in self.__dict__.items() if _jsonable(v)}, f, indent=4)
+
+    def update(self, json_path):
+        with open(json_path) as f:
+            self.__dict__.update(json.load(f))
+
+    @property
+    def dict(self):
+        return self.__dict__
+
+
+class ParamsPlain(object):
+    def __init__(self):
+        pass
+
+    @property
+    def dict(self):
+        return self.__dict__
+
+
+def _jsonable(v):
+    try:
+        json.dumps(v)
+        return True
+    except TypeError:
+        return False
+
+
+def save_codes_and_config(cont, model, config):
+    """Snapshot code + config into <model>/{codes,lib,nnet} exactly like the reference (utils.py:64-123);
+    with `cont` reload <model>/nnet/config.json instead."""
+    if cont:
+        if not os.path.isdir(os.path.join(model, "nnet")) or not os.path.isdir(os.path.join(model, "codes")):
+            sys.exit("To continue training the model, nnet and codes must be existed in %s." % model)
+        log.info("Continue training from %s." % model)
+        return Params(os.path.join(model, "nnet/config.json"))
+    if os.path.isdir(os.path.join(model, "nnet")):
+        backup = os.path.join(model, ".backup")
+        log.info("Save backup to %s" % backup)
+        if os.path.isdir(backup):
+            shutil.rmtree(backup)
+        os.makedirs(backup)
+        for d in ("codes", "nnet", "lib"):
+            if os.path.exists(os.path.join(model, d)):
+                shutil.move(os.path.join(model, d), backup + "/")
+    for d in ("codes", "lib"):
+        if os.path.isdir(os.path.join(model, d)):
+            shutil.rmtree(os.path.join(model, d))
+    os.makedirs(os.path.join(model, "codes"))
+    root = os.environ.get("TF_KALDI_ROOT")
+    if not root:
+        log.error("TF_KALDI_ROOT should be set before training. Refer to path.sh to set the value manually. ")
+        sys.exit(1)
+    for d in ("dataset", "model", "misc"):
+        shutil.copytree(os.path.join(root, d), os.path.join(model, "codes", d),
+                        ignore=shutil.ignore_patterns("__pycache__", "*.pyc"))
+    lib_src = os.path.join(os.getcwd(), "nnet/lib")
+    if os.path.isdir(lib_src):
+        shutil.copytree(lib_src, os.path.join(model, "lib"), ignore=shutil.ignore_patterns("__pycache__", "*.pyc"))
+    if not os.path.isdir(os.path.join(model, "nnet")):
+        os.makedirs(os.path.join(model, "nnet"))
+    shutil.copyfile(config, os.path.join(model, "nnet", "config.json"))
+    log.info("Train the model from scratch.")
+    return Params(config)
+
+
+class ValidLoss(object):
+    def __init__(self):
+        self.min_loss = 1e16
+        self.min_loss_epoch = -1
+
+
+def load_lr(filename):
+    out = []
+    with open(filename, "r") as f:
+        for line in f:
+            if line.strip():
+                out.append(float(line.strip().split(" ")[1]))
+    return out
+
+
+def load_valid_loss(filename):
+    best = ValidLoss()
+    with open(filename, "r") as f:
+        for line in f:
+            if not line.strip():
+                continue
+            epoch, loss = line.strip().split(" ")[:2]
+            if float(loss) < best.min_loss:
+                best.min_loss = float(loss)
+                best.min_loss_epoch = int(epoch)
+    return best
+
+
+def read_checkpoint_state(model):
+    """Parse the TF-style `checkpoint` index file -> (model_checkpoint_path, [all paths])."""
+    path = os.path.join(model, "checkpoint")
+    if not os.path.isfile(path):
+        return None, []
+    current, all_paths = None, []
+    with open(path) as f:
+        for line in f:
+            m = re.match(r'\s*(model_checkpoint_path|all_model_checkpoint_paths):\s*"(.*)"', line)
+            if not m:
+                continue
+            if m.group(1) == "model_checkpoint_path":
+                current = m.group(2)
+            else:
+                all_paths.append(m.group(2))
+    return current, all_paths
+
+
+def write_checkpoint_state(model, current, all_paths):
+    with open(os.path.join(model, "checkpoint"), "w") as f:
+        f.write("model_checkpoint_path: \"%s\"\n" % current)
+        for p in all_paths:
+            f.write("all_model_checkpoint_paths: \"%s\"\n" % p)
+
+
+def get_checkpoint(model, checkpoint="-1"):
+    """Select a checkpoint and rewrite the index: "last", an explicit step, or -1 = best by
+    valid_loss -> (min_epoch + 1) * num_steps_per_epoch (reference utils.py:217-270)."""
+    if not os.path.isfile(os.path.join(model, "checkpoint")):
+        sys.exit("[ERROR] Cannot find checkpoint in %s." % model)
+    current, all_paths = read_checkpoint_state(model)
+    if not current:
+        sys.exit("[ERROR] Cannot read checkpoint %s." % os.path.join(model, "checkpoint"))
+    steps = sorted(int(c.rsplit("-", 1)[1]) for c in all_paths)
+    if checkpoint == "last":
+        checkpoint = steps[-1]
+    else:
+        checkpoint = int(checkpoint)
+        if checkpoint == -1:
+            min_epoch, min_loss = -1, 1e10
+            with open(os.path.join(model, "valid_loss")) as f:
+                for line in f:
+                    if not line.strip():
+                        continue
+                    epoch, loss = line.split(" ")[:2]
+                    if float(loss) < min_loss:
+                        min_loss, min_epoch = float(loss), int(epoch)
+            params = Params(os.path.join(model, "config.json"))
+            checkpoint = (min_epoch + 1) * params.num_steps_per_epoch
+    log.info("The checkpoint is %d" % checkpoint)
+    assert checkpoint in steps, "The checkpoint %d not in the model directory" % checkpoint
+    path = os.path.join(model, os.path.basename(current.rsplit("-", 1)[0] + "-" + str(checkpoint)))
+    write_checkpoint_state(model, path, [os.path.join(model, os.path.basename(p)) for p in all_paths])
+    return path
+
+
+def compute_cos_pairwise_eer(embeddings, labels, max_num_embeddings=1000):
+    """Pairwise cosine EER (reference utils.py:273-312): L2-normalise, subsample to <= max_num_embeddings
+    with an integer stride, score all pairs i<j, EER = root of 1 - x - tpr(x) on the ROC curve."""
+    from scipy.interpolate import interp1d
+    from scipy.optimize import brentq
+    from sklearn import metrics
+    embeddings = embeddings / np.sqrt(np.sum(embeddings ** 2, axis=1, keepdims=True) + 1e-12)
+    labels = np.asarray(labels)
+    n = embeddings.shape[0]
+    if n > max_num_embeddings:
+        step = n // max_num_embeddings          # py2 integer division in the reference
+        idx = np.arange(0, n, step)
+        embeddings, labels = embeddings[idx], labels[idx]
+        n = embeddings.shape[0]
+    score_mat = embeddings @ embeddings.T
+    iu = np.triu_indices(n, k=1)                # same (i, j>i) order as the reference's double loop
+    scores = score_mat[iu]
+    keys = (labels[iu[0]] == labels[iu[1]]).astype(np.float64)
+    fpr, tpr, _ = metrics.roc_curve(keys, scores, pos_label=1)
+    return float(brentq(lambda x: 1.0 - x - interp1d(fpr, tpr)(x), 0.0, 1.0))
+
+
+def substring_in_list(s, varlist):
+    if varlist is None:
+        return False
+    return any(v in s for v in varlist)
+
+
+def activation_summaries(endpoints):
+    """TensorBoard histograms in the reference (utils.py:333-346); this engine logs scalars only."""
+    return None
+
+
+def remove_params_prefix(params, prefix):
+    for k in list(params.dict.keys()):
+        if k.startswith(prefix + "_"):
+            params.dict[k[len(prefix) + 1:]] = params.dict[k]
+    return params
+
+
+def add_dict_prefix(d, prefix):
+    return {prefix + "_" + k: v for k, v in d.items()}
+
+
+# ------------------------------------------------------------------------------------------
+# Pure host logic of the reference drivers, factored out so it can be tested without a GPU
+# ------------------------------------------------------------------------------------------
+def tune_learning_rate(epoch, lr_now, valid_loss, min_valid_loss, reduce_lr_epochs):
+    """LR-halving state machine of egs/voxceleb/v1/nnet/lib/train.py:108-120.
+    Mutates `min_valid_loss` (ValidLoss) exactly as the reference does - including the
+    `min_loss_epoch += 2` bump after a halving - and returns the learning rate of epoch+1."""
+    new_lr = lr_now
+    if valid_loss < min_valid_loss.min_loss:
+        min_valid_loss.min_loss = valid_loss
+        min_valid_loss.min_loss_epoch = epoch
+    elif epoch - min_valid_loss.min_loss_epoch >= reduce_lr_epochs:
+        new_lr = lr_now / 2
+        log.info("After epoch %d, no improvement. Reduce the learning rate to %.8f" % (min_valid_loss.min_loss_epoch, new_lr))
+        min_valid_loss.min_loss_epoch += 2
+    return new_lr
+
+
+def should_stop(epoch, next_lr, min_valid_loss, min_learning_rate, early_stop_epochs):
+    """train.py:134-139."""
+    return next_lr < (min_learning_rate - 1e-12) or epoch - min_valid_loss.min_loss_epoch >= early_stop_epochs
+
+
+def split_into_chunks(num_frames, chunk_size):
+    """[(start, length)] of the half-overlapping chunks extract.py:69-79 cuts a long utterance into.
+    (`chunk_size / 2` is Python-2 integer division in the reference.)"""
+    if num_frames <= chunk_size:
+        return [(0, num_frames)]
+    half = chunk_size // 2
+    num_chunks = int(np.ceil(float(num_frames - chunk_size) / half)) + 1
+    out = []
+    for i in range(num_chunks):
+        start = i * half
+        out.append((start, chunk_size if num_frames - start > chunk_size else num_frames - start))
+    return out
+
+
+def average_chunk_embeddings(embeddings, lengths, normalize):
+    """Length-weighted mean of per-chunk embeddings (extract.py:81-89)."""
+    embeddings = np.array(embeddings, dtype=np.float32)
+    lengths = np.expand_dims(np.array(lengths), axis=1)
+    if normalize:
+        embeddings = embeddings / np.sqrt(np.sum(np.square(embeddings), axis=1, keepdims=True))
+    return np.sum(embeddings * lengths, axis=0) / np.sum(lengths)

@@ -1,0 +1,116 @@
+"""tdnn(features, params, is_training, reuse_variables, aux_features) -> (features, endpoints)
+with the reference's endpoint names and order (model/tdnn.py:8-191), executed by the native engine.
+
+The variables of the "tdnn" scope are owned by an engine held in a module-level graph (the
+analogue of TF's default graph): the first call creates them (Glorot-uniform, seed = params.seed),
+`reuse_variables=True` re-enters the same variables, a second creating call raises like TF does.
+Trainer builds its own engine (with the loss head) and does not go through this module-level graph.
+"""
+from collections import OrderedDict
+
+import torch
+
+try:
+    from .. import engine as E
+    from .common import to_device
+except (ImportError, ValueError):
+    import engine as E
+    from model.common import to_device
+
+_GRAPH = {"engine": None, "key": None}
+
+ENDPOINT_ORDER = ["tdnn1_conv", "tdnn1_bn", "tdnn1_relu", "tdnn2_conv", "tdnn2_bn", "tdnn2_relu",
+                  "tdnn3_conv", "tdnn3_bn", "tdnn3_relu", "tdnn4_dense", "tdnn4_bn", "tdnn4_relu",
+                  "tdnn5_dense", "tdnn5_bn", "tdnn5_relu", "pooling", "tdnn6_dense", "tdnn6_bn", "tdnn6_relu",
+                  "tdnn7_dense", "tdnn7_bn", "tdnn7_relu"]
+
+
+def reset_default_graph():
+    if _GRAPH["engine"] is not None:
+        _GRAPH["engine"].close()
+    _GRAPH["engine"], _GRAPH["key"] = None, None
+
+
+def check_params(params):
+    """The static checks of model/tdnn.py:24-30,111-113,133-142,162-184 (defaults are inserted into params)."""
+    if "network_relu_type" in params.dict and params.network_relu_type in ("prelu", "lrelu"):
+        raise NotImplementedError("network_relu_type %s is not implemented (no shipped config uses it)" % params.network_relu_type)
+    if "num_nodes_pooling_layer" not in params.dict:
+        params.dict["num_nodes_pooling_layer"] = 1500
+    if params.pooling_type != "statistics_pooling":
+        if params.pooling_type in ("self_attention", "ghost_vlad"):
+            raise NotImplementedError("Not implement %s pooling on the MI355X engine yet" % params.pooling_type)
+        raise NotImplementedError("Not implement %s pooling" % params.pooling_type)
+    if "num_nodes_last_layer" not in params.dict:
+        params.dict["num_nodes_last_layer"] = 512
+    if "last_layer_no_bn" not in params.dict:
+        params.last_layer_no_bn = False
+    if "last_layer_linear" not in params.dict:
+        params.last_layer_linear = False
+
+
+def engine_config(params, dim, num_speakers=0, loss_type="softmax", max_batch=128, max_frames=400):
+    check_params(params)
+    d = params.dict
+    kw = dict(num_nodes_pooling_layer=d["num_nodes_pooling_layer"], num_nodes_last_layer=d["num_nodes_last_layer"],
+              last_layer_no_bn=d["last_layer_no_bn"], last_layer_linear=d["last_layer_linear"],
+              feature_norm=bool(d.get("feature_norm", False)), feature_scaling_factor=float(d.get("feature_scaling_factor", 1.0)),
+              weight_l2_regularizer=float(d["weight_l2_regularizer"]),
+              output_weight_l2_regularizer=d.get("output_weight_l2_regularizer", None),
+              batchnorm_momentum=float(d["batchnorm_momentum"]), optimizer=d.get("optimizer", "sgd"),
+              momentum=float(d.get("momentum", 0.0) or 0.0), use_nesterov=bool(d.get("use_nesterov", False)),
+              clip_gradient_norm=float(d["clip_gradient_norm"]) if d.get("clip_gradient", False) else 0.0,
+              max_batch=max_batch, max_frames=max_frames)
+    if d.get("feature_norm", False):
+        assert "feature_scaling_factor" in d, "If feature normalization is applied, scaling factor is necessary."
+    prefix = {"asoftmax": "asoftmax", "additive_margin_softmax": "amsoftmax", "additive_angular_margin_softmax": "arcsoftmax"}.get(loss_type)
+    if prefix is not None and num_speakers:
+        kw.update(margin_m=float(d[prefix + "_m"]), lambda_min=float(d[prefix + "_lambda_min"]),
+                  lambda_base=float(d[prefix + "_lambda_base"]), lambda_gamma=float(d[prefix + "_lambda_gamma"]),
+                  lambda_power=float(d[prefix + "_lambda_power"]))
+    return E.make_config(dim, num_speakers, loss_func=loss_type if num_speakers else "softmax", **kw)
+
+
+def collect_endpoints(eng, b, names=None):
+    """OrderedDict of device tensors in the reference's insertion order; frame-level ones are [B,T_l,C]."""
+    out = OrderedDict()
+    for name in (names or ENDPOINT_ORDER):
+        try:
+            t = eng.endpoint(name)
+        except Exception:
+            continue
+        if t.shape[0] != b:
+            t = t.view(b, t.shape[0] // b, t.shape[1])
+        out[name] = t
+    return out
+
+
+def tdnn(features, params, is_training=None, reuse_variables=None, aux_features=None):
+    x = to_device(features)
+    assert x.dim() == 3, "features must be [batch, length, dim]"
+    b, t, dim = x.shape
+    check_params(params)
+    key = (dim, params.dict["num_nodes_pooling_layer"], params.dict["num_nodes_last_layer"],
+           bool(params.last_layer_no_bn), bool(params.last_layer_linear))
+    eng = _GRAPH["engine"]
+    if eng is None:
+        if reuse_variables is True:
+            raise ValueError("Variable tdnn/tdnn1_conv/kernel does not exist, or was not created with tf.get_variable().")
+        eng = E.Engine(engine_config(params, dim, 0, "softmax", max_batch=max(b, 1), max_frames=max(t, 15)))
+        eng.init_variables(seed=int(params.dict.get("seed", 0)))
+        _GRAPH["engine"], _GRAPH["key"] = eng, key
+    else:
+        if not reuse_variables:
+            raise ValueError("Variable tdnn/tdnn1_conv/kernel already exists, disallowed. Did you mean to set reuse=True?")
+        assert key == _GRAPH["key"], "tdnn() re-entered with a different architecture"
+        if b > eng.config.max_batch or t > eng.config.max_frames:     # grow: new capacity, same variables
+            values = eng.get_variables()
+            eng.close()
+            eng = E.Engine(engine_config(params, dim, 0, "softmax", max_batch=max(b, eng.config.max_batch),
+                                         max_frames=max(t, eng.config.max_frames)))
+            eng.set_variables(values)
+            _GRAPH["engine"] = eng
+    eng.forward(x, bool(is_training))
+    endpoints = collect_endpoints(eng, b)
+    last = [k for k in endpoints if k.startswith("tdnn7")][-1]
+    return endpoints[last], endpoints

@@ -1,0 +1,389 @@
+"""Trainer with the reference's public surface (model/trainer.py:17-730):
+
+    Trainer(params, model_dir, single_cpu=False)
+    .build(mode in {"train","valid","predict"}, dim, loss_type=None, num_speakers=None, noupdate_var_list=None)
+    .train(data, spklist, learning_rate, aux_data=None)       one epoch, resumes from the latest checkpoint
+    .valid(data, spklist, batch_type="softmax", output_embeddings=False, aux_data=None) -> (loss, emb, labels)
+    .predict(features [T,D] | [B,T,D]) -> [E] | [B,E]
+    .save(step) / .load() -> step / .reset() / .close()
+    attributes callers touch: .sess, .embeddings, .endpoints, .params, .model
+
+The TF1 session/graph is replaced by the native MI355X engine (csrc/xv_engine.hip) reached through
+the C-ABI; this file is host logic only (loader, loop, logging, checkpoints, data parallelism).
+Checkpoints: <model>/nnet/model-<step>.npz (variables by TF name + optimiser state) plus the
+TF-format text index <model>/nnet/checkpoint that run_extract_embeddings.sh tests for.
+"""
+import logging
+import os
+import re
+import sys
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+try:
+    from .. import engine as E
+    from ..parallel import GradAllReduce, average_bn_statistics, broadcast_variables
+    from ..dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, DataOutOfRange
+    from ..misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state
+    from .tdnn import tdnn, engine_config, collect_endpoints, check_params
+    from . import loss as _loss
+except (ImportError, ValueError):      # drop-in layout: PYTHONPATH=$TF_KALDI_ROOT
+    import engine as E
+    from parallel import GradAllReduce, average_bn_statistics, broadcast_variables
+    from dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, DataOutOfRange
+    from misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state
+    from model.tdnn import tdnn, engine_config, collect_endpoints, check_params
+    from model import loss as _loss
+
+log = logging.getLogger("tf_kaldi_speaker_amd")
+
+SOFTMAX_FAMILY = ("softmax", "asoftmax", "additive_margin_softmax", "additive_angular_margin_softmax")
+OTHER_LOSSES = ("semihard_triplet_loss", "angular_triplet_loss", "generalized_angular_triplet_loss")
+
+
+class _Session(object):
+    """Stand-in for the tf.Session attribute some callers close explicitly."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def close(self):
+        self._owner._close_engine()
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist
+    except Exception:
+        pass
+    return None
+
+
+class Trainer(object):
+    def __init__(self, params, model_dir, single_cpu=False):
+        self.network_type = params.network_type
+        if params.network_type == "tdnn":
+            self.network = tdnn
+        else:
+            raise NotImplementedError("Not implement %s network" % params.network_type)
+        self.loss_type = None
+        self.loss_network = None
+        self.params = params
+        self.single_cpu = single_cpu       # accepted for signature parity; the engine always runs on the GPU
+        self.model = os.path.join(model_dir, "nnet")
+        self.sess = _Session(self)
+        self.engine = None
+        self.dim = None
+        self.num_speakers = None
+        self.global_step = None
+        self.learning_rate = None
+        self.embeddings = None
+        self.endpoints = None
+        self.optimizer = None
+        self.total_loss = None
+        self.train_op = None
+        self.train_ops = {}
+        self.valid_ops = {}
+        self.saver = None
+        self.is_built = False
+        self.is_loaded = False
+        self.modes = set()
+        self.device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+
+    # ------------------------------------------------------------------ lifecycle
+    def _close_engine(self):
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+
+    def reset(self):
+        """Drop the graph so a new one can be built (reference trainer.py:114-133)."""
+        self._close_engine()
+        self.is_built = False
+        self.is_loaded = False
+        self.modes = set()
+        self.saver = None
+
+    def close(self):
+        self._close_engine()
+
+    def _capacity(self):
+        p = self.params.dict
+        b = int(p.get("num_speakers_per_batch", 64)) * int(p.get("num_segments_per_speaker", 1))
+        t = int(p.get("max_segment_len", 400))
+        return max(b, 1), max(t, 15)
+
+    def _make_engine(self, num_speakers, loss_type, max_batch, max_frames, keep=None):
+        cfg = engine_config(self.params, self.dim, num_speakers or 0, loss_type or "softmax", max_batch, max_frames)
+        eng = E.Engine(cfg, device=self.device)
+        seed = int(self.params.dict.get("seed", 0))
+        eng.init_variables(seed=seed)
+        if keep:
+            eng.set_variables({k: v for k, v in keep.items() if k in eng.table})
+        return eng
+
+    def _ensure_capacity(self, b, t):
+        eng = self.engine
+        if b <= eng.config.max_batch and t <= eng.config.max_frames:
+            return
+        values = eng.get_variables()
+        opt, cnt = eng.opt_state.clone(), eng.update_count
+        nb, nt = max(b, eng.config.max_batch), max(t, eng.config.max_frames)
+        if t > eng.config.max_frames:
+            nt = max(t, min(2 * eng.config.max_frames, 20000))
+        self._close_engine()
+        self.engine = self._make_engine(self.num_speakers, self.loss_type, nb, nt, keep=values)
+        if self.engine.opt_state.numel() == opt.numel():
+            self.engine.opt_state.copy_(opt)
+        self.engine.update_count = cnt
+
+    # ------------------------------------------------------------------ build
+    def build(self, mode, dim, loss_type=None, num_speakers=None, noupdate_var_list=None):
+        assert (mode == "train" or mode == "valid" or mode == "predict")
+        if noupdate_var_list is not None:
+            raise NotImplementedError("fine-tuning with noupdate_var_list is outside the hot path (SURVEY.md section 2, item 6)")
+        check_params(self.params)
+        self.dim = int(dim)
+        if mode == "predict":
+            if "embedding_node" not in self.params.dict:
+                raise KeyError("embedding_node")
+            log.info("Extract embedding from node %s" % self.params.embedding_node)
+            if self.engine is None:
+                self.engine = self._make_engine(0, "softmax", 1, 400)
+            self.embeddings = self.params.embedding_node
+            self.modes.add(mode)
+            self.is_built = True
+            return
+
+        self.params.dict["global_step"] = 0
+        self.loss_type = loss_type
+        if loss_type in SOFTMAX_FAMILY:
+            self.loss_network = getattr(_loss, loss_type)
+        elif loss_type in OTHER_LOSSES:
+            raise NotImplementedError("Not implement %s loss on the MI355X engine (outside the hot path)" % loss_type)
+        else:
+            raise NotImplementedError("Not implement %s loss" % self.loss_type)
+        if mode == "train":
+            if "optimizer" not in self.params.dict:
+                self.params.dict["optimizer"] = "sgd"
+            if self.params.optimizer == "sgd":
+                if "momentum" in self.params.dict:
+                    sys.exit("Using sgd as the optimizer and you should not specify the momentum.")
+            elif self.params.optimizer not in ("momentum", "adam"):
+                sys.exit("Optimizer %s is not supported." % self.params.optimizer)
+            self.optimizer = self.params.optimizer
+        self.num_speakers = int(num_speakers)
+        b, t = self._capacity()
+        if self.engine is None:
+            self.engine = self._make_engine(self.num_speakers, loss_type, b, t)
+        elif self.engine.config.num_speakers != self.num_speakers:
+            keep = self.engine.get_variables()
+            self._close_engine()
+            self.engine = self._make_engine(self.num_speakers, loss_type, b, t, keep=keep)
+        self.embeddings = "output"          # valid embeddings = endpoints["output"], trainer.py:308
+        self.modes.add(mode)
+        self.is_built = True
+
+    # ------------------------------------------------------------------ checkpoints
+    def save(self, step):
+        dist = _dist()
+        if dist is not None:
+            average_bn_statistics(dist, self.engine.variables, self.engine.n_train, dist.get_world_size())
+            if dist.get_rank() != 0:
+                return
+        os.makedirs(self.model, exist_ok=True)
+        path = os.path.join(self.model, "model-%d" % step)
+        arrays = dict(self.engine.get_variables())
+        arrays["__opt_state__"] = self.engine.opt_state.cpu().numpy()
+        arrays["__update_count__"] = np.array([self.engine.update_count], np.int64)
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, **arrays)
+        os.replace(tmp, path + ".npz")
+        _, all_paths = read_checkpoint_state(self.model)
+        all_paths = [p for p in all_paths if p != path] + [path]
+        keep = int(self.params.dict.get("keep_checkpoint_max", 5))
+        while keep > 0 and len(all_paths) > keep:
+            old = all_paths.pop(0)
+            for suffix in (".npz",):
+                if os.path.exists(old + suffix):
+                    os.remove(old + suffix)
+        write_checkpoint_state(self.model, path, all_paths)
+
+    def load(self):
+        log.info("Reading checkpoints...")
+        current, _ = read_checkpoint_state(self.model)
+        if not current:
+            sys.exit("Failed to find a checkpoint in {}".format(self.model))
+        ckpt_name = os.path.basename(current)
+        step = int(next(re.finditer(r"(\d+)(?!.*\d)", ckpt_name)).group(0))
+        path = os.path.join(self.model, ckpt_name + ".npz")
+        if not os.path.isfile(path):
+            sys.exit("Failed to find a checkpoint in {}".format(self.model))
+        data = np.load(path)
+        values = {k: data[k] for k in data.files if not k.startswith("__") and k in self.engine.table}
+        missing = [k for k in self.engine.table if k not in values]
+        if missing:
+            sys.exit("Checkpoint %s lacks variables: %s" % (path, ", ".join(missing[:5])))
+        self.engine.set_variables(values)
+        if "__opt_state__" in data.files and data["__opt_state__"].size == self.engine.opt_state.numel():
+            self.engine.opt_state.copy_(torch.from_numpy(data["__opt_state__"]))
+        if "__update_count__" in data.files:
+            self.engine.update_count = int(data["__update_count__"][0])
+        log.info("Succeed to load checkpoint {}".format(ckpt_name))
+        self.is_loaded = True
+        return step
+
+    # ------------------------------------------------------------------ training
+    def train(self, data, spklist, learning_rate, aux_data=None):
+        """One epoch over `num_steps_per_epoch` random batches (reference trainer.py:451-520)."""
+        assert "train" in self.modes, "call build('train', ...) first"
+        p = self.params
+        curr_step = 0
+        if os.path.isfile(os.path.join(self.model, "checkpoint")):
+            curr_step = self.load()
+        dist = _dist()
+        if dist is not None:
+            broadcast_variables(dist, self.engine.variables, 0)
+            self.engine.lib.xv_engine_invalidate_weights(self.engine.h)
+        loader = KaldiDataRandomQueue(data, spklist, num_parallel=p.num_parallel_datasets, max_qsize=p.max_queue_size,
+                                      num_speakers=p.num_speakers_per_batch, num_segments=p.num_segments_per_speaker,
+                                      min_len=p.min_segment_len, max_len=p.max_segment_len, shuffle=True)
+        loader.start()
+        try:
+            curr_step = self.train_batches(iter(loader.fetch, None), learning_rate, curr_step)
+        finally:
+            loader.stop()
+        self.save(curr_step)
+        return
+
+    def train_batches(self, batches, learning_rate, curr_step=0, num_steps=None):
+        """The hot loop on an iterator of (features [B,T,D], labels [B]); returns the new global step.
+        curr_step (the count of optimiser steps incl. resumed ones) feeds the lambda schedule."""
+        p = self.params
+        dist = _dist()
+        allreduce = GradAllReduce(dist, dist.get_world_size()) if dist is not None else None
+        rank0 = dist is None or dist.get_rank() == 0
+        steps_per_epoch = int(p.num_steps_per_epoch) if num_steps is None else int(num_steps)
+        epoch = int(curr_step / p.num_steps_per_epoch) if num_steps is None else 0
+        first = curr_step % steps_per_epoch if num_steps is None else 0
+        show = int(p.dict.get("show_training_progress", 100))
+        save_every = int(p.dict.get("save_checkpoints_steps", 0) or 0)
+        for step in range(first, steps_per_epoch):
+            try:
+                start_time = time.time()
+                features, labels = next(batches)
+            except (DataOutOfRange, StopIteration):
+                log.info("Finished reading features.")
+                break
+            self._ensure_capacity(features.shape[0], features.shape[1])
+            verbose = show > 0 and step % show == 0
+            losses = self.engine.train_step(features, labels, learning_rate, curr_step, allreduce=allreduce,
+                                            fetch_losses=verbose)
+            if verbose and rank0:
+                raw, reg = losses
+                self.train_ops = {"raw_loss": raw, "loss": raw + reg}
+                log.info("Epoch: [%2d] step: [%2d/%2d] time: %.4f s/step, raw loss: %f, total loss: %f"
+                         % (epoch, step, steps_per_epoch, time.time() - start_time, raw, raw + reg))
+            if save_every > 0 and step % save_every == 0 and curr_step != 0:
+                self.save(curr_step)
+            curr_step += 1
+        return curr_step
+
+    # ------------------------------------------------------------------ validation / inference
+    def valid(self, data, spklist, batch_type="softmax", output_embeddings=False, aux_data=None):
+        """Mean validation loss with the margin switched off (trainer.py:261-271) and BN in inference
+        mode; optionally all "output" embeddings + labels in file order (trainer.py:592-706)."""
+        assert "valid" in self.modes, "call build('valid', ...) first"
+        assert batch_type == "softmax" or batch_type == "end2end", "The batch_type can only be softmax or end2end"
+        if batch_type == "end2end":
+            raise NotImplementedError("end2end validation batches belong to the triplet/GE2E losses (outside the hot path)")
+        p = self.params
+        curr_step = 0
+        if os.path.isfile(os.path.join(self.model, "checkpoint")):
+            curr_step = self.load()
+        else:
+            log.info("[Warning] Cannot find model in %s. Random initialization is used in validation." % self.model)
+        bsz = p.num_speakers_per_batch * p.num_segments_per_speaker
+        embeddings_val, labels_val = None, None
+        if output_embeddings:
+            loader = KaldiDataSeqQueue(data, spklist, num_parallel=2, max_qsize=10, batch_size=bsz,
+                                       min_len=p.min_segment_len, max_len=p.max_segment_len, shuffle=False)
+            loader.start()
+            embs, labs = [], []
+            try:
+                while True:
+                    try:
+                        features, labels = loader.fetch()
+                    except DataOutOfRange:
+                        break
+                    self._ensure_capacity(features.shape[0], features.shape[1])
+                    self.engine.forward(features, False)
+                    embs.append(self.engine.endpoint("output").cpu().numpy())
+                    labs.append(np.asarray(labels))
+            finally:
+                loader.stop()
+            if embs:
+                embeddings_val, labels_val = np.concatenate(embs, 0), np.concatenate(labs, 0)
+        loader = KaldiDataSeqQueue(data, spklist, num_parallel=2, max_qsize=10, batch_size=bsz,
+                                   min_len=p.min_segment_len, max_len=p.max_segment_len, shuffle=True)
+        loader.start()
+        total, num_batches = 0.0, 0
+        try:
+            for _ in range(int(p.valid_max_iterations)):
+                try:
+                    features, labels = loader.fetch()
+                except DataOutOfRange:
+                    break
+                self._ensure_capacity(features.shape[0], features.shape[1])
+                self.engine.forward(features, False)
+                self.engine.loss(labels, curr_step, with_margin=False)
+                total += self.engine.raw_loss()
+                num_batches += 1
+        finally:
+            loader.stop()
+        loss = total / max(num_batches, 1)
+        log.info("[Validation %d batches] valid loss: %f" % (num_batches, loss))
+        return loss, embeddings_val, labels_val
+
+    def predict(self, features):
+        """Embedding(s) of `embedding_node` with BN in inference mode (trainer.py:708-726)."""
+        if not self.is_loaded:
+            if os.path.isfile(os.path.join(self.model, "checkpoint")):
+                self.load()
+            else:
+                sys.exit("Cannot find model in %s" % self.model)
+        features = np.asarray(features, np.float32)
+        rank = len(features.shape)
+        assert (rank == 2 or rank == 3)
+        if rank == 2:
+            features = np.expand_dims(features, axis=0)
+        self._ensure_capacity(features.shape[0], features.shape[1])
+        self.engine.forward(features, False)
+        node = self.params.embedding_node
+        emb = self.engine.endpoint(node)
+        b = features.shape[0]
+        if emb.shape[0] != b:
+            emb = emb.view(b, emb.shape[0] // b, emb.shape[1])
+        emb = emb.cpu().numpy()
+        self.endpoints = OrderedDict([(node, emb)])
+        if rank == 2:
+            emb = np.squeeze(emb, axis=0)
+        return emb
+
+    # ------------------------------------------------------------------ research tooling of the reference: not on the hot path
+    def train_tune_lr(self, *a, **k):
+        raise NotImplementedError("train_tune_lr is research tooling outside the hot path (SURVEY.md section 2, item 6)")
+
+    def set_trainable_variables(self, *a, **k):
+        raise NotImplementedError("fine-tuning helpers are outside the hot path (SURVEY.md section 2, item 6)")
+
+    def get_finetune_model(self, *a, **k):
+        raise NotImplementedError("fine-tuning helpers are outside the hot path (SURVEY.md section 2, item 6)")
+
+    def insight(self, *a, **k):
+        raise NotImplementedError("insight() is debug tooling outside the hot path")

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Drop-in for egs/voxceleb/v1/nnet/lib/extract.py (same CLI, wrap/extract_wrapper.sh:39-40):
+
+    python nnet/lib/extract.py [-g GPU] [-m MIN] [-s CHUNK] [-n] [--node NAME] model_dir rspecifier wspecifier
+
+Reads an ark / input pipe of feature matrices, writes a Kaldi float-vector ark of embeddings
+(is_training=False graph, moving BN statistics).  Utterances longer than --chunk-size are cut into
+half-overlapping chunks whose embeddings are length-weighted averaged (reference extract.py:65-94).
+-g selects the HIP device (the reference's CPU mode `-g -1` maps to device 0: there is no CPU path).
+"""
+import argparse
+import logging
+import os
+import sys
+
+import numpy as np
+
+from model.trainer import Trainer
+from misc.utils import Params, split_into_chunks, average_chunk_embeddings
+from dataset.kaldi_io import open_or_fd, read_mat_ark, write_vec_flt
+
+parser = argparse.ArgumentParser()
+parser.add_argument("-g", "--gpu", type=int, default=-1, help="The GPU id (-1: device 0).")
+parser.add_argument("-m", "--min-chunk-size", type=int, default=25, help="Segments shorter than this are skipped.")
+parser.add_argument("-s", "--chunk-size", type=int, default=10000, help="Longer segments are split and averaged.")
+parser.add_argument("-n", "--normalize", action="store_true", help="Normalize the embedding before averaging and output.")
+parser.add_argument("--node", type=str, default="", help="The node to output the embeddings.")
+parser.add_argument("model_dir", type=str, help="The model directory.")
+parser.add_argument("rspecifier", type=str, help="Kaldi feature rspecifier (or ark file).")
+parser.add_argument("wspecifier", type=str, help="Kaldi output wspecifier (or ark file).")
+
+
+def main():
+    logging.basicConfig(level=logging.INFO, format="%(levelname)s:%(name)s:%(message)s")
+    log = logging.getLogger("tf_kaldi_speaker_amd")
+    args = parser.parse_args()
+    if args.gpu >= 0:
+        os.environ["LOCAL_RANK"] = str(args.gpu)
+    nnet_dir = os.path.join(args.model_dir, "nnet")
+    config_json = os.path.join(args.model_dir, "nnet/config.json")
+    if not os.path.isfile(config_json):
+        sys.exit("Cannot find params.json in %s" % config_json)
+    params = Params(config_json)
+    if len(args.node) != 0:
+        params.embedding_node = args.node
+    log.info("Extract embedding from %s" % params.embedding_node)
+    trainer = Trainer(params, args.model_dir, single_cpu=True)
+    with open(os.path.join(nnet_dir, "feature_dim"), "r") as f:
+        dim = int(f.readline().strip())
+    trainer.build("predict", dim=dim)
+    if "." in args.rspecifier and args.rspecifier.rsplit(".", 1)[1] == "scp":
+        sys.exit("The rspecifier must be ark or input pipe")
+    fp_out = open_or_fd(args.wspecifier, "wb")
+    for index, (key, feature) in enumerate(read_mat_ark(args.rspecifier)):
+        if feature.shape[0] < args.min_chunk_size:
+            log.info("[INFO] Key %s length too short, %d < %d, skip." % (key, feature.shape[0], args.min_chunk_size))
+            continue
+        if feature.shape[0] > args.chunk_size:
+            chunks = split_into_chunks(feature.shape[0], args.chunk_size)
+            log.info("[INFO] Key %s length %d > %d, split to %d segments." % (key, feature.shape[0], args.chunk_size, len(chunks)))
+            full = np.array([feature[s:s + n] for s, n in chunks[:-1]], dtype=np.float32)
+            embeddings = trainer.predict(full)
+            s, n = chunks[-1]
+            last = trainer.predict(feature[s:s + n])
+            embeddings = np.concatenate([embeddings, np.expand_dims(last, axis=0)], axis=0)
+            embedding = average_chunk_embeddings(embeddings, [n for _, n in chunks], args.normalize)
+        else:
+            log.info("[INFO] Key %s length %d." % (key, feature.shape[0]))
+            embedding = trainer.predict(feature)
+        if args.normalize:
+            embedding = embedding / np.sqrt(np.sum(np.square(embedding)))
+        write_vec_flt(fp_out, np.asarray(embedding, np.float32), key=key)
+    fp_out.close()
+    trainer.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,7 +8,10 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+try:
+    from . import _lib
+except ImportError:
+    import _lib
 
 TILE_M = 128
 
