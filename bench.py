@@ -160,6 +160,22 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # Untimed extra pass with the side stream off: the weight-gradient launches of the timed region run
+    # concurrently with data-gradient launches, so their in-region durations include time shared with
+    # another kernel.  This pass times every GEMM launch alone (kernel quality in isolation).
+    iso_steps = 5
+    _lib.check(lib.xv_engine_set_concurrency(eng.h, 0))
+    one_step(args.warmup + args.steps)
+    torch.cuda.synchronize()
+    _lib.check(lib.xv_profile_begin(int(iso_steps * launches_per_step)), "xv_profile_begin")
+    for i in range(iso_steps):
+        one_step(args.warmup + args.steps + 1 + i)
+    torch.cuda.synchronize()
+    icnt = (C.c_int64 * 3)()
+    ims = (C.c_double * 3)()
+    ifl = (C.c_double * 3)()
+    _lib.check(lib.xv_profile_end(icnt, ims, ifl), "xv_profile_end")
+    _lib.check(lib.xv_engine_set_concurrency(eng.h, 1))
     raw, reg = eng.losses()
     if not np.isfinite(raw):
         sys.exit("bench.py: loss is not finite (%r)" % raw)
@@ -173,7 +189,8 @@ def main():
         for k in range(3):
             if cnt[k]:
                 kernels.append({"kernel": KIND_NAMES[k], "launches": int(cnt[k]), "avg_ms": ms[k] / cnt[k],
-                                "tflops": fl[k] / (ms[k] * 1e-3) / 1e12, "share_of_step": ms[k] / args.steps / ms_per_step})
+                                "tflops": fl[k] / (ms[k] * 1e-3) / 1e12, "share_of_step": ms[k] / args.steps / ms_per_step,
+                                "isolated_tflops": ifl[k] / (ims[k] * 1e-3) / 1e12 if icnt[k] else None})
         achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12
         out = {
             "metric": "utterance-chunks/sec (200-frame x 30-dim)",
@@ -197,7 +214,11 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
                          "traffic_unit": "bytes/launch past L2 (rocprofv3 PMC, profiles/)",
                          "avg_launch_ms": round(ms[dom] / cnt[dom], 4), "launches": int(cnt[dom]),
-                         "algorithmic_flops_per_launch": fl[dom] / cnt[dom]},
+                         "algorithmic_flops_per_launch": fl[dom] / cnt[dom],
+                         "note": "weight-gradient launches (side stream) overlap data-gradient launches in the timed region; "
+                                 "`isolated_*` = same kernel timed alone in an extra untimed pass of %d steps" % iso_steps,
+                         "isolated_achieved": round(ifl[dom] / (ims[dom] * 1e-3) / 1e12, 2),
+                         "isolated_frac": round(ifl[dom] / (ims[dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
             "step_flops": {"algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
                            "whole_step_tflops": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
                            "whole_step_frac_of_f32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},

@@ -122,11 +122,14 @@ int xv_bn_apply(void* stream, const float* z, int rows, int n, int ldz, const fl
                 int relu, float* a, int lda);
 /* Backward of ReLU(BN(z)) given da (both dense [segs*t][n]): dy = da * (y>0); dgamma = sum dy*xhat; dbeta = sum dy;
  * dz = gamma*invstd*(dy - dbeta/rows - xhat*dgamma/rows) written into a segment-padded buffer
- * dz_pad [segs][t + 2*pad][n] (pad rows zeroed).  relu != 0 means a ReLU follows the BN. */
+ * dz_pad [segs][t + 2*pad][n] (pad rows zeroed).  relu != 0 means a ReLU follows the BN.
+ * dbias (optional): gradient of a bias added in FRONT of this BN = column sum of dz.  It is 0 in exact
+ * arithmetic (BN removes the mean); TF's reduce_sum(dz) leaves rounding noise there, and so does this
+ * (gamma*invstd*(sum dy - rows*mean dy)) without a separate pass over dz. */
 int xv_bn_relu_backward(void* stream, const float* da, const float* z, int segs, int t, int n,
                         const float* gamma, const float* mean, const float* invstd,
                         const float* scale, const float* shift, int relu, int pad,
-                        float* dz_pad, float* dgamma, float* dbeta, void* ws, size_t ws_bytes);
+                        float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes);
 /* Backward of a bare ReLU (no BN in front): dz = da * (a > 0). */
 int xv_relu_backward(void* stream, const float* da, const float* a, size_t count, float* dz);
 
@@ -237,6 +240,9 @@ int xv_engine_loss_ptrs(xv_engine* e, float** raw_loss, float** reg_loss);
 /* endpoint by reference name ("tdnn1_conv", ..., "pooling", "tdnn6_dense", "output", "logits"):
  * device pointer, rows, cols, leading dimension of the most recent forward. */
 int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, int32_t* rows, int32_t* cols, int32_t* ld);
+/* 1 (default): weight gradients run on an internal second HIP stream beside the data-gradient chain;
+ * 0: everything in order on the caller's stream (used to time kernels in isolation). */
+int xv_engine_set_concurrency(xv_engine* e, int enabled);
 /* Mark kernel-layout weight copies stale (call after writing the variables buffer directly). */
 int xv_engine_invalidate_weights(xv_engine* e);
 

@@ -130,7 +130,10 @@ def test_bn_relu_backward(ops, relu, pad):
     dz_ref, dg_ref, db_ref = O.batchnorm_train_bwd(dy, cache, gamma.astype(np.float64))
     part = ops.col_stats(dev(z))
     mean, invstd, scale, shift = ops.bn_finalize(part, segs * t, dev(gamma), dev(beta), 1e-3, 0.99, False, None, None)
-    dz, dg, db = ops.bn_relu_backward(dev(da), dev(z), segs, t, dev(gamma), mean, invstd, scale, shift, relu, pad)
+    dz, dg, db, dbias = ops.bn_relu_backward(dev(da), dev(z), segs, t, dev(gamma), mean, invstd, scale, shift, relu, pad,
+                                             with_dbias=True)
+    # gradient of a bias in front of the BN: zero in exact arithmetic, rounding noise in fp32 (TF: reduce_sum(dz))
+    assert np.abs(host(dbias)).max() <= 1e-4 * np.abs(dz_ref).sum(axis=0).max()
     dzh = host(dz).reshape(segs, t + 2 * pad, n)
     if pad:
         assert np.all(dzh[:, :pad] == 0) and np.all(dzh[:, pad + t:] == 0)

@@ -82,7 +82,7 @@ SIGNATURES = {
     "xv_bn_finalize": (_I, [_VP, _VP, _I, _I, _VP, _VP, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "xv_bn_inference_scale": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _F, _VP, _VP]),
     "xv_bn_apply": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP, _I]),
-    "xv_bn_relu_backward": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _SZ]),
+    "xv_bn_relu_backward": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _SZ]),
     "xv_relu_backward": (_I, [_VP, _VP, _VP, _SZ, _VP]),
     "xv_stat_pool_forward": (_I, [_VP, _VP, _I, _I, _I, _VP]),
     "xv_stat_pool_backward": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
@@ -112,6 +112,7 @@ SIGNATURES = {
     "xv_engine_apply": (_I, [_VP, _VP, _F, _F, _I]),
     "xv_engine_loss_ptrs": (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),
     "xv_engine_endpoint": (_I, [_VP, C.c_char_p, C.POINTER(_VP), c_int32_p, c_int32_p, c_int32_p]),
+    "xv_engine_set_concurrency": (_I, [_VP, _I]),
     "xv_engine_invalidate_weights": (_I, [_VP]),
 }
 

@@ -367,7 +367,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 // block = 256 threads = 32 channels x 8 chunk lanes, fixed-order combine
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int n, int rows,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ coef /* [2][n] */) {
+                                                              float* __restrict__ coef /* [2][n] */,
+                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                              float* __restrict__ dbias) {
     __shared__ float r1[8][32], r2[8][32];
     const int cx = threadIdx.x & 31, cl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
@@ -385,8 +387,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     for (int k = 0; k < 8; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; }
     dbeta[c] = s1;
     dgamma[c] = s2;
-    coef[c] = s1 / (float)rows;
+    const float c1 = s1 / (float)rows;
+    coef[c] = c1;
     coef[n + c] = s2 / (float)rows;
+    if (dbias) dbias[c] = gamma[c] * invstd[c] * (s1 - c1 * (float)rows);   // == sum(dz) up to rounding: 0 + noise
 }
 
 // Backward pass 2: dz = gamma*invstd*(dy - c1 - xhat*c2) into the segment-padded layout.
@@ -422,7 +426,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, const float* _
 
 extern "C" int xv_bn_relu_backward(void* stream, const float* da, const float* z, int segs, int t, int n, const float* gamma,
                                    const float* mean, const float* invstd, const float* scale, const float* shift, int relu,
-                                   int pad, float* dz_pad, float* dgamma, float* dbeta, void* ws, size_t ws_bytes) {
+                                   int pad, float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
     XV_REQUIRE(segs > 0 && t > 0 && n > 0 && n % 4 == 0 && pad >= 0, "bn_relu_backward: bad shape (n=%d must be a multiple of 4)", n);
     const int rows = segs * t;
     const int chunks = xv_cdiv(rows, BB_ROWS);
@@ -435,7 +439,7 @@ extern "C" int xv_bn_relu_backward(void* stream, const float* da, const float* z
                        scale, shift, relu, part);
     XV_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, 32)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
-                       dgamma, dbeta, coef);
+                       dgamma, dbeta, coef, gamma, invstd, dbias);
     XV_LAUNCH_CHECK();
     long total = (long)segs * (t + 2 * pad) * (n / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, da, z, segs, t, n / 4, gamma, mean,

@@ -60,7 +60,14 @@ struct xv_engine {
     float *h7 = nullptr, *out = nullptr;   // views of the most recent forward (may alias tdnn7's z / h7)
     float *logits = nullptr, *dlogits = nullptr, *dnorm = nullptr, *row_loss = nullptr;
     float *inv_norm = nullptr, *wn = nullptr, *wnt = nullptr, *dwn = nullptr;
-    float *bufD = nullptr, *bufZ = nullptr, *d_small0 = nullptr, *d_small1 = nullptr;
+    float *bufD = nullptr, *bufZ[2] = {nullptr, nullptr}, *d_small0 = nullptr, *d_small1 = nullptr;
+    // second stream: weight gradients run beside the data-gradient chain (they only share dz)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_dz = nullptr, ev_w[2] = {nullptr, nullptr};
+    bool w_pending[2] = {false, false};
+    bool concurrent = true;
+    int zcur = 0;
+    void* ws_side = nullptr;
     float *scalars = nullptr;   // [0] raw loss, [1] reg loss, [2] grad sumsq
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -192,7 +199,7 @@ int alloc_buffers(xv_engine* e) {
     if (B * (T - 14 + 12) * 512 > bufz) bufz = B * (T - 14 + 12) * 512;
     if (rows[5] * maxc > bufz) bufz = rows[5] * maxc;
     if (rows[1] * 512 > bufz) bufz = rows[1] * 512;
-    want(bufd); want(bufz);
+    want(bufd); want(bufz); want(bufz);
     want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512)); want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512));
     want(16);
     // GEMM split slabs: weight-gradient partials dominate
@@ -213,7 +220,7 @@ int alloc_buffers(xv_engine* e) {
     size_t opws = xv_op_workspace_bytes((int)rows[1], 2 * e->P, 2 * e->P);
     if (opws > ws) ws = opws;
     ws = xv_align(ws, 256);
-    need += ws + 4096;
+    need += 2 * ws + 8192;
     XV_CHECK_HIP(hipMalloc((void**)&e->arena, need));
     XV_CHECK_HIP(hipMemset(e->arena, 0, need));
     e->arena_bytes = need;
@@ -244,14 +251,20 @@ int alloc_buffers(xv_engine* e) {
         e->dwn = carve(e, (size_t)e->Lout * e->ldl);
     }
     e->bufD = carve(e, bufd);
-    e->bufZ = carve(e, bufz);
+    e->bufZ[0] = carve(e, bufz);
+    e->bufZ[1] = carve(e, bufz);
     size_t small = B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512);
     e->d_small0 = carve(e, small);
     e->d_small1 = carve(e, small);
     e->scalars = carve(e, 16);
     e->ws = carve(e, ws / sizeof(float));
+    e->ws_side = carve(e, ws / sizeof(float));
     e->ws_bytes = ws;
-    XV_REQUIRE(e->ws != nullptr && e->scalars != nullptr, "engine: internal arena accounting error");
+    XV_REQUIRE(e->ws != nullptr && e->ws_side != nullptr && e->scalars != nullptr, "engine: internal arena accounting error");
+    XV_CHECK_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_dz, hipEventDisableTiming));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_w[0], hipEventDisableTiming));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_w[1], hipEventDisableTiming));
     return 0;
 }
 
@@ -320,6 +333,9 @@ extern "C" int xv_engine_create(const xv_config* cfg, xv_engine** out) {
 
 extern "C" void xv_engine_destroy(xv_engine* e) {
     if (!e) return;
+    if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+    if (e->ev_dz) (void)hipEventDestroy(e->ev_dz);
+    for (int i = 0; i < 2; ++i) if (e->ev_w[i]) (void)hipEventDestroy(e->ev_w[i]);
     if (e->arena) (void)hipFree(e->arena);
     delete e;
 }
@@ -347,6 +363,12 @@ extern "C" int xv_engine_bind(xv_engine* e, float* variables, float* grads, floa
     XV_REQUIRE(((uintptr_t)variables % 16) == 0 && ((uintptr_t)grads % 16) == 0, "engine_bind: buffers must be 16-byte aligned");
     e->V = variables; e->G = grads; e->S = opt_state;
     e->weights_dirty = true;
+    return 0;
+}
+
+extern "C" int xv_engine_set_concurrency(xv_engine* e, int enabled) {
+    XV_REQUIRE(e, "null engine");
+    e->concurrent = enabled != 0;
     return 0;
 }
 
@@ -471,9 +493,30 @@ static int compute_reg_loss(xv_engine* e, hipStream_t s) {
 
 namespace {
 
+// Make `waiter` wait for everything enqueued so far on `signaller` (through `ev`).
+int chain(hipStream_t signaller, hipStream_t waiter, hipEvent_t ev) {
+    XV_CHECK_HIP(hipEventRecord(ev, signaller));
+    XV_CHECK_HIP(hipStreamWaitEvent(waiter, ev, 0));
+    return 0;
+}
+
+// All weight-gradient work enqueued on the side stream so far becomes visible to `s`.
+int join_side(xv_engine* e, hipStream_t s) {
+    for (int i = 0; i < 2; ++i)
+        if (e->w_pending[i]) {
+            XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_w[i], 0));
+            e->w_pending[i] = false;
+        }
+    return 0;
+}
+
 // backward of one affine(+BN+ReLU) layer.  da: gradient w.r.t. the layer OUTPUT (after BN/ReLU),
 // dense [segs*t_out][c_out].  x/t_in: the layer input view.  Writes parameter gradients and, if
 // dx != nullptr, the gradient w.r.t. the layer input ([segs*t_in][c_in]).
+// The weight/bias gradient only shares dz with the data-gradient chain, so it is enqueued on the
+// side stream: its workgroups fill the CUs that the tail of the data-gradient GEMM (and the small
+// BN kernels of the next layer) leave idle.  dz ping-pongs between two buffers; a buffer is rewritten
+// only after the weight gradient that read it has finished (ev_w).
 int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, const float* x, int segs, int t_in, float* dx,
                    const float* act_out) {
     const xv_config& c = e->cfg;
@@ -481,24 +524,44 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     const int pad = (dx && a.k > 1) ? a.k - 1 : 0;
     int rc;
     const float* dz = nullptr;
+    const int zi = e->zcur;
+    float* Z = e->bufZ[zi];
+    if (e->w_pending[zi]) {                       // WAR: the weight gradient two layers up read this buffer
+        XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_w[zi], 0));
+        e->w_pending[zi] = false;
+    }
     if (a.has_bn) {
         rc = xv_bn_relu_backward(s, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift,
-                                 a.has_relu ? 1 : 0, pad, e->bufZ, gptr(e, a.v_gamma), gptr(e, a.v_beta), e->ws, e->ws_bytes);
+                                 a.has_relu ? 1 : 0, pad, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
         if (rc) return rc;
-        dz = e->bufZ;
+        dz = Z;
     } else if (a.has_relu) {
-        rc = xv_relu_backward(s, da, act_out, (size_t)segs * t_out * a.c_out, e->bufZ);
+        rc = xv_relu_backward(s, da, act_out, (size_t)segs * t_out * a.c_out, Z);
         if (rc) return rc;
-        dz = e->bufZ;
+        dz = Z;
     } else {
         dz = da;
     }
     const int seg_pitch = t_out + 2 * pad;
-    rc = xv_affine_wgrad(s, x, segs, t_in, a.c_pad, a.k, a.c_in, dz, seg_pitch, pad, a.c_out, vptr(e, a.v_kernel),
-                         c.weight_l2_regularizer, gptr(e, a.v_kernel), e->ws, e->ws_bytes);
+    const bool concurrent = e->concurrent && (dz == Z);   // dz aliasing the caller's buffer: keep everything in order
+    hipStream_t ws_stream = concurrent ? e->side : s;
+    void* wws = concurrent ? e->ws_side : e->ws;
+    if (concurrent) {
+        rc = chain(s, e->side, e->ev_dz);
+        if (rc) return rc;
+    }
+    rc = xv_affine_wgrad(ws_stream, x, segs, t_in, a.c_pad, a.k, a.c_in, dz, seg_pitch, pad, a.c_out, vptr(e, a.v_kernel),
+                         c.weight_l2_regularizer, gptr(e, a.v_kernel), wws, e->ws_bytes);
     if (rc) return rc;
-    rc = xv_colsum(s, dz, segs * seg_pitch, a.c_out, a.c_out, gptr(e, a.v_bias), e->ws, e->ws_bytes);
-    if (rc) return rc;
+    if (!a.has_bn) {      // a bias in front of a BN gets its (zero + rounding noise) gradient from the BN backward
+        rc = xv_colsum(ws_stream, dz, segs * seg_pitch, a.c_out, a.c_out, gptr(e, a.v_bias), wws, e->ws_bytes);
+        if (rc) return rc;
+    }
+    if (concurrent) {
+        XV_CHECK_HIP(hipEventRecord(e->ev_w[zi], e->side));
+        e->w_pending[zi] = true;
+    }
+    if (dz == Z) e->zcur ^= 1;
     if (dx) {
         const float* wf = a.k > 1 ? a.wf : vptr(e, a.v_kernel);
         rc = xv_affine_dgrad(s, dz, segs, t_out, a.c_out, a.k, wf, dx, a.c_in, e->ws, e->ws_bytes);
@@ -529,25 +592,38 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
         if (rc) return rc;
         rc = xv_add_norm_grad(s, e->out, e->dnorm, b, e->Lout, e->d_small0);
         if (rc) return rc;
-        // d wn = out^T . dlogits
-        XvGemmTN w = {};
-        w.A = e->out; w.lda = e->Lout; w.a_rps = b; w.a_pitch = b;
-        w.B = e->dlogits; w.ldb = e->ldl; w.b_rps = b; w.b_pitch = b;
-        w.M = e->Lout; w.N = e->ldl; w.R = b;
-        w.splits = xv_tn_splits(w.M, w.N, w.R);
-        XV_REQUIRE((size_t)w.splits * w.M * w.N * sizeof(float) <= e->ws_bytes, "engine_backward: workspace too small for the loss weight gradient");
-        w.P = (float*)e->ws;
-        rc = xv_launch_gemm_tn(s, w);
-        if (rc) return rc;
-        rc = xv_launch_wgrad_reduce(s, w.P, w.splits, 1, e->Lout, e->Lout, e->ldl, e->ldl, nullptr, 0, 0.f, e->dwn, e->ldl);
-        if (rc) return rc;
-        float ol2 = c.output_weight_l2_regularizer >= 0.f ? c.output_weight_l2_regularizer : c.weight_l2_regularizer;
-        rc = xv_loss_weight_backward(s, e->dwn, e->ldl, e->wn, e->ldl, e->inv_norm, vptr(e, e->v_loss_kernel), e->Lout, e->N,
-                                     c.loss_kind != XV_LOSS_SOFTMAX, ol2, gptr(e, e->v_loss_kernel), e->ws, e->ws_bytes);
-        if (rc) return rc;
-        if (e->v_loss_bias >= 0) {
-            rc = xv_colsum(s, e->dlogits, b, e->N, e->ldl, gptr(e, e->v_loss_bias), e->ws, e->ws_bytes);
+        // d wn = out^T . dlogits and the gradient through l2_normalize: on the side stream (only reads
+        // dlogits / out / wn, which the main chain never rewrites during backward)
+        {
+            hipStream_t ss = e->concurrent ? e->side : s;
+            if (e->concurrent) {
+                rc = chain(s, ss, e->ev_dz);
+                if (rc) return rc;
+            }
+            XvGemmTN w = {};
+            w.A = e->out; w.lda = e->Lout; w.a_rps = b; w.a_pitch = b;
+            w.B = e->dlogits; w.ldb = e->ldl; w.b_rps = b; w.b_pitch = b;
+            w.M = e->Lout; w.N = e->ldl; w.R = b;
+            w.splits = xv_tn_splits(w.M, w.N, w.R);
+            XV_REQUIRE((size_t)w.splits * w.M * w.N * sizeof(float) <= e->ws_bytes, "engine_backward: workspace too small for the loss weight gradient");
+            w.P = (float*)e->ws_side;
+            rc = xv_launch_gemm_tn(ss, w);
             if (rc) return rc;
+            rc = xv_launch_wgrad_reduce(ss, w.P, w.splits, 1, e->Lout, e->Lout, e->ldl, e->ldl, nullptr, 0, 0.f, e->dwn, e->ldl);
+            if (rc) return rc;
+            float ol2 = c.output_weight_l2_regularizer >= 0.f ? c.output_weight_l2_regularizer : c.weight_l2_regularizer;
+            rc = xv_loss_weight_backward(ss, e->dwn, e->ldl, e->wn, e->ldl, e->inv_norm, vptr(e, e->v_loss_kernel), e->Lout, e->N,
+                                         c.loss_kind != XV_LOSS_SOFTMAX, ol2, gptr(e, e->v_loss_kernel), e->ws_side, e->ws_bytes);
+            if (rc) return rc;
+            if (e->v_loss_bias >= 0) {
+                rc = xv_colsum(ss, e->dlogits, b, e->N, e->ldl, gptr(e, e->v_loss_bias), e->ws_side, e->ws_bytes);
+                if (rc) return rc;
+            }
+            // tracked through ev_w[zcur^1]'s slot so join_side() covers it (the side stream is in-order)
+            if (e->concurrent) {
+                XV_CHECK_HIP(hipEventRecord(e->ev_w[e->zcur ^ 1], ss));
+                e->w_pending[e->zcur ^ 1] = true;
+            }
         }
         const float* d = e->d_small0;
         if (c.feature_norm) {
@@ -562,21 +638,26 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
         if (rc) return rc;
         rc = xv_stat_pool_backward(s, e->L[4].a, e->pool, e->d_small0, b, e->Tl[5], e->P, e->bufD);
         if (rc) return rc;
+        if (stage == 0) { rc = join_side(e, s); if (rc) return rc; }
     }
     if (stage == -1 || stage == 1) {
         rc = layer_backward(e, s, e->L[4], e->bufD, e->L[3].a, b * e->Tl[5], 1, e->bufD, nullptr);   // tdnn5: da4 overwrites da5
         if (rc) return rc;
         rc = layer_backward(e, s, e->L[3], e->bufD, e->L[2].a, b * e->Tl[4], 1, e->bufD, nullptr);   // tdnn4
         if (rc) return rc;
+        if (stage == 1) { rc = join_side(e, s); if (rc) return rc; }
     }
     if (stage == -1 || stage == 2) {
         rc = layer_backward(e, s, e->L[2], e->bufD, e->L[1].a, b, e->Tl[2], e->bufD, nullptr);        // tdnn3 -> d a2
         if (rc) return rc;
+        if (stage == 2) { rc = join_side(e, s); if (rc) return rc; }
     }
     if (stage == -1 || stage == 3) {
         rc = layer_backward(e, s, e->L[1], e->bufD, e->L[0].a, b, e->Tl[1], e->bufD, nullptr);        // tdnn2 -> d a1
         if (rc) return rc;
         rc = layer_backward(e, s, e->L[0], e->bufD, e->xpad, b, e->Tl[0], nullptr, nullptr);           // tdnn1
+        if (rc) return rc;
+        rc = join_side(e, s);       // end of the backward pass: every gradient is visible to `stream`
         if (rc) return rc;
     }
     return 0;
@@ -642,9 +723,9 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
         if (n == a.prefix + "_bn" && a.has_bn) {
             if (!a.has_relu) return set(i == 6 ? e->h7 : a.a, a.rows, a.c_out, a.c_out);
             // BN output is never materialised on the hot path (fused with ReLU): rebuild on demand
-            int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 0, e->bufZ, a.c_out);
+            int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 0, e->bufZ[0], a.c_out);
             if (rc) return rc;
-            return set(e->bufZ, a.rows, a.c_out, a.c_out);
+            return set(e->bufZ[0], a.rows, a.c_out, a.c_out);
         }
     }
     // debug views of the backward scratch (valid right after backward stage 0)

@@ -130,14 +130,15 @@ def bn_apply(z, scale, shift, relu):
     return a
 
 
-def bn_relu_backward(da, z, segs, t, gamma, mean, invstd, scale, shift, relu, pad):
+def bn_relu_backward(da, z, segs, t, gamma, mean, invstd, scale, shift, relu, pad, with_dbias=False):
     n = z.shape[1]
     dz = _f32((segs * (t + 2 * pad), n), z)
     dgamma, dbeta = _f32((n,), z), _f32((n,), z)
+    dbias = _f32((n,), z) if with_dbias else None
     wp, wb = _ws(z)
     _lib.call("xv_bn_relu_backward", _s(), _p(da), _p(z), segs, t, n, _p(gamma), _p(mean), _p(invstd), _p(scale), _p(shift),
-              int(relu), int(pad), _p(dz), _p(dgamma), _p(dbeta), wp, wb)
-    return dz, dgamma, dbeta
+              int(relu), int(pad), _p(dz), _p(dgamma), _p(dbeta), _p(dbias), wp, wb)
+    return (dz, dgamma, dbeta, dbias) if with_dbias else (dz, dgamma, dbeta)
 
 
 def relu_backward(da, a):
