@@ -88,6 +88,65 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
     const int k_end = min(p.K, k_begin + p.k_chunk);
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
+#ifndef XV_GLDS
+#define XV_GLDS 1
+#endif
+#if XV_GLDS
+    // ---- global -> LDS staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write.
+    // One wave-instruction writes 1 KiB linearly (wave-uniform base + lane*16 B) = NT_RPI whole tile rows,
+    // so lane l lands on row RPI*(RPT*wave+i) + l/KQ at chunk POSITION l%KQ; the XOR swizzle therefore
+    // moves to the SOURCE: that lane fetches chunk (l%KQ) ^ f(row) of its row (rule: swizzle source +
+    // read, never the DMA destination).  Out-of-range rows / k fetch the zero page.
+    constexpr int NT_RPI = 64 / NT_KQ;          // tile rows per wave-instruction (16 at BK=16)
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int lrow = lane / NT_KQ, lpos = lane % NT_KQ;
+    const float* ap[NT_RPT];
+    const float* bp[NT_RPT];
+    bool av[NT_RPT], bv[NT_RPT];
+    int ksrc[NT_RPT];
+#pragma unroll
+    for (int i = 0; i < NT_RPT; ++i) {
+        int row = NT_RPI * (NT_RPT * wave + i) + lrow;
+        ksrc[i] = ((lpos ^ NT_SWZ(row)) << 2);
+#if defined(XV_ABL) && (XV_ABL & 64)
+        // timing-only: fetch full 128-B lines (8 rows x 128 B per instruction) instead of 16 rows x 64 B
+        row = NT_RPI * (NT_RPT * wave + i) + (lane >> 3);
+        ksrc[i] = (lane & 7) << 2;
+#endif
+        int m = m0 + row;
+        av[i] = m < p.M;
+        int mm = av[i] ? m : 0;
+        int seg = mm / p.a_rps, tt = mm - seg * p.a_rps;
+        ap[i] = p.A + ((long)seg * p.a_pitch + tt) * p.lda;
+        int n = n0 + row;
+        bv[i] = n < p.N;
+        bp[i] = p.Bt + (long)(bv[i] ? n : 0) * p.ldb;
+    }
+    const float* __restrict__ zp = p.zero;
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto gstage = [&](int kt, int buf) {
+        float* sa = smem + buf * (2 * BM * NT_PITCH) + NT_RPI * NT_RPT * uwave * NT_PITCH;
+        float* sb = sa + BM * NT_PITCH;
+#if defined(XV_ABL) && (XV_ABL & 64)
+        const int k0 = k_begin + ((kt * BK) & ~31);
+#else
+        const int k0 = k_begin + kt * BK;
+#endif
+#pragma unroll
+        for (int i = 0; i < NT_RPT; ++i) {
+            const int k = k0 + ksrc[i];
+            const bool kv = k < k_end;
+            const float* pa = (kv && av[i]) ? ap[i] + k : zp;
+            const float* pb = (kv && bv[i]) ? bp[i] + k : zp;
+            __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+        }
+    };
+#define NT_STAGE_FIRST() gstage(0, 0)
+#define NT_STAGE_NEXT(kt, buf) gstage((kt) + 1, (buf) ^ 1)
+#define NT_COMMIT(buf) ((void)0)
+#else
     // ---- global -> register staging: thread owns rows lrow+32i, 4 consecutive k at lk
     const int lrow = tid / NT_KQ, lk = (tid % NT_KQ) * 4;
     const float* ap[NT_RPT];
@@ -128,6 +187,10 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
             *(f32x4*)(sb + row * NT_PITCH + pos) = rb[i];
         }
     };
+#define NT_STAGE_FIRST() do { gload(0); lstore(0); } while (0)
+#define NT_STAGE_NEXT(kt, buf) gload((kt) + 1)
+#define NT_COMMIT(buf) lstore((buf) ^ 1)
+#endif
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -137,28 +200,44 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    if (nk > 0) {
-        gload(0);
-        lstore(0);
-    }
+#ifdef XV_STAGGER
+    // de-phase co-resident workgroups (they start together and would hit their barrier / staging
+    // phases together, idling the MFMA pipe): 0..3 quarter K-steps of sleep by workgroup id
+    for (int d = (blockIdx.x * 2654435761u >> 13) & 3; d > 0; --d) __builtin_amdgcn_s_sleep(XV_STAGGER);
+#endif
+    if (nk > 0) NT_STAGE_FIRST();
     __syncthreads();
 
     const int a_off = (wr * 64 + li) * NT_PITCH;
     const int b_off = (wc * 64 + li) * NT_PITCH;
     const int fsw = NT_SWZ(li);     // rows wr*64 + a*32 + li share f(li): the offsets are multiples of 16
+#ifndef XV_ABL
+#define XV_ABL 0
+#endif
+    // XV_ABL (timing-only ablation builds, wrong results): 1 = no global loads / LDS staging in the loop,
+    // 2 = no LDS fragment reads, 3 = neither (MFMA + barrier only), 4 = 3 without the barrier
+    f32x4 cf = {1.f, 2.f, 3.f, 4.f};
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        if (!(XV_ABL & 1) && kt + 1 < nk) NT_STAGE_NEXT(kt, buf);
         const float* sa = smem + buf * (2 * BM * NT_PITCH);
         const float* sb = sa + BM * NT_PITCH;
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 af[2], bf[2];
             const int pos = (((2 * q + lh) ^ fsw) << 2);
+            if (XV_ABL & 2) {
+                asm volatile("" : "+v"(cf));
+                af[0] = cf; af[1] = cf; bf[0] = cf; bf[1] = cf;
+            } else {
             af[0] = *(const f32x4*)(sa + a_off + pos);
             af[1] = *(const f32x4*)(sa + a_off + 32 * NT_PITCH + pos);
             bf[0] = *(const f32x4*)(sb + b_off + pos);
             bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
+            }
+#ifdef XV_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[0][e], acc[0][0], 0, 0, 0);
@@ -166,9 +245,15 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[0][e], acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[1][e], acc[1][1], 0, 0, 0);
             }
+#ifdef XV_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
+        if (!(XV_ABL & 1) && kt + 1 < nk) NT_COMMIT(buf);
+        if (XV_ABL & 32) {              // timing-only: barrier WITHOUT waiting for the DMA (wrong results)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else if (XV_ABL != 4 && XV_ABL != 7) __syncthreads();
     }
 
     // ---- epilogue
@@ -401,36 +486,32 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p
     const int r_end = min(p.R, r_begin + p.r_chunk);
     const int nk = (r_end - r_begin + BK - 1) / BK;
 
-    // thread owns reduction rows lr+8i of each K-step, 4 consecutive output columns at lc
-    const int lr = tid >> 5, lc = (tid & 31) * 4;
+    // LDS-DMA staging: one wave-instruction = 1 KiB = two whole [r][128] rows of the image; lane l lands on
+    // row 2*(RPT*wave+i) + l/32, columns 4*(l%32)..+3.  The reduction-row -> address map (spliced view)
+    // is evaluated per lane without an integer divide (r < 2^24, float quotient off by <= 1).
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int lc = (lane & 31) * 4;
     const bool a_cv = (m0 + lc) < p.M, b_cv = (n0 + lc) < p.N;
     const float* __restrict__ zp = p.zero;
     const float* abase = p.A + (a_cv ? m0 + lc : 0);
     const float* bbase = p.B + (b_cv ? n0 + lc : 0);
-    f32x4 ra[TN_RPT], rb[TN_RPT];
-    auto gload = [&](int kt) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto gstage = [&](int kt, int buf) {
+        float* sa = smem + buf * (2 * BK * BM) + 2 * TN_RPT * uwave * BM;
+        float* sb = sa + BK * BM;
 #pragma unroll
         for (int i = 0; i < TN_RPT; ++i) {
-            int r = r_begin + kt * BK + lr + 8 * i;
+            int r = r_begin + kt * BK + 2 * (TN_RPT * wave + i) + (lane >> 5);
             bool rv = r < r_end;
-            // seg = r / rps without an integer divide (r < 2^24, so the float quotient is off by <= 1)
             int seg = (int)((float)r * p.inv_rps);
             int tt = r - seg * p.rps;
             seg += (tt >= p.rps) - (tt < 0);
             tt = r - seg * p.rps;
             const float* pa = (rv && a_cv) ? abase + ((long)seg * p.a_pitch + tt) * p.lda : zp;
             const float* pb = (rv && b_cv) ? bbase + ((long)seg * p.b_pitch + tt) * p.ldb : zp;
-            ra[i] = *(const f32x4*)pa;
-            rb[i] = *(const f32x4*)pb;
-        }
-    };
-    auto lstore = [&](int buf) {
-        float* sa = smem + buf * (2 * BK * BM);
-        float* sb = sa + BK * BM;
-#pragma unroll
-        for (int i = 0; i < TN_RPT; ++i) {
-            *(f32x4*)(sa + (lr + 8 * i) * BM + lc) = ra[i];
-            *(f32x4*)(sb + (lr + 8 * i) * BN + lc) = rb[i];
+            __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(sa + 2 * i * BM), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(sb + 2 * i * BN), 16, 0, 0);
         }
     };
 
@@ -442,16 +523,13 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    if (nk > 0) {
-        gload(0);
-        lstore(0);
-    }
+    if (nk > 0) gstage(0, 0);
     __syncthreads();
     const int a_off = lh * BM + wr * 64 + 2 * li;
     const int b_off = lh * BN + wc * 64 + 2 * li;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
         const float* sa = smem + buf * (2 * BK * BM) + a_off;
         const float* sb = smem + buf * (2 * BK * BM) + BK * BM + b_off;
         // Software pipeline over the two halves of the K-step: the second half's 16 fragment reads
@@ -484,7 +562,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].y, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
