@@ -261,7 +261,12 @@ int alloc_buffers(xv_engine* e) {
     e->ws_side = carve(e, ws / sizeof(float));
     e->ws_bytes = ws;
     XV_REQUIRE(e->ws != nullptr && e->ws_side != nullptr && e->scalars != nullptr, "engine: internal arena accounting error");
-    XV_CHECK_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    {   // lowest priority: the weight-gradient GEMMs are filler work; the small kernels of the critical
+        // data-gradient chain must not queue behind their workgroups
+        int least = 0, greatest = 0;
+        XV_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        XV_CHECK_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
+    }
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_dz, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_w[0], hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_w[1], hipEventDisableTiming));
