@@ -76,7 +76,7 @@ int xv_prep_weight_dgrad(void* stream, const float* kernel, int k, int c, int o,
  *   tdnn.py:96-100,115-119,147-151,166-170 (k = 1, segs = rows, t_in = 1).
  * x: [segs][t_in][c_pad] spliced view, wt from xv_prep_weight_fwd, z: [segs*(t_in-k+1)][ldz].
  * If bn_part != NULL it receives per-128-row-tile column statistics of z (sum and centred
- * sum of squares, layout [2][tiles_m][o]) for xv_bn_finalize - the batch statistics of
+ * sum of squares, min, max: layout [4][tiles_m][o]) for xv_bn_finalize - the batch statistics of
  * tf.layers.batch_normalization(training=True), tdnn.py:46.  `ws` is scratch
  * (xv_op_workspace_bytes) used when the launcher splits the reduction. */
 int xv_affine_forward(void* stream, const float* x, int segs, int t_in, int c_pad, int k,
@@ -108,11 +108,14 @@ int xv_col_stats(void* stream, const float* z, int rows, int n, int ldz, float* 
 /* tf.layers.batch_normalization(training=True) statistics, tdnn.py:46,64,82,102,121,153,177:
  * combine bn_part -> mean, biased var; scale = gamma*rsqrt(var+eps), shift = beta-mean*scale;
  * moving <- moving*momentum + batch*(1-momentum) (unbiased var if unbiased_moving != 0).
- * Outputs: mean[n], invstd[n], scale[n], shift[n]. */
+ * Outputs: mean[n], invstd[n], scale[n], shift[n]; optional zmin[n]/zmax[n] (range of z per channel) and
+ * *amax |= max over the tensor of relu?(z*scale+shift) as float bits (atomicMax; zero it first) - the
+ * exact output range the split-precision path scales its fp16 operand planes with. */
 int xv_bn_finalize(void* stream, const float* bn_part, int rows, int n,
                    const float* gamma, const float* beta, float eps, float momentum, int unbiased_moving,
                    float* moving_mean, float* moving_var,
-                   float* mean, float* invstd, float* scale, float* shift);
+                   float* mean, float* invstd, float* scale, float* shift,
+                   float* zmin, float* zmax, uint32_t* amax, int relu);
 /* Inference statistics (training=False): scale/shift from the moving averages. */
 int xv_bn_inference_scale(void* stream, int n, const float* gamma, const float* beta,
                           const float* moving_mean, const float* moving_var, float eps,
@@ -132,6 +135,38 @@ int xv_bn_relu_backward(void* stream, const float* da, const float* z, int segs,
                         float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes);
 /* Backward of a bare ReLU (no BN in front): dz = da * (a > 0). */
 int xv_relu_backward(void* stream, const float* da, const float* a, size_t count, float* dz);
+
+/* ---------------------------------------------------------------------------------
+ * Split precision ("f16x3"): the big TDNN contractions on the 16-bit matrix cores at fp32-class accuracy.
+ * An fp32 tensor is carried as two fp16 planes [2][rows][ld] (ld multiple of 8, zero padded):
+ * x*s = hi + lo with a power-of-two scale s derived from the tensor's max |x|, which travels in device
+ * memory as the uint32 bits of a float (`amax`; producers atomicMax into it, so zero it first).  Products
+ * hi.hi + hi.lo + lo.hi are accumulated in fp32 and multiplied by 1/(sA*sB) (2^-22 relative per product).
+ * Same reference call sites as the fp32 entry points they mirror.
+ * --------------------------------------------------------------------------------- */
+int xv_amax(void* stream, const float* x, size_t count, uint32_t* amax_accum);
+int xv_split_planes(void* stream, const float* src, int rows, int c, int lds, void* planes, int ldp, size_t plane_stride,
+                    const uint32_t* amax);
+/* planes <- relu?(z*scale+shift): BN(+ReLU) output written directly as the next layer's operand (tdnn.py:46-52) */
+int xv_bn_apply_split(void* stream, const float* z, int rows, int n, int ldz, const float* scale, const float* shift, int relu,
+                      const uint32_t* amax, void* planes, int ldp, size_t plane_stride);
+/* xv_bn_relu_backward with dz written as planes in the segment-padded layout; *dz_amax receives an upper bound of
+ * max |dz| computed from per-channel max |dy| and the forward range zmin/zmax (xv_bn_finalize). */
+int xv_bn_relu_backward_split(void* stream, const float* da, const float* z, int segs, int t, int n, const float* gamma,
+                              const float* mean, const float* invstd, const float* scale, const float* shift,
+                              const float* zmin, const float* zmax, int relu, int pad, void* dz_planes, int ldp,
+                              size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
+                              size_t ws_bytes);
+/* xv_affine_forward / _dgrad / _wgrad on planes.  c_ld / o_ld: plane row pitches (multiples of 8). */
+int xv_affine_forward_f16x3(void* stream, const void* x_planes, size_t x_plane_stride, const uint32_t* x_amax, int segs, int t_in,
+                            int c_ld, int k, const void* wt_planes, size_t wt_plane_stride, const uint32_t* wt_amax,
+                            const float* bias, float* z, int o, int ldz, float* bn_part);
+int xv_affine_dgrad_f16x3(void* stream, const void* dz_planes, size_t dz_plane_stride, const uint32_t* dz_amax, int segs, int t_out,
+                          int o_ld, int k, const void* wf_planes, size_t wf_plane_stride, const uint32_t* wf_amax, float* dx, int c);
+int xv_affine_wgrad_f16x3(void* stream, const void* x_planes, size_t x_plane_stride, const uint32_t* x_amax, int segs, int t_in,
+                          int c_ld, int k, int c, const void* dz_planes, size_t dz_plane_stride, const uint32_t* dz_amax,
+                          int dz_seg_pitch, int dz_row0, int o_ld, int o, const float* kernel, float l2_scale, float* dkernel,
+                          void* ws, size_t ws_bytes);
 
 /* statistics_pooling, pooling.py:9-34: out[b] = concat(mean_t x, sqrt(max-masked var_t x)). */
 int xv_stat_pool_forward(void* stream, const float* x, int b, int t, int c, float* out);

@@ -79,11 +79,19 @@ SIGNATURES = {
     "xv_affine_wgrad": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _I, _VP, _F, _VP, _VP, _SZ]),
     "xv_colsum": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ]),
     "xv_col_stats": (_I, [_VP, _VP, _I, _I, _I, _VP]),
-    "xv_bn_finalize": (_I, [_VP, _VP, _I, _I, _VP, _VP, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "xv_bn_finalize": (_I, [_VP, _VP, _I, _I, _VP, _VP, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I]),
     "xv_bn_inference_scale": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _F, _VP, _VP]),
     "xv_bn_apply": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP, _I]),
     "xv_bn_relu_backward": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _SZ]),
     "xv_relu_backward": (_I, [_VP, _VP, _VP, _SZ, _VP]),
+    "xv_amax": (_I, [_VP, _VP, _SZ, _VP]),
+    "xv_split_planes": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _SZ, _VP]),
+    "xv_bn_apply_split": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _I, _SZ]),
+    "xv_bn_relu_backward_split": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _I, _SZ, _VP, _VP, _VP,
+                                       _VP, _VP, _SZ]),
+    "xv_affine_forward_f16x3": (_I, [_VP, _VP, _SZ, _VP, _I, _I, _I, _I, _VP, _SZ, _VP, _VP, _VP, _I, _I, _VP]),
+    "xv_affine_dgrad_f16x3": (_I, [_VP, _VP, _SZ, _VP, _I, _I, _I, _I, _VP, _SZ, _VP, _VP, _I]),
+    "xv_affine_wgrad_f16x3": (_I, [_VP, _VP, _SZ, _VP, _I, _I, _I, _I, _I, _VP, _SZ, _VP, _I, _I, _I, _I, _VP, _F, _VP, _VP, _SZ]),
     "xv_stat_pool_forward": (_I, [_VP, _VP, _I, _I, _I, _VP]),
     "xv_stat_pool_backward": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "xv_l2_scaling_forward": (_I, [_VP, _VP, _I, _I, _F, _VP]),

@@ -66,7 +66,7 @@ struct XvGemmNT {
     float* C; long ldc;
     int M, N, K;
     const float* bias;      // optional, [N]
-    float* bn_part;         // optional, [2][tiles_m][N]
+    float* bn_part;         // optional, [4][tiles_m][N]: sum, centred squares, min, max (xv_epilogue.h)
     void* ws; size_t ws_bytes;
 };
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g);
@@ -83,3 +83,32 @@ int xv_tn_splits(int M, int N, int R);
 int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g);
 int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int C, int c_pad, int n_in, int n_out, const float* w,
                            long ldw, float l2, float* out, long ldo);
+
+// ---- split-precision (f16x3) GEMMs on fp16 planes (xv_gemm16.hip) ------------------------------
+struct XvGemm16NT {
+    const void* A; long lda; long a_plane; int a_rps; int a_pitch;   // planes [2][rows][lda] fp16
+    const void* Bt; long ldb; long b_plane;
+    float* C; long ldc;
+    int M, N, K;
+    const float* bias;
+    float* bn_part;                       // optional [4][tiles_m][N]
+    const unsigned* a_amax; const unsigned* b_amax;   // device: float bits of the operands' max |x| (scale source)
+};
+int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g);
+struct XvGemm16TN {
+    const void* A; long lda; long a_plane; int a_pitch;
+    const void* B; long ldb; long b_plane; int b_pitch;
+    int rps;
+    int M, N, R;
+    float* P; int splits;                 // slabs [splits][M][N]; splits from xv_tn16_splits
+    const unsigned* a_amax; const unsigned* b_amax;
+};
+int xv_tn16_splits(int M, int N, int R);
+int xv_launch_gemm16_tn(hipStream_t s, const XvGemm16TN& g);
+
+// Live launch timing (xv_profile_begin/end): brackets one GEMM launch with hipEvents on its stream.
+struct XvProfScope {
+    hipStream_t s; int idx;
+    XvProfScope(hipStream_t st, int kind, double flops);
+    ~XvProfScope();
+};

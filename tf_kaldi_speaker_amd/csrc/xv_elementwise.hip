@@ -6,6 +6,7 @@
 #include <stdarg.h>
 
 #include "xv_common.h"
+#include "xv_epilogue.h"
 
 // ------------------------------------------------------------------------------------
 // error plumbing
@@ -164,26 +165,34 @@ extern "C" int xv_colsum(void* stream, const float* a, int rows, int n, int lda,
 }
 
 // bn_part layout: [2][tiles][n] with tiles = ceil(rows / XV_TILE_M): sum, then centred sum of squares.
-// block = 256 threads = 32 columns x 8 row lanes over one 128-row tile; two passes (sum, then
-// squares centred on the tile mean) with fixed-order combines through LDS.
+// block = 256 threads = 32 columns x 8 row lanes over one 128-row tile; two passes (sum/min/max, then
+// squares centred on the tile mean) with fixed-order combines through LDS.  Output layout: xv_epilogue.h.
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ z, int rows, int n, long ldz,
                                                         float* __restrict__ part, int tiles) {
-    __shared__ float red[8][32];
+    __shared__ float red[8][32], rmin[8][32], rmax[8][32];
     __shared__ float s_mean[32];
     const int cx = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + cx;
     const int tile = blockIdx.y;
     const int r0 = tile * XV_TILE_M, r1 = min(rows, r0 + XV_TILE_M);
-    float s = 0.f;
+    const long plane = (long)tiles * n;
+    float s = 0.f, mn = INFINITY, mx = -INFINITY;
     if (col < n)
-        for (int r = r0 + rl; r < r1; r += 8) s += z[(long)r * ldz + col];
-    red[rl][cx] = s;
+        for (int r = r0 + rl; r < r1; r += 8) {
+            float v = z[(long)r * ldz + col];
+            s += v; mn = fminf(mn, v); mx = fmaxf(mx, v);
+        }
+    red[rl][cx] = s; rmin[rl][cx] = mn; rmax[rl][cx] = mx;
     __syncthreads();
     if (rl == 0) {
-        float t = 0.f;
+        float t = 0.f, a = INFINITY, b = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][cx];
-        if (col < n) part[(long)tile * n + col] = t;
+        for (int k = 0; k < 8; ++k) { t += red[k][cx]; a = fminf(a, rmin[k][cx]); b = fmaxf(b, rmax[k][cx]); }
+        if (col < n) {
+            part[(long)tile * n + col] = t;
+            part[2 * plane + (long)tile * n + col] = a;
+            part[3 * plane + (long)tile * n + col] = b;
+        }
         s_mean[cx] = t / (float)(r1 - r0);
     }
     __syncthreads();
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][cx];
-        part[((long)tiles + tile) * n + col] = t;
+        part[plane + (long)tile * n + col] = t;
     }
 }
 
@@ -223,13 +232,18 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float momentum, int unbiased, float* __restrict__ mmean,
                                                           float* __restrict__ mvar, float* __restrict__ mean_o,
                                                           float* __restrict__ invstd_o, float* __restrict__ scale_o,
-                                                          float* __restrict__ shift_o) {
+                                                          float* __restrict__ shift_o, float* __restrict__ zmin_o,
+                                                          float* __restrict__ zmax_o, unsigned* __restrict__ amax_o, int relu) {
     __shared__ double s_cnt[8][32], s_mean[8][32], s_m2[8][32];
+    __shared__ float s_mn[8][32], s_mx[8][32], s_am[32];
     const int cx = threadIdx.x & 31, tl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
     double cnt = 0.0, mean = 0.0, m2 = 0.0;
+    float zmn = INFINITY, zmx = -INFINITY;
     if (c < n) {
         for (int t = tl; t < tiles; t += 8) {
+            zmn = fminf(zmn, part[(2L * tiles + t) * n + c]);
+            zmx = fmaxf(zmx, part[(3L * tiles + t) * n + c]);
             int tc = min(XV_TILE_M, rows - t * XV_TILE_M);
             double tm = (double)(part[(long)t * n + c] / (float)tc);   // the tile mean the producer centred on
             double tq = (double)part[((long)tiles + t) * n + c];
@@ -240,8 +254,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         }
     }
     s_cnt[tl][cx] = cnt; s_mean[tl][cx] = mean; s_m2[tl][cx] = m2;
+    s_mn[tl][cx] = zmn; s_mx[tl][cx] = zmx;
+    if (tl == 0) s_am[cx] = 0.f;
     __syncthreads();
     if (tl != 0 || c >= n) return;
+    for (int k = 1; k < 8; ++k) { zmn = fminf(zmn, s_mn[k][cx]); zmx = fmaxf(zmx, s_mx[k][cx]); }
     for (int k = 1; k < 8; ++k) {
         double cb = s_cnt[k][cx];
         if (cb > 0.0) {
@@ -257,8 +274,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     float sc = gamma[c] * invstd;
     mean_o[c] = meanf;
     invstd_o[c] = invstd;
+    const float sh = beta[c] - meanf * sc;
     scale_o[c] = sc;
-    shift_o[c] = beta[c] - meanf * sc;
+    shift_o[c] = sh;
+    if (zmin_o) { zmin_o[c] = zmn; zmax_o[c] = zmx; }
+    if (amax_o) {
+        // exact range of y = z*sc + sh over the batch (affine => extremes at the ends), same fma as bn_apply
+        float y0 = zmn * sc + sh, y1 = zmx * sc + sh;
+        float am = relu ? fmaxf(0.f, fmaxf(y0, y1)) : fmaxf(fabsf(y0), fabsf(y1));
+        atomicMax(amax_o, __float_as_uint(am));          // max of non-negative floats == max of their bit patterns
+    }
     if (mmean) {
         float v = (unbiased && rows > 1) ? var * ((float)rows / (float)(rows - 1)) : var;
         mmean[c] = mmean[c] * momentum + meanf * (1.0f - momentum);
@@ -268,11 +293,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 
 extern "C" int xv_bn_finalize(void* stream, const float* bn_part, int rows, int n, const float* gamma, const float* beta,
                               float eps, float momentum, int unbiased_moving, float* moving_mean, float* moving_var,
-                              float* mean, float* invstd, float* scale, float* shift) {
+                              float* mean, float* invstd, float* scale, float* shift, float* zmin, float* zmax,
+                              uint32_t* amax, int relu) {
     XV_REQUIRE(rows > 0 && n > 0, "bn_finalize: bad shape");
     int tiles = xv_cdiv(rows, XV_TILE_M);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(xv_cdiv(n, 32)), dim3(256), 0, (hipStream_t)stream, bn_part, rows, n, tiles,
-                       gamma, beta, eps, momentum, unbiased_moving, moving_mean, moving_var, mean, invstd, scale, shift);
+                       gamma, beta, eps, momentum, unbiased_moving, moving_mean, moving_var, mean, invstd, scale, shift, zmin, zmax, amax, relu);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -331,12 +357,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             int n, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu,
-                                                            float* __restrict__ part /* [chunks][2][n] */) {
-    __shared__ f32x4 red[2][4][64];
+                                                            float* __restrict__ part /* [chunks][3][n]: sum dy, sum dy*xhat, max |dy| */) {
+    __shared__ f32x4 red[3][4][64];
     const int qx = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + qx) * 4;
     const int r0 = blockIdx.y * BB_ROWS, r1 = min(rows, r0 + BB_ROWS);
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0};
     if (col < n) {
         f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
         f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
@@ -351,16 +377,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             f32x4 xh = (zz - mu) * is;
             s1 += dd;
             s2 += dd * xh;
+            s3.x = fmaxf(s3.x, fabsf(dd.x)); s3.y = fmaxf(s3.y, fabsf(dd.y));
+            s3.z = fmaxf(s3.z, fabsf(dd.z)); s3.w = fmaxf(s3.w, fabsf(dd.w));
         }
     }
     red[0][rl][qx] = s1;
     red[1][rl][qx] = s2;
+    red[2][rl][qx] = s3;
     __syncthreads();
     if (rl == 0 && col < n) {
         f32x4 t1 = (red[0][0][qx] + red[0][1][qx]) + (red[0][2][qx] + red[0][3][qx]);
         f32x4 t2 = (red[1][0][qx] + red[1][1][qx]) + (red[1][2][qx] + red[1][3][qx]);
-        *(f32x4*)(part + ((long)blockIdx.y * 2 + 0) * n + col) = t1;
-        *(f32x4*)(part + ((long)blockIdx.y * 2 + 1) * n + col) = t2;
+        f32x4 t3;
+        t3.x = fmaxf(fmaxf(red[2][0][qx].x, red[2][1][qx].x), fmaxf(red[2][2][qx].x, red[2][3][qx].x));
+        t3.y = fmaxf(fmaxf(red[2][0][qx].y, red[2][1][qx].y), fmaxf(red[2][2][qx].y, red[2][3][qx].y));
+        t3.z = fmaxf(fmaxf(red[2][0][qx].z, red[2][1][qx].z), fmaxf(red[2][2][qx].z, red[2][3][qx].z));
+        t3.w = fmaxf(fmaxf(red[2][0][qx].w, red[2][1][qx].w), fmaxf(red[2][2][qx].w, red[2][3][qx].w));
+        *(f32x4*)(part + ((long)blockIdx.y * 3 + 0) * n + col) = t1;
+        *(f32x4*)(part + ((long)blockIdx.y * 3 + 1) * n + col) = t2;
+        *(f32x4*)(part + ((long)blockIdx.y * 3 + 2) * n + col) = t3;
     }
 }
 
@@ -369,28 +404,37 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef /* [2][n] */,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                                              float* __restrict__ dbias) {
-    __shared__ float r1[8][32], r2[8][32];
+                                                              float* __restrict__ dbias, const float* __restrict__ mean,
+                                                              const float* __restrict__ zmin, const float* __restrict__ zmax,
+                                                              unsigned* __restrict__ dz_amax) {
+    __shared__ float r1[8][32], r2[8][32], r3[8][32];
     const int cx = threadIdx.x & 31, cl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < n)
         for (int k = cl; k < chunks; k += 8) {
-            s1 += part[((long)k * 2 + 0) * n + c];
-            s2 += part[((long)k * 2 + 1) * n + c];
+            s1 += part[((long)k * 3 + 0) * n + c];
+            s2 += part[((long)k * 3 + 1) * n + c];
+            s3 = fmaxf(s3, part[((long)k * 3 + 2) * n + c]);
         }
-    r1[cl][cx] = s1; r2[cl][cx] = s2;
+    r1[cl][cx] = s1; r2[cl][cx] = s2; r3[cl][cx] = s3;
     __syncthreads();
     if (cl != 0 || c >= n) return;
-    s1 = 0.f; s2 = 0.f;
+    s1 = 0.f; s2 = 0.f; s3 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; }
+    for (int k = 0; k < 8; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; s3 = fmaxf(s3, r3[k][cx]); }
     dbeta[c] = s1;
     dgamma[c] = s2;
     const float c1 = s1 / (float)rows;
     coef[c] = c1;
     coef[n + c] = s2 / (float)rows;
     if (dbias) dbias[c] = gamma[c] * invstd[c] * (s1 - c1 * (float)rows);   // == sum(dz) up to rounding: 0 + noise
+    if (dz_amax) {
+        // upper bound of |dz| = |gamma*invstd| * |dy - c1 - xhat*c2| over the batch (split-precision operand scale)
+        float xh = fmaxf(fabsf(zmax[c] - mean[c]), fabsf(zmin[c] - mean[c])) * invstd[c];
+        float bound = fabsf(gamma[c] * invstd[c]) * (s3 + fabsf(c1) + xh * fabsf(s2 / (float)rows)) * 1.0001f;
+        atomicMax(dz_amax, __float_as_uint(bound));
+    }
 }
 
 // Backward pass 2: dz = gamma*invstd*(dy - c1 - xhat*c2) into the segment-padded layout.
@@ -424,26 +468,94 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, const float* _
     }
 }
 
+// Same as bn_bwd_apply_kernel but dz is written as two fp16 planes [2][segs*(t+2pad)][ldd] scaled by the power of two
+// derived from *amax (xv_gemm16.hip); 8 channels (one 16-byte chunk per plane) per thread; pad rows / columns are zero.
+__global__ void bn_bwd_apply_split_kernel(const float* __restrict__ da, const float* __restrict__ z, int segs, int t, int n,
+                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                          const float* __restrict__ invstd, const float* __restrict__ scale,
+                                          const float* __restrict__ shift, const float* __restrict__ coef, int relu, int pad,
+                                          const unsigned* __restrict__ amax, unsigned short* __restrict__ dst, long ldd,
+                                          long plane_stride) {
+    const float s = xv_pow2_scale(*amax);
+    const int tp = t + 2 * pad;
+    const long cq = ldd / 8, total = (long)segs * tp * cq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long dr = i / cq;
+        int col = (int)(i - dr * cq) * 8;
+        int seg = (int)(dr / tp), u = (int)(dr - (long)seg * tp) - pad;
+        unsigned short h[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+            int c = col + j;
+            if (u >= 0 && u < t && c < n) {
+                long r = (long)seg * t + u;
+                float zz = z[r * n + c], dd = da[r * n + c];
+                if (relu && !(zz * scale[c] + shift[c] > 0.f)) dd = 0.f;
+                float xh = (zz - mean[c]) * invstd[c];
+                v = (gamma[c] * invstd[c]) * (dd - coef[c] - xh * coef[n + c]);
+            }
+            float xs = v * s;
+            _Float16 hh = (_Float16)xs;
+            _Float16 ll = (_Float16)(xs - (float)hh);
+            h[j] = __builtin_bit_cast(unsigned short, hh);
+            l[j] = __builtin_bit_cast(unsigned short, ll);
+        }
+        *(uint4*)(dst + dr * ldd + col) = *(const uint4*)h;
+        *(uint4*)(dst + plane_stride + dr * ldd + col) = *(const uint4*)l;
+    }
+}
+
 extern "C" int xv_bn_relu_backward(void* stream, const float* da, const float* z, int segs, int t, int n, const float* gamma,
                                    const float* mean, const float* invstd, const float* scale, const float* shift, int relu,
                                    int pad, float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
     XV_REQUIRE(segs > 0 && t > 0 && n > 0 && n % 4 == 0 && pad >= 0, "bn_relu_backward: bad shape (n=%d must be a multiple of 4)", n);
     const int rows = segs * t;
     const int chunks = xv_cdiv(rows, BB_ROWS);
-    size_t need = ((size_t)chunks * 2 * n + 2 * n) * sizeof(float);
+    size_t need = ((size_t)chunks * 3 * n + 2 * n) * sizeof(float);
     XV_REQUIRE(need <= ws_bytes, "bn_relu_backward: workspace too small (%zu > %zu)", need, ws_bytes);
     float* part = (float*)ws;
-    float* coef = part + (size_t)chunks * 2 * n;
+    float* coef = part + (size_t)chunks * 3 * n;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s, da, z, rows, n, mean, invstd,
                        scale, shift, relu, part);
     XV_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, 32)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
-                       dgamma, dbeta, coef, gamma, invstd, dbias);
+                       dgamma, dbeta, coef, gamma, invstd, dbias, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (unsigned*)nullptr);
     XV_LAUNCH_CHECK();
     long total = (long)segs * (t + 2 * pad) * (n / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, da, z, segs, t, n / 4, gamma, mean,
                        invstd, scale, shift, (const float*)coef, relu, pad, dz_pad);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xv_bn_relu_backward_split(void* stream, const float* da, const float* z, int segs, int t, int n, const float* gamma,
+                                         const float* mean, const float* invstd, const float* scale, const float* shift,
+                                         const float* zmin, const float* zmax, int relu, int pad, void* dz_planes, int ldp,
+                                         size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
+                                         size_t ws_bytes) {
+    XV_REQUIRE(segs > 0 && t > 0 && n > 0 && n % 4 == 0 && pad >= 0, "bn_relu_backward_split: bad shape (n=%d must be a multiple of 4)", n);
+    XV_REQUIRE(ldp % 8 == 0 && ldp >= n && plane_stride % 8 == 0 && zmin && zmax && dz_amax, "bn_relu_backward_split: bad plane arguments");
+    const int rows = segs * t;
+    const int chunks = xv_cdiv(rows, BB_ROWS);
+    size_t need = ((size_t)chunks * 3 * n + 2 * n) * sizeof(float);
+    XV_REQUIRE(need <= ws_bytes, "bn_relu_backward_split: workspace too small (%zu > %zu)", need, ws_bytes);
+    float* part = (float*)ws;
+    float* coef = part + (size_t)chunks * 3 * n;
+    hipStream_t s = (hipStream_t)stream;
+    XV_CHECK_HIP(hipMemsetAsync(dz_amax, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s, da, z, rows, n, mean, invstd,
+                       scale, shift, relu, part);
+    XV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, 32)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
+                       dgamma, dbeta, coef, gamma, invstd, dbias, mean, zmin, zmax, (unsigned*)dz_amax);
+    XV_LAUNCH_CHECK();
+    long total = (long)segs * (t + 2 * pad) * (ldp / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_split_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, da, z, segs, t, n, gamma, mean,
+                       invstd, scale, shift, (const float*)coef, relu, pad, (const unsigned*)dz_amax, (unsigned short*)dz_planes,
+                       (long)ldp, (long)plane_stride);
     XV_LAUNCH_CHECK();
     return 0;
 }

@@ -184,7 +184,7 @@ int alloc_buffers(xv_engine* e) {
         want((size_t)a.c_out * a.k * a.c_pad);                 // wt
         if (a.k > 1) want((size_t)a.c_in * a.k * a.c_out);     // wf
         want(r * a.c_out); want(r * a.c_out);                  // z, a
-        want(2 * (size_t)xv_cdiv(r, XV_TILE_M) * a.c_out);     // bn_part
+        want(4 * (size_t)xv_cdiv(r, XV_TILE_M) * a.c_out);     // bn_part
         for (int j = 0; j < 4; ++j) want(a.c_out);
     }
     want(B * 2 * e->P); want(B * e->Lout); want(B * e->Lout);
@@ -234,7 +234,7 @@ int alloc_buffers(xv_engine* e) {
         a.wf = a.k > 1 ? carve(e, (size_t)a.c_in * a.k * a.c_out) : nullptr;
         a.z = carve(e, r * a.c_out);
         a.a = carve(e, r * a.c_out);
-        a.bn_part = carve(e, 2 * (size_t)xv_cdiv(r, XV_TILE_M) * a.c_out);
+        a.bn_part = carve(e, 4 * (size_t)xv_cdiv(r, XV_TILE_M) * a.c_out);
         a.mean = carve(e, a.c_out); a.invstd = carve(e, a.c_out);
         a.scale = carve(e, a.c_out); a.shift = carve(e, a.c_out);
         a.rows = 0;
@@ -304,7 +304,7 @@ int bn_forward(xv_engine* e, hipStream_t s, Affine& a, int rows, bool stats_from
         }
         rc = xv_bn_finalize(s, a.bn_part, rows, a.c_out, vptr(e, a.v_gamma), vptr(e, a.v_beta), c.bn_epsilon, c.batchnorm_momentum,
                             a.fused_bn && c.fused_bn_unbiased_moving_var, vptr(e, a.v_mmean), vptr(e, a.v_mvar), a.mean, a.invstd,
-                            a.scale, a.shift);
+                            a.scale, a.shift, nullptr, nullptr, nullptr, 1);
     } else {
         rc = xv_bn_inference_scale(s, a.c_out, vptr(e, a.v_gamma), vptr(e, a.v_beta), vptr(e, a.v_mmean), vptr(e, a.v_mvar),
                                    c.bn_epsilon, a.scale, a.shift);

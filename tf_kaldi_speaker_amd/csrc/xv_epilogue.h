@@ -1,0 +1,83 @@
+// Shared GEMM epilogue: per-128-row-tile column statistics of the output tile held in the
+// 2x2 v_mfma 32x32 accumulators of a 4-wave (2x2) workgroup.
+//   part layout: [4][tiles_m][N] = column sum | sum of squares centred on the TILE mean (Chan-combinable,
+//   no E[x^2]-E[x]^2 cancellation) | column min | column max  (valid rows only).
+// sum/M2 feed BatchNorm (tdnn.py:46); min/max give the exact range of the BN output, which the
+// split-precision path needs to pick the power-of-two scale of the next layer's fp16 operand planes.
+// Deterministic: fixed-order combines through LDS, no atomics.
+#pragma once
+#include "xv_common.h"
+
+__device__ __forceinline__ void xv_tile_stats_epilogue(const f32x16 (&acc)[2][2], float* red /* >= 1024 floats of LDS, free */,
+                                                       int tid, int wr, int wc, int li, int lh, int m0, int n0, int M, int N,
+                                                       int tile_m, int tiles_m, float* __restrict__ part) {
+    float* r_sum = red;          // [2][128]
+    float* r_m2 = red + 256;
+    float* r_min = red + 512;
+    float* r_max = red + 768;
+    const int cnt = min(XV_TILE_M, M - m0);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        float v = 0.f, mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                bool ok = m < M;
+                float x = acc[a][b][r];
+                v += ok ? x : 0.f;
+                mn = ok ? fminf(mn, x) : mn;
+                mx = ok ? fmaxf(mx, x) : mx;
+            }
+        v += __shfl_xor(v, 32);
+        mn = fminf(mn, __shfl_xor(mn, 32));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (lh == 0) {
+            int col = wc * 64 + b * 32 + li;
+            r_sum[wr * 128 + col] = v;
+            r_min[wr * 128 + col] = mn;
+            r_max[wr * 128 + col] = mx;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        int col = wc * 64 + b * 32 + li;
+        float mean = (r_sum[col] + r_sum[128 + col]) / (float)cnt;
+        float v = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float d = acc[a][b][r] - mean;
+                v += (m < M) ? d * d : 0.f;
+            }
+        v += __shfl_xor(v, 32);
+        if (lh == 0) r_m2[wr * 128 + col] = v;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        int n = n0 + tid;
+        if (n < N) {
+            const long plane = (long)tiles_m * N;
+            const long o = (long)tile_m * N + n;
+            part[o] = r_sum[tid] + r_sum[128 + tid];
+            part[plane + o] = r_m2[tid] + r_m2[128 + tid];
+            part[2 * plane + o] = fminf(r_min[tid], r_min[128 + tid]);
+            part[3 * plane + o] = fmaxf(r_max[tid], r_max[128 + tid]);
+        }
+    }
+}
+
+// power-of-two scale that brings a tensor with max |x| = amax (given as the uint bits of a non-negative
+// float) to [2^12, 2^13): exact to apply and to undo, 3 bits of headroom below the fp16 maximum.
+__device__ __forceinline__ float xv_pow2_scale(unsigned amax_bits) {
+    float amax = __uint_as_float(amax_bits);
+    if (!(amax > 0.f) || !(amax < INFINITY)) return 1.0f;
+    int e = (int)((amax_bits >> 23) & 0xff) - 127;       // floor(log2(amax)) for normal numbers
+    int s = 12 - e;
+    s = max(-100, min(100, s));
+    return __uint_as_float((unsigned)(s + 127) << 23);
+}

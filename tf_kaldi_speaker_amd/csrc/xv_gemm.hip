@@ -22,6 +22,7 @@
 // The contraction is order-insensitive in k as long as A and B agree, so the NT kernel lets
 // lane-half h own 4 CONSECUTIVE k of every 8 (one ds_read_b128 feeds 4 MFMAs).
 #include "xv_common.h"
+#include "xv_epilogue.h"
 
 #define BM XV_TILE_M
 #define BN XV_TILE_N
@@ -280,53 +281,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
             }
         }
 
-    if (STATS) {
-        // Per-tile column statistics for BatchNorm: sum and sum of squares centred on the TILE
-        // mean (Chan-combinable, no E[x^2]-E[x]^2 cancellation).  Deterministic, no atomics.
-        float* red = smem;             // [2][128] sums per wave-row
-        float* red2 = smem + 256;      // [2][128] centred squares
-        const int cnt = min(BM, p.M - m0);
-        float s[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            float v = 0.f;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    v += (m < p.M) ? acc[a][b][r] : 0.f;
-                }
-            v += __shfl_xor(v, 32);
-            s[b] = v;
-            if (lh == 0) red[wr * 128 + wc * 64 + b * 32 + li] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            int col = wc * 64 + b * 32 + li;
-            float mean = (red[col] + red[128 + col]) / (float)cnt;
-            float v = 0.f;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    float d = acc[a][b][r] - mean;
-                    v += (m < p.M) ? d * d : 0.f;
-                }
-            v += __shfl_xor(v, 32);
-            if (lh == 0) red2[wr * 128 + col] = v;
-        }
-        __syncthreads();
-        if (tid < 128) {
-            int n = n0 + tid;
-            if (n < p.N) {
-                p.part_sum[(long)tile_m * p.N + n] = red[tid] + red[128 + tid];
-                p.part_m2[(long)tile_m * p.N + n] = red2[tid] + red2[128 + tid];
-            }
-        }
-    }
+    if (STATS) xv_tile_stats_epilogue(acc, smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part_sum);
 }
 
 // out[m][n] = sum_z slab[z][m][n] (+ bias[n])
@@ -351,18 +306,16 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 size_t g_prof_cap = 0;
 std::vector<hipEvent_t> g_prof_events;   // pool, two per record slot
-struct ProfScope {
-    hipStream_t s; int idx;
-    ProfScope(hipStream_t st, int kind, double flops) : s(st), idx(-1) {
-        if (!g_prof_on || g_prof.size() >= g_prof_cap) return;
-        idx = (int)g_prof.size();
-        ProfRec r = {g_prof_events[2 * idx], g_prof_events[2 * idx + 1], kind, flops};
-        g_prof.push_back(r);
-        (void)hipEventRecord(r.a, s);
-    }
-    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, s); }
-};
 }  // namespace
+
+XvProfScope::XvProfScope(hipStream_t st, int kind, double flops) : s(st), idx(-1) {
+    if (!g_prof_on || g_prof.size() >= g_prof_cap) return;
+    idx = (int)g_prof.size();
+    ProfRec r = {g_prof_events[2 * idx], g_prof_events[2 * idx + 1], kind, flops};
+    g_prof.push_back(r);
+    (void)hipEventRecord(r.a, s);
+}
+XvProfScope::~XvProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, s); }
 
 extern "C" int xv_profile_begin(int max_launches) {
     XV_REQUIRE(max_launches > 0, "profile_begin: max_launches must be positive");
@@ -415,10 +368,10 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     if (splits == 1) {
         p.C = g.C; p.ldc = g.ldc; p.c_split_stride = 0; p.k_chunk = ksteps * BK;
         dim3 grid(tiles, 1, 1);
-        ProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
+        XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
         if (g.bn_part) {
             p.part_sum = g.bn_part;
-            p.part_m2 = g.bn_part + (long)p.tiles_m * g.N;
+            p.part_m2 = nullptr;
             hipLaunchKernelGGL(xv_gemm_nt_kernel<true>, grid, dim3(256), 0, s, p);
         } else {
             hipLaunchKernelGGL(xv_gemm_nt_kernel<false>, grid, dim3(256), 0, s, p);
@@ -435,7 +388,7 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     p.bias = nullptr;
     dim3 grid(tiles, 1, splits);
     {
-        ProfScope prof(s, 1, 2.0 * g.M * g.N * g.K);
+        XvProfScope prof(s, 1, 2.0 * g.M * g.N * g.K);
         hipLaunchKernelGGL(xv_gemm_nt_kernel<false>, grid, dim3(256), 0, s, p);
     }
     XV_LAUNCH_CHECK();
@@ -613,7 +566,7 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     XV_REQUIRE(splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", splits, g.splits);
     dim3 grid(p.tiles_m * p.tiles_n * splits, 1, 1);
     {
-        ProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
+        XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
         hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
     }
     XV_LAUNCH_CHECK();

@@ -1,92 +1,29 @@
-// Split-precision MFMA GEMM (experimental): fp32 operands carried as planes of 16-bit pieces so the
-// contraction runs on the 16x faster 16-bit matrix cores while keeping fp32-class accuracy.
+// Split-precision ("f16x3") MFMA GEMMs: fp32 tensors carried as TWO planes of fp16 pieces so the big
+// contractions of the TDNN run on the 16-bit matrix cores (16x the fp32-input MFMA rate) at fp32-class
+// accuracy.
 //
-//   mode 3  "bf16x6": x = h + m + l, three bf16 pieces (8+8+8 mantissa bits); products hh, hm, mh, mm, hl, lh
-//           (everything down to 2^-24 relative) accumulated in fp32 -> same error class as v_mfma_f32_32x32x2_f32.
-//   mode 2  "f16x3":  x*s = h + l, two fp16 pieces (11+11 bits) with a power-of-two tensor scale s; products hh, hl, lh
-//           (2^-22 relative), result multiplied by 1/(sA*sB).
+//   x * s = h + l + eps,   h = fp16(x*s),  l = fp16(x*s - h),   |eps| <= 2^-22 |x*s|
+//   a.b  ~=  (ha.hb + ha.lb + la.hb) / (sa*sb)      three v_mfma_f32_32x32x16_f16 per 16-deep block, fp32 accumulate
 //
-// Operand planes: [PLANES][rows][ld] 16-bit, channel axis contiguous, ld a multiple of 8 (16-byte chunks),
-// zero padded; the spliced (context-window) row map of xv_gemm.hip applies unchanged.
-// Kernel: 128x128 tile, 4 waves (2x2) x 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16_{bf16,f16}; K-step BK16 in
-// {16,32}; LDS image per plane [128 rows][BK] 16-bit with an XOR chunk swizzle (conflict-free ds_read_b128),
-// filled by LDS-DMA with the swizzle applied on the source address.
+// s is a power of two per tensor (exact to apply and undo) chosen from the tensor's max |x| so that
+// max |x*s| lies in [2^12, 2^13): 3 bits below the fp16 maximum, and the low piece of every element that
+// matters stays a normal fp16.  The max is produced by whoever writes the tensor (exact output range of
+// BN+ReLU from the GEMM epilogue's column min/max; a bound for the BN backward; a reduction for inputs and
+// weights) and travels as the uint bits of a float in device memory - no host round trip.
+// Measured on MI355X (tools/gemm16_proto.py): max error vs float64 5e-7..8e-7 of the output scale (fp32-input MFMA:
+// 1.7e-7), 2.0-2.7x the speed of the fp32-input MFMA kernels of xv_gemm.hip.
+//
+// Plane layout: [2][rows][ld] 16-bit, channel axis contiguous, ld a multiple of 8 (16-byte chunks), zero padded.
+// The spliced (context-window) row map of xv_gemm.hip applies unchanged to both kernels.
 #include "xv_common.h"
+#include "xv_epilogue.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
-
-#ifndef XV16_BK
-#define XV16_BK 32
-#endif
-#ifndef XV16_NBUF
-#define XV16_NBUF 2
-#endif
-
-// ---------------------------------------------------------------------------------------------
-// fp32 -> planes
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u16 bf16_rne(float x) {
-    __bf16 b = (__bf16)x;                       // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN-safe
-    return __builtin_bit_cast(u16, b);
-}
-__device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float((unsigned)v << 16); }
-
-template <int MODE>
-__global__ void split_planes_kernel(const float* __restrict__ src, long rows, int c, long lds, u16* __restrict__ dst, long ldd,
-                                    long plane_stride, float scale) {
-    long total = rows * ldd;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / ldd;
-        int col = (int)(i - r * ldd);
-        float x = col < c ? src[r * lds + col] : 0.f;
-        if (MODE == 3) {
-            u16 h = bf16_rne(x);
-            float r1 = x - bf16_to_f32(h);
-            u16 m = bf16_rne(r1);
-            float r2 = r1 - bf16_to_f32(m);
-            u16 l = bf16_rne(r2);
-            dst[i] = h; dst[plane_stride + i] = m; dst[2 * plane_stride + i] = l;
-        } else {
-            float xs = x * scale;
-            _Float16 h = (_Float16)xs;
-            _Float16 l = (_Float16)(xs - (float)h);
-            dst[i] = __builtin_bit_cast(u16, h); dst[plane_stride + i] = __builtin_bit_cast(u16, l);
-        }
-    }
-}
-
-extern "C" int xvx_split_planes(void* stream, const float* src, int rows, int c, int lds, void* dst, int ldd, long plane_stride,
-                                int mode, float scale) {
-    XV_REQUIRE(mode == 2 || mode == 3, "split_planes: mode must be 2 (f16 pair) or 3 (bf16 triple)");
-    XV_REQUIRE(ldd % 8 == 0 && ldd >= c, "split_planes: ld must be a multiple of 8");
-    long total = (long)rows * ldd;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
-    if (mode == 3)
-        hipLaunchKernelGGL(split_planes_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (long)rows, c, (long)lds,
-                           (u16*)dst, (long)ldd, plane_stride, scale);
-    else
-        hipLaunchKernelGGL(split_planes_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (long)rows, c, (long)lds,
-                           (u16*)dst, (long)ldd, plane_stride, scale);
-    XV_LAUNCH_CHECK();
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// NT GEMM on planes
-// ---------------------------------------------------------------------------------------------
-struct NT16Args {
-    const u16* A; long lda; long a_plane; int a_rps; int a_pitch;
-    const u16* Bt; long ldb; long b_plane;
-    float* C; long ldc;
-    int M, N, K;
-    int tiles_m, tiles_n;
-    const float* bias;
-    float out_scale;
-    const u16* zero;
-};
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 static u16* g_zero16 = nullptr;
 static int ensure_zero16() {
@@ -101,16 +38,130 @@ __device__ __forceinline__ int xcd_swizzle16(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int PLANES>
+__device__ __forceinline__ void split_f16(float x, float s, u16& h, u16& l) {
+    float xs = x * s;
+    _Float16 hh = (_Float16)xs;
+    _Float16 ll = (_Float16)(xs - (float)hh);
+    h = __builtin_bit_cast(u16, hh);
+    l = __builtin_bit_cast(u16, ll);
+}
+
+// ---------------------------------------------------------------------------------------------
+// producers of planes
+// ---------------------------------------------------------------------------------------------
+__global__ void amax_kernel(const float* __restrict__ x, size_t count, unsigned* __restrict__ amax) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
+}
+
+extern "C" int xv_amax(void* stream, const float* x, size_t count, uint32_t* amax_accum) {
+    XV_REQUIRE(x && amax_accum && count > 0, "amax: bad arguments");
+    long blocks = (long)((count + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(amax_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, count, (unsigned*)amax_accum);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// dst planes [2][rows][ldd] <- src [rows][lds] (columns >= c zero).  8 elements (one 16-byte chunk per plane) per thread.
+__global__ void split_planes_kernel(const float* __restrict__ src, long rows, int c, long lds, u16* __restrict__ dst, long ldd,
+                                    long plane_stride, const unsigned* __restrict__ amax) {
+    const float s = xv_pow2_scale(*amax);
+    const long cq = ldd / 8, total = rows * cq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / cq;
+        int col = (int)(i - r * cq) * 8;
+        u16 h[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = (col + j) < c ? src[r * lds + col + j] : 0.f;
+            split_f16(x, s, h[j], l[j]);
+        }
+        *(uint4*)(dst + r * ldd + col) = *(const uint4*)h;
+        *(uint4*)(dst + plane_stride + r * ldd + col) = *(const uint4*)l;
+    }
+}
+
+extern "C" int xv_split_planes(void* stream, const float* src, int rows, int c, int lds, void* planes, int ldp, size_t plane_stride,
+                               const uint32_t* amax) {
+    XV_REQUIRE(src && planes && amax && rows > 0 && c > 0 && lds >= c, "split_planes: bad arguments");
+    XV_REQUIRE(ldp % 8 == 0 && ldp >= c && ((uintptr_t)planes % 16) == 0 && plane_stride % 8 == 0, "split_planes: ldp must be a multiple of 8 and >= c");
+    long total = (long)rows * (ldp / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (long)rows, c, (long)lds, (u16*)planes,
+                       (long)ldp, (long)plane_stride, (const unsigned*)amax);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// planes <- relu?(z*scale + shift)   (BN + ReLU output written directly as the next layer's operand planes)
+__global__ void bn_apply_split_kernel(const float* __restrict__ z, long rows, int n, long ldz, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, int relu, const unsigned* __restrict__ amax,
+                                      u16* __restrict__ dst, long ldd, long plane_stride) {
+    const float s = xv_pow2_scale(*amax);
+    const long cq = ldd / 8, total = rows * cq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / cq;
+        int col = (int)(i - r * cq) * 8;
+        u16 h[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float y = 0.f;
+            if (col + j < n) {
+                y = z[r * ldz + col + j] * scale[col + j] + shift[col + j];
+                if (relu) y = fmaxf(y, 0.f);
+            }
+            split_f16(y, s, h[j], l[j]);
+        }
+        *(uint4*)(dst + r * ldd + col) = *(const uint4*)h;
+        *(uint4*)(dst + plane_stride + r * ldd + col) = *(const uint4*)l;
+    }
+}
+
+extern "C" int xv_bn_apply_split(void* stream, const float* z, int rows, int n, int ldz, const float* scale, const float* shift, int relu,
+                                 const uint32_t* amax, void* planes, int ldp, size_t plane_stride) {
+    XV_REQUIRE(rows > 0 && n > 0 && ldz >= n && ldp % 8 == 0 && ldp >= n && plane_stride % 8 == 0, "bn_apply_split: bad shape");
+    long total = (long)rows * (ldp / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_apply_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, (long)rows, n, (long)ldz, scale, shift,
+                       relu, (const unsigned*)amax, (u16*)planes, (long)ldp, (long)plane_stride);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT: C[m][n] = (sum_k A[rowmap(m)][k] * Bt[n][k]) / (sA*sB) + bias[n]
+// 128x128 tile, 4 waves (2x2) x 64x64 = 2x2 v_mfma_f32_32x32x16_f16 accumulators, K-step 32, two operands x two
+// planes x [128][32] fp16 LDS images (64 KB double-buffered, 2 workgroups per CU) filled by LDS-DMA; 16-byte
+// chunks XOR-swizzled by (row>>2)&3 on the DMA source and the ds_read_b128 address (conflict-free).
+// ---------------------------------------------------------------------------------------------
+struct NT16Args {
+    const u16* A; long lda; long a_plane; int a_rps; int a_pitch;
+    const u16* Bt; long ldb; long b_plane;
+    float* C; long ldc;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    const float* bias;
+    float* part;
+    const unsigned* a_amax; const unsigned* b_amax;
+    const u16* zero;
+};
+
+#define BK16 32
+#define CQ16 (BK16 / 8)
+#define PLANE_HALFS (128 * BK16)
+#define BUF_HALFS (4 * PLANE_HALFS)
+
+template <bool STATS>
 __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_kernel(NT16Args p) {
-    constexpr int BK16 = XV16_BK;                  // k per K-step (16-bit elements)
-    constexpr int CQ = BK16 / 8;                   // 16-byte chunks per tile row (2 or 4)
-    constexpr int RPI = 64 / CQ;                   // tile rows per LDS-DMA wave-instruction (32 or 16)
-    constexpr int IPW = 128 / RPI / 4;             // DMA instructions per wave per plane per operand (1 or 2)
-    constexpr int SW_SHIFT = (CQ == 4) ? 2 : 3;    // f(row) = (row >> SW_SHIFT) & (CQ-1)
-    constexpr int PLANE_HALFS = 128 * BK16;        // 16-bit elements of one plane image
-    constexpr int BUF_HALFS = 2 * PLANES * PLANE_HALFS;
-    __shared__ __attribute__((aligned(16))) u16 smem[XV16_NBUF * BUF_HALFS];
+    constexpr int RPI = 64 / CQ16;                 // tile rows per LDS-DMA wave-instruction (16)
+    constexpr int IPW = 128 / RPI / 4;             // DMA instructions per wave per plane per operand (2)
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * BUF_HALFS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
@@ -121,15 +172,14 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_kernel(NT16Args p) {
     const int m0 = tile_m * 128, n0 = tile_n * 128;
     const int nk = (p.K + BK16 - 1) / BK16;
 
-    // DMA source bookkeeping: lane -> (row, chunk position); source chunk = pos ^ f(row)
-    const int lrow = lane / CQ, lpos = lane % CQ;
+    const int lrow = lane / CQ16, lpos = lane % CQ16;
     long aoff[IPW], boff[IPW];
     bool av[IPW], bv[IPW];
     int ksrc[IPW];
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
         const int row = RPI * (IPW * wave + i) + lrow;
-        ksrc[i] = ((lpos ^ ((row >> SW_SHIFT) & (CQ - 1))) << 3);
+        ksrc[i] = ((lpos ^ ((row >> 2) & 3)) << 3);
         int m = m0 + row;
         av[i] = m < p.M;
         int mm = av[i] ? m : 0;
@@ -139,8 +189,6 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_kernel(NT16Args p) {
         bv[i] = n < p.N;
         boff[i] = (long)(bv[i] ? n : 0) * p.ldb;
     }
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
     auto gstage = [&](int kt, int buf) {
         u16* base = smem + buf * BUF_HALFS + RPI * IPW * uwave * BK16;
         const int k0 = kt * BK16;
@@ -149,11 +197,11 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_kernel(NT16Args p) {
             const int k = k0 + ksrc[i];
             const bool kv = k < p.K;
 #pragma unroll
-            for (int pl = 0; pl < PLANES; ++pl) {
+            for (int pl = 0; pl < 2; ++pl) {
                 const u16* pa = (kv && av[i]) ? p.A + pl * p.a_plane + aoff[i] + k : p.zero;
                 const u16* pb = (kv && bv[i]) ? p.Bt + pl * p.b_plane + boff[i] + k : p.zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(base + pl * PLANE_HALFS + RPI * i * BK16), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + (PLANES + pl) * PLANE_HALFS + RPI * i * BK16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + (2 + pl) * PLANE_HALFS + RPI * i * BK16), 16, 0, 0);
             }
         }
     };
@@ -166,57 +214,38 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_kernel(NT16Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int fsw = (li >> SW_SHIFT) & (CQ - 1);
+    const int fsw = (li >> 2) & 3;
     const int a_row = (wr * 64 + li) * BK16, b_row = (wc * 64 + li) * BK16;
-
-    auto compute = [&](int buf) {
+    if (nk > 0) gstage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
         const u16* base = smem + buf * BUF_HALFS;
 #pragma unroll
         for (int kb = 0; kb < BK16 / 16; ++kb) {
             const int pos = (((2 * kb + lh) ^ fsw) << 3);
-            f32x4 af[PLANES][2], bf[PLANES][2];
+            f32x4 af[2][2], bf[2][2];
 #pragma unroll
-            for (int pl = 0; pl < PLANES; ++pl) {
+            for (int pl = 0; pl < 2; ++pl) {
                 af[pl][0] = *(const f32x4*)(base + pl * PLANE_HALFS + a_row + pos);
                 af[pl][1] = *(const f32x4*)(base + pl * PLANE_HALFS + a_row + 32 * BK16 + pos);
-                bf[pl][0] = *(const f32x4*)(base + (PLANES + pl) * PLANE_HALFS + b_row + pos);
-                bf[pl][1] = *(const f32x4*)(base + (PLANES + pl) * PLANE_HALFS + b_row + 32 * BK16 + pos);
+                bf[pl][0] = *(const f32x4*)(base + (2 + pl) * PLANE_HALFS + b_row + pos);
+                bf[pl][1] = *(const f32x4*)(base + (2 + pl) * PLANE_HALFS + b_row + 32 * BK16 + pos);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    if (PLANES == 3) {
-#define MM3(i, j) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][a]), __builtin_bit_cast(bf16x8, bf[j][b]), acc[a][b], 0, 0, 0)
-                        MM3(0, 2); MM3(2, 0); MM3(1, 1); MM3(0, 1); MM3(1, 0); MM3(0, 0);   // smallest terms first
-#undef MM3
-                    } else {
-#define MM2(i, j) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][a]), __builtin_bit_cast(f16x8, bf[j][b]), acc[a][b], 0, 0, 0)
-                        MM2(0, 1); MM2(1, 0); MM2(0, 0);
-#undef MM2
-                    }
+#define MM(i, j) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][a]), __builtin_bit_cast(f16x8, bf[j][b]), acc[a][b], 0, 0, 0)
+                    MM(0, 1); MM(1, 0); MM(0, 0);          // cross terms first, then the leading product
+#undef MM
                 }
         }
-    };
-
-    if (XV16_NBUF == 2) {
-        if (nk > 0) gstage(0, 0);
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
-            compute(buf);
-            __syncthreads();
-        }
-    } else {
-        for (int kt = 0; kt < nk; ++kt) {
-            gstage(kt, 0);
-            __syncthreads();
-            compute(0);
-            __syncthreads();
-        }
     }
 
+    const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
     float bias_v[2] = {0.f, 0.f};
     if (p.bias) {
 #pragma unroll
@@ -233,40 +262,42 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_kernel(NT16Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = acc[a][b][r] * p.out_scale + bias_v[b];
+                float v = acc[a][b][r] * out_scale + bias_v[b];
+                acc[a][b][r] = v;
+                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = v;
             }
         }
+    if (STATS) xv_tile_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
 }
 
-extern "C" int xvx_gemm16_nt(void* stream, const void* A, long lda, long a_plane, int a_rps, int a_pitch, const void* Bt, long ldb,
-                             long b_plane, float* C, long ldc, int M, int N, int K, const float* bias, int mode, float out_scale) {
-    XV_REQUIRE(mode == 2 || mode == 3, "gemm16_nt: mode must be 2 or 3");
-    XV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && K % 8 == 0, "gemm16_nt: lda/ldb/K must be multiples of 8");
+int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
+    XV_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0, "gemm16_nt: lda/ldb must be multiples of 8 (lda=%ld ldb=%ld)", g.lda, g.ldb);
+    XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0 && g.a_plane % 8 == 0 && g.b_plane % 8 == 0,
+               "gemm16_nt: planes must be 16-byte aligned");
+    XV_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.a_rps > 0, "gemm16_nt: empty problem");
     if (ensure_zero16()) return 1;
     NT16Args p;
-    p.A = (const u16*)A; p.lda = lda; p.a_plane = a_plane; p.a_rps = a_rps; p.a_pitch = a_pitch;
-    p.Bt = (const u16*)Bt; p.ldb = ldb; p.b_plane = b_plane;
-    p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
-    p.tiles_m = xv_cdiv(M, 128); p.tiles_n = xv_cdiv(N, 128);
-    p.bias = bias; p.out_scale = out_scale; p.zero = g_zero16;
+    p.A = (const u16*)g.A; p.lda = g.lda; p.a_plane = g.a_plane; p.a_rps = g.a_rps; p.a_pitch = g.a_pitch;
+    p.Bt = (const u16*)g.Bt; p.ldb = g.ldb; p.b_plane = g.b_plane;
+    p.C = g.C; p.ldc = g.ldc; p.M = g.M; p.N = g.N; p.K = (int)xv_align(g.K, 8);
+    p.tiles_m = xv_cdiv(g.M, 128); p.tiles_n = xv_cdiv(g.N, 128);
+    p.bias = g.bias; p.part = g.bn_part; p.a_amax = g.a_amax; p.b_amax = g.b_amax; p.zero = g_zero16;
     dim3 grid(p.tiles_m * p.tiles_n);
-    if (mode == 3) hipLaunchKernelGGL(xv_gemm16_nt_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(xv_gemm16_nt_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
+    if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_kernel<true>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(xv_gemm16_nt_kernel<false>, grid, dim3(256), 0, s, p);
     XV_LAUNCH_CHECK();
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// TN GEMM on planes (weight gradients): P[split][m][n] = sum_r A[rowmap_a(r)][m] * B[rowmap_b(r)][n]
-// LDS image per plane: [BR reduction rows][128 columns] 16-bit, exactly as in HBM (filled by LDS-DMA).  The MFMA
-// wants 8 consecutive r per lane at a fixed column, i.e. a column read: ds_read_b64_tr_b16 delivers a 4-row x
-// 16-column block transposed (lane t of a 16-lane group gets column t of the 4 rows), two of them make one
-// operand.  Rows are 256 B = one full bank row apart, so 32-byte column blocks are XOR-swizzled by the row
-// (block ^= 2*(row&3)) - applied on the DMA source address and on the read address.
+// TN (weight gradients): P[split][m][n] = (sum_r A[amap(r)][m] * B[bmap(r)][n]) / (sA*sB)
+// LDS image per plane: [32 reduction rows][128 columns] fp16, exactly as in HBM (LDS-DMA, no transpose).  The MFMA
+// wants 8 consecutive r per lane at a fixed column - a column read: ds_read_b64_tr_b16 delivers a 4-row x 16-column
+// block transposed (lane t of a 16-lane group gets column t of the 4 rows); two of them form one operand.
+// Rows are 256 B = one full bank row apart, so the 32-byte column blocks are XOR-swizzled by the row
+// (block ^= 2*(row&3)) on the DMA source address and on the read address: conflict-free.
 // ---------------------------------------------------------------------------------------------
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
 struct TN16Args {
     const u16* A; long lda; long a_plane; int a_pitch;
     const u16* B; long ldb; long b_plane; int b_pitch;
@@ -274,16 +305,15 @@ struct TN16Args {
     float* P;
     int M, N, R, r_chunk;
     int tiles_m, tiles_n;
-    float out_scale;
+    const unsigned* a_amax; const unsigned* b_amax;
     const u16* zero;
 };
 
-template <int PLANES>
 __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
-    constexpr int BR = 32;                               // reduction rows per K-step
-    constexpr int PLANE_HALFS = BR * 128;
-    constexpr int BUF_HALFS = 2 * PLANES * PLANE_HALFS;
-    __shared__ __attribute__((aligned(16))) u16 smem[2 * BUF_HALFS];
+    constexpr int BR = 32;
+    constexpr int PH = BR * 128;                  // halfs per plane image
+    constexpr int BH = 4 * PH;                    // per buffer: A planes, B planes
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * BH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int wr = wave >> 1, wc = wave & 1;
@@ -299,31 +329,27 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
 
     // DMA: one wave-instruction = 4 image rows x 256 B; lane -> row l>>4, 16-byte chunk position l&15
     const int drow = lane >> 4, dpos = lane & 15;
-    // source 16-byte chunk for that position: 32-byte block index (pos>>1) ^ 2*(row&3); rows 4*(..)+drow => row&3 == drow
-    const int schunk = ((((dpos >> 1) ^ (2 * drow)) << 1) | (dpos & 1));
-    const int scol = schunk * 8;                          // 16-bit elements
+    const int scol = (((((dpos >> 1) ^ (2 * drow)) << 1) | (dpos & 1))) * 8;    // source column (16-bit elements)
     const bool a_cv = (m0 + scol) < p.M, b_cv = (n0 + scol) < p.N;
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
     auto gstage = [&](int kt, int buf) {
-        u16* base = smem + buf * BUF_HALFS;
+        u16* base = smem + buf * BH;
 #pragma unroll
-        for (int i = 0; i < BR / 16; ++i) {              // 8 DMA row-groups per plane image, 2 per wave
-            const int rg = (BR / 16) * uwave + i;         // row group: image rows 4*rg .. 4*rg+3
-            int r = r_begin + kt * BR + 4 * ((BR / 16) * wave + i) + drow;
+        for (int i = 0; i < 2; ++i) {
+            const int rg = 2 * uwave + i;                     // image rows 4*rg .. 4*rg+3
+            int r = r_begin + kt * BR + 4 * (2 * wave + i) + drow;
             bool rv = r < r_end;
-            int seg = (int)((float)r * p.inv_rps);
+            int seg = (int)((float)r * p.inv_rps);            // r / rps without an integer divide (r < 2^24)
             int tt = r - seg * p.rps;
             seg += (tt >= p.rps) - (tt < 0);
             tt = r - seg * p.rps;
             const long ao = ((long)seg * p.a_pitch + tt) * p.lda + m0 + scol;
             const long bo = ((long)seg * p.b_pitch + tt) * p.ldb + n0 + scol;
 #pragma unroll
-            for (int pl = 0; pl < PLANES; ++pl) {
+            for (int pl = 0; pl < 2; ++pl) {
                 const u16* pa = (rv && a_cv) ? p.A + pl * p.a_plane + ao : p.zero;
                 const u16* pb = (rv && b_cv) ? p.B + pl * p.b_plane + bo : p.zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(base + pl * PLANE_HALFS + 4 * rg * 128), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + (PLANES + pl) * PLANE_HALFS + 4 * rg * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(base + pl * PH + 4 * rg * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + (2 + pl) * PH + 4 * rg * 128), 16, 0, 0);
             }
         }
     };
@@ -336,32 +362,34 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // transposed-read lane geometry: 16-lane group g = lane>>4: column half (g&1), k half (g>>1) == lh
-    const int tq = (lane & 15) >> 2, tp = lane & 3;       // row q and 4-column piece p inside the 4x16 block
+    // transposed-read lane geometry: 16-lane group g = lane>>4: column half g&1, k half g>>1 (== lh)
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
     const int ghalf = (lane >> 4) & 1;
-    auto tr_addr = [&](int colbase /* multiple of 32 */, int row /* image row of the block's first row */) {
-        // block of 16 columns = 32 B: index within the 128-column row
-        const int blk = (colbase >> 4) + ghalf;
-        const int r = row + tq;
-        const int sblk = blk ^ (2 * (r & 3));
-        return r * 128 + sblk * 16 + tp * 4;
+    auto tr_off = [&](int colbase /* multiple of 32 */, int row0) {
+        const int r = row0 + tq;
+        return r * 128 + ((((colbase >> 4) + ghalf) ^ (2 * (r & 3))) << 4) + tp * 4;
     };
-    auto compute = [&](int buf) {
-        const u16* base = smem + buf * BUF_HALFS;
+    typedef __attribute__((address_space(3))) s16x4* ltr_t;
+    if (nk > 0) gstage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
+        const u16* base = smem + buf * BH;
 #pragma unroll
         for (int kb = 0; kb < BR / 16; ++kb) {
-            s16x8 af[PLANES][2], bf[PLANES][2];
+            const int row0 = kb * 16 + 8 * lh;
+            s16x8 af[2][2], bf[2][2];
 #pragma unroll
-            for (int pl = 0; pl < PLANES; ++pl)
+            for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const int row0 = kb * 16 + 8 * lh;
-                    const u16* ia = base + pl * PLANE_HALFS;
-                    const u16* ib = base + (PLANES + pl) * PLANE_HALFS;
-                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ia + tr_addr(wr * 64 + s * 32, row0)));
-                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ia + tr_addr(wr * 64 + s * 32, row0 + 4)));
-                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ib + tr_addr(wc * 64 + s * 32, row0)));
-                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ib + tr_addr(wc * 64 + s * 32, row0 + 4)));
+                    const u16* ia = base + pl * PH;
+                    const u16* ib = base + (2 + pl) * PH;
+                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(ia + tr_off(wr * 64 + s * 32, row0)));
+                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(ia + tr_off(wr * 64 + s * 32, row0 + 4)));
+                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(ib + tr_off(wc * 64 + s * 32, row0)));
+                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(ib + tr_off(wc * 64 + s * 32, row0 + 4)));
                     af[pl][s] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                     bf[pl][s] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
@@ -369,28 +397,15 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    if (PLANES == 3) {
-#define MM3(i, j) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][a]), __builtin_bit_cast(bf16x8, bf[j][b]), acc[a][b], 0, 0, 0)
-                        MM3(0, 2); MM3(2, 0); MM3(1, 1); MM3(0, 1); MM3(1, 0); MM3(0, 0);
-#undef MM3
-                    } else {
-#define MM2(i, j) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][a]), __builtin_bit_cast(f16x8, bf[j][b]), acc[a][b], 0, 0, 0)
-                        MM2(0, 1); MM2(1, 0); MM2(0, 0);
-#undef MM2
-                    }
+#define MM(i, j) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][a]), __builtin_bit_cast(f16x8, bf[j][b]), acc[a][b], 0, 0, 0)
+                    MM(0, 1); MM(1, 0); MM(0, 0);
+#undef MM
                 }
         }
-    };
-
-    if (nk > 0) gstage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
-        compute(buf);
         __syncthreads();
     }
 
+    const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
     float* P = p.P + (long)split * p.M * p.N;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -400,31 +415,88 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M && n < p.N) P[(long)m * p.N + n] = acc[a][b][r] * p.out_scale;
+                if (m < p.M && n < p.N) P[(long)m * p.N + n] = acc[a][b][r] * out_scale;
             }
         }
 }
 
-extern "C" int xvx_gemm16_tn(void* stream, const void* A, long lda, long a_plane, int a_pitch, const void* B, long ldb, long b_plane,
-                             int b_pitch, int rps, float* P, int M, int N, int R, int splits, int mode, float out_scale) {
-    XV_REQUIRE(mode == 2 || mode == 3, "gemm16_tn: mode must be 2 or 3");
-    XV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && M % 8 == 0 && N % 8 == 0, "gemm16_tn: lda/ldb/M/N must be multiples of 8");
-    XV_REQUIRE(R < (1 << 24) && rps > 0 && splits >= 1, "gemm16_tn: bad reduction shape");
+int xv_tn16_splits(int M, int N, int R) {
+    int tiles = xv_cdiv(M, 128) * xv_cdiv(N, 128);
+    int ksteps = xv_cdiv(R, 32);
+    int splits = 512 / tiles;                      // 2 resident workgroups per CU (64 KB LDS each): one co-resident round
+    if (splits > ksteps / 2) splits = ksteps / 2;
+    if (splits < 1) splits = 1;
+    int chunk = xv_cdiv(ksteps, splits) * 32;
+    return xv_cdiv(R, chunk);
+}
+
+int xv_launch_gemm16_tn(hipStream_t s, const XvGemm16TN& g) {
+    XV_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && g.M % 8 == 0 && g.N % 8 == 0, "gemm16_tn: lda/ldb/M/N must be multiples of 8 (M=%d N=%d)", g.M, g.N);
+    XV_REQUIRE(g.R > 0 && g.R < (1 << 24) && g.rps > 0 && g.splits >= 1, "gemm16_tn: bad reduction shape");
     if (ensure_zero16()) return 1;
     TN16Args p;
-    p.A = (const u16*)A; p.lda = lda; p.a_plane = a_plane; p.a_pitch = a_pitch;
-    p.B = (const u16*)B; p.ldb = ldb; p.b_plane = b_plane; p.b_pitch = b_pitch;
-    p.rps = rps; p.inv_rps = 1.0f / (float)rps;
-    p.P = P; p.M = M; p.N = N; p.R = R;
-    p.tiles_m = xv_cdiv(M, 128); p.tiles_n = xv_cdiv(N, 128);
-    int ksteps = xv_cdiv(R, 32);
-    p.r_chunk = xv_cdiv(ksteps, splits) * 32;
-    int nsplit = xv_cdiv(R, p.r_chunk);
-    XV_REQUIRE(nsplit == splits, "gemm16_tn: splits %d does not divide the reduction evenly (got %d)", splits, nsplit);
-    p.out_scale = out_scale; p.zero = g_zero16;
-    dim3 grid(p.tiles_m * p.tiles_n * splits);
-    if (mode == 3) hipLaunchKernelGGL(xv_gemm16_tn_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(xv_gemm16_tn_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    p.A = (const u16*)g.A; p.lda = g.lda; p.a_plane = g.a_plane; p.a_pitch = g.a_pitch;
+    p.B = (const u16*)g.B; p.ldb = g.ldb; p.b_plane = g.b_plane; p.b_pitch = g.b_pitch;
+    p.rps = g.rps; p.inv_rps = 1.0f / (float)g.rps;
+    p.P = g.P; p.M = g.M; p.N = g.N; p.R = g.R;
+    p.tiles_m = xv_cdiv(g.M, 128); p.tiles_n = xv_cdiv(g.N, 128);
+    int ksteps = xv_cdiv(g.R, 32);
+    p.r_chunk = xv_cdiv(ksteps, g.splits) * 32;
+    XV_REQUIRE(xv_cdiv(g.R, p.r_chunk) == g.splits, "gemm16_tn: splits must come from xv_tn16_splits");
+    p.a_amax = g.a_amax; p.b_amax = g.b_amax; p.zero = g_zero16;
+    dim3 grid(p.tiles_m * p.tiles_n * g.splits);
+    XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
+    hipLaunchKernelGGL(xv_gemm16_tn_kernel, grid, dim3(256), 0, s, p);
     XV_LAUNCH_CHECK();
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Public op-level wrappers (include/xvector_hip.h, "split precision")
+// ---------------------------------------------------------------------------------------------
+extern "C" int xv_affine_forward_f16x3(void* stream, const void* x_planes, size_t x_plane_stride, const uint32_t* x_amax, int segs, int t_in,
+                                       int c_ld, int k, const void* wt_planes, size_t wt_plane_stride, const uint32_t* wt_amax,
+                                       const float* bias, float* z, int o, int ldz, float* bn_part) {
+    XV_REQUIRE(segs > 0 && k >= 1 && t_in >= k && c_ld > 0 && o > 0 && ldz >= o, "affine_forward_f16x3: bad shape (t_in=%d k=%d)", t_in, k);
+    XvGemm16NT g = {};
+    g.A = x_planes; g.lda = c_ld; g.a_plane = (long)x_plane_stride; g.a_rps = t_in - k + 1; g.a_pitch = t_in;
+    g.Bt = wt_planes; g.ldb = (long)k * c_ld; g.b_plane = (long)wt_plane_stride;
+    g.C = z; g.ldc = ldz; g.M = segs * (t_in - k + 1); g.N = o; g.K = k * c_ld;
+    g.bias = bias; g.bn_part = bn_part; g.a_amax = x_amax; g.b_amax = wt_amax;
+    return xv_launch_gemm16_nt((hipStream_t)stream, g);
+}
+
+extern "C" int xv_affine_dgrad_f16x3(void* stream, const void* dz_planes, size_t dz_plane_stride, const uint32_t* dz_amax, int segs, int t_out,
+                                     int o_ld, int k, const void* wf_planes, size_t wf_plane_stride, const uint32_t* wf_amax, float* dx,
+                                     int c) {
+    XV_REQUIRE(segs > 0 && k >= 1 && t_out >= 1 && o_ld > 0 && c > 0, "affine_dgrad_f16x3: bad shape");
+    XvGemm16NT g = {};
+    g.A = dz_planes; g.lda = o_ld; g.a_plane = (long)dz_plane_stride; g.a_rps = t_out + k - 1; g.a_pitch = t_out + 2 * (k - 1);
+    g.Bt = wf_planes; g.ldb = (long)k * o_ld; g.b_plane = (long)wf_plane_stride;
+    g.C = dx; g.ldc = c; g.M = segs * (t_out + k - 1); g.N = c; g.K = k * o_ld;
+    g.a_amax = dz_amax; g.b_amax = wf_amax;
+    return xv_launch_gemm16_nt((hipStream_t)stream, g);
+}
+
+extern "C" int xv_affine_wgrad_f16x3(void* stream, const void* x_planes, size_t x_plane_stride, const uint32_t* x_amax, int segs, int t_in,
+                                     int c_ld, int k, int c, const void* dz_planes, size_t dz_plane_stride, const uint32_t* dz_amax,
+                                     int dz_seg_pitch, int dz_row0, int o_ld, int o, const float* kernel, float l2_scale, float* dkernel,
+                                     void* ws, size_t ws_bytes) {
+    XV_REQUIRE(segs > 0 && k >= 1 && t_in >= k && c_ld >= c && o_ld >= o && o_ld % 8 == 0 && c_ld % 8 == 0,
+               "affine_wgrad_f16x3: bad shape (c_ld=%d and o_ld=%d must be multiples of 8)", c_ld, o_ld);
+    const int t_out = t_in - k + 1;
+    XvGemm16TN g = {};
+    g.A = x_planes; g.lda = c_ld; g.a_plane = (long)x_plane_stride; g.a_pitch = t_in;
+    g.B = (const u16*)dz_planes + (long)dz_row0 * o_ld; g.ldb = o_ld; g.b_plane = (long)dz_plane_stride; g.b_pitch = dz_seg_pitch;
+    g.rps = t_out;
+    g.M = k * c_ld; g.N = o_ld; g.R = segs * t_out;
+    g.splits = xv_tn16_splits(g.M, g.N, g.R);
+    XV_REQUIRE((size_t)g.splits * g.M * g.N * sizeof(float) <= ws_bytes, "affine_wgrad_f16x3: workspace too small (%zu needed)",
+               (size_t)g.splits * g.M * g.N * sizeof(float));
+    g.P = (float*)ws;
+    g.a_amax = x_amax; g.b_amax = dz_amax;
+    int rc = xv_launch_gemm16_tn((hipStream_t)stream, g);
+    if (rc) return rc;
+    return xv_launch_wgrad_reduce((hipStream_t)stream, g.P, g.splits, k, c, c_ld, o_ld, o, l2_scale != 0.f ? kernel : nullptr, o, l2_scale,
+                                  dkernel, o);
 }

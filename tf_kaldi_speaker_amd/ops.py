@@ -71,7 +71,7 @@ def affine_forward(x, k, wt, bias, o, with_stats=False):
     segs, t_in, c_pad = x.shape
     rows = segs * (t_in - k + 1)
     z = _f32((rows, o), x)
-    part = _f32((2, (rows + TILE_M - 1) // TILE_M, o), x) if with_stats else None
+    part = _f32((4, (rows + TILE_M - 1) // TILE_M, o), x) if with_stats else None
     wp, wb = _ws(x)
     _lib.call("xv_affine_forward", _s(), _p(x), segs, t_in, c_pad, k, _p(wt), _p(bias), _p(z), o, o, _p(part), wp, wb)
     return (z, part) if with_stats else z
@@ -103,16 +103,21 @@ def colsum(a):
 
 def col_stats(z):
     rows, n = z.shape
-    part = _f32((2, (rows + TILE_M - 1) // TILE_M, n), z)
+    part = _f32((4, (rows + TILE_M - 1) // TILE_M, n), z)
     _lib.call("xv_col_stats", _s(), _p(z), rows, n, z.stride(0), _p(part))
     return part
 
 
-def bn_finalize(part, rows, gamma, beta, eps, momentum, unbiased, moving_mean, moving_var):
+def bn_finalize(part, rows, gamma, beta, eps, momentum, unbiased, moving_mean, moving_var, with_range=False, relu=True):
     n = gamma.numel()
     mean, invstd, scale, shift = (_f32((n,), gamma) for _ in range(4))
+    zmin = _f32((n,), gamma) if with_range else None
+    zmax = _f32((n,), gamma) if with_range else None
+    amax = torch.zeros(1, dtype=torch.int32, device=gamma.device) if with_range else None
     _lib.call("xv_bn_finalize", _s(), _p(part), rows, n, _p(gamma), _p(beta), float(eps), float(momentum), int(unbiased),
-              _p(moving_mean), _p(moving_var), _p(mean), _p(invstd), _p(scale), _p(shift))
+              _p(moving_mean), _p(moving_var), _p(mean), _p(invstd), _p(scale), _p(shift), _p(zmin), _p(zmax), _p(amax), int(relu))
+    if with_range:
+        return mean, invstd, scale, shift, zmin, zmax, amax.view(torch.float32)
     return mean, invstd, scale, shift
 
 
@@ -227,3 +232,78 @@ def momentum_update(p, g, acc, lr, momentum, nesterov, grad_scale=1.0):
 def adam_update(p, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     _lib.call("xv_adam_update", _s(), _p(p), _p(g), _p(m), _p(v), C.c_size_t(p.numel()), float(lr), float(beta1), float(beta2),
               float(eps), int(t), float(grad_scale))
+
+
+# ---- split precision (f16x3): fp32 tensors as two fp16 planes + a device-side max |x| -------------------------
+class Planes(object):
+    """[2][rows][ld] fp16 planes of an fp32 matrix plus the uint32 float-bits of its max |x| (device)."""
+
+    def __init__(self, data, rows, ld, amax):
+        self.data, self.rows, self.ld, self.amax = data, rows, ld, amax
+
+    @property
+    def stride(self):
+        return self.rows * self.ld
+
+
+def amax_of(x):
+    a = torch.zeros(1, dtype=torch.int32, device=x.device)
+    _lib.call("xv_amax", _s(), _p(x), C.c_size_t(x.numel()), _p(a))
+    return a
+
+
+def split_planes(x2d, amax=None):
+    rows, c = x2d.shape
+    ld = (c + 7) // 8 * 8
+    if amax is None:
+        amax = amax_of(x2d)
+    data = torch.empty((2, rows, ld), dtype=torch.int16, device=x2d.device)
+    _lib.call("xv_split_planes", _s(), _p(x2d), rows, c, x2d.stride(0), _p(data), ld, C.c_size_t(rows * ld), _p(amax))
+    return Planes(data, rows, ld, amax)
+
+
+def bn_apply_split(z, scale, shift, relu, amax):
+    rows, n = z.shape
+    ld = (n + 7) // 8 * 8
+    data = torch.empty((2, rows, ld), dtype=torch.int16, device=z.device)
+    _lib.call("xv_bn_apply_split", _s(), _p(z), rows, n, n, _p(scale), _p(shift), int(relu), _p(amax), _p(data), ld, C.c_size_t(rows * ld))
+    return Planes(data, rows, ld, amax)
+
+
+def bn_relu_backward_split(da, z, segs, t, gamma, mean, invstd, scale, shift, zmin, zmax, relu, pad):
+    n = z.shape[1]
+    ld = (n + 7) // 8 * 8
+    rows = segs * (t + 2 * pad)
+    data = torch.empty((2, rows, ld), dtype=torch.int16, device=z.device)
+    amax = torch.zeros(1, dtype=torch.int32, device=z.device)
+    dgamma, dbeta, dbias = _f32((n,), z), _f32((n,), z), _f32((n,), z)
+    wp, wb = _ws(z)
+    _lib.call("xv_bn_relu_backward_split", _s(), _p(da), _p(z), segs, t, n, _p(gamma), _p(mean), _p(invstd), _p(scale), _p(shift),
+              _p(zmin), _p(zmax), int(relu), int(pad), _p(data), ld, C.c_size_t(rows * ld), _p(amax), _p(dgamma), _p(dbeta), _p(dbias),
+              wp, wb)
+    return Planes(data, rows, ld, amax), dgamma, dbeta, dbias
+
+
+def affine_forward_f16x3(xp, segs, t_in, k, wtp, bias, o, with_stats=False):
+    """xp: Planes of x [segs*t_in][c_ld]; wtp: Planes of Wt [o][k*c_ld]."""
+    rows = segs * (t_in - k + 1)
+    z = torch.empty((rows, o), dtype=torch.float32, device=xp.data.device)
+    part = torch.empty((4, (rows + TILE_M - 1) // TILE_M, o), dtype=torch.float32, device=z.device) if with_stats else None
+    _lib.call("xv_affine_forward_f16x3", _s(), _p(xp.data), C.c_size_t(xp.stride), _p(xp.amax), segs, t_in, xp.ld, k, _p(wtp.data),
+              C.c_size_t(wtp.stride), _p(wtp.amax), _p(bias), _p(z), o, o, _p(part))
+    return (z, part) if with_stats else z
+
+
+def affine_dgrad_f16x3(dzp, segs, t_out, k, wfp, c):
+    dx = torch.empty((segs * (t_out + k - 1), c), dtype=torch.float32, device=dzp.data.device)
+    _lib.call("xv_affine_dgrad_f16x3", _s(), _p(dzp.data), C.c_size_t(dzp.stride), _p(dzp.amax), segs, t_out, dzp.ld, k, _p(wfp.data),
+              C.c_size_t(wfp.stride), _p(wfp.amax), _p(dx), c)
+    return dx
+
+
+def affine_wgrad_f16x3(xp, segs, t_in, k, c, dzp, dz_seg_pitch, dz_row0, o, kernel, l2_scale):
+    dk = torch.empty((k, c, o), dtype=torch.float32, device=xp.data.device)
+    wp, wb = _ws(dk)
+    _lib.call("xv_affine_wgrad_f16x3", _s(), _p(xp.data), C.c_size_t(xp.stride), _p(xp.amax), segs, t_in, xp.ld, k, c, _p(dzp.data),
+              C.c_size_t(dzp.stride), _p(dzp.amax), dz_seg_pitch, dz_row0, dzp.ld, o, _p(kernel), float(l2_scale), _p(dk), wp, wb)
+    return dk
