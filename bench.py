@@ -30,12 +30,18 @@ import torch
 # algorithmic work of shape S1 (per 128-chunk step)
 B, T, D, NSPK = 128, 200, 30, 7351
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32-input MFMA peak
+PEAK_F16_MFMA_TFLOPS = 16 * 157.3   # same guide: fp32-input MFMA = 1/16 of the BF16/F16 rate (~2.5 PF dense)
+NKINDS = 6
 KIND_NAMES = ["xv_gemm_nt_kernel<true> (forward conv/dense + BN stats)",
               "xv_gemm_nt_kernel<false> (data gradients / logits)",
-              "xv_gemm_tn_kernel (weight gradients)"]
-
-
-KIND_SYMBOLS = ["xv_gemm_nt_kernel<true>", "xv_gemm_nt_kernel<false>", "xv_gemm_tn_kernel"]
+              "xv_gemm_tn_kernel (weight gradients)",
+              "xv_gemm16_nt_kernel<true> (f16x3 forward conv/dense + BN stats)",
+              "xv_gemm16_nt_kernel<false> (f16x3 data gradients)",
+              "xv_gemm16_tn_kernel (f16x3 weight gradients)"]
+KIND_SYMBOLS = ["xv_gemm_nt_kernel<true>", "xv_gemm_nt_kernel<false>", "xv_gemm_tn_kernel",
+                "xv_gemm16_nt_kernel<true>", "xv_gemm16_nt_kernel<false>", "xv_gemm16_tn_kernel"]
+# algorithmic-FLOP peak of each kind: an f16x3 product issues 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi)
+KIND_PEAK = [PEAK_F32_MFMA_TFLOPS] * 3 + [PEAK_F16_MFMA_TFLOPS / 3.0] * 3
 
 
 def pmc_traffic(kind):
@@ -99,6 +105,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default=None,
+                    help="frame-level GEMM arithmetic (default: the engine's default, env XV_PRECISION)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,7 +131,8 @@ def main():
 
     cfg = E.make_config(D, NSPK, loss_func="additive_margin_softmax", margin_m=0.2, lambda_min=0.0, lambda_base=1000.0,
                         lambda_gamma=1e-4, lambda_power=5.0, last_layer_linear=True, weight_l2_regularizer=1e-2,
-                        batchnorm_momentum=0.99, optimizer="sgd", max_batch=B, max_frames=T)
+                        batchnorm_momentum=0.99, optimizer="sgd", max_batch=B, max_frames=T, precision=args.precision)
+    precision = {v: k for k, v in _lib.PRECISIONS.items()}[int(cfg.precision)]
     eng = E.Engine(cfg, device=str(dev))
     eng.init_variables(seed=0)       # identical replicas on every rank
     rs = np.random.RandomState(1000 + rank)
@@ -152,9 +161,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    cnt = (C.c_int64 * 3)()
-    ms = (C.c_double * 3)()
-    fl = (C.c_double * 3)()
+    cnt = (C.c_int64 * NKINDS)()
+    ms = (C.c_double * NKINDS)()
+    fl = (C.c_double * NKINDS)()
     _lib.check(lib.xv_profile_end(cnt, ms, fl), "xv_profile_end")
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -171,9 +180,9 @@ def main():
     for i in range(iso_steps):
         one_step(args.warmup + args.steps + 1 + i)
     torch.cuda.synchronize()
-    icnt = (C.c_int64 * 3)()
-    ims = (C.c_double * 3)()
-    ifl = (C.c_double * 3)()
+    icnt = (C.c_int64 * NKINDS)()
+    ims = (C.c_double * NKINDS)()
+    ifl = (C.c_double * NKINDS)()
     _lib.check(lib.xv_profile_end(icnt, ims, ifl), "xv_profile_end")
     _lib.check(lib.xv_engine_set_concurrency(eng.h, 1))
     raw, reg = eng.losses()
@@ -184,9 +193,10 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         fwd_flops, total_flops = step_flops(B, T, D, NSPK)
-        dom = int(np.argmax([ms[k] for k in range(3)]))
+        dom = int(np.argmax([ms[k] for k in range(NKINDS)]))
+        peak = KIND_PEAK[dom]
         kernels = []
-        for k in range(3):
+        for k in range(NKINDS):
             if cnt[k]:
                 kernels.append({"kernel": KIND_NAMES[k], "launches": int(cnt[k]), "avg_ms": ms[k] / cnt[k],
                                 "tflops": fl[k] / (ms[k] * 1e-3) / 1e12, "share_of_step": ms[k] / args.steps / ms_per_step,
@@ -203,22 +213,26 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if precision == "f32" else "f32 (frame-level GEMMs as 3 fp16-plane MFMA products, fp32 accumulate; fp32-level results)",
             "data": "synthetic",
             "config": {"workload": "TDNN x-vector (tdnn.py 5 frame + 2 segment layers, stat pooling) + AM-Softmax m=0.2, "
                                    "full optimiser step (fwd+bwd+L2+SGD%s), %d chunks/GPU x %d frames x %d-dim, %d speakers"
                                    % ("+RCCL all-reduce" if world > 1 else "", B, T, D, NSPK),
                        "chunks_per_gpu": B, "frames": T, "feat_dim": D, "num_speakers": NSPK,
-                       "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                       "precision": precision, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": round(achieved, 2), "peak": round(peak, 1),
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom),
+                         "peak_note": ("dense fp32-input MFMA peak" if dom < 3 else
+                                       "algorithmic peak of the f16x3 scheme = dense fp16 MFMA peak (16 x 157.3 TF) / 3 products; "
+                                       "achieved counts algorithmic 2*M*N*K once, executed MFMA FLOPs are 3x that"),
+                         "achieved_vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "traffic_unit": "bytes/launch past L2 (rocprofv3 PMC, profiles/)",
                          "avg_launch_ms": round(ms[dom] / cnt[dom], 4), "launches": int(cnt[dom]),
                          "algorithmic_flops_per_launch": fl[dom] / cnt[dom],
                          "note": "weight-gradient launches (side stream) overlap data-gradient launches in the timed region; "
                                  "`isolated_*` = same kernel timed alone in an extra untimed pass of %d steps" % iso_steps,
                          "isolated_achieved": round(ifl[dom] / (ims[dom] * 1e-3) / 1e12, 2),
-                         "isolated_frac": round(ifl[dom] / (ims[dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+                         "isolated_frac": round(ifl[dom] / (ims[dom] * 1e-3) / 1e12 / peak, 4)},
             "step_flops": {"algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
                            "whole_step_tflops": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
                            "whole_step_frac_of_f32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},

@@ -45,10 +45,13 @@ int xv_device_count(void);
  *   kind 0 = xv_gemm_nt_kernel<true>  (forward conv/dense + BN-statistics epilogue)
  *   kind 1 = xv_gemm_nt_kernel<false> (data gradients, logits, split launches)
  *   kind 2 = xv_gemm_tn_kernel        (weight gradients)
+ *   kind 3 = xv_gemm16_nt_kernel<true>, kind 4 = xv_gemm16_nt_kernel<false>, kind 5 = xv_gemm16_tn_kernel
+ *            (the same three roles on fp16 hi/lo planes, XV_PRECISION_F16X3)
  * xv_profile_end synchronises the recorded events and returns, per kind, the number of launches,
  * their summed duration in ms and their summed algorithmic FLOPs (2*M*N*K each). */
 int xv_profile_begin(int max_launches);
-int xv_profile_end(int64_t launches[3], double ms[3], double flops[3]);
+#define XV_PROFILE_KINDS 6
+int xv_profile_end(int64_t launches[XV_PROFILE_KINDS], double ms[XV_PROFILE_KINDS], double flops[XV_PROFILE_KINDS]);
 
 /* dst[r][0..cols) = src[r][0..cols) for r < rows (device to device, pitches in floats). */
 int xv_copy_2d(void* stream, float* dst, size_t ldd, const float* src, size_t lds, int rows, int cols);
@@ -150,6 +153,10 @@ int xv_split_planes(void* stream, const float* src, int rows, int c, int lds, vo
 /* planes <- relu?(z*scale+shift): BN(+ReLU) output written directly as the next layer's operand (tdnn.py:46-52) */
 int xv_bn_apply_split(void* stream, const float* z, int rows, int n, int ldz, const float* scale, const float* shift, int relu,
                       const uint32_t* amax, void* planes, int ldp, size_t plane_stride);
+/* Range of z (per channel) and of relu?(z*scale+shift) (whole tensor, into *amax) from the bn_part min/max planes,
+ * for scale/shift that did not come from xv_bn_finalize (training=False: moving statistics). */
+int xv_bn_output_range(void* stream, const float* bn_part, int rows, int n, const float* scale, const float* shift, int relu,
+                       float* zmin, float* zmax, uint32_t* amax);
 /* xv_bn_relu_backward with dz written as planes in the segment-padded layout; *dz_amax receives an upper bound of
  * max |dz| computed from per-channel max |dy| and the forward range zmin/zmax (xv_bn_finalize). */
 int xv_bn_relu_backward_split(void* stream, const float* da, const float* z, int segs, int t, int n, const float* gamma,
@@ -237,7 +244,12 @@ typedef struct xv_config {
     float clip_gradient_norm;         /* trainer.py:408-410; <= 0 => clip_gradient:false */
     int32_t max_batch;                /* capacity: chunks per step */
     int32_t max_frames;               /* capacity: frames per chunk */
+    int32_t precision;                /* XV_PRECISION_*: how the tdnn1-5 contractions are evaluated */
 } xv_config;
+/* fp32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products) */
+#define XV_PRECISION_F32 0
+/* split precision: three fp16 MFMA products of (hi,lo) pieces per fp32 product, fp32 accumulate (2^-22 relative) */
+#define XV_PRECISION_F16X3 1
 
 int xv_engine_create(const xv_config* cfg, xv_engine** out);
 void xv_engine_destroy(xv_engine* e);

@@ -14,6 +14,14 @@ from oracle import xvector_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["f32", "f16x3"], autouse=True)
+def xv_precision(request, monkeypatch):
+    """Every test of this module runs twice: fp32-input MFMA and the split-precision (f16x3) path,
+    against the same oracle and the same tolerances."""
+    monkeypatch.setenv("XV_PRECISION", request.param)
+    return request.param
+
+
 def rel_err(got, ref):
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)

@@ -14,6 +14,14 @@ from tests.kaldi_fixture import make_data_dir
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["f32", "f16x3"], autouse=True)
+def xv_precision(request, monkeypatch):
+    """Every test of this module runs twice: fp32-input MFMA and the split-precision (f16x3) path,
+    against the same oracle and the same tolerances."""
+    monkeypatch.setenv("XV_PRECISION", request.param)
+    return request.param
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "tf_kaldi_speaker_amd")
 

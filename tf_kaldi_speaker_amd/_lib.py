@@ -45,6 +45,7 @@ class XvConfig(C.Structure):
         ("clip_gradient_norm", C.c_float),
         ("max_batch", C.c_int32),
         ("max_frames", C.c_int32),
+        ("precision", C.c_int32),
     ]
 
 
@@ -55,6 +56,7 @@ LOSS_KINDS = {
     "additive_angular_margin_softmax": 3,
 }
 OPTIMIZERS = {"sgd": 0, "momentum": 1, "adam": 2}
+PRECISIONS = {"f32": 0, "f16x3": 1}
 
 _VP = C.c_void_p
 _SZ = C.c_size_t
@@ -87,6 +89,7 @@ SIGNATURES = {
     "xv_amax": (_I, [_VP, _VP, _SZ, _VP]),
     "xv_split_planes": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _SZ, _VP]),
     "xv_bn_apply_split": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _I, _SZ]),
+    "xv_bn_output_range": (_I, [_VP, _VP, _I, _I, _VP, _VP, _I, _VP, _VP, _VP]),
     "xv_bn_relu_backward_split": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _I, _SZ, _VP, _VP, _VP,
                                        _VP, _VP, _SZ]),
     "xv_affine_forward_f16x3": (_I, [_VP, _VP, _SZ, _VP, _I, _I, _I, _I, _VP, _SZ, _VP, _VP, _VP, _I, _I, _VP]),

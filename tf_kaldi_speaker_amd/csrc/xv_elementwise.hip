@@ -303,6 +303,34 @@ extern "C" int xv_bn_finalize(void* stream, const float* bn_part, int rows, int 
     return 0;
 }
 
+// Range of z per channel from the GEMM epilogue's min/max partials and the exact output range of
+// relu?(z*scale+shift) for given (e.g. inference) scale/shift: *amax |= its float bits.
+__global__ void bn_output_range_kernel(const float* __restrict__ part, int rows, int n, int tiles, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, int relu, float* __restrict__ zmin_o,
+                                       float* __restrict__ zmax_o, unsigned* __restrict__ amax_o) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int t = 0; t < tiles; ++t) {
+        mn = fminf(mn, part[(2L * tiles + t) * n + c]);
+        mx = fmaxf(mx, part[(3L * tiles + t) * n + c]);
+    }
+    if (zmin_o) { zmin_o[c] = mn; zmax_o[c] = mx; }
+    float y0 = mn * scale[c] + shift[c], y1 = mx * scale[c] + shift[c];
+    float am = relu ? fmaxf(0.f, fmaxf(y0, y1)) : fmaxf(fabsf(y0), fabsf(y1));
+    atomicMax(amax_o, __float_as_uint(am));
+}
+
+extern "C" int xv_bn_output_range(void* stream, const float* bn_part, int rows, int n, const float* scale, const float* shift, int relu,
+                                  float* zmin, float* zmax, uint32_t* amax) {
+    XV_REQUIRE(bn_part && rows > 0 && n > 0 && scale && shift && amax, "bn_output_range: bad arguments");
+    int tiles = xv_cdiv(rows, XV_TILE_M);
+    hipLaunchKernelGGL(bn_output_range_kernel, dim3(xv_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, bn_part, rows, n, tiles, scale, shift,
+                       relu, zmin, zmax, (unsigned*)amax);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void bn_inference_scale_kernel(int n, const float* __restrict__ gamma, const float* __restrict__ beta,
                                           const float* __restrict__ mmean, const float* __restrict__ mvar, float eps,
                                           float* __restrict__ scale, float* __restrict__ shift) {

@@ -39,6 +39,11 @@ struct Affine {   // one conv/dense layer (+ optional BN, ReLU)
     float *wt, *wf;                       // kernel-layout weights (wf only when k > 1)
     float *z, *a;                         // activations
     float *bn_part, *mean, *invstd, *scale, *shift;
+    // split precision (f16x3): fp16 planes of the kernel-layout weights and of this layer's BN+ReLU output
+    unsigned short *wth = nullptr, *wfh = nullptr, *ah = nullptr;
+    size_t wth_stride = 0, wfh_stride = 0;    // plane strides (elements)
+    int o_ld = 0;                             // plane pitch of c_out (multiple of 8)
+    float *zmin = nullptr, *zmax = nullptr;
     int rows;                             // rows of the most recent forward
 };
 
@@ -69,6 +74,12 @@ struct xv_engine {
     int zcur = 0;
     void* ws_side = nullptr;
     float *scalars = nullptr;   // [0] raw loss, [1] reg loss, [2] grad sumsq
+    // split precision state
+    bool f16 = false;
+    unsigned short* xh = nullptr;             // planes of the (channel-padded) input features
+    unsigned short* dzh[2] = {nullptr, nullptr};
+    size_t dzh_halfs = 0;                     // halfs per plane of a dz buffer
+    uint32_t* amax = nullptr;                 // [AMAX_SLOTS] float bits, see amax_slot()
     void* ws = nullptr;
     size_t ws_bytes = 0;
     int32_t* labels_dev = nullptr;   // caller's pointer of the current step
@@ -84,6 +95,9 @@ struct xv_engine {
 };
 
 namespace {
+
+// amax slots: 0 input x | 1..4 BN+ReLU outputs of tdnn1..4 | 8..12 forward weights | 16..20 dgrad weights | 24,25 dz buffers
+enum { AMAX_X = 0, AMAX_A = 1, AMAX_WT = 8, AMAX_WF = 16, AMAX_DZ = 24, AMAX_SLOTS = 32 };
 
 float* carve(xv_engine* e, size_t floats) {
     size_t bytes = xv_align(floats * sizeof(float), 256);
@@ -131,7 +145,8 @@ void build_variables(xv_engine* e) {
         const Spec& s = specs[i];
         a.prefix = s.prefix; a.kind = s.kind;
         a.k = s.k; a.c_in = s.cin; a.c_out = s.cout;
-        a.c_pad = (int)xv_align(s.cin, 4);   // == c_in except for the feature layer (30 -> 32)
+        a.c_pad = (int)xv_align(s.cin, i == 0 ? 8 : 4);   // == c_in except for the feature layer (30 -> 32)
+        a.o_ld = (int)xv_align(s.cout, 8);
         a.has_bn = s.bn; a.has_relu = s.relu; a.fused_bn = s.fused;
         std::string base = std::string("tdnn/") + s.prefix + "_" + s.kind;
         if (s.k > 1) a.v_kernel = add_var(e, base + "/kernel", {1, s.k, s.cin, s.cout}, true);
@@ -187,6 +202,17 @@ int alloc_buffers(xv_engine* e) {
         want(4 * (size_t)xv_cdiv(r, XV_TILE_M) * a.c_out);     // bn_part
         for (int j = 0; j < 4; ++j) want(a.c_out);
     }
+    if (e->f16) {
+        want(rows[0] * e->c_pad0);                                              // xh: 2 planes of halfs == 1 float per element
+        for (int i = 0; i < 5; ++i) {
+            Affine& a = e->L[i];
+            want((size_t)a.c_out * a.k * a.c_pad);                              // wth
+            if (i > 0) want((size_t)a.c_in * a.k * a.o_ld);                     // wfh
+            if (i < 4) want(rows[i + 1] * a.o_ld);                              // ah
+            want(a.c_out); want(a.c_out);                                       // zmin, zmax
+        }
+        want(AMAX_SLOTS);
+    }
     want(B * 2 * e->P); want(B * e->Lout); want(B * e->Lout);
     if (e->N > 0) {
         want(B * e->ldl); want(B * e->ldl); want(B); want(B);
@@ -200,6 +226,8 @@ int alloc_buffers(xv_engine* e) {
     if (rows[5] * maxc > bufz) bufz = rows[5] * maxc;
     if (rows[1] * 512 > bufz) bufz = rows[1] * 512;
     want(bufd); want(bufz); want(bufz);
+    const size_t dzh_halfs = xv_align(B * (T + 12) * (size_t)xv_align(maxc, 8), 8);
+    if (e->f16) { want(dzh_halfs); want(dzh_halfs); }
     want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512)); want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512));
     want(16);
     // GEMM split slabs: weight-gradient partials dominate
@@ -210,6 +238,10 @@ int alloc_buffers(xv_engine* e) {
         int M = a.k * a.c_pad, Nn = a.c_out;
         size_t s = (size_t)xv_tn_splits(M, Nn, (int)r) * M * Nn * sizeof(float);
         if (s > ws) ws = s;
+        if (e->f16 && i < 5) {
+            s = (size_t)xv_tn16_splits(M, a.o_ld, (int)r) * M * a.o_ld * sizeof(float);
+            if (s > ws) ws = s;
+        }
     }
     if (e->N > 0) {
         size_t s = (size_t)xv_tn_splits(e->Lout, e->ldl, (int)B) * e->Lout * e->ldl * sizeof(float);
@@ -239,6 +271,22 @@ int alloc_buffers(xv_engine* e) {
         a.scale = carve(e, a.c_out); a.shift = carve(e, a.c_out);
         a.rows = 0;
     }
+    if (e->f16) {
+        e->xh = (unsigned short*)carve(e, rows[0] * e->c_pad0);
+        for (int i = 0; i < 5; ++i) {
+            Affine& a = e->L[i];
+            a.wth_stride = (size_t)a.c_out * a.k * a.c_pad;
+            a.wth = (unsigned short*)carve(e, a.wth_stride);
+            if (i > 0) {
+                a.wfh_stride = (size_t)a.c_in * a.k * a.o_ld;
+                a.wfh = (unsigned short*)carve(e, a.wfh_stride);
+            }
+            if (i < 4) a.ah = (unsigned short*)carve(e, rows[i + 1] * a.o_ld);
+            a.zmin = carve(e, a.c_out);
+            a.zmax = carve(e, a.c_out);
+        }
+        e->amax = (uint32_t*)carve(e, AMAX_SLOTS);
+    }
     e->pool = carve(e, B * 2 * e->P);
     e->h7_buf = carve(e, B * e->Lout);
     e->out_buf = carve(e, B * e->Lout);
@@ -253,6 +301,11 @@ int alloc_buffers(xv_engine* e) {
     e->bufD = carve(e, bufd);
     e->bufZ[0] = carve(e, bufz);
     e->bufZ[1] = carve(e, bufz);
+    if (e->f16) {
+        e->dzh_halfs = dzh_halfs;
+        e->dzh[0] = (unsigned short*)carve(e, dzh_halfs);
+        e->dzh[1] = (unsigned short*)carve(e, dzh_halfs);
+    }
     size_t small = B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512);
     e->d_small0 = carve(e, small);
     e->d_small1 = carve(e, small);
@@ -281,6 +334,29 @@ int ensure_weights(xv_engine* e, hipStream_t s) {
         if (rc) return rc;
         if (a.k > 1 && i > 0) {
             rc = xv_prep_weight_dgrad(s, vptr(e, a.v_kernel), a.k, a.c_in, a.c_out, a.wf);
+            if (rc) return rc;
+        }
+    }
+    if (e->f16) {
+        // fp16 planes of the kernel-layout weights, scaled by each tensor's own max |w|
+        XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_WT, 0, 16 * sizeof(uint32_t), s));
+        for (int i = 0; i < 5; ++i) {
+            Affine& a = e->L[i];
+            const int kw = a.k * a.c_pad;
+            int rc = xv_amax(s, a.wt, (size_t)a.c_out * kw, e->amax + AMAX_WT + i);
+            if (rc) return rc;
+            rc = xv_split_planes(s, a.wt, a.c_out, kw, kw, a.wth, kw, a.wth_stride, e->amax + AMAX_WT + i);
+            if (rc) return rc;
+            if (i == 0) continue;
+            if (a.k > 1) {      // tap-flipped copy [c_in][k*c_out] (c_out is a multiple of 8 for the conv layers)
+                rc = xv_amax(s, a.wf, (size_t)a.c_in * a.k * a.c_out, e->amax + AMAX_WF + i);
+                if (rc) return rc;
+                rc = xv_split_planes(s, a.wf, a.c_in, a.k * a.c_out, a.k * a.c_out, a.wfh, a.k * a.o_ld, a.wfh_stride, e->amax + AMAX_WF + i);
+            } else {            // dense: the TF-layout kernel [c_in][c_out] is already the dgrad operand
+                rc = xv_amax(s, vptr(e, a.v_kernel), (size_t)a.c_in * a.c_out, e->amax + AMAX_WF + i);
+                if (rc) return rc;
+                rc = xv_split_planes(s, vptr(e, a.v_kernel), a.c_in, a.c_out, a.c_out, a.wfh, a.o_ld, a.wfh_stride, e->amax + AMAX_WF + i);
+            }
             if (rc) return rc;
         }
     }
@@ -327,8 +403,10 @@ extern "C" int xv_engine_create(const xv_config* cfg, xv_engine** out) {
     if (cfg->loss_kind == XV_LOSS_ASOFTMAX && cfg->num_speakers > 0)
         XV_REQUIRE(cfg->margin_m == 1.f || cfg->margin_m == 2.f || cfg->margin_m == 4.f, "[ERROR] m=%d is not unsupported.", (int)cfg->margin_m);
     XV_REQUIRE(!cfg->feature_norm || cfg->feature_scaling_factor > 0.f, "If feature normalization is applied, scaling factor is necessary.");
+    XV_REQUIRE(cfg->precision == XV_PRECISION_F32 || cfg->precision == XV_PRECISION_F16X3, "engine_create: unknown precision %d", cfg->precision);
     xv_engine* e = new xv_engine();
     e->cfg = *cfg;
+    e->f16 = cfg->precision == XV_PRECISION_F16X3;
     build_variables(e);
     int rc = alloc_buffers(e);
     if (rc) { xv_engine_destroy(e); return rc; }
@@ -392,23 +470,69 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
     e->B = b; e->T = t; e->training = training;
     int rc = ensure_weights(e, s);
     if (rc) return rc;
-    rc = xv_pad_channels(s, features, b * t, e->cfg.feat_dim, e->xpad, e->c_pad0);
-    if (rc) return rc;
-    const float* cur = e->xpad;
     int cur_t = t;
     e->Tl[0] = t;
-    for (int i = 0; i < 5; ++i) {
-        Affine& a = e->L[i];
-        int t_out = cur_t - a.k + 1;
-        int rows = b * t_out;
-        rc = xv_affine_forward(s, cur, b, cur_t, a.c_pad, a.k, a.wt, vptr(e, a.v_bias), a.z, a.c_out, a.c_out,
-                               training ? a.bn_part : nullptr, e->ws, e->ws_bytes);
+    if (e->f16) {
+        // split precision: every frame-level operand travels as two fp16 planes + a device-side max |x|
+        XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_X, 0, 8 * sizeof(uint32_t), s));
+        rc = xv_amax(s, features, (size_t)b * t * e->cfg.feat_dim, e->amax + AMAX_X);
         if (rc) return rc;
-        rc = bn_forward(e, s, a, rows, true, a.a);
+        rc = xv_split_planes(s, features, b * t, e->cfg.feat_dim, e->cfg.feat_dim, e->xh, e->c_pad0, (size_t)b * t * e->c_pad0,
+                             e->amax + AMAX_X);
         if (rc) return rc;
-        a.rows = rows;
-        cur = a.a; cur_t = t_out;
-        e->Tl[i + 1] = t_out;
+        const unsigned short* curh = e->xh;
+        size_t cur_stride = (size_t)b * t * e->c_pad0;
+        const uint32_t* cur_amax = e->amax + AMAX_X;
+        for (int i = 0; i < 5; ++i) {
+            Affine& a = e->L[i];
+            int t_out = cur_t - a.k + 1;
+            int rows = b * t_out;
+            // the epilogue's column min/max are needed in inference too (they fix the next operand's scale)
+            rc = xv_affine_forward_f16x3(s, curh, cur_stride, cur_amax, b, cur_t, a.c_pad, a.k, a.wth, a.wth_stride,
+                                         e->amax + AMAX_WT + i, vptr(e, a.v_bias), a.z, a.c_out, a.c_out, a.bn_part);
+            if (rc) return rc;
+            uint32_t* out_amax = i < 4 ? e->amax + AMAX_A + i : nullptr;
+            const xv_config& c = e->cfg;
+            if (training) {
+                rc = xv_bn_finalize(s, a.bn_part, rows, a.c_out, vptr(e, a.v_gamma), vptr(e, a.v_beta), c.bn_epsilon, c.batchnorm_momentum,
+                                    a.fused_bn && c.fused_bn_unbiased_moving_var, vptr(e, a.v_mmean), vptr(e, a.v_mvar), a.mean, a.invstd,
+                                    a.scale, a.shift, a.zmin, a.zmax, out_amax, 1);
+            } else {
+                rc = xv_bn_inference_scale(s, a.c_out, vptr(e, a.v_gamma), vptr(e, a.v_beta), vptr(e, a.v_mmean), vptr(e, a.v_mvar),
+                                           c.bn_epsilon, a.scale, a.shift);
+                if (rc) return rc;
+                if (out_amax) rc = xv_bn_output_range(s, a.bn_part, rows, a.c_out, a.scale, a.shift, 1, a.zmin, a.zmax, out_amax);
+            }
+            if (rc) return rc;
+            if (i < 4) {
+                rc = xv_bn_apply_split(s, a.z, rows, a.c_out, a.c_out, a.scale, a.shift, 1, out_amax, a.ah, a.o_ld, (size_t)rows * a.o_ld);
+                if (rc) return rc;
+                curh = a.ah; cur_stride = (size_t)rows * a.o_ld; cur_amax = out_amax;
+            } else {
+                rc = xv_bn_apply(s, a.z, rows, a.c_out, a.c_out, a.scale, a.shift, 1, a.a, a.c_out);   // pooling reads fp32
+                if (rc) return rc;
+            }
+            a.rows = rows;
+            cur_t = t_out;
+            e->Tl[i + 1] = t_out;
+        }
+    } else {
+        rc = xv_pad_channels(s, features, b * t, e->cfg.feat_dim, e->xpad, e->c_pad0);
+        if (rc) return rc;
+        const float* cur = e->xpad;
+        for (int i = 0; i < 5; ++i) {
+            Affine& a = e->L[i];
+            int t_out = cur_t - a.k + 1;
+            int rows = b * t_out;
+            rc = xv_affine_forward(s, cur, b, cur_t, a.c_pad, a.k, a.wt, vptr(e, a.v_bias), a.z, a.c_out, a.c_out,
+                                   training ? a.bn_part : nullptr, e->ws, e->ws_bytes);
+            if (rc) return rc;
+            rc = bn_forward(e, s, a, rows, true, a.a);
+            if (rc) return rc;
+            a.rows = rows;
+            cur = a.a; cur_t = t_out;
+            e->Tl[i + 1] = t_out;
+        }
     }
     rc = xv_stat_pool_forward(s, e->L[4].a, b, cur_t, e->P, e->pool);
     if (rc) return rc;
@@ -522,12 +646,15 @@ int join_side(xv_engine* e, hipStream_t s) {
 // side stream: its workgroups fill the CUs that the tail of the data-gradient GEMM (and the small
 // BN kernels of the next layer) leave idle.  dz ping-pongs between two buffers; a buffer is rewritten
 // only after the weight gradient that read it has finished (ev_w).
+int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int segs, int t_in, float* dx);
+
 int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, const float* x, int segs, int t_in, float* dx,
                    const float* act_out) {
     const xv_config& c = e->cfg;
     const int t_out = t_in - a.k + 1;
     const int pad = (dx && a.k > 1) ? a.k - 1 : 0;
     int rc;
+    if (e->f16 && &a <= &e->L[4]) return layer_backward_f16(e, s, (int)(&a - &e->L[0]), da, segs, t_in, dx);
     const float* dz = nullptr;
     const int zi = e->zcur;
     float* Z = e->bufZ[zi];
@@ -570,6 +697,54 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     if (dx) {
         const float* wf = a.k > 1 ? a.wf : vptr(e, a.v_kernel);
         rc = xv_affine_dgrad(s, dz, segs, t_out, a.c_out, a.k, wf, dx, a.c_in, e->ws, e->ws_bytes);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Split-precision backward of a frame layer: dz is written once as fp16 planes (padded layout) and feeds both the
+// weight gradient (TN, side stream; A operand = the planes the forward pass already consumed) and the data gradient
+// (NT, tap-flipped weight planes).  Same stream / ping-pong protocol as layer_backward.
+int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int segs, int t_in, float* dx) {
+    Affine& a = e->L[li];
+    const xv_config& c = e->cfg;
+    const int t_out = t_in - a.k + 1;
+    const int pad = (dx && a.k > 1) ? a.k - 1 : 0;
+    const int zi = e->zcur;
+    unsigned short* Z = e->dzh[zi];
+    uint32_t* zamax = e->amax + AMAX_DZ + zi;
+    if (e->w_pending[zi]) {
+        XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_w[zi], 0));
+        e->w_pending[zi] = false;
+    }
+    const int seg_pitch = t_out + 2 * pad;
+    const size_t zstride = (size_t)segs * seg_pitch * a.o_ld;
+    XV_REQUIRE(zstride <= e->dzh_halfs, "engine_backward: dz plane buffer too small");
+    int rc = xv_bn_relu_backward_split(s, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift, a.zmin,
+                                       a.zmax, 1, pad, Z, a.o_ld, zstride, zamax, gptr(e, a.v_gamma), gptr(e, a.v_beta),
+                                       gptr(e, a.v_bias), e->ws, e->ws_bytes);
+    if (rc) return rc;
+    // operand planes of this layer's input: the feature planes for tdnn1, the previous layer's BN+ReLU planes otherwise
+    const unsigned short* xin = li == 0 ? e->xh : e->L[li - 1].ah;
+    const int xin_rows = li == 0 ? e->B * e->Tl[0] : e->L[li - 1].rows;
+    const uint32_t* xin_amax = li == 0 ? e->amax + AMAX_X : e->amax + AMAX_A + (li - 1);
+    hipStream_t wst = e->concurrent ? e->side : s;
+    void* wws = e->concurrent ? e->ws_side : e->ws;
+    if (e->concurrent) {
+        rc = chain(s, e->side, e->ev_dz);
+        if (rc) return rc;
+    }
+    rc = xv_affine_wgrad_f16x3(wst, xin, (size_t)xin_rows * a.c_pad, xin_amax, segs, t_in, a.c_pad, a.k, a.c_in, Z, zstride, zamax,
+                               seg_pitch, pad, a.o_ld, a.c_out, vptr(e, a.v_kernel), c.weight_l2_regularizer, gptr(e, a.v_kernel), wws,
+                               e->ws_bytes);
+    if (rc) return rc;
+    if (e->concurrent) {
+        XV_CHECK_HIP(hipEventRecord(e->ev_w[zi], e->side));
+        e->w_pending[zi] = true;
+    }
+    e->zcur ^= 1;
+    if (dx) {
+        rc = xv_affine_dgrad_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WF + li, dx, a.c_in);
         if (rc) return rc;
     }
     return 0;
@@ -724,7 +899,13 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
     for (int i = 0; i < 7; ++i) {
         Affine& a = e->L[i];
         if (n == a.prefix + "_" + a.kind) return set(a.z, a.rows, a.c_out, a.c_out);
-        if (n == a.prefix + "_relu" && a.has_relu) return set(i == 6 ? e->h7 : a.a, a.rows, a.c_out, a.c_out);
+        if (n == a.prefix + "_relu" && a.has_relu) {
+            if (e->f16 && i < 4) {     // only the fp16 planes exist on the hot path: rebuild the fp32 view on demand
+                int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 1, a.a, a.c_out);
+                if (rc) return rc;
+            }
+            return set(i == 6 ? e->h7 : a.a, a.rows, a.c_out, a.c_out);
+        }
         if (n == a.prefix + "_bn" && a.has_bn) {
             if (!a.has_relu) return set(i == 6 ? e->h7 : a.a, a.rows, a.c_out, a.c_out);
             // BN output is never materialised on the hot path (fused with ReLU): rebuild on demand

@@ -330,9 +330,9 @@ extern "C" int xv_profile_begin(int max_launches) {
     return 0;
 }
 
-extern "C" int xv_profile_end(int64_t launches[3], double ms[3], double flops[3]) {
+extern "C" int xv_profile_end(int64_t launches[XV_PROFILE_KINDS], double ms[XV_PROFILE_KINDS], double flops[XV_PROFILE_KINDS]) {
     g_prof_on = false;
-    for (int k = 0; k < 3; ++k) { launches[k] = 0; ms[k] = 0.0; flops[k] = 0.0; }
+    for (int k = 0; k < XV_PROFILE_KINDS; ++k) { launches[k] = 0; ms[k] = 0.0; flops[k] = 0.0; }
     for (auto& r : g_prof) {
         XV_CHECK_HIP(hipEventSynchronize(r.b));
         float t = 0.f;

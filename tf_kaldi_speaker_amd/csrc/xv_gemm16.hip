@@ -283,7 +283,7 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
     p.tiles_m = xv_cdiv(g.M, 128); p.tiles_n = xv_cdiv(g.N, 128);
     p.bias = g.bias; p.part = g.bn_part; p.a_amax = g.a_amax; p.b_amax = g.b_amax; p.zero = g_zero16;
     dim3 grid(p.tiles_m * p.tiles_n);
-    XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
+    XvProfScope prof(s, g.bn_part ? 3 : 4, 2.0 * g.M * g.N * g.K);
     if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_kernel<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(xv_gemm16_nt_kernel<false>, grid, dim3(256), 0, s, p);
     XV_LAUNCH_CHECK();
@@ -445,7 +445,7 @@ int xv_launch_gemm16_tn(hipStream_t s, const XvGemm16TN& g) {
     XV_REQUIRE(xv_cdiv(g.R, p.r_chunk) == g.splits, "gemm16_tn: splits must come from xv_tn16_splits");
     p.a_amax = g.a_amax; p.b_amax = g.b_amax; p.zero = g_zero16;
     dim3 grid(p.tiles_m * p.tiles_n * g.splits);
-    XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
+    XvProfScope prof(s, 5, 2.0 * g.M * g.N * g.R);
     hipLaunchKernelGGL(xv_gemm16_tn_kernel, grid, dim3(256), 0, s, p);
     XV_LAUNCH_CHECK();
     return 0;

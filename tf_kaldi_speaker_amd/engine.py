@@ -6,16 +6,21 @@ variables / gradient / optimiser-state buffers), naming the HIP stream, and
 """
 from collections import OrderedDict
 import ctypes as C
+import os
 
 import numpy as np
 import torch
 
 try:
     from . import _lib
-    from ._lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, XV_BWD_STAGES
+    from ._lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, PRECISIONS, XV_BWD_STAGES
 except ImportError:      # drop-in layout: PYTHONPATH=$TF_KALDI_ROOT makes these top-level modules
     import _lib
-    from _lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, XV_BWD_STAGES
+    from _lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, PRECISIONS, XV_BWD_STAGES
+
+
+# How tdnn1-5's contractions are evaluated unless make_config(precision=...) / $XV_PRECISION says otherwise.
+DEFAULT_PRECISION = "f32"
 
 
 def _ptr(t):
@@ -31,7 +36,7 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
                 last_layer_no_bn=False, last_layer_linear=False, feature_norm=False, feature_scaling_factor=1.0,
                 weight_l2_regularizer=1e-2, output_weight_l2_regularizer=None, batchnorm_momentum=0.99,
                 bn_epsilon=1e-3, fused_bn_unbiased_moving_var=True, optimizer="sgd", momentum=0.9, use_nesterov=False,
-                clip_gradient_norm=0.0, max_batch=128, max_frames=400):
+                clip_gradient_norm=0.0, max_batch=128, max_frames=400, precision=None):
     if loss_func not in LOSS_KINDS:
         raise NotImplementedError("Not implement %s loss" % loss_func)
     if optimizer not in OPTIMIZERS:
@@ -60,6 +65,11 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
     c.clip_gradient_norm = float(clip_gradient_norm)
     c.max_batch = int(max_batch)
     c.max_frames = int(max_frames)
+    if precision is None:
+        precision = os.environ.get("XV_PRECISION", DEFAULT_PRECISION)
+    if precision not in PRECISIONS:
+        raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
+    c.precision = PRECISIONS[precision]
     return c
 
 
