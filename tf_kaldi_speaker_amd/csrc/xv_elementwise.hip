@@ -511,19 +511,31 @@ __global__ void bn_bwd_apply_split_kernel(const float* __restrict__ da, const fl
         long dr = i / cq;
         int col = (int)(i - dr * cq) * 8;
         int seg = (int)(dr / tp), u = (int)(dr - (long)seg * tp) - pad;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (u >= 0 && u < t) {
+            const long r = (long)seg * t + u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = col + 4 * q;
+                if (c >= n) break;
+                f32x4 zz = *(const f32x4*)(z + r * n + c);
+                f32x4 dd = *(const f32x4*)(da + r * n + c);
+                f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
+                if (relu) {
+                    f32x4 y = zz * *(const f32x4*)(scale + c) + *(const f32x4*)(shift + c);
+                    dd.x = y.x > 0.f ? dd.x : 0.f; dd.y = y.y > 0.f ? dd.y : 0.f;
+                    dd.z = y.z > 0.f ? dd.z : 0.f; dd.w = y.w > 0.f ? dd.w : 0.f;
+                }
+                f32x4 xh = (zz - mu) * is;
+                f32x4 c1 = *(const f32x4*)(coef + c), c2 = *(const f32x4*)(coef + n + c);
+                f32x4 o = (*(const f32x4*)(gamma + c) * is) * (dd - c1 - xh * c2);
+                v[4 * q] = o.x; v[4 * q + 1] = o.y; v[4 * q + 2] = o.z; v[4 * q + 3] = o.w;
+            }
+        }
         unsigned short h[8], l[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float v = 0.f;
-            int c = col + j;
-            if (u >= 0 && u < t && c < n) {
-                long r = (long)seg * t + u;
-                float zz = z[r * n + c], dd = da[r * n + c];
-                if (relu && !(zz * scale[c] + shift[c] > 0.f)) dd = 0.f;
-                float xh = (zz - mean[c]) * invstd[c];
-                v = (gamma[c] * invstd[c]) * (dd - coef[c] - xh * coef[n + c]);
-            }
-            float xs = v * s;
+            float xs = v[j] * s;
             _Float16 hh = (_Float16)xs;
             _Float16 ll = (_Float16)(xs - (float)hh);
             h[j] = __builtin_bit_cast(unsigned short, hh);

@@ -96,8 +96,8 @@ struct xv_engine {
 
 namespace {
 
-// amax slots: 0 input x | 1..4 BN+ReLU outputs of tdnn1..4 | 8..12 forward weights | 16..20 dgrad weights | 24,25 dz buffers
-enum { AMAX_X = 0, AMAX_A = 1, AMAX_WT = 8, AMAX_WF = 16, AMAX_DZ = 24, AMAX_SLOTS = 32 };
+// amax slots: 0 input x | 1..4 BN+ReLU outputs of tdnn1..4 | 8..12 weights of tdnn1..5 (both layouts) | 24,25 dz buffers
+enum { AMAX_X = 0, AMAX_A = 1, AMAX_WT = 8, AMAX_DZ = 24, AMAX_SLOTS = 32 };
 
 float* carve(xv_engine* e, size_t floats) {
     size_t bytes = xv_align(floats * sizeof(float), 256);
@@ -343,19 +343,16 @@ int ensure_weights(xv_engine* e, hipStream_t s) {
         for (int i = 0; i < 5; ++i) {
             Affine& a = e->L[i];
             const int kw = a.k * a.c_pad;
-            int rc = xv_amax(s, a.wt, (size_t)a.c_out * kw, e->amax + AMAX_WT + i);
+            // the forward and dgrad layouts hold the same values: one max per layer, taken on the variable itself
+            int rc = xv_amax(s, vptr(e, a.v_kernel), (size_t)a.k * a.c_in * a.c_out, e->amax + AMAX_WT + i);
             if (rc) return rc;
             rc = xv_split_planes(s, a.wt, a.c_out, kw, kw, a.wth, kw, a.wth_stride, e->amax + AMAX_WT + i);
             if (rc) return rc;
             if (i == 0) continue;
             if (a.k > 1) {      // tap-flipped copy [c_in][k*c_out] (c_out is a multiple of 8 for the conv layers)
-                rc = xv_amax(s, a.wf, (size_t)a.c_in * a.k * a.c_out, e->amax + AMAX_WF + i);
-                if (rc) return rc;
-                rc = xv_split_planes(s, a.wf, a.c_in, a.k * a.c_out, a.k * a.c_out, a.wfh, a.k * a.o_ld, a.wfh_stride, e->amax + AMAX_WF + i);
+                rc = xv_split_planes(s, a.wf, a.c_in, a.k * a.c_out, a.k * a.c_out, a.wfh, a.k * a.o_ld, a.wfh_stride, e->amax + AMAX_WT + i);
             } else {            // dense: the TF-layout kernel [c_in][c_out] is already the dgrad operand
-                rc = xv_amax(s, vptr(e, a.v_kernel), (size_t)a.c_in * a.c_out, e->amax + AMAX_WF + i);
-                if (rc) return rc;
-                rc = xv_split_planes(s, vptr(e, a.v_kernel), a.c_in, a.c_out, a.c_out, a.wfh, a.o_ld, a.wfh_stride, e->amax + AMAX_WF + i);
+                rc = xv_split_planes(s, vptr(e, a.v_kernel), a.c_in, a.c_out, a.c_out, a.wfh, a.o_ld, a.wfh_stride, e->amax + AMAX_WT + i);
             }
             if (rc) return rc;
         }
@@ -744,7 +741,7 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
     }
     e->zcur ^= 1;
     if (dx) {
-        rc = xv_affine_dgrad_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WF + li, dx, a.c_in);
+        rc = xv_affine_dgrad_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WT + li, dx, a.c_in);
         if (rc) return rc;
     }
     return 0;

@@ -49,24 +49,54 @@ __device__ __forceinline__ void split_f16(float x, float s, u16& h, u16& l) {
 // ---------------------------------------------------------------------------------------------
 // producers of planes
 // ---------------------------------------------------------------------------------------------
-__global__ void amax_kernel(const float* __restrict__ x, size_t count, unsigned* __restrict__ amax) {
+// One atomicMax per WORKGROUP, and only when it can raise the value (same-address atomics serialise in L2:
+// thousands of them cost more than the read of the tensor).
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, size_t count, unsigned* __restrict__ amax) {
+    __shared__ float red[4];
     float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    const size_t nq = count / 4, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((uintptr_t)x & 15) == 0) {
+        for (size_t i = i0; i < nq; i += stride) {
+            float4 v = ((const float4*)x)[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        for (size_t i = nq * 4 + i0; i < count; i += stride) m = fmaxf(m, fabsf(x[i]));
+    } else {
+        for (size_t i = i0; i < count; i += stride) m = fmaxf(m, fabsf(x[i]));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        unsigned bits = __float_as_uint(m);
+        if (bits > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, bits);
+    }
 }
 
 extern "C" int xv_amax(void* stream, const float* x, size_t count, uint32_t* amax_accum) {
     XV_REQUIRE(x && amax_accum && count > 0, "amax: bad arguments");
-    long blocks = (long)((count + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    long blocks = (long)((count / 4 + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(amax_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, count, (unsigned*)amax_accum);
     XV_LAUNCH_CHECK();
     return 0;
 }
 
-// dst planes [2][rows][ldd] <- src [rows][lds] (columns >= c zero).  8 elements (one 16-byte chunk per plane) per thread.
+__device__ __forceinline__ void store_split8(const float (&v)[8], float s, u16* __restrict__ hi, u16* __restrict__ lo) {
+    u16 h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_f16(v[j], s, h[j], l[j]);
+    *(uint4*)hi = *(const uint4*)h;
+    *(uint4*)lo = *(const uint4*)l;
+}
+
+// dst planes [2][rows][ldd] <- src [rows][lds] (columns >= c zero).  8 elements (one 16-byte chunk per plane) per thread;
+// VEC: c and lds are multiples of 4 and src is 16-byte aligned, so the 8 inputs are two float4 loads.
+template <bool VEC>
 __global__ void split_planes_kernel(const float* __restrict__ src, long rows, int c, long lds, u16* __restrict__ dst, long ldd,
                                     long plane_stride, const unsigned* __restrict__ amax) {
     const float s = xv_pow2_scale(*amax);
@@ -74,14 +104,16 @@ __global__ void split_planes_kernel(const float* __restrict__ src, long rows, in
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i / cq;
         int col = (int)(i - r * cq) * 8;
-        u16 h[8], l[8];
+        float v[8];
+        if (VEC) {
+            float4 a = col < c ? *(const float4*)(src + r * lds + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 b = col + 4 < c ? *(const float4*)(src + r * lds + col + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float x = (col + j) < c ? src[r * lds + col + j] : 0.f;
-            split_f16(x, s, h[j], l[j]);
+            for (int j = 0; j < 8; ++j) v[j] = (col + j) < c ? src[r * lds + col + j] : 0.f;
         }
-        *(uint4*)(dst + r * ldd + col) = *(const uint4*)h;
-        *(uint4*)(dst + plane_stride + r * ldd + col) = *(const uint4*)l;
+        store_split8(v, s, dst + r * ldd + col, dst + plane_stride + r * ldd + col);
     }
 }
 
@@ -92,13 +124,15 @@ extern "C" int xv_split_planes(void* stream, const float* src, int rows, int c, 
     long total = (long)rows * (ldp / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (long)rows, c, (long)lds, (u16*)planes,
-                       (long)ldp, (long)plane_stride, (const unsigned*)amax);
+    const bool vec = c % 4 == 0 && lds % 4 == 0 && ((uintptr_t)src % 16) == 0;
+    hipLaunchKernelGGL(vec ? split_planes_kernel<true> : split_planes_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
+                       (long)rows, c, (long)lds, (u16*)planes, (long)ldp, (long)plane_stride, (const unsigned*)amax);
     XV_LAUNCH_CHECK();
     return 0;
 }
 
 // planes <- relu?(z*scale + shift)   (BN + ReLU output written directly as the next layer's operand planes)
+// n and ldz are multiples of 4 (checked by the wrapper): two float4 loads of z per thread.
 __global__ void bn_apply_split_kernel(const float* __restrict__ z, long rows, int n, long ldz, const float* __restrict__ scale,
                                       const float* __restrict__ shift, int relu, const unsigned* __restrict__ amax,
                                       u16* __restrict__ dst, long ldd, long plane_stride) {
@@ -107,24 +141,26 @@ __global__ void bn_apply_split_kernel(const float* __restrict__ z, long rows, in
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i / cq;
         int col = (int)(i - r * cq) * 8;
-        u16 h[8], l[8];
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float y = 0.f;
-            if (col + j < n) {
-                y = z[r * ldz + col + j] * scale[col + j] + shift[col + j];
-                if (relu) y = fmaxf(y, 0.f);
+        for (int q = 0; q < 2; ++q) {
+            const int c = col + 4 * q;
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < n) {
+                float4 zz = *(const float4*)(z + r * ldz + c), sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
+                y.x = zz.x * sc.x + sh.x; y.y = zz.y * sc.y + sh.y; y.z = zz.z * sc.z + sh.z; y.w = zz.w * sc.w + sh.w;
+                if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
             }
-            split_f16(y, s, h[j], l[j]);
+            v[4 * q] = y.x; v[4 * q + 1] = y.y; v[4 * q + 2] = y.z; v[4 * q + 3] = y.w;
         }
-        *(uint4*)(dst + r * ldd + col) = *(const uint4*)h;
-        *(uint4*)(dst + plane_stride + r * ldd + col) = *(const uint4*)l;
+        store_split8(v, s, dst + r * ldd + col, dst + plane_stride + r * ldd + col);
     }
 }
 
 extern "C" int xv_bn_apply_split(void* stream, const float* z, int rows, int n, int ldz, const float* scale, const float* shift, int relu,
                                  const uint32_t* amax, void* planes, int ldp, size_t plane_stride) {
     XV_REQUIRE(rows > 0 && n > 0 && ldz >= n && ldp % 8 == 0 && ldp >= n && plane_stride % 8 == 0, "bn_apply_split: bad shape");
+    XV_REQUIRE(n % 4 == 0 && ldz % 4 == 0 && ((uintptr_t)z % 16) == 0, "bn_apply_split: n and ldz must be multiples of 4 (n=%d ldz=%d)", n, ldz);
     long total = (long)rows * (ldp / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
