@@ -164,6 +164,21 @@ int xv_bn_relu_backward_split(void* stream, const float* da, const float* z, int
                               const float* zmin, const float* zmax, int relu, int pad, void* dz_planes, int ldp,
                               size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
                               size_t ws_bytes);
+
+/* xv_bn_relu_backward / _split for the layer whose output feeds statistics pooling (tdnn5): the upstream gradient is not
+ * read from memory but evaluated from the pooled statistics pool_out [b][mean | std] (xv_stat_pool_forward_bn) and their
+ * gradient dpool [b][2n] -  d a = dmean/t + dstd/(t*std) * (a - mean), a = relu?(z*scale + shift), zero where the
+ * variance was clamped (pooling.py:28-29) - i.e. pooling backward + ReLU backward + BN backward in one pass over z.
+ * rows = b*t, no segment padding. */
+int xv_bn_relu_backward_pooled(void* stream, const float* pool_out, const float* dpool, int b, int t, const float* z, int n,
+                               const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
+                               int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes);
+int xv_bn_relu_backward_pooled_split(void* stream, const float* pool_out, const float* dpool, int b, int t, const float* z, int n,
+                                     const float* gamma, const float* mean, const float* invstd, const float* scale,
+                                     const float* shift, const float* zmin, const float* zmax, int relu, void* dz_planes, int ldp,
+                                     size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
+                                     size_t ws_bytes);
+
 /* xv_affine_forward / _dgrad / _wgrad on planes.  c_ld / o_ld: plane row pitches (multiples of 8). */
 int xv_affine_forward_f16x3(void* stream, const void* x_planes, size_t x_plane_stride, const uint32_t* x_amax, int segs, int t_in,
                             int c_ld, int k, const void* wt_planes, size_t wt_plane_stride, const uint32_t* wt_amax,
@@ -179,6 +194,12 @@ int xv_affine_wgrad_f16x3(void* stream, const void* x_planes, size_t x_plane_str
 int xv_stat_pool_forward(void* stream, const float* x, int b, int t, int c, float* out);
 int xv_stat_pool_backward(void* stream, const float* x, const float* out, const float* dout,
                           int b, int t, int c, float* dx);
+
+/* Statistics pooling over relu?(z*scale + shift) evaluated on the fly (tdnn5's BN + ReLU, tdnn.py:124-131, fused into
+ * pooling.py:9-34): out[b] = [mean_t | std_t] of the activation, which is never written to memory. */
+int xv_stat_pool_forward_bn(void* stream, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
+                            float* out);
+
 
 /* l2_scaling, common.py:45-58 (feature_norm:true, trainer.py:183-186). */
 int xv_l2_scaling_forward(void* stream, const float* x, int rows, int n, float factor, float* y);

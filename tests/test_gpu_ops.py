@@ -177,6 +177,35 @@ def test_statistics_pooling_lengths(ops, t):
     assert_close(got, ref, 5e-6, 5e-5, "pool T=%d" % t)
 
 
+def _pooled_case(seed, b, t, n):
+    rs = np.random.RandomState(seed)
+    z = (rs.randn(b * t, n) * 2 + 0.3).astype(np.float32)
+    gamma, beta = (rs.rand(n) + 0.5).astype(np.float32), (0.3 * rs.randn(n)).astype(np.float32)
+    dout = rs.randn(b, 2 * n).astype(np.float32)
+    z64, g64, b64 = z.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64)
+    y, cache = O.batchnorm_train_fwd(z64, g64, b64)
+    a = np.maximum(y, 0).reshape(b, t, n)
+    pool_ref, pcache = O.statistics_pooling_fwd(a)
+    da = O.statistics_pooling_bwd(a, pcache, dout.astype(np.float64)).reshape(b * t, n)
+    dz_ref, dg_ref, db_ref = O.batchnorm_train_bwd(da * (y > 0), cache, g64)
+    return z, gamma, beta, dout, pool_ref, dz_ref, dg_ref, db_ref
+
+
+@pytest.mark.parametrize("b,t,n", [(5, 37, 1500), (3, 186, 512)])
+def test_pooling_fused_into_bn(ops, b, t, n):
+    """tdnn5 -> statistics pooling without the activation in memory: forward pools relu(bn(z)) on the fly, backward
+    evaluates pooling backward + ReLU backward + BN backward from (pool, d pool) - against the composed oracle."""
+    z, gamma, beta, dout, pool_ref, dz_ref, dg_ref, db_ref = _pooled_case(17 + t, b, t, n)
+    part = ops.col_stats(dev(z))
+    mean, invstd, scale, shift = ops.bn_finalize(part, b * t, dev(gamma), dev(beta), 1e-3, 0.99, False, None, None)
+    pool = ops.stat_pool_forward_bn(dev(z), b, t, scale, shift, True)
+    assert_close(host(pool), pool_ref, 5e-6, 5e-5, "fused pool")
+    dz, dg, db, dbias = ops.bn_relu_backward_pooled(pool, dev(dout), b, t, dev(z), dev(gamma), mean, invstd, scale, shift, True)
+    assert_close(host(dz), dz_ref, 2e-5, 2e-4, "pooled bn dz")
+    assert_close(host(dg), dg_ref, 2e-5, 1e-4, "pooled dgamma")
+    assert_close(host(db), db_ref, 2e-5, 1e-4, "pooled dbeta")
+
+
 def test_l2_scaling(ops):
     rs = np.random.RandomState(3)
     x = rs.randn(100, 512).astype(np.float32)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import xvector_oracle as O
-from tests.test_gpu_ops import assert_close, dev, host, AFFINE_CASES
+from tests.test_gpu_ops import assert_close, dev, host, AFFINE_CASES, _pooled_case
 
 pytestmark = pytest.mark.gpu
 
@@ -134,3 +134,22 @@ def test_bn_relu_backward_split(ops, relu, pad, n):
     assert_close(rec[:, pad:pad + t, :n].reshape(-1, n), dz_ref, 2e-5, 2e-4, "dz planes")
     assert_close(host(dg), dg_ref, 2e-5, 1e-4, "dgamma")
     assert_close(host(db), db_ref, 2e-5, 1e-4, "dbeta")
+
+
+def test_pooling_fused_into_bn_split(ops):
+    b, t, n = 4, 37, 1500
+    z, gamma, beta, dout, pool_ref, dz_ref, dg_ref, db_ref = _pooled_case(23, b, t, n)
+    part = ops.col_stats(dev(z))
+    mean, invstd, scale, shift, zmin, zmax, _ = ops.bn_finalize(part, b * t, dev(gamma), dev(beta), 1e-3, 0.99, False, None, None,
+                                                                with_range=True)
+    pool = ops.stat_pool_forward_bn(dev(z), b, t, scale, shift, True)
+    dzp, dg, db, dbias = ops.bn_relu_backward_pooled_split(pool, dev(dout), b, t, dev(z), dev(gamma), mean, invstd, scale, shift, zmin, zmax)
+    bound = _bits_to_float(dzp.amax)
+    assert np.abs(dz_ref).max() <= bound
+    planes = dzp.data.cpu().numpy().view(np.float16).astype(np.float64)
+    s = 2.0 ** (12 - np.floor(np.log2(bound)))
+    rec = (planes[0] + planes[1]) / s
+    assert np.all(rec[:, n:] == 0)
+    assert_close(rec[:, :n], dz_ref, 2e-5, 2e-4, "pooled split dz")
+    assert_close(host(dg), dg_ref, 2e-5, 1e-4, "pooled split dgamma")
+    assert_close(host(db), db_ref, 2e-5, 1e-4, "pooled split dbeta")

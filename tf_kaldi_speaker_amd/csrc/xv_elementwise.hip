@@ -225,8 +225,11 @@ extern "C" int xv_col_stats(void* stream, const float* z, int rows, int n, int l
 // ------------------------------------------------------------------------------------
 // BatchNorm
 // ------------------------------------------------------------------------------------
-// block = 256 threads = 32 channels x 8 tile lanes.  Each lane folds its tiles' (count, mean, M2)
-// with Chan's pairwise formula in double, lanes are then folded in lane order (deterministic).
+// block = 256 threads = 8 channels x 32 tile lanes (n/8 workgroups: the partials are few, the latency of a
+// serial walk over them is what this kernel costs).  Each lane folds its tiles' (count, mean, M2) with Chan's
+// pairwise formula in double, lanes are then folded in lane order (deterministic).
+#define FIN_CH 8
+#define FIN_LANES 32
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int n, int tiles,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                           float momentum, int unbiased, float* __restrict__ mmean,
@@ -234,14 +237,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ invstd_o, float* __restrict__ scale_o,
                                                           float* __restrict__ shift_o, float* __restrict__ zmin_o,
                                                           float* __restrict__ zmax_o, unsigned* __restrict__ amax_o, int relu) {
-    __shared__ double s_cnt[8][32], s_mean[8][32], s_m2[8][32];
-    __shared__ float s_mn[8][32], s_mx[8][32], s_am[32];
-    const int cx = threadIdx.x & 31, tl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
+    __shared__ double s_cnt[FIN_LANES][FIN_CH], s_mean[FIN_LANES][FIN_CH], s_m2[FIN_LANES][FIN_CH];
+    __shared__ float s_mn[FIN_LANES][FIN_CH], s_mx[FIN_LANES][FIN_CH];
+    const int cx = threadIdx.x & (FIN_CH - 1), tl = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + cx;
     double cnt = 0.0, mean = 0.0, m2 = 0.0;
     float zmn = INFINITY, zmx = -INFINITY;
     if (c < n) {
-        for (int t = tl; t < tiles; t += 8) {
+        for (int t = tl; t < tiles; t += FIN_LANES) {
             zmn = fminf(zmn, part[(2L * tiles + t) * n + c]);
             zmx = fmaxf(zmx, part[(3L * tiles + t) * n + c]);
             int tc = min(XV_TILE_M, rows - t * XV_TILE_M);
@@ -255,11 +258,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
     s_cnt[tl][cx] = cnt; s_mean[tl][cx] = mean; s_m2[tl][cx] = m2;
     s_mn[tl][cx] = zmn; s_mx[tl][cx] = zmx;
-    if (tl == 0) s_am[cx] = 0.f;
     __syncthreads();
     if (tl != 0 || c >= n) return;
-    for (int k = 1; k < 8; ++k) { zmn = fminf(zmn, s_mn[k][cx]); zmx = fmaxf(zmx, s_mx[k][cx]); }
-    for (int k = 1; k < 8; ++k) {
+    for (int k = 1; k < FIN_LANES; ++k) { zmn = fminf(zmn, s_mn[k][cx]); zmx = fmaxf(zmx, s_mx[k][cx]); }
+    for (int k = 1; k < FIN_LANES; ++k) {
         double cb = s_cnt[k][cx];
         if (cb > 0.0) {
             double nn = cnt + cb, d = s_mean[k][cx] - mean;
@@ -297,7 +299,7 @@ extern "C" int xv_bn_finalize(void* stream, const float* bn_part, int rows, int 
                               uint32_t* amax, int relu) {
     XV_REQUIRE(rows > 0 && n > 0, "bn_finalize: bad shape");
     int tiles = xv_cdiv(rows, XV_TILE_M);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(xv_cdiv(n, 32)), dim3(256), 0, (hipStream_t)stream, bn_part, rows, n, tiles,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, (hipStream_t)stream, bn_part, rows, n, tiles,
                        gamma, beta, eps, momentum, unbiased_moving, moving_mean, moving_var, mean, invstd, scale, shift, zmin, zmax, amax, relu);
     XV_LAUNCH_CHECK();
     return 0;
@@ -378,10 +380,50 @@ extern "C" int xv_bn_apply(void* stream, const float* z, int rows, int n, int ld
     return 0;
 }
 
+// Upstream gradient of a layer whose output feeds statistics pooling directly (tdnn5): instead of reading a
+// materialised d(activation), the BN backward evaluates the pooling backward (pooling.py:9-34) on the fly from the
+// pooled statistics [b][mean | std] and their gradient:  da = dmean/T + dstd/(T*std) * (a - mean),  a = relu?(z*scale+shift).
+struct PoolGrad { const float* out; const float* dout; int t; };
+
+__device__ __forceinline__ f32x4 pool_grad(const PoolGrad& pg, long row, int n, int col, f32x4 a) {
+    const int b = (int)(row / pg.t);
+    const float invT = 1.f / (float)pg.t;
+    const float sd_eps = 1e-6f;      // sqrt(1e-12): the forward clamps the variance there (pooling.py:28-29)
+    const float* o = pg.out + (long)b * 2 * n;
+    const float* g = pg.dout + (long)b * 2 * n;
+    f32x4 mean = *(const f32x4*)(o + col), sd = *(const f32x4*)(o + n + col);
+    f32x4 dm = *(const f32x4*)(g + col), ds = *(const f32x4*)(g + n + col);
+    f32x4 k;
+    k.x = sd.x <= sd_eps ? 0.f : ds.x / sd.x * invT; k.y = sd.y <= sd_eps ? 0.f : ds.y / sd.y * invT;
+    k.z = sd.z <= sd_eps ? 0.f : ds.z / sd.z * invT; k.w = sd.w <= sd_eps ? 0.f : ds.w / sd.w * invT;
+    return dm * invT + k * (a - mean);
+}
+
+// masked upstream gradient of one channel quad: POOLED ? pooling backward on the fly : da, zeroed where the ReLU was off
+template <bool POOLED>
+__device__ __forceinline__ f32x4 upstream_grad(const float* __restrict__ da, const PoolGrad& pg, long r, int n, int col, f32x4 zz,
+                                               f32x4 sc, f32x4 sh, int relu) {
+    f32x4 y = zz * sc + sh;
+    f32x4 dd;
+    if (POOLED) {
+        f32x4 a = y;
+        if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+        dd = pool_grad(pg, r, n, col, a);
+    } else {
+        dd = *(const f32x4*)(da + r * n + col);
+    }
+    if (relu) {
+        dd.x = y.x > 0.f ? dd.x : 0.f; dd.y = y.y > 0.f ? dd.y : 0.f;
+        dd.z = y.z > 0.f ? dd.z : 0.f; dd.w = y.w > 0.f ? dd.w : 0.f;
+    }
+    return dd;
+}
+
 // Backward pass 1: per (64-row chunk, 256-column block) partial sums of dy and dy*xhat.
 // block = 256 threads = 64 column-quads x 4 row lanes.
 #define BB_ROWS 64
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ z, int rows,
+template <bool POOLED>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, PoolGrad pg, const float* __restrict__ z, int rows,
                                                             int n, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu,
@@ -396,12 +438,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
         for (int r = r0 + rl; r < r1; r += 4) {
             f32x4 zz = *(const f32x4*)(z + (long)r * n + col);
-            f32x4 dd = *(const f32x4*)(da + (long)r * n + col);
-            if (relu) {
-                f32x4 y = zz * sc + sh;
-                dd.x = y.x > 0.f ? dd.x : 0.f; dd.y = y.y > 0.f ? dd.y : 0.f;
-                dd.z = y.z > 0.f ? dd.z : 0.f; dd.w = y.w > 0.f ? dd.w : 0.f;
-            }
+            f32x4 dd = upstream_grad<POOLED>(da, pg, (long)r, n, col, zz, sc, sh, relu);
             f32x4 xh = (zz - mu) * is;
             s1 += dd;
             s2 += dd * xh;
@@ -427,7 +464,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-// block = 256 threads = 32 channels x 8 chunk lanes, fixed-order combine
+// block = 256 threads = 8 channels x 32 chunk lanes, fixed-order combine
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int n, int rows,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef /* [2][n] */,
@@ -435,12 +472,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               float* __restrict__ dbias, const float* __restrict__ mean,
                                                               const float* __restrict__ zmin, const float* __restrict__ zmax,
                                                               unsigned* __restrict__ dz_amax) {
-    __shared__ float r1[8][32], r2[8][32], r3[8][32];
-    const int cx = threadIdx.x & 31, cl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
+    __shared__ float r1[FIN_LANES][FIN_CH], r2[FIN_LANES][FIN_CH], r3[FIN_LANES][FIN_CH];
+    const int cx = threadIdx.x & (FIN_CH - 1), cl = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + cx;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < n)
-        for (int k = cl; k < chunks; k += 8) {
+        for (int k = cl; k < chunks; k += FIN_LANES) {
             s1 += part[((long)k * 3 + 0) * n + c];
             s2 += part[((long)k * 3 + 1) * n + c];
             s3 = fmaxf(s3, part[((long)k * 3 + 2) * n + c]);
@@ -450,7 +487,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     if (cl != 0 || c >= n) return;
     s1 = 0.f; s2 = 0.f; s3 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; s3 = fmaxf(s3, r3[k][cx]); }
+    for (int k = 0; k < FIN_LANES; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; s3 = fmaxf(s3, r3[k][cx]); }
     dbeta[c] = s1;
     dgamma[c] = s2;
     const float c1 = s1 / (float)rows;
@@ -466,7 +503,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 // Backward pass 2: dz = gamma*invstd*(dy - c1 - xhat*c2) into the segment-padded layout.
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ z, int segs, int t, int nq,
+template <bool POOLED>
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ da, PoolGrad pg, const float* __restrict__ z, int segs, int t, int nq,
                                     const float* __restrict__ gamma, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ scale,
                                     const float* __restrict__ shift, const float* __restrict__ coef, int relu, int pad,
@@ -481,13 +519,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, const float* _
         if (u >= 0 && u < t) {
             long r = (long)seg * t + u;
             f32x4 zz = *(const f32x4*)(z + r * n + col);
-            f32x4 dd = *(const f32x4*)(da + r * n + col);
             f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
-            if (relu) {
-                f32x4 y = zz * *(const f32x4*)(scale + col) + *(const f32x4*)(shift + col);
-                dd.x = y.x > 0.f ? dd.x : 0.f; dd.y = y.y > 0.f ? dd.y : 0.f;
-                dd.z = y.z > 0.f ? dd.z : 0.f; dd.w = y.w > 0.f ? dd.w : 0.f;
-            }
+            f32x4 dd = upstream_grad<POOLED>(da, pg, r, n, col, zz, *(const f32x4*)(scale + col), *(const f32x4*)(shift + col), relu);
             f32x4 xh = (zz - mu) * is;
             f32x4 c1 = *(const f32x4*)(coef + col), c2 = *(const f32x4*)(coef + n + col);
             out = (*(const f32x4*)(gamma + col) * is) * (dd - c1 - xh * c2);
@@ -498,7 +531,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, const float* _
 
 // Same as bn_bwd_apply_kernel but dz is written as two fp16 planes [2][segs*(t+2pad)][ldd] scaled by the power of two
 // derived from *amax (xv_gemm16.hip); 8 channels (one 16-byte chunk per plane) per thread; pad rows / columns are zero.
-__global__ void bn_bwd_apply_split_kernel(const float* __restrict__ da, const float* __restrict__ z, int segs, int t, int n,
+template <bool POOLED>
+__global__ void bn_bwd_apply_split_kernel(const float* __restrict__ da, PoolGrad pg, const float* __restrict__ z, int segs, int t, int n,
                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                           const float* __restrict__ invstd, const float* __restrict__ scale,
                                           const float* __restrict__ shift, const float* __restrict__ coef, int relu, int pad,
@@ -519,13 +553,8 @@ __global__ void bn_bwd_apply_split_kernel(const float* __restrict__ da, const fl
                 const int c = col + 4 * q;
                 if (c >= n) break;
                 f32x4 zz = *(const f32x4*)(z + r * n + c);
-                f32x4 dd = *(const f32x4*)(da + r * n + c);
                 f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
-                if (relu) {
-                    f32x4 y = zz * *(const f32x4*)(scale + c) + *(const f32x4*)(shift + c);
-                    dd.x = y.x > 0.f ? dd.x : 0.f; dd.y = y.y > 0.f ? dd.y : 0.f;
-                    dd.z = y.z > 0.f ? dd.z : 0.f; dd.w = y.w > 0.f ? dd.w : 0.f;
-                }
+                f32x4 dd = upstream_grad<POOLED>(da, pg, r, n, c, zz, *(const f32x4*)(scale + c), *(const f32x4*)(shift + c), relu);
                 f32x4 xh = (zz - mu) * is;
                 f32x4 c1 = *(const f32x4*)(coef + c), c2 = *(const f32x4*)(coef + n + c);
                 f32x4 o = (*(const f32x4*)(gamma + c) * is) * (dd - c1 - xh * c2);
@@ -546,9 +575,9 @@ __global__ void bn_bwd_apply_split_kernel(const float* __restrict__ da, const fl
     }
 }
 
-extern "C" int xv_bn_relu_backward(void* stream, const float* da, const float* z, int segs, int t, int n, const float* gamma,
-                                   const float* mean, const float* invstd, const float* scale, const float* shift, int relu,
-                                   int pad, float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
+static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, const float* z, int segs, int t, int n, const float* gamma,
+                                 const float* mean, const float* invstd, const float* scale, const float* shift, int relu, int pad,
+                                 float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
     XV_REQUIRE(segs > 0 && t > 0 && n > 0 && n % 4 == 0 && pad >= 0, "bn_relu_backward: bad shape (n=%d must be a multiple of 4)", n);
     const int rows = segs * t;
     const int chunks = xv_cdiv(rows, BB_ROWS);
@@ -556,26 +585,26 @@ extern "C" int xv_bn_relu_backward(void* stream, const float* da, const float* z
     XV_REQUIRE(need <= ws_bytes, "bn_relu_backward: workspace too small (%zu > %zu)", need, ws_bytes);
     float* part = (float*)ws;
     float* coef = part + (size_t)chunks * 3 * n;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s, da, z, rows, n, mean, invstd,
-                       scale, shift, relu, part);
+    const bool pooled = pg.out != nullptr;
+    hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
+                       da, pg, z, rows, n, mean, invstd, scale, shift, relu, part);
     XV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, 32)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
                        dgamma, dbeta, coef, gamma, invstd, dbias, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (unsigned*)nullptr);
     XV_LAUNCH_CHECK();
     long total = (long)segs * (t + 2 * pad) * (n / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, da, z, segs, t, n / 4, gamma, mean,
-                       invstd, scale, shift, (const float*)coef, relu, pad, dz_pad);
+    hipLaunchKernelGGL(pooled ? bn_bwd_apply_kernel<true> : bn_bwd_apply_kernel<false>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, da,
+                       pg, z, segs, t, n / 4, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad, dz_pad);
     XV_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int xv_bn_relu_backward_split(void* stream, const float* da, const float* z, int segs, int t, int n, const float* gamma,
-                                         const float* mean, const float* invstd, const float* scale, const float* shift,
-                                         const float* zmin, const float* zmax, int relu, int pad, void* dz_planes, int ldp,
-                                         size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
-                                         size_t ws_bytes) {
+static int bn_relu_backward_split_impl(hipStream_t s, const float* da, PoolGrad pg, const float* z, int segs, int t, int n,
+                                       const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                       const float* zmin, const float* zmax, int relu, int pad, void* dz_planes, int ldp,
+                                       size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
+                                       size_t ws_bytes) {
     XV_REQUIRE(segs > 0 && t > 0 && n > 0 && n % 4 == 0 && pad >= 0, "bn_relu_backward_split: bad shape (n=%d must be a multiple of 4)", n);
     XV_REQUIRE(ldp % 8 == 0 && ldp >= n && plane_stride % 8 == 0 && zmin && zmax && dz_amax, "bn_relu_backward_split: bad plane arguments");
     const int rows = segs * t;
@@ -584,20 +613,61 @@ extern "C" int xv_bn_relu_backward_split(void* stream, const float* da, const fl
     XV_REQUIRE(need <= ws_bytes, "bn_relu_backward_split: workspace too small (%zu > %zu)", need, ws_bytes);
     float* part = (float*)ws;
     float* coef = part + (size_t)chunks * 3 * n;
-    hipStream_t s = (hipStream_t)stream;
+    const bool pooled = pg.out != nullptr;
     XV_CHECK_HIP(hipMemsetAsync(dz_amax, 0, sizeof(uint32_t), s));
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s, da, z, rows, n, mean, invstd,
-                       scale, shift, relu, part);
+    hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
+                       da, pg, z, rows, n, mean, invstd, scale, shift, relu, part);
     XV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, 32)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
                        dgamma, dbeta, coef, gamma, invstd, dbias, mean, zmin, zmax, (unsigned*)dz_amax);
     XV_LAUNCH_CHECK();
     long total = (long)segs * (t + 2 * pad) * (ldp / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_split_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, da, z, segs, t, n, gamma, mean,
-                       invstd, scale, shift, (const float*)coef, relu, pad, (const unsigned*)dz_amax, (unsigned short*)dz_planes,
-                       (long)ldp, (long)plane_stride);
+    hipLaunchKernelGGL(pooled ? bn_bwd_apply_split_kernel<true> : bn_bwd_apply_split_kernel<false>, dim3(grid_for(total, 256, 8192)),
+                       dim3(256), 0, s, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad,
+                       (const unsigned*)dz_amax, (unsigned short*)dz_planes, (long)ldp, (long)plane_stride);
     XV_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int xv_bn_relu_backward(void* stream, const float* da, const float* z, int segs, int t, int n, const float* gamma,
+                                   const float* mean, const float* invstd, const float* scale, const float* shift, int relu,
+                                   int pad, float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
+    XV_REQUIRE(da, "bn_relu_backward: null upstream gradient");
+    PoolGrad pg = {nullptr, nullptr, 1};
+    return bn_relu_backward_impl((hipStream_t)stream, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, relu, pad, dz_pad, dgamma,
+                                 dbeta, dbias, ws, ws_bytes);
+}
+
+extern "C" int xv_bn_relu_backward_split(void* stream, const float* da, const float* z, int segs, int t, int n, const float* gamma,
+                                         const float* mean, const float* invstd, const float* scale, const float* shift,
+                                         const float* zmin, const float* zmax, int relu, int pad, void* dz_planes, int ldp,
+                                         size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
+                                         size_t ws_bytes) {
+    XV_REQUIRE(da, "bn_relu_backward_split: null upstream gradient");
+    PoolGrad pg = {nullptr, nullptr, 1};
+    return bn_relu_backward_split_impl((hipStream_t)stream, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, zmin, zmax, relu, pad,
+                                       dz_planes, ldp, plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes);
+}
+
+extern "C" int xv_bn_relu_backward_pooled(void* stream, const float* pool_out, const float* dpool, int b, int t, const float* z, int n,
+                                          const float* gamma, const float* mean, const float* invstd, const float* scale,
+                                          const float* shift, int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws,
+                                          size_t ws_bytes) {
+    XV_REQUIRE(pool_out && dpool && b > 0 && t > 0, "bn_relu_backward_pooled: bad arguments");
+    PoolGrad pg = {pool_out, dpool, t};
+    return bn_relu_backward_impl((hipStream_t)stream, nullptr, pg, z, b * t, 1, n, gamma, mean, invstd, scale, shift, relu, 0, dz, dgamma,
+                                 dbeta, dbias, ws, ws_bytes);
+}
+
+extern "C" int xv_bn_relu_backward_pooled_split(void* stream, const float* pool_out, const float* dpool, int b, int t, const float* z, int n,
+                                                const float* gamma, const float* mean, const float* invstd, const float* scale,
+                                                const float* shift, const float* zmin, const float* zmax, int relu, void* dz_planes,
+                                                int ldp, size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta,
+                                                float* dbias, void* ws, size_t ws_bytes) {
+    XV_REQUIRE(pool_out && dpool && b > 0 && t > 0, "bn_relu_backward_pooled_split: bad arguments");
+    PoolGrad pg = {pool_out, dpool, t};
+    return bn_relu_backward_split_impl((hipStream_t)stream, nullptr, pg, z, b * t, 1, n, gamma, mean, invstd, scale, shift, zmin, zmax, relu,
+                                       0, dz_planes, ldp, plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes);
 }
 
 __global__ void relu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ a, size_t count, float* __restrict__ dz) {
@@ -629,7 +699,11 @@ __device__ __forceinline__ void wf_merge(f32x4& mean, f32x4& m2, float& n, const
     n = nn;
 }
 
-__global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restrict__ x, int T, int C, float* __restrict__ out) {
+// BN: the pooled tensor is relu?(x*scale + shift) evaluated on the fly (x = the pre-BN output of tdnn5), so the
+// activation is never written to memory.
+template <bool BN>
+__global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restrict__ x, int T, int C, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu, float* __restrict__ out) {
     __shared__ f32x4 s_mean[4][32], s_m2[4][32];
     __shared__ float s_n[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -640,14 +714,23 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
     const bool cv = col < C;
     const float* xp = x + (long)b * T * C + (cv ? col : 0);
     f32x4 mean = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+    f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+    if (BN && cv) { sc = *(const f32x4*)(scale + col); sh = *(const f32x4*)(shift + col); }
+    auto act = [&](f32x4 v) {
+        if (BN) {
+            v = v * sc + sh;
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        return v;
+    };
     float n = 0.f;
     int t = fl;
     // 4 loads in flight per lane
     for (; t + 24 < T; t += 32) {
-        f32x4 v0 = *(const f32x4*)(xp + (long)t * C);
-        f32x4 v1 = *(const f32x4*)(xp + (long)(t + 8) * C);
-        f32x4 v2 = *(const f32x4*)(xp + (long)(t + 16) * C);
-        f32x4 v3 = *(const f32x4*)(xp + (long)(t + 24) * C);
+        f32x4 v0 = act(*(const f32x4*)(xp + (long)t * C));
+        f32x4 v1 = act(*(const f32x4*)(xp + (long)(t + 8) * C));
+        f32x4 v2 = act(*(const f32x4*)(xp + (long)(t + 16) * C));
+        f32x4 v3 = act(*(const f32x4*)(xp + (long)(t + 24) * C));
         f32x4 d;
         n += 1.f; d = v0 - mean; mean += d * (1.f / n); m2 += d * (v0 - mean);
         n += 1.f; d = v1 - mean; mean += d * (1.f / n); m2 += d * (v1 - mean);
@@ -655,7 +738,7 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
         n += 1.f; d = v3 - mean; mean += d * (1.f / n); m2 += d * (v3 - mean);
     }
     for (; t < T; t += 8) {
-        f32x4 v = *(const f32x4*)(xp + (long)t * C);
+        f32x4 v = act(*(const f32x4*)(xp + (long)t * C));
         n += 1.f;
         f32x4 d = v - mean;
         mean += d * (1.f / n);
@@ -690,7 +773,17 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
 
 extern "C" int xv_stat_pool_forward(void* stream, const float* x, int b, int t, int c, float* out) {
     XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0, "stat_pool_forward: bad shape (c=%d must be a multiple of 4)", c);
-    hipLaunchKernelGGL(stat_pool_fwd_kernel, dim3(xv_cdiv(c / 4, 32), b), dim3(256), 0, (hipStream_t)stream, x, t, c, out);
+    hipLaunchKernelGGL(stat_pool_fwd_kernel<false>, dim3(xv_cdiv(c / 4, 32), b), dim3(256), 0, (hipStream_t)stream, x, t, c,
+                       (const float*)nullptr, (const float*)nullptr, 0, out);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xv_stat_pool_forward_bn(void* stream, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
+                                       float* out) {
+    XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0 && scale && shift, "stat_pool_forward_bn: bad shape (c=%d must be a multiple of 4)", c);
+    hipLaunchKernelGGL(stat_pool_fwd_kernel<true>, dim3(xv_cdiv(c / 4, 32), b), dim3(256), 0, (hipStream_t)stream, z, t, c, scale, shift,
+                       relu, out);
     XV_LAUNCH_CHECK();
     return 0;
 }

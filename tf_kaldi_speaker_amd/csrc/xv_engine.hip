@@ -383,6 +383,7 @@ int bn_forward(xv_engine* e, hipStream_t s, Affine& a, int rows, bool stats_from
                                    c.bn_epsilon, a.scale, a.shift);
     }
     if (rc) return rc;
+    if (!dst_a) return 0;       // the consumer applies scale/shift itself (tdnn5: statistics pooling)
     return xv_bn_apply(s, a.z, rows, a.c_out, a.c_out, a.scale, a.shift, a.has_relu ? 1 : 0, dst_a, a.c_out);
 }
 
@@ -505,9 +506,6 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
                 rc = xv_bn_apply_split(s, a.z, rows, a.c_out, a.c_out, a.scale, a.shift, 1, out_amax, a.ah, a.o_ld, (size_t)rows * a.o_ld);
                 if (rc) return rc;
                 curh = a.ah; cur_stride = (size_t)rows * a.o_ld; cur_amax = out_amax;
-            } else {
-                rc = xv_bn_apply(s, a.z, rows, a.c_out, a.c_out, a.scale, a.shift, 1, a.a, a.c_out);   // pooling reads fp32
-                if (rc) return rc;
             }
             a.rows = rows;
             cur_t = t_out;
@@ -524,14 +522,15 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             rc = xv_affine_forward(s, cur, b, cur_t, a.c_pad, a.k, a.wt, vptr(e, a.v_bias), a.z, a.c_out, a.c_out,
                                    training ? a.bn_part : nullptr, e->ws, e->ws_bytes);
             if (rc) return rc;
-            rc = bn_forward(e, s, a, rows, true, a.a);
+            rc = bn_forward(e, s, a, rows, true, i < 4 ? a.a : nullptr);
             if (rc) return rc;
             a.rows = rows;
             cur = a.a; cur_t = t_out;
             e->Tl[i + 1] = t_out;
         }
     }
-    rc = xv_stat_pool_forward(s, e->L[4].a, b, cur_t, e->P, e->pool);
+    // tdnn5's BN + ReLU is applied inside the pooling reduction: its [b*t][1500] activation is never written
+    rc = xv_stat_pool_forward_bn(s, e->L[4].z, b, cur_t, e->P, e->L[4].scale, e->L[4].shift, 1, e->pool);
     if (rc) return rc;
     // segment-level layers
     Affine& l6 = e->L[5];
@@ -659,7 +658,13 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
         XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_w[zi], 0));
         e->w_pending[zi] = false;
     }
-    if (a.has_bn) {
+    if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
+        XV_REQUIRE(&a == &e->L[4] && a.has_bn, "engine_backward: only tdnn5 takes its gradient from the pooling layer");
+        rc = xv_bn_relu_backward_pooled(s, e->pool, e->d_small0, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale,
+                                        a.shift, 1, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
+        if (rc) return rc;
+        dz = Z;
+    } else if (a.has_bn) {
         rc = xv_bn_relu_backward(s, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift,
                                  a.has_relu ? 1 : 0, pad, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
         if (rc) return rc;
@@ -717,9 +722,17 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
     const int seg_pitch = t_out + 2 * pad;
     const size_t zstride = (size_t)segs * seg_pitch * a.o_ld;
     XV_REQUIRE(zstride <= e->dzh_halfs, "engine_backward: dz plane buffer too small");
-    int rc = xv_bn_relu_backward_split(s, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift, a.zmin,
+    int rc;
+    if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
+        XV_REQUIRE(li == 4, "engine_backward: only tdnn5 takes its gradient from the pooling layer");
+        rc = xv_bn_relu_backward_pooled_split(s, e->pool, e->d_small0, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd,
+                                              a.scale, a.shift, a.zmin, a.zmax, 1, Z, a.o_ld, zstride, zamax, gptr(e, a.v_gamma),
+                                              gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
+    } else {
+        rc = xv_bn_relu_backward_split(s, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift, a.zmin,
                                        a.zmax, 1, pad, Z, a.o_ld, zstride, zamax, gptr(e, a.v_gamma), gptr(e, a.v_beta),
                                        gptr(e, a.v_bias), e->ws, e->ws_bytes);
+    }
     if (rc) return rc;
     // operand planes of this layer's input: the feature planes for tdnn1, the previous layer's BN+ReLU planes otherwise
     const unsigned short* xin = li == 0 ? e->xh : e->L[li - 1].ah;
@@ -808,17 +821,16 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
             if (rc) return rc;
             d = e->d_small1;
         }
-        // tdnn7 -> d a6 (into bufD), tdnn6 -> d pool (into d_small0), pooling -> d a5 (into bufD)
+        // tdnn7 -> d a6 (into bufD), tdnn6 -> d pool (into d_small0); the pooling backward itself is evaluated
+        // inside tdnn5's BN backward (stage 1) from (pool, d pool): d a5 is never written
         rc = layer_backward(e, s, e->L[6], d, e->L[5].a, b, 1, e->bufD, e->h7);
         if (rc) return rc;
         rc = layer_backward(e, s, e->L[5], e->bufD, e->pool, b, 1, e->d_small0, nullptr);
         if (rc) return rc;
-        rc = xv_stat_pool_backward(s, e->L[4].a, e->pool, e->d_small0, b, e->Tl[5], e->P, e->bufD);
-        if (rc) return rc;
         if (stage == 0) { rc = join_side(e, s); if (rc) return rc; }
     }
     if (stage == -1 || stage == 1) {
-        rc = layer_backward(e, s, e->L[4], e->bufD, e->L[3].a, b * e->Tl[5], 1, e->bufD, nullptr);   // tdnn5: da4 overwrites da5
+        rc = layer_backward(e, s, e->L[4], nullptr, e->L[3].a, b * e->Tl[5], 1, e->bufD, nullptr);   // tdnn5 (da = pooling backward) -> d a4
         if (rc) return rc;
         rc = layer_backward(e, s, e->L[3], e->bufD, e->L[2].a, b * e->Tl[4], 1, e->bufD, nullptr);   // tdnn4
         if (rc) return rc;
@@ -897,7 +909,7 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
         Affine& a = e->L[i];
         if (n == a.prefix + "_" + a.kind) return set(a.z, a.rows, a.c_out, a.c_out);
         if (n == a.prefix + "_relu" && a.has_relu) {
-            if (e->f16 && i < 4) {     // only the fp16 planes exist on the hot path: rebuild the fp32 view on demand
+            if ((e->f16 && i < 4) || i == 4) {     // not materialised on the hot path (fp16 planes / fused into pooling): rebuild on demand
                 int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 1, a.a, a.c_out);
                 if (rc) return rc;
             }
@@ -912,7 +924,14 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
         }
     }
     // debug views of the backward scratch (valid right after backward stage 0)
-    if (n == "debug:da5") return set(e->bufD, e->B * e->Tl[5], e->P, e->P);
+    if (n == "debug:da5") {     // evaluated on demand with the standalone pooling backward (valid after backward stage 0, before stage 1)
+        Affine& a5 = e->L[4];
+        int rc = xv_bn_apply(e->last_stream, a5.z, a5.rows, a5.c_out, a5.c_out, a5.scale, a5.shift, 1, a5.a, a5.c_out);
+        if (rc) return rc;
+        rc = xv_stat_pool_backward(e->last_stream, a5.a, e->pool, e->d_small0, e->B, e->Tl[5], e->P, e->bufD);
+        if (rc) return rc;
+        return set(e->bufD, e->B * e->Tl[5], e->P, e->P);
+    }
     if (n == "debug:dpool") return set(e->d_small0, e->B, 2 * e->P, 2 * e->P);
     if (n == "pooling") return set(e->pool, e->B, 2 * e->P, 2 * e->P);
     if (n == "output") return set(e->out, e->B, e->Lout, e->Lout);

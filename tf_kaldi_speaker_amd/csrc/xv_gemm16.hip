@@ -188,13 +188,23 @@ struct NT16Args {
     const u16* zero;
 };
 
-#define BK16 32
+#ifndef XV16_ABL
+#define XV16_ABL 0     // ablation builds only (tools/variant_bench16.sh): 1 = no LDS-DMA, 2 = no LDS reads
+#endif
+#ifndef XV16_BK
+#define XV16_BK 32
+#endif
+#ifndef XV16_WGS
+#define XV16_WGS 2
+#endif
+#define BK16 XV16_BK
+#define SWZ16(row) (BK16 == 32 ? (((row) >> 2) & 3) : 0)
 #define CQ16 (BK16 / 8)
 #define PLANE_HALFS (128 * BK16)
 #define BUF_HALFS (4 * PLANE_HALFS)
 
 template <bool STATS>
-__global__ __launch_bounds__(256, 2) void xv_gemm16_nt_kernel(NT16Args p) {
+__global__ __launch_bounds__(256, XV16_WGS) void xv_gemm16_nt_kernel(NT16Args p) {
     constexpr int RPI = 64 / CQ16;                 // tile rows per LDS-DMA wave-instruction (16)
     constexpr int IPW = 128 / RPI / 4;             // DMA instructions per wave per plane per operand (2)
     __shared__ __attribute__((aligned(16))) u16 smem[2 * BUF_HALFS];
@@ -214,8 +224,13 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_kernel(NT16Args p) {
     int ksrc[IPW];
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
+#if XV16_ABL & 4   // perf-only experiment (wrong results): every DMA instruction reads 8 rows x full 128-byte lines
+        const int row = 8 * (IPW * wave + i) + (lane >> 3);
+        ksrc[i] = (lane & 7) << 3;
+#else
         const int row = RPI * (IPW * wave + i) + lrow;
-        ksrc[i] = ((lpos ^ ((row >> 2) & 3)) << 3);
+        ksrc[i] = ((lpos ^ SWZ16(row)) << 3);
+#endif
         int m = m0 + row;
         av[i] = m < p.M;
         int mm = av[i] ? m : 0;
@@ -230,7 +245,11 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_kernel(NT16Args p) {
         const int k0 = kt * BK16;
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
+#if XV16_ABL & 4
+            const int k = (2 * k0) % p.K + ksrc[i];
+#else
             const int k = k0 + ksrc[i];
+#endif
             const bool kv = k < p.K;
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
@@ -250,18 +269,30 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_kernel(NT16Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int fsw = (li >> 2) & 3;
+    const int fsw = SWZ16(li);
     const int a_row = (wr * 64 + li) * BK16, b_row = (wc * 64 + li) * BK16;
     if (nk > 0) gstage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+#if !(XV16_ABL & 1)
         if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
+#endif
         const u16* base = smem + buf * BUF_HALFS;
 #pragma unroll
         for (int kb = 0; kb < BK16 / 16; ++kb) {
             const int pos = (((2 * kb + lh) ^ fsw) << 3);
             f32x4 af[2][2], bf[2][2];
+#if XV16_ABL & 2
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    af[pl][q] = (f32x4){(float)kt, (float)lane, (float)pl, (float)q};
+                    bf[pl][q] = (f32x4){(float)q, (float)kt, (float)lane, (float)pl};
+                    asm volatile("" : "+v"(af[pl][q]), "+v"(bf[pl][q]));
+                }
+#else
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
                 af[pl][0] = *(const f32x4*)(base + pl * PLANE_HALFS + a_row + pos);
@@ -269,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_kernel(NT16Args p) {
                 bf[pl][0] = *(const f32x4*)(base + (2 + pl) * PLANE_HALFS + b_row + pos);
                 bf[pl][1] = *(const f32x4*)(base + (2 + pl) * PLANE_HALFS + b_row + 32 * BK16 + pos);
             }
+#endif
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -278,7 +310,11 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_kernel(NT16Args p) {
 #undef MM
                 }
         }
+#if XV16_ABL & 8   // perf-only experiment (wrong results): never wait for the prefetch
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
         __syncthreads();
+#endif
     }
 
     const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));

@@ -159,6 +159,25 @@ def stat_pool_forward(x):
     return out
 
 
+def stat_pool_forward_bn(z, b, t, scale, shift, relu=True):
+    """[b, 2c] statistics of relu?(z*scale+shift) without materialising it (z: [b*t, c])."""
+    c = z.shape[1]
+    out = _f32((b, 2 * c), z)
+    _lib.call("xv_stat_pool_forward_bn", _s(), _p(z), b, t, c, _p(scale), _p(shift), int(relu), _p(out))
+    return out
+
+
+def bn_relu_backward_pooled(pool_out, dpool, b, t, z, gamma, mean, invstd, scale, shift, relu=True):
+    """BN(+ReLU) backward of the layer feeding statistics pooling, upstream gradient = pooling backward on the fly."""
+    n = z.shape[1]
+    dz = _f32((b * t, n), z)
+    dgamma, dbeta, dbias = _f32((n,), z), _f32((n,), z), _f32((n,), z)
+    wp, wb = _ws(z)
+    _lib.call("xv_bn_relu_backward_pooled", _s(), _p(pool_out), _p(dpool), b, t, _p(z), n, _p(gamma), _p(mean), _p(invstd), _p(scale),
+              _p(shift), int(relu), _p(dz), _p(dgamma), _p(dbeta), _p(dbias), wp, wb)
+    return dz, dgamma, dbeta, dbias
+
+
 def stat_pool_backward(x, out, dout):
     b, t, c = x.shape
     dx = torch.empty_like(x)
@@ -280,6 +299,20 @@ def bn_relu_backward_split(da, z, segs, t, gamma, mean, invstd, scale, shift, zm
     wp, wb = _ws(z)
     _lib.call("xv_bn_relu_backward_split", _s(), _p(da), _p(z), segs, t, n, _p(gamma), _p(mean), _p(invstd), _p(scale), _p(shift),
               _p(zmin), _p(zmax), int(relu), int(pad), _p(data), ld, C.c_size_t(rows * ld), _p(amax), _p(dgamma), _p(dbeta), _p(dbias),
+              wp, wb)
+    return Planes(data, rows, ld, amax), dgamma, dbeta, dbias
+
+
+def bn_relu_backward_pooled_split(pool_out, dpool, b, t, z, gamma, mean, invstd, scale, shift, zmin, zmax, relu=True):
+    n = z.shape[1]
+    ld = (n + 7) // 8 * 8
+    rows = b * t
+    data = torch.empty((2, rows, ld), dtype=torch.int16, device=z.device)
+    amax = torch.zeros(1, dtype=torch.int32, device=z.device)
+    dgamma, dbeta, dbias = _f32((n,), z), _f32((n,), z), _f32((n,), z)
+    wp, wb = _ws(z)
+    _lib.call("xv_bn_relu_backward_pooled_split", _s(), _p(pool_out), _p(dpool), b, t, _p(z), n, _p(gamma), _p(mean), _p(invstd), _p(scale),
+              _p(shift), _p(zmin), _p(zmax), int(relu), _p(data), ld, C.c_size_t(rows * ld), _p(amax), _p(dgamma), _p(dbeta), _p(dbias),
               wp, wb)
     return Planes(data, rows, ld, amax), dgamma, dbeta, dbias
 
