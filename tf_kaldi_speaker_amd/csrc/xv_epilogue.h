@@ -1,5 +1,5 @@
-// Shared GEMM epilogue: per-128-row-tile column statistics of the output tile held in the
-// 2x2 v_mfma 32x32 accumulators of a 4-wave (2x2) workgroup.
+// Shared GEMM epilogue: per-128-row-tile column statistics of the output tile held in the 2 x NB v_mfma 32x32
+// accumulators per wave of a workgroup of 2 x (4/NB) waves (NB = 2: four waves of 64x64, NB = 1: eight of 64x32).
 //   part layout: [4][tiles_m][N] = column sum | sum of squares centred on the TILE mean (Chan-combinable,
 //   no E[x^2]-E[x]^2 cancellation) | column min | column max  (valid rows only).
 // sum/M2 feed BatchNorm (tdnn.py:46); min/max give the exact range of the BN output, which the
@@ -8,7 +8,8 @@
 #pragma once
 #include "xv_common.h"
 
-__device__ __forceinline__ void xv_tile_stats_epilogue(const f32x16 (&acc)[2][2], float* red /* >= 1024 floats of LDS, free */,
+template <int NB>
+__device__ __forceinline__ void xv_tile_stats_epilogue(const f32x16 (&acc)[2][NB], float* red /* >= 1024 floats of LDS, free */,
                                                        int tid, int wr, int wc, int li, int lh, int m0, int n0, int M, int N,
                                                        int tile_m, int tiles_m, float* __restrict__ part) {
     float* r_sum = red;          // [2][128]
@@ -17,7 +18,7 @@ __device__ __forceinline__ void xv_tile_stats_epilogue(const f32x16 (&acc)[2][2]
     float* r_max = red + 768;
     const int cnt = min(XV_TILE_M, M - m0);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < NB; ++b) {
         float v = 0.f, mn = INFINITY, mx = -INFINITY;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -34,7 +35,7 @@ __device__ __forceinline__ void xv_tile_stats_epilogue(const f32x16 (&acc)[2][2]
         mn = fminf(mn, __shfl_xor(mn, 32));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         if (lh == 0) {
-            int col = wc * 64 + b * 32 + li;
+            int col = (wc * NB + b) * 32 + li;
             r_sum[wr * 128 + col] = v;
             r_min[wr * 128 + col] = mn;
             r_max[wr * 128 + col] = mx;
@@ -42,8 +43,8 @@ __device__ __forceinline__ void xv_tile_stats_epilogue(const f32x16 (&acc)[2][2]
     }
     __syncthreads();
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        int col = wc * 64 + b * 32 + li;
+    for (int b = 0; b < NB; ++b) {
+        int col = (wc * NB + b) * 32 + li;
         float mean = (r_sum[col] + r_sum[128 + col]) / (float)cnt;
         float v = 0.f;
 #pragma unroll

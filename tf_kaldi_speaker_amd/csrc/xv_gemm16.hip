@@ -189,7 +189,8 @@ struct NT16Args {
 };
 
 #ifndef XV16_ABL
-#define XV16_ABL 0     // ablation builds only (tools/variant_bench16.sh): 1 = no LDS-DMA, 2 = no LDS reads
+#define XV16_ABL 0     // ablation builds only (tools/variant_bench16.sh; results are wrong): 1 = no LDS-DMA, 2 = no LDS reads (generic NT kernel);
+                       // 16 = no weight-tile DMA, 32 = no x-row DMA (context-window NT kernel)
 #endif
 #ifndef XV16_BK
 #define XV16_BK 32
@@ -197,21 +198,26 @@ struct NT16Args {
 #ifndef XV16_WGS
 #define XV16_WGS 2
 #endif
+#ifndef XV16_WAVES
+#define XV16_WAVES 4     // 4: 2x2 waves of 64x64;  8: 2x4 waves of 64x32 (4 waves per SIMD at 2 workgroups per CU)
+#endif
+#define WN16 (XV16_WAVES / 2)          // waves along N
+#define NB16 (4 / WN16)                // 32-column accumulator blocks per wave
 #define BK16 XV16_BK
-#define SWZ16(row) (BK16 == 32 ? (((row) >> 2) & 3) : 0)
+#define SWZ16(row) (BK16 == 64 ? (((row) >> 1) & 7) : BK16 == 32 ? (((row) >> 2) & 3) : 0)
 #define CQ16 (BK16 / 8)
 #define PLANE_HALFS (128 * BK16)
 #define BUF_HALFS (4 * PLANE_HALFS)
 
 template <bool STATS>
-__global__ __launch_bounds__(256, XV16_WGS) void xv_gemm16_nt_kernel(NT16Args p) {
+__global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel(NT16Args p) {
     constexpr int RPI = 64 / CQ16;                 // tile rows per LDS-DMA wave-instruction (16)
-    constexpr int IPW = 128 / RPI / 4;             // DMA instructions per wave per plane per operand (2)
+    constexpr int IPW = 128 / RPI / XV16_WAVES;    // DMA instructions per wave per plane per operand
     __shared__ __attribute__((aligned(16))) u16 smem[2 * BUF_HALFS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN16, wc = wave % WN16;
     const int li = lane & 31, lh = lane >> 5;
     const int t = xcd_swizzle16(blockIdx.x, gridDim.x);
     const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
@@ -224,13 +230,8 @@ __global__ __launch_bounds__(256, XV16_WGS) void xv_gemm16_nt_kernel(NT16Args p)
     int ksrc[IPW];
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
-#if XV16_ABL & 4   // perf-only experiment (wrong results): every DMA instruction reads 8 rows x full 128-byte lines
-        const int row = 8 * (IPW * wave + i) + (lane >> 3);
-        ksrc[i] = (lane & 7) << 3;
-#else
         const int row = RPI * (IPW * wave + i) + lrow;
         ksrc[i] = ((lpos ^ SWZ16(row)) << 3);
-#endif
         int m = m0 + row;
         av[i] = m < p.M;
         int mm = av[i] ? m : 0;
@@ -245,11 +246,7 @@ __global__ __launch_bounds__(256, XV16_WGS) void xv_gemm16_nt_kernel(NT16Args p)
         const int k0 = kt * BK16;
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
-#if XV16_ABL & 4
-            const int k = (2 * k0) % p.K + ksrc[i];
-#else
             const int k = k0 + ksrc[i];
-#endif
             const bool kv = k < p.K;
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
@@ -261,16 +258,16 @@ __global__ __launch_bounds__(256, XV16_WGS) void xv_gemm16_nt_kernel(NT16Args p)
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NB16];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB16; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int fsw = SWZ16(li);
-    const int a_row = (wr * 64 + li) * BK16, b_row = (wc * 64 + li) * BK16;
+    const int a_row = (wr * 64 + li) * BK16, b_row = (wc * 32 * NB16 + li) * BK16;
     if (nk > 0) gstage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -282,49 +279,209 @@ __global__ __launch_bounds__(256, XV16_WGS) void xv_gemm16_nt_kernel(NT16Args p)
 #pragma unroll
         for (int kb = 0; kb < BK16 / 16; ++kb) {
             const int pos = (((2 * kb + lh) ^ fsw) << 3);
-            f32x4 af[2][2], bf[2][2];
+            f32x4 af[2][2], bf[2][NB16];
 #if XV16_ABL & 2
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     af[pl][q] = (f32x4){(float)kt, (float)lane, (float)pl, (float)q};
-                    bf[pl][q] = (f32x4){(float)q, (float)kt, (float)lane, (float)pl};
-                    asm volatile("" : "+v"(af[pl][q]), "+v"(bf[pl][q]));
+                    bf[pl][q % NB16] = (f32x4){(float)q, (float)kt, (float)lane, (float)pl};
+                    asm volatile("" : "+v"(af[pl][q]), "+v"(bf[pl][q % NB16]));
                 }
 #else
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
                 af[pl][0] = *(const f32x4*)(base + pl * PLANE_HALFS + a_row + pos);
                 af[pl][1] = *(const f32x4*)(base + pl * PLANE_HALFS + a_row + 32 * BK16 + pos);
-                bf[pl][0] = *(const f32x4*)(base + (2 + pl) * PLANE_HALFS + b_row + pos);
-                bf[pl][1] = *(const f32x4*)(base + (2 + pl) * PLANE_HALFS + b_row + 32 * BK16 + pos);
+#pragma unroll
+                for (int nb = 0; nb < NB16; ++nb) bf[pl][nb] = *(const f32x4*)(base + (2 + pl) * PLANE_HALFS + b_row + nb * 32 * BK16 + pos);
             }
 #endif
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < NB16; ++b) {
 #define MM(i, j) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][a]), __builtin_bit_cast(f16x8, bf[j][b]), acc[a][b], 0, 0, 0)
                     MM(0, 1); MM(1, 0); MM(0, 0);          // cross terms first, then the leading product
 #undef MM
                 }
         }
-#if XV16_ABL & 8   // perf-only experiment (wrong results): never wait for the prefetch
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
         __syncthreads();
-#endif
     }
 
     const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
-    float bias_v[2] = {0.f, 0.f};
-    if (p.bias) {
+    float bias_v[NB16];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            int n = n0 + wc * 64 + b * 32 + li;
-            bias_v[b] = n < p.N ? p.bias[n] : 0.f;
+    for (int b = 0; b < NB16; ++b) {
+        int n = n0 + (wc * NB16 + b) * 32 + li;
+        bias_v[b] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB16; ++b) {
+            int n = n0 + (wc * NB16 + b) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[a][b][r] * out_scale + bias_v[b];
+                acc[a][b][r] = v;
+                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = v;
+            }
         }
+    if (STATS) xv_tile_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Context-window ("conv") form of the NT kernel: K = taps x C with A row (m, tap j) = x row xrow(m) + j.
+// The generic kernel re-reads every x row once per tap from L2 (its A image for tap j+1 is the image for tap j
+// shifted by one row) - and the L2 request rate is what bounds it (PMC: 92 % L2 hits, TCP stalled on pending
+// requests 45 % of the time, MFMA busy 40 %).  Here one LDS image of the x rows xrow(m0) .. xrow(m0+127)+taps-1
+// for a 32-channel chunk serves all taps: the K loop runs channel chunk outer, tap inner, the MFMA A fragments
+// of tap j are read at LDS row offset j, and only the weight tile (B) is staged per K-step.  The next chunk's
+// x rows are fetched in `taps` slices, one per K-step, so every step issues about the same number of LDS-DMAs
+// (5 per wave instead of 8 for taps = 5).  Rows of one tile may straddle segments: aoff(q) = xrow(m0+q) - xrow(m0)
+// grows by (pitch - rps) at every crossing; the launcher falls back to the generic kernel when the rows of a
+// tile do not fit the CONV_AR-row image.
+// LDS: A 2 x 2 planes x 160 rows x 64 B = 40 KB, B 2 x 2 planes x 128 x 64 B = 32 KB: two workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+#define CONV_AR 160                                  // x rows per A image (128 + halo)
+#define CONV_APLANE (CONV_AR * 32)                   // halfs per A plane image
+#define CONV_ABUF (2 * CONV_APLANE)
+#define CONV_BPLANE (128 * 32)
+#define CONV_BBUF (2 * CONV_BPLANE)
+
+struct NT16ConvArgs {
+    NT16Args g;
+    int taps, chunks;          // K = taps * C, chunks = C / 32
+    long a_rows;               // rows of the A planes (reads beyond are zero)
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void xv_gemm16_nt_conv_kernel(NT16ConvArgs q) {
+    const NT16Args& p = q.g;
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * CONV_ABUF + 2 * CONV_BBUF];
+    u16* const sA = smem;
+    u16* const sB = smem + 2 * CONV_ABUF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int t = xcd_swizzle16(blockIdx.x, gridDim.x);
+    const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int taps = q.taps, nc = q.chunks;
+    const long C = p.lda;
+
+    auto xrow = [&](int m) {
+        int mm = min(m, p.M - 1);
+        int seg = mm / p.a_rps, tt = mm - seg * p.a_rps;
+        return (long)seg * p.a_pitch + tt;
+    };
+    const long xr0 = xrow(m0);
+    // LDS row of output row (wr*64 + a*32 + li) at tap 0
+    int arow[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) arow[a] = (int)(xrow(m0 + wr * 64 + a * 32 + li) - xr0);
+
+    // DMA lane geometry: one wave-instruction = 16 image rows x 64 B; lane -> row l>>2, 16-byte chunk l&3 (source chunk swizzled)
+    const int drow = lane >> 2, dchunk = lane & 3;
+    // B: rows 32*wave + 16*i + drow of the weight tile
+    long boff[2];
+    bool bv[2];
+    int bsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * (2 * wave + i) + drow;
+        bsrc[i] = (dchunk ^ ((row >> 2) & 3)) << 3;
+        int n = n0 + row;
+        bv[i] = n < p.N;
+        boff[i] = (long)(bv[i] ? n : 0) * p.ldb;
+    }
+    auto stage_b = [&](int cc, int j, int buf) {
+        u16* base = sB + buf * CONV_BBUF + 32 * uwave * 32;
+        const long k0 = (long)j * C + cc * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const u16* pb = bv[i] ? p.Bt + pl * p.b_plane + boff[i] + k0 + bsrc[i] : p.zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + pl * CONV_BPLANE + 16 * i * 32), 16, 0, 0);
+            }
+    };
+    // A: 10 row groups x 2 planes = 20 wave-instructions per chunk, id = plane*10 + group; slice `part` of `nparts`
+    // hands ids part*4 + wave + s*4*nparts to this wave.
+    auto stage_a = [&](int cc, int buf, int part, int nparts) {
+        for (int id = part * 4 + uwave; id < 20; id += 4 * nparts) {
+            const int pl = id >= 10 ? 1 : 0, grp = id - 10 * pl;
+            const int row = 16 * grp + drow;
+            const long xr = xr0 + row;
+            const int src = (dchunk ^ ((row >> 2) & 3)) << 3;
+            const u16* pa = xr < q.a_rows ? p.A + pl * p.a_plane + xr * C + cc * 32 + src : p.zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(sA + buf * CONV_ABUF + pl * CONV_APLANE + 16 * grp * 32), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int b_row = (wc * 64 + li) * 32;
+    const int bsw = (li >> 2) & 3;
+    stage_a(0, 0, 0, 1);
+    stage_b(0, 0, 0);
+    __syncthreads();
+    int st = 0;
+    for (int cc = 0; cc < nc; ++cc) {
+        const u16* abase = sA + (cc & 1) * CONV_ABUF;
+        for (int j = 0; j < taps; ++j, ++st) {
+            // prefetch: next step's weight tile, and this step's slice of the next chunk's x rows
+#if !(XV16_ABL & 16)
+            if (j + 1 < taps) stage_b(cc, j + 1, (st + 1) & 1);
+            else if (cc + 1 < nc) stage_b(cc + 1, 0, (st + 1) & 1);
+#endif
+#if !(XV16_ABL & 32)
+            if (cc + 1 < nc) stage_a(cc + 1, (cc + 1) & 1, j, taps);
+#endif
+            const u16* bbase = sB + (st & 1) * CONV_BBUF;
+            const int r0 = arow[0] + j, r1 = arow[1] + j;
+            const int asw0 = (r0 >> 2) & 3, asw1 = (r1 >> 2) & 3;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int c = 2 * kb + lh;
+                f32x4 af[2][2], bf[2][2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    af[pl][0] = *(const f32x4*)(abase + pl * CONV_APLANE + r0 * 32 + ((c ^ asw0) << 3));
+                    af[pl][1] = *(const f32x4*)(abase + pl * CONV_APLANE + r1 * 32 + ((c ^ asw1) << 3));
+                    bf[pl][0] = *(const f32x4*)(bbase + pl * CONV_BPLANE + b_row + ((c ^ bsw) << 3));
+                    bf[pl][1] = *(const f32x4*)(bbase + pl * CONV_BPLANE + b_row + 32 * 32 + ((c ^ bsw) << 3));
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+#define MM(i, jj) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][a]), __builtin_bit_cast(f16x8, bf[jj][b]), acc[a][b], 0, 0, 0)
+                        MM(0, 1); MM(1, 0); MM(0, 0);
+#undef MM
+                    }
+            }
+            __syncthreads();
+        }
+    }
+
+    const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
+    float bias_v[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        int n = n0 + wc * 64 + b * 32 + li;
+        bias_v[b] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -342,6 +499,23 @@ __global__ __launch_bounds__(256, XV16_WGS) void xv_gemm16_nt_kernel(NT16Args p)
     if (STATS) xv_tile_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
 }
 
+#ifndef XV16_CONV
+#define XV16_CONV 1
+#endif
+
+// Does the context-window kernel apply?  K = taps*lda with whole 32-channel chunks, and the x rows of any 128-row tile
+// (one extra (pitch - rps) per segment crossing, plus the taps) fit the A image.
+static bool conv_form_applies(const XvGemm16NT& g, int* taps_out) {
+    if (!XV16_CONV || XV16_WAVES != 4 || g.lda % 32 != 0 || g.K % g.lda != 0) return false;
+    const int taps = (int)(g.K / g.lda);
+    if (taps < 2 || g.a_pitch < g.a_rps) return false;
+    const long crossings = 127 / g.a_rps + 1;
+    const long span = 127 + (long)(g.a_pitch - g.a_rps) * crossings + (taps - 1);
+    if (span >= CONV_AR) return false;
+    *taps_out = taps;
+    return true;
+}
+
 int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
     XV_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0, "gemm16_nt: lda/ldb must be multiples of 8 (lda=%ld ldb=%ld)", g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0 && g.a_plane % 8 == 0 && g.b_plane % 8 == 0,
@@ -356,8 +530,18 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
     p.bias = g.bias; p.part = g.bn_part; p.a_amax = g.a_amax; p.b_amax = g.b_amax; p.zero = g_zero16;
     dim3 grid(p.tiles_m * p.tiles_n);
     XvProfScope prof(s, g.bn_part ? 3 : 4, 2.0 * g.M * g.N * g.K);
-    if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_kernel<true>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(xv_gemm16_nt_kernel<false>, grid, dim3(256), 0, s, p);
+    int taps = 0;
+    if (conv_form_applies(g, &taps)) {
+        NT16ConvArgs q;
+        q.g = p; q.taps = taps; q.chunks = (int)(g.lda / 32);
+        q.a_rows = (long)xv_cdiv(g.M, g.a_rps) * g.a_pitch;
+        if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_conv_kernel<true>, grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL(xv_gemm16_nt_conv_kernel<false>, grid, dim3(256), 0, s, q);
+        XV_LAUNCH_CHECK();
+        return 0;
+    }
+    if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_kernel<true>, grid, dim3(64 * XV16_WAVES), 0, s, p);
+    else hipLaunchKernelGGL(xv_gemm16_nt_kernel<false>, grid, dim3(64 * XV16_WAVES), 0, s, p);
     XV_LAUNCH_CHECK();
     return 0;
 }
