@@ -30,6 +30,7 @@ import torch
 # algorithmic work of shape S1 (per 128-chunk step)
 B, T, D, NSPK = 128, 200, 30, 7351
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32-input MFMA peak
+PEAK_HBM_GBS = 8000.0            # same guide: HBM3E peak (6.29 TB/s measured by a float4 copy)
 PEAK_F16_MFMA_TFLOPS = 16 * 157.3   # same guide: fp32-input MFMA = 1/16 of the BF16/F16 rate (~2.5 PF dense)
 NKINDS = 6
 KIND_NAMES = ["xv_gemm_nt_kernel<true> (forward conv/dense + BN stats)",
@@ -68,6 +69,17 @@ def step_flops(b, t, d, n):
     fwd = 2.0 * b * (t1 * 5 * d * 512 + t2 * 2560 * 512 + t3 * 3584 * 512 + t3 * 512 * 512 + t3 * 512 * 1500)
     fwd += 2.0 * b * (3000 * 512 + 512 * 512 + 512 * n)
     return fwd, 3.0 * fwd
+
+
+def step_bytes(b, t, d, n):
+    """Compulsory HBM traffic of one step under perfect fusion: every frame-level activation
+    written once + read once forward, read once more backward, its gradient written + read (5 S); input read twice;
+    parameters read fwd + bwd, gradient written + read, parameter written (5 P).  fp32 bytes."""
+    t1, t2, t3 = t - 4, t - 8, t - 14
+    S = 4.0 * b * (t1 * 512 + t2 * 512 + t3 * 512 + t3 * 512 + t3 * 1500)
+    P = 4.0 * (5 * d * 512 + 5 * 512 * 512 + 7 * 512 * 512 + 512 * 512 + 512 * 1500 + 3000 * 512 + 512 * 512 + 512 * n
+               + 6 * 512 * 5 + 1500 * 5)
+    return 5.0 * S + 2.0 * 4.0 * b * t * d + 5.0 * P
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -235,7 +247,13 @@ def main():
                          "isolated_frac": round(ifl[dom] / (ims[dom] * 1e-3) / 1e12 / peak, 4)},
             "step_flops": {"algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
                            "whole_step_tflops": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
-                           "whole_step_frac_of_f32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+                           "whole_step_frac_of_f32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                           "whole_step_frac_of_f16x3_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)},
+            "step_bytes": {"algorithmic_mb_per_step": round(step_bytes(B, T, D, NSPK) / 1e6, 1),
+                           "whole_step_gbs": round(step_bytes(B, T, D, NSPK) / (ms_per_step * 1e-3) / 1e9, 1),
+                           "whole_step_frac_of_hbm_peak": round(step_bytes(B, T, D, NSPK) / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                           "note": "compulsory bytes under perfect fusion (5 S + 2 X + 5 P); the step is MFMA-bound, this fraction "
+                                   "cannot exceed ~0.25 even at the f16x3 MFMA roof"},
             "kernels": kernels,
             "loss": round(raw, 5),
         }

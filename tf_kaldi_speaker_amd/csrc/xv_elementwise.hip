@@ -355,10 +355,10 @@ extern "C" int xv_bn_inference_scale(void* stream, int n, const float* gamma, co
 // a = relu?(z*scale+shift), 16 B per lane along channels
 __global__ void bn_apply_kernel(const float* __restrict__ z, long rows, int nq, long ldz, const float* __restrict__ scale,
                                 const float* __restrict__ shift, int relu, float* __restrict__ a, long lda) {
-    long total = rows * nq;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / nq;
-        int q = (int)(i - r * nq);
+    const unsigned total = (unsigned)(rows * nq);      // < 2^31 (checked by the wrapper)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const long r = i / (unsigned)nq;
+        int q = (int)(i - (unsigned)r * nq);
         f32x4 v = *(const f32x4*)(z + r * ldz + 4 * q);
         f32x4 sc = *(const f32x4*)(scale + 4 * q);
         f32x4 sh = *(const f32x4*)(shift + 4 * q);
@@ -374,6 +374,7 @@ extern "C" int xv_bn_apply(void* stream, const float* z, int rows, int n, int ld
                            int relu, float* a, int lda) {
     XV_REQUIRE(rows > 0 && n > 0 && n % 4 == 0 && ldz % 4 == 0 && lda % 4 == 0, "bn_apply: n/ld must be multiples of 4 (n=%d)", n);
     long total = (long)rows * (n / 4);
+    XV_REQUIRE(total < (1L << 31), "bn_apply: tensor too large for 32-bit indexing");
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, z, (long)rows, n / 4,
                        (long)ldz, scale, shift, relu, a, (long)lda);
     XV_LAUNCH_CHECK();
@@ -510,11 +511,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, PoolGrad pg, c
                                     const float* __restrict__ shift, const float* __restrict__ coef, int relu, int pad,
                                     float* __restrict__ dz) {
     const int tp = t + 2 * pad, n = nq * 4;
-    long total = (long)segs * tp * nq;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long dr = i / nq;
+    const unsigned total = (unsigned)segs * tp * nq;      // < 2^31 (checked by the wrapper): 32-bit index arithmetic
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned dr = i / nq;
         int col = (int)(i - dr * nq) * 4;
-        int seg = (int)(dr / tp), u = (int)(dr - (long)seg * tp) - pad;
+        int seg = (int)(dr / tp), u = (int)(dr - (unsigned)seg * tp) - pad;
         f32x4 out = {0, 0, 0, 0};
         if (u >= 0 && u < t) {
             long r = (long)seg * t + u;
@@ -525,7 +526,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, PoolGrad pg, c
             f32x4 c1 = *(const f32x4*)(coef + col), c2 = *(const f32x4*)(coef + n + col);
             out = (*(const f32x4*)(gamma + col) * is) * (dd - c1 - xh * c2);
         }
-        *(f32x4*)(dz + dr * n + col) = out;
+        *(f32x4*)(dz + (long)dr * n + col) = out;
     }
 }
 
@@ -540,11 +541,11 @@ __global__ void bn_bwd_apply_split_kernel(const float* __restrict__ da, PoolGrad
                                           long plane_stride) {
     const float s = xv_pow2_scale(*amax);
     const int tp = t + 2 * pad;
-    const long cq = ldd / 8, total = (long)segs * tp * cq;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long dr = i / cq;
+    const unsigned cq = (unsigned)(ldd / 8), total = (unsigned)segs * tp * cq;      // < 2^31 (checked by the wrapper)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned dr = i / cq;
         int col = (int)(i - dr * cq) * 8;
-        int seg = (int)(dr / tp), u = (int)(dr - (long)seg * tp) - pad;
+        int seg = (int)(dr / tp), u = (int)(dr - (unsigned)seg * tp) - pad;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (u >= 0 && u < t) {
             const long r = (long)seg * t + u;
@@ -570,8 +571,8 @@ __global__ void bn_bwd_apply_split_kernel(const float* __restrict__ da, PoolGrad
             h[j] = __builtin_bit_cast(unsigned short, hh);
             l[j] = __builtin_bit_cast(unsigned short, ll);
         }
-        *(uint4*)(dst + dr * ldd + col) = *(const uint4*)h;
-        *(uint4*)(dst + plane_stride + dr * ldd + col) = *(const uint4*)l;
+        *(uint4*)(dst + (long)dr * ldd + col) = *(const uint4*)h;
+        *(uint4*)(dst + plane_stride + (long)dr * ldd + col) = *(const uint4*)l;
     }
 }
 
@@ -579,6 +580,7 @@ static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, co
                                  const float* mean, const float* invstd, const float* scale, const float* shift, int relu, int pad,
                                  float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
     XV_REQUIRE(segs > 0 && t > 0 && n > 0 && n % 4 == 0 && pad >= 0, "bn_relu_backward: bad shape (n=%d must be a multiple of 4)", n);
+    XV_REQUIRE((long)segs * (t + 2 * pad) * (n / 4) < (1L << 31), "bn_relu_backward: tensor too large for 32-bit indexing");
     const int rows = segs * t;
     const int chunks = xv_cdiv(rows, BB_ROWS);
     size_t need = ((size_t)chunks * 3 * n + 2 * n) * sizeof(float);
@@ -607,6 +609,7 @@ static int bn_relu_backward_split_impl(hipStream_t s, const float* da, PoolGrad 
                                        size_t ws_bytes) {
     XV_REQUIRE(segs > 0 && t > 0 && n > 0 && n % 4 == 0 && pad >= 0, "bn_relu_backward_split: bad shape (n=%d must be a multiple of 4)", n);
     XV_REQUIRE(ldp % 8 == 0 && ldp >= n && plane_stride % 8 == 0 && zmin && zmax && dz_amax, "bn_relu_backward_split: bad plane arguments");
+    XV_REQUIRE((long)segs * (t + 2 * pad) * (ldp / 8) < (1L << 31), "bn_relu_backward_split: tensor too large for 32-bit indexing");
     const int rows = segs * t;
     const int chunks = xv_cdiv(rows, BB_ROWS);
     size_t need = ((size_t)chunks * 3 * n + 2 * n) * sizeof(float);

@@ -100,10 +100,10 @@ template <bool VEC>
 __global__ void split_planes_kernel(const float* __restrict__ src, long rows, int c, long lds, u16* __restrict__ dst, long ldd,
                                     long plane_stride, const unsigned* __restrict__ amax) {
     const float s = xv_pow2_scale(*amax);
-    const long cq = ldd / 8, total = rows * cq;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / cq;
-        int col = (int)(i - r * cq) * 8;
+    const unsigned cq = (unsigned)(ldd / 8), total = (unsigned)rows * cq;      // < 2^31 (checked by the wrapper)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const long r = i / cq;
+        int col = (int)(i - (unsigned)r * cq) * 8;
         float v[8];
         if (VEC) {
             float4 a = col < c ? *(const float4*)(src + r * lds + col) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -122,6 +122,7 @@ extern "C" int xv_split_planes(void* stream, const float* src, int rows, int c, 
     XV_REQUIRE(src && planes && amax && rows > 0 && c > 0 && lds >= c, "split_planes: bad arguments");
     XV_REQUIRE(ldp % 8 == 0 && ldp >= c && ((uintptr_t)planes % 16) == 0 && plane_stride % 8 == 0, "split_planes: ldp must be a multiple of 8 and >= c");
     long total = (long)rows * (ldp / 8);
+    XV_REQUIRE(total < (1L << 31), "split_planes: tensor too large for 32-bit indexing");
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     const bool vec = c % 4 == 0 && lds % 4 == 0 && ((uintptr_t)src % 16) == 0;
@@ -137,10 +138,10 @@ __global__ void bn_apply_split_kernel(const float* __restrict__ z, long rows, in
                                       const float* __restrict__ shift, int relu, const unsigned* __restrict__ amax,
                                       u16* __restrict__ dst, long ldd, long plane_stride) {
     const float s = xv_pow2_scale(*amax);
-    const long cq = ldd / 8, total = rows * cq;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / cq;
-        int col = (int)(i - r * cq) * 8;
+    const unsigned cq = (unsigned)(ldd / 8), total = (unsigned)rows * cq;      // < 2^31 (checked by the wrapper)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const long r = i / cq;
+        int col = (int)(i - (unsigned)r * cq) * 8;
         float v[8];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -162,6 +163,7 @@ extern "C" int xv_bn_apply_split(void* stream, const float* z, int rows, int n, 
     XV_REQUIRE(rows > 0 && n > 0 && ldz >= n && ldp % 8 == 0 && ldp >= n && plane_stride % 8 == 0, "bn_apply_split: bad shape");
     XV_REQUIRE(n % 4 == 0 && ldz % 4 == 0 && ((uintptr_t)z % 16) == 0, "bn_apply_split: n and ldz must be multiples of 4 (n=%d ldz=%d)", n, ldz);
     long total = (long)rows * (ldp / 8);
+    XV_REQUIRE(total < (1L << 31), "bn_apply_split: tensor too large for 32-bit indexing");
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(bn_apply_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, (long)rows, n, (long)ldz, scale, shift,

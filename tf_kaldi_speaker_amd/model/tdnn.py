@@ -60,7 +60,8 @@ def engine_config(params, dim, num_speakers=0, loss_type="softmax", max_batch=12
               batchnorm_momentum=float(d["batchnorm_momentum"]), optimizer=d.get("optimizer", "sgd"),
               momentum=float(d.get("momentum", 0.0) or 0.0), use_nesterov=bool(d.get("use_nesterov", False)),
               clip_gradient_norm=float(d["clip_gradient_norm"]) if d.get("clip_gradient", False) else 0.0,
-              max_batch=max_batch, max_frames=max_frames)
+              max_batch=max_batch, max_frames=max_frames,
+              precision=d.get("precision", None))      # engine extension: "f16x3" (default) | "f32"; absent from reference configs
     if d.get("feature_norm", False):
         assert "feature_scaling_factor" in d, "If feature normalization is applied, scaling factor is necessary."
     prefix = {"asoftmax": "asoftmax", "additive_margin_softmax": "amsoftmax", "additive_angular_margin_softmax": "arcsoftmax"}.get(loss_type)
