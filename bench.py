@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames", default=str(T), help="frames per chunk: N (default %d = shape S1) or LO:HI = a length drawn per step "
+                    "from a seeded stream, as the reference's loader does (SURVEY 8d shape S3)" % T)
+    ap.add_argument("--chunks", type=int, default=B, help="chunks per GPU per step (default %d)" % B)
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=None,
                     help="frame-level GEMM arithmetic (default: the engine's default, env XV_PRECISION)")
     args = ap.parse_args()
@@ -137,25 +140,34 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    chunks = args.chunks
+    if ":" in args.frames:
+        t_lo, t_hi = [int(v) for v in args.frames.split(":")]
+    else:
+        t_lo = t_hi = int(args.frames)
     from tf_kaldi_speaker_amd import _lib, engine as E
     from tf_kaldi_speaker_amd.parallel import GradAllReduce
     lib = _lib.load()
 
     cfg = E.make_config(D, NSPK, loss_func="additive_margin_softmax", margin_m=0.2, lambda_min=0.0, lambda_base=1000.0,
                         lambda_gamma=1e-4, lambda_power=5.0, last_layer_linear=True, weight_l2_regularizer=1e-2,
-                        batchnorm_momentum=0.99, optimizer="sgd", max_batch=B, max_frames=T, precision=args.precision)
+                        batchnorm_momentum=0.99, optimizer="sgd", max_batch=chunks, max_frames=t_hi, precision=args.precision)
     precision = {v: k for k, v in _lib.PRECISIONS.items()}[int(cfg.precision)]
     eng = E.Engine(cfg, device=str(dev))
     eng.init_variables(seed=0)       # identical replicas on every rank
     rs = np.random.RandomState(1000 + rank)
-    nb = 4                           # rotate a few resident batches
-    xs = [torch.from_numpy(rs.randn(B, T, D).astype(np.float32)).to(dev) for _ in range(nb)]
-    ys = [torch.from_numpy(rs.randint(0, NSPK, B).astype(np.int32)).to(dev) for _ in range(nb)]
+    nb = 4 if t_lo == t_hi else 16   # rotate a few resident batches (variable length: 16 seeded draws of T)
+    ts = [int(rs.randint(t_lo, t_hi + 1)) for _ in range(nb)]
+    xs = [torch.from_numpy(rs.randn(chunks, ts[i], D).astype(np.float32)).to(dev) for i in range(nb)]
+    ys = [torch.from_numpy(rs.randint(0, NSPK, chunks).astype(np.int32)).to(dev) for _ in range(nb)]
     allreduce = GradAllReduce(dist, world) if world > 1 else None
     lr = 0.01
 
     def one_step(i):
         eng.train_step(xs[i % nb], ys[i % nb], lr, i, allreduce=allreduce)
+
+    if world > 1 and t_lo != t_hi:
+        sys.exit("bench.py: variable-length batches are a single-GPU diagnostic (ranks would draw different T)")
 
     for i in range(args.warmup):
         one_step(i)
@@ -203,8 +215,11 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
-        fwd_flops, total_flops = step_flops(B, T, D, NSPK)
+        value = world * chunks * args.steps / elapsed
+        t_mean = float(np.mean([ts[(args.warmup + i) % nb] for i in range(args.steps)]))
+        fl_steps = [step_flops(chunks, ts[(args.warmup + i) % nb], D, NSPK) for i in range(args.steps)]
+        fwd_flops, total_flops = float(np.mean([f[0] for f in fl_steps])), float(np.mean([f[1] for f in fl_steps]))
+        by_steps = float(np.mean([step_bytes(chunks, ts[(args.warmup + i) % nb], D, NSPK) for i in range(args.steps)]))
         dom = int(np.argmax([ms[k] for k in range(NKINDS)]))
         peak = KIND_PEAK[dom]
         kernels = []
@@ -215,7 +230,7 @@ def main():
                                 "isolated_tflops": ifl[k] / (ims[k] * 1e-3) / 1e12 if icnt[k] else None})
         achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12
         out = {
-            "metric": "utterance-chunks/sec (200-frame x 30-dim)",
+            "metric": "utterance-chunks/sec (%s-frame x 30-dim)" % (args.frames.replace(":", "-")),
             "value": round(value, 1),
             "unit": "chunks/s",
             "n_gpus": world,
@@ -228,9 +243,10 @@ def main():
             "dtype": "f32" if precision == "f32" else "f32 (frame-level GEMMs as 3 fp16-plane MFMA products, fp32 accumulate; fp32-level results)",
             "data": "synthetic",
             "config": {"workload": "TDNN x-vector (tdnn.py 5 frame + 2 segment layers, stat pooling) + AM-Softmax m=0.2, "
-                                   "full optimiser step (fwd+bwd+L2+SGD%s), %d chunks/GPU x %d frames x %d-dim, %d speakers"
-                                   % ("+RCCL all-reduce" if world > 1 else "", B, T, D, NSPK),
-                       "chunks_per_gpu": B, "frames": T, "feat_dim": D, "num_speakers": NSPK,
+                                   "full optimiser step (fwd+bwd+L2+SGD%s), %d chunks/GPU x %s frames x %d-dim, %d speakers"
+                                   % ("+RCCL all-reduce" if world > 1 else "", chunks, args.frames, D, NSPK),
+                       "chunks_per_gpu": chunks, "frames": t_lo if t_lo == t_hi else [t_lo, t_hi], "mean_frames": t_mean,
+                       "feat_dim": D, "num_speakers": NSPK,
                        "precision": precision, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": round(achieved, 2), "peak": round(peak, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom),
@@ -249,9 +265,9 @@ def main():
                            "whole_step_tflops": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
                            "whole_step_frac_of_f32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                            "whole_step_frac_of_f16x3_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)},
-            "step_bytes": {"algorithmic_mb_per_step": round(step_bytes(B, T, D, NSPK) / 1e6, 1),
-                           "whole_step_gbs": round(step_bytes(B, T, D, NSPK) / (ms_per_step * 1e-3) / 1e9, 1),
-                           "whole_step_frac_of_hbm_peak": round(step_bytes(B, T, D, NSPK) / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "step_bytes": {"algorithmic_mb_per_step": round(by_steps / 1e6, 1),
+                           "whole_step_gbs": round(by_steps / (ms_per_step * 1e-3) / 1e9, 1),
+                           "whole_step_frac_of_hbm_peak": round(by_steps / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                            "note": "compulsory bytes under perfect fusion (5 S + 2 X + 5 P); the step is MFMA-bound, this fraction "
                                    "cannot exceed ~0.25 even at the f16x3 MFMA roof"},
             "kernels": kernels,
