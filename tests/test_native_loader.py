@@ -1,0 +1,166 @@
+"""libxvector_io.so (the native Kaldi loader) on the CPU: ABI vs include/xvector_io.h, the 'CM ' sub-range codec bit-exact
+against the Python reader (which tests/test_host_io.py pins against the reference's kaldi_io through tests/golden), the
+reference's sampling rules, determinism in (seed, batch index) for any thread count, error behaviour."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.kaldi_fixture import make_data_dir
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "xvector_io.h")
+
+
+@pytest.fixture(scope="module")
+def nl():
+    from tf_kaldi_speaker_amd.dataset import native_loader
+    native_loader.load()
+    return native_loader
+
+
+@pytest.fixture(scope="module")
+def data(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("kaldi_native"))
+    return make_data_dir(root, num_spk=8, utts_per_spk=4, dim=30, min_frames=70, max_frames=160, seed=3)
+
+
+def test_abi_matches_header(nl):
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(xvio_[a-z0-9_]+)\s*\(", src)))
+    assert names == sorted(nl.SIGNATURES)
+    lib = ctypes.CDLL(nl.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libxvector_io.so does not export %s" % n
+    assert nl.load().xvio_abi_version() == 1
+    body = src[src.index("typedef struct xvio_config {") + len("typedef struct xvio_config {"):src.index("} xvio_config;")]
+    fields = []
+    for line in body.split(";"):
+        m = re.match(r"\s*(const char\*|int32_t|uint64_t)\s+(.+)", line.strip(), flags=re.S)
+        if m:
+            fields += [(m.group(1), nm.strip()) for nm in m.group(2).split(",")]
+    kinds = {ctypes.c_char_p: "const char*", ctypes.c_int32: "int32_t", ctypes.c_uint64: "uint64_t"}
+    assert fields == [(kinds[t], n) for n, t in nl.XvioConfig._fields_]
+
+
+def _scp(root):
+    out = {}
+    for line in open(os.path.join(root, "feats.scp")):
+        utt, rx = line.strip().split(" ", 1)
+        path, off = rx.rsplit(":", 1)
+        out[utt] = (path, int(off))
+    return out
+
+
+def test_cm_rows_bit_exact_with_python_reader(nl, data):
+    from tf_kaldi_speaker_amd.dataset.kaldi_io import FeatureReader
+    root, spklist, mats = data
+    reader = FeatureReader(root)
+    scp = _scp(root)
+    rs = np.random.RandomState(0)
+    for utt, (path, off) in list(scp.items())[:12]:
+        n = mats[utt].shape[0]
+        whole = nl.read_rows(path, off)
+        ref, _ = reader.read("%s %s:%d" % (utt, path, off))
+        assert whole.shape == (n, 30) and np.array_equal(whole, ref)
+        for _ in range(3):
+            length = int(rs.randint(1, n + 1))
+            start = int(rs.randint(0, n - length + 1))
+            seg = nl.read_rows(path, off, start, length)
+            ref, _ = reader.read_segment("%s %s:%d" % (utt, path, off), length, start=start)
+            assert np.array_equal(seg, ref), (utt, start, length)
+        assert np.abs(whole - mats[utt]).max() < 0.05          # the codec is lossy: sanity only
+    reader.close()
+
+
+def test_fm_and_dm_matrices(nl, tmp_path):
+    from tf_kaldi_speaker_amd.dataset import kaldi_io
+    rs = np.random.RandomState(1)
+    for dt in (np.float32, np.float64):
+        m = rs.randn(37, 24).astype(dt)
+        path = str(tmp_path / ("m_%s.ark" % np.dtype(dt).name))
+        with open(path, "wb") as f:
+            f.write(b"key ")
+            off = f.tell()
+            kaldi_io.write_mat(f, m)
+        assert np.array_equal(nl.read_rows(path, off), m.astype(np.float32))
+        assert np.array_equal(nl.read_rows(path, off, 5, 11), m[5:16].astype(np.float32))
+
+
+def test_errors_are_reported(nl, data, tmp_path):
+    root, spklist, _ = data
+    path, off = next(iter(_scp(root).values()))
+    with pytest.raises(nl.XvioError, match="not enough"):
+        nl.read_rows(path, off, 0, 100000)
+    with pytest.raises(nl.XvioError, match="cannot open"):
+        nl.read_rows(str(tmp_path / "missing.ark"), 0)
+    with pytest.raises(nl.XvioError, match="not a binary Kaldi object"):
+        nl.read_rows(path, off + 1)
+    q = nl.NativeRandomQueue(str(tmp_path), spklist, num_speakers=2, num_segments=2, min_len=10, max_len=20)
+    with pytest.raises(nl.XvioError, match="cannot open"):
+        q.start()
+    q = nl.NativeRandomQueue(root, spklist, num_speakers=4, num_segments=2, min_len=1000, max_len=1200, seed=1)
+    q.start()
+    with pytest.raises(nl.XvioError, match="longer than"):      # no utterance is that long: reported, not hung
+        q.fetch()
+    q.stop()
+
+
+def _collect(nl, root, spklist, threads, n, seed=11, **kw):
+    args = dict(num_speakers=5, num_segments=3, min_len=40, max_len=65, shuffle=True)
+    args.update(kw)
+    q = nl.NativeRandomQueue(root, spklist, num_parallel=threads, max_qsize=4, seed=seed, **args)
+    q.start()
+    out = [q.fetch() for _ in range(n)]
+    stats = q.stats()
+    q.stop()
+    return out, stats
+
+
+def test_batches_follow_the_reference_sampling_rules(nl, data):
+    root, spklist, mats = data
+    spk_of = {int(l.split()[1]): l.split()[0] for l in open(spklist)}
+    decoded = {utt: nl.read_rows(*_scp(root)[utt]) for utt in mats}
+    batches, (nb, sec) = _collect(nl, root, spklist, threads=3, n=12)
+    assert nb >= 12 and sec > 0
+    lengths = set()
+    for feats, labels in batches:
+        b, t, d = feats.shape
+        assert b == 15 and d == 30 and 40 <= t <= 65 and labels.shape == (15,) and labels.dtype == np.int32
+        lengths.add(t)
+        per_spk = labels.reshape(5, 3)
+        assert np.all(per_spk == per_spk[:, :1])                       # num_segments consecutive chunks per speaker
+        assert len(set(per_spk[:, 0])) == 5                            # distinct speakers within a batch
+        for i in range(b):
+            spk = spk_of[int(labels[i])]
+            hit = False
+            for utt, m in decoded.items():                             # the chunk is T consecutive rows of one utterance of that speaker
+                if not utt.startswith(spk) or m.shape[0] <= t:
+                    continue
+                for s in np.nonzero(np.all(m[:m.shape[0] - t + 1] == feats[i, 0], axis=1))[0]:
+                    if np.array_equal(m[s:s + t], feats[i]):
+                        hit = True
+            assert hit, "row %d of the batch is not a window of an utterance of %s" % (i, spk)
+    assert len(lengths) > 3                                            # one T per batch, varying between batches
+
+
+def test_stream_is_a_function_of_seed_and_index_only(nl, data):
+    root, spklist, _ = data
+    a, _ = _collect(nl, root, spklist, threads=1, n=10)
+    b, _ = _collect(nl, root, spklist, threads=4, n=10)
+    for (fa, la), (fb, lb) in zip(a, b):
+        assert np.array_equal(fa, fb) and np.array_equal(la, lb)
+    c, _ = _collect(nl, root, spklist, threads=2, n=3, seed=12)
+    assert not all(np.array_equal(x[1], y[1]) and x[0].shape == y[0].shape for x, y in zip(a, c))
+
+
+def test_no_shuffle_starts_at_frame_zero_and_few_speakers_are_duplicated(nl, data):
+    root, spklist, mats = data
+    decoded = {utt: nl.read_rows(*_scp(root)[utt]) for utt in mats}
+    batches, _ = _collect(nl, root, spklist, threads=2, n=3, shuffle=False, num_speakers=12, num_segments=2, min_len=30, max_len=30)
+    for feats, labels in batches:
+        assert feats.shape == (24, 30, 30)
+        for i in range(24):
+            assert any(np.array_equal(m[:30], feats[i]) for m in decoded.values())

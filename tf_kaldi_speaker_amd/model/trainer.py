@@ -27,6 +27,7 @@ try:
     from .. import engine as E
     from ..parallel import GradAllReduce, average_bn_statistics, broadcast_variables
     from ..dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, DataOutOfRange
+    from ..dataset.native_loader import NativeRandomQueue
     from ..misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state
     from .tdnn import tdnn, engine_config, collect_endpoints, check_params
     from . import loss as _loss
@@ -34,6 +35,7 @@ except (ImportError, ValueError):      # drop-in layout: PYTHONPATH=$TF_KALDI_RO
     import engine as E
     from parallel import GradAllReduce, average_bn_statistics, broadcast_variables
     from dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, DataOutOfRange
+    from dataset.native_loader import NativeRandomQueue
     from misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state
     from model.tdnn import tdnn, engine_config, collect_endpoints, check_params
     from model import loss as _loss
@@ -250,12 +252,19 @@ class Trainer(object):
         if dist is not None:
             broadcast_variables(dist, self.engine.variables, 0)
             self.engine.lib.xv_engine_invalidate_weights(self.engine.h)
-        loader = KaldiDataRandomQueue(data, spklist, num_parallel=p.num_parallel_datasets, max_qsize=p.max_queue_size,
-                                      num_speakers=p.num_speakers_per_batch, num_segments=p.num_segments_per_speaker,
-                                      min_len=p.min_segment_len, max_len=p.max_segment_len, shuffle=True)
+        # C++ decoder threads by default (libxvector_io.so); XV_LOADER=python selects the multiprocessing mirror of the
+        # reference's queue (dataset/data_loader.py) - same sampling rules, same batch contract
+        queue_cls = KaldiDataRandomQueue if os.environ.get("XV_LOADER", "native") == "python" else NativeRandomQueue
+        loader = queue_cls(data, spklist, num_parallel=p.num_parallel_datasets, max_qsize=p.max_queue_size,
+                           num_speakers=p.num_speakers_per_batch, num_segments=p.num_segments_per_speaker,
+                           min_len=p.min_segment_len, max_len=p.max_segment_len, shuffle=True)
         loader.start()
         try:
-            curr_step = self.train_batches(iter(loader.fetch, None), learning_rate, curr_step)
+            if hasattr(loader, "device_batches"):        # pinned staging + asynchronous H2D on a copy stream
+                batches = loader.device_batches(self.device)
+            else:
+                batches = iter(loader.fetch, None)
+            curr_step = self.train_batches(batches, learning_rate, curr_step)
         finally:
             loader.stop()
         self.save(curr_step)
