@@ -106,6 +106,26 @@ struct XvGemm16TN {
 int xv_tn16_splits(int M, int N, int R);
 int xv_launch_gemm16_tn(hipStream_t s, const XvGemm16TN& g);
 
+// All kernel-layout weight copies of one optimiser step in two launches (xv_elementwise.hip): the per-layer
+// prep / amax / split launches (~25 of 5 us each) were 5 % of a step.
+enum { XV_PREP_T32 = 0,     // wt[o][j*c_pad + c] = w[(j*C + c)*O + o]                (fp32, forward layout)
+       XV_PREP_F32 = 1,     // wf[c][(k-1-j)*o_ld + o] = w[(j*C + c)*O + o]           (fp32, tap-flipped data-gradient layout)
+       XV_PREP_T16 = 2,     // as T32, written as two fp16 planes scaled by pow2(*amax)
+       XV_PREP_F16 = 3 };   // as F32, planes
+struct XvPrepJob {
+    int type, k, C, O, c_pad, o_ld;
+    int tiles_x, tile0;              // 32x32 tiles per row of tiles, first global tile index
+    const float* w;
+    void* dst;
+    long plane;                      // plane stride in elements (16-bit types)
+    const unsigned* amax;
+};
+struct XvPrepJobs { int n, total_tiles; XvPrepJob j[16]; };
+struct XvAmaxJobs { int n; const float* x[8]; size_t count[8]; unsigned* out[8]; };
+int xv_prep_add(XvPrepJobs& J, int type, const float* w, int k, int C, int O, int c_pad, int o_ld, void* dst, long plane, const unsigned* amax);
+int xv_launch_weight_prep(hipStream_t s, const XvPrepJobs& J);
+int xv_launch_amax_multi(hipStream_t s, const XvAmaxJobs& J);
+
 // Live launch timing (xv_profile_begin/end): brackets one GEMM launch with hipEvents on its stream.
 struct XvProfScope {
     hipStream_t s; int idx;

@@ -110,6 +110,117 @@ extern "C" int xv_prep_weight_dgrad(void* stream, const float* kernel, int k, in
 }
 
 // ------------------------------------------------------------------------------------
+// multi-job weight preparation (xv_common.h): one launch for every layout copy of every layer
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void weight_prep_multi_kernel(XvPrepJobs J) {
+    __shared__ float tile[32][33];
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < J.n; ++i) if ((int)blockIdx.x >= J.j[i].tile0) ji = i;
+    const XvPrepJob& q = J.j[ji];
+    const int lt = blockIdx.x - q.tile0;
+    const int txt = lt % q.tiles_x, tyt = lt / q.tiles_x;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const bool planes = q.type >= XV_PREP_T16;
+    const float sc = planes ? xv_pow2_scale(*q.amax) : 1.0f;
+    if (q.type == XV_PREP_T32 || q.type == XV_PREP_T16) {
+        // transpose through LDS: reads run along o (contiguous in w), writes along the padded k axis
+        const int kp = q.k * q.c_pad;
+        const int kk0 = txt * 32, o0 = tyt * 32;
+        for (int r = ty; r < 32; r += 8) {
+            int kk = kk0 + r, o = o0 + tx;
+            float v = 0.f;
+            if (kk < kp && o < q.O) {
+                int j = kk / q.c_pad, c = kk - j * q.c_pad;
+                if (c < q.C) v = q.w[((long)j * q.C + c) * q.O + o];
+            }
+            tile[r][tx] = v;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            int o = o0 + r, kk = kk0 + tx;
+            if (o < q.O && kk < kp) {
+                float v = tile[tx][r];
+                if (!planes) ((float*)q.dst)[(long)o * kp + kk] = v;
+                else {
+                    float xs = v * sc;
+                    _Float16 h = (_Float16)xs, l = (_Float16)(xs - (float)h);
+                    unsigned short* d = (unsigned short*)q.dst;
+                    d[(long)o * kp + kk] = __builtin_bit_cast(unsigned short, h);
+                    d[q.plane + (long)o * kp + kk] = __builtin_bit_cast(unsigned short, l);
+                }
+            }
+        }
+    } else {
+        // tap flip, no transpose: rows jc = j*C + c of w, columns o (pad columns o in [O, o_ld) are zero)
+        const int jc0 = tyt * 32, o0 = txt * 32;
+        const long ldd = (long)q.k * q.o_ld;
+        for (int r = ty; r < 32; r += 8) {
+            int jc = jc0 + r, o = o0 + tx;
+            if (jc < q.k * q.C && o < q.o_ld) {
+                int j = jc / q.C, c = jc - j * q.C;
+                float v = o < q.O ? q.w[(long)jc * q.O + o] : 0.f;
+                long di = (long)c * ldd + (long)(q.k - 1 - j) * q.o_ld + o;
+                if (!planes) ((float*)q.dst)[di] = v;
+                else {
+                    float xs = v * sc;
+                    _Float16 h = (_Float16)xs, l = (_Float16)(xs - (float)h);
+                    unsigned short* d = (unsigned short*)q.dst;
+                    d[di] = __builtin_bit_cast(unsigned short, h);
+                    d[q.plane + di] = __builtin_bit_cast(unsigned short, l);
+                }
+            }
+        }
+    }
+}
+
+int xv_prep_add(XvPrepJobs& J, int type, const float* w, int k, int C, int O, int c_pad, int o_ld, void* dst, long plane,
+                const unsigned* amax) {
+    XV_REQUIRE(J.n < 16, "weight_prep: too many jobs");
+    XvPrepJob& q = J.j[J.n++];
+    q.type = type; q.k = k; q.C = C; q.O = O; q.c_pad = c_pad; q.o_ld = o_ld; q.w = w; q.dst = dst; q.plane = plane; q.amax = amax;
+    int tiles_y;
+    if (type == XV_PREP_T32 || type == XV_PREP_T16) { q.tiles_x = xv_cdiv((long)k * c_pad, 32); tiles_y = xv_cdiv(O, 32); }
+    else { q.tiles_x = xv_cdiv(o_ld, 32); tiles_y = xv_cdiv((long)k * C, 32); }
+    q.tile0 = J.total_tiles;
+    J.total_tiles += q.tiles_x * tiles_y;
+    return 0;
+}
+
+int xv_launch_weight_prep(hipStream_t s, const XvPrepJobs& J) {
+    if (J.n == 0) return 0;
+    hipLaunchKernelGGL(weight_prep_multi_kernel, dim3(J.total_tiles), dim3(256), 0, s, J);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// max |x| of up to 8 tensors in one launch: blockIdx.y = tensor, one atomicMax per workgroup (slots zeroed by the caller)
+__global__ __launch_bounds__(256) void amax_multi_kernel(XvAmaxJobs J) {
+    __shared__ float red[4];
+    const float* x = J.x[blockIdx.y];
+    const size_t count = J.count[blockIdx.y];
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        unsigned bits = __float_as_uint(m);
+        unsigned* out = J.out[blockIdx.y];
+        if (bits > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, bits);
+    }
+}
+
+int xv_launch_amax_multi(hipStream_t s, const XvAmaxJobs& J) {
+    if (J.n == 0) return 0;
+    hipLaunchKernelGGL(amax_multi_kernel, dim3(256, J.n), dim3(256), 0, s, J);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
 // column sums / column statistics (row-chunk partials, then a fixed-order combine)
 // ------------------------------------------------------------------------------------
 #define CS_ROWS 128

@@ -14,6 +14,7 @@
 //                GEMM as the forward pass (xv_gemm.hip).
 //   weights    : kernel-layout copies (transposed / tap-flipped / channel-padded) rebuilt once
 //                per optimiser step.
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -70,8 +71,6 @@ struct xv_engine {
     hipStream_t side = nullptr;
     hipEvent_t ev_dz = nullptr, ev_w[2] = {nullptr, nullptr};
     bool w_pending[2] = {false, false};
-    hipEvent_t ev_wt[8] = {};                 // prepared weights of layer i (7 = loss head) are ready (side stream)
-    bool wt_pending[8] = {};
     bool concurrent = true;
     int zcur = 0;
     void* ws_side = nullptr;
@@ -325,74 +324,51 @@ int alloc_buffers(xv_engine* e) {
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_dz, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_w[0], hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_w[1], hipEventDisableTiming));
-    for (int i = 0; i < 8; ++i) XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_wt[i], hipEventDisableTiming));
     return 0;
 }
 
-// Kernel-layout (and, in split precision, fp16-plane) copies of the weights, rebuilt after every update.  These are
-// ~25 tiny launches: with the side stream available they are enqueued there, layer by layer, and the forward pass
-// waits per layer (wait_weights) - layer i's preparation hides behind layer i-1's GEMM instead of sitting in
-// front of the whole step.
+// Kernel-layout (and, in split precision, fp16-plane) copies of the weights, rebuilt after every update: one
+// memset + one multi-tensor amax + one multi-job layout kernel (+ the loss head's two) instead of ~28 launches.
 int ensure_weights(xv_engine* e, hipStream_t s) {
     if (!e->weights_dirty) return 0;
-    const bool async = e->concurrent && e->side;
-    hipStream_t ps = async ? e->side : s;
-    if (async) {      // the preparation reads the variables: after everything enqueued on `s` so far (optimiser step, copies)
-        XV_CHECK_HIP(hipEventRecord(e->ev_dz, s));
-        XV_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_dz, 0));
-    }
-    if (e->f16) XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_WT, 0, 16 * sizeof(uint32_t), ps));
+    XvPrepJobs J = {};
+    XvAmaxJobs A = {};
     for (int i = 0; i < 7; ++i) {
         Affine& a = e->L[i];
-        int rc = xv_prep_weight_fwd(ps, vptr(e, a.v_kernel), a.k, a.c_in, a.c_out, a.wt, a.c_pad);
-        if (rc) return rc;
-        if (a.k > 1 && i > 0) {
-            rc = xv_prep_weight_dgrad(ps, vptr(e, a.v_kernel), a.k, a.c_in, a.c_out, a.wf);
-            if (rc) return rc;
-        }
+        const float* w = vptr(e, a.v_kernel);
         if (e->f16 && i < 5) {
-            // fp16 planes of the kernel-layout weights, scaled by the tensor's own max |w|; the forward and dgrad
-            // layouts hold the same values: one max per layer, taken on the variable itself
-            const int kw = a.k * a.c_pad;
-            rc = xv_amax(ps, vptr(e, a.v_kernel), (size_t)a.k * a.c_in * a.c_out, e->amax + AMAX_WT + i);
-            if (rc) return rc;
-            rc = xv_split_planes(ps, a.wt, a.c_out, kw, kw, a.wth, kw, a.wth_stride, e->amax + AMAX_WT + i);
+            // fp16 planes scaled by the tensor's own max |w|; the forward and dgrad layouts hold the same values, so one
+            // max per layer, taken on the variable itself
+            const unsigned* am = e->amax + AMAX_WT + i;
+            A.x[A.n] = w; A.count[A.n] = (size_t)a.k * a.c_in * a.c_out; A.out[A.n] = e->amax + AMAX_WT + i; A.n++;
+            int rc = xv_prep_add(J, XV_PREP_T16, w, a.k, a.c_in, a.c_out, a.c_pad, a.o_ld, a.wth, (long)a.wth_stride, am);
             if (rc) return rc;
             if (i > 0) {
-                if (a.k > 1) {      // tap-flipped copy [c_in][k*c_out] (c_out is a multiple of 8 for the conv layers)
-                    rc = xv_split_planes(ps, a.wf, a.c_in, a.k * a.c_out, a.k * a.c_out, a.wfh, a.k * a.o_ld, a.wfh_stride,
-                                         e->amax + AMAX_WT + i);
-                } else {            // dense: the TF-layout kernel [c_in][c_out] is already the dgrad operand
-                    rc = xv_split_planes(ps, vptr(e, a.v_kernel), a.c_in, a.c_out, a.c_out, a.wfh, a.o_ld, a.wfh_stride,
-                                         e->amax + AMAX_WT + i);
-                }
+                rc = xv_prep_add(J, XV_PREP_F16, w, a.k, a.c_in, a.c_out, a.c_pad, a.o_ld, a.wfh, (long)a.wfh_stride, am);
+                if (rc) return rc;
+            }
+        } else {
+            int rc = xv_prep_add(J, XV_PREP_T32, w, a.k, a.c_in, a.c_out, a.c_pad, a.c_out, a.wt, 0, nullptr);
+            if (rc) return rc;
+            if (a.k > 1 && i > 0) {
+                rc = xv_prep_add(J, XV_PREP_F32, w, a.k, a.c_in, a.c_out, a.c_pad, a.c_out, a.wf, 0, nullptr);
                 if (rc) return rc;
             }
         }
-        if (async) {
-            XV_CHECK_HIP(hipEventRecord(e->ev_wt[i], e->side));
-            e->wt_pending[i] = true;
-        }
     }
-    if (e->N > 0) {
-        int rc = xv_loss_prep_weight(ps, vptr(e, e->v_loss_kernel), e->Lout, e->N, e->cfg.loss_kind != XV_LOSS_SOFTMAX, e->inv_norm,
-                                     e->wn, e->ldl, e->wnt);
+    if (A.n) {
+        XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_WT, 0, 16 * sizeof(uint32_t), s));
+        int rc = xv_launch_amax_multi(s, A);
         if (rc) return rc;
-        if (async) {
-            XV_CHECK_HIP(hipEventRecord(e->ev_wt[7], e->side));
-            e->wt_pending[7] = true;
-        }
+    }
+    int rc = xv_launch_weight_prep(s, J);
+    if (rc) return rc;
+    if (e->N > 0) {
+        rc = xv_loss_prep_weight(s, vptr(e, e->v_loss_kernel), e->Lout, e->N, e->cfg.loss_kind != XV_LOSS_SOFTMAX, e->inv_norm,
+                                 e->wn, e->ldl, e->wnt);
+        if (rc) return rc;
     }
     e->weights_dirty = false;
-    return 0;
-}
-
-// `s` may use layer i's prepared weights (7 = loss head) from here on
-int wait_weights(xv_engine* e, hipStream_t s, int i) {
-    if (e->wt_pending[i]) {
-        XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_wt[i], 0));
-        e->wt_pending[i] = false;
-    }
     return 0;
 }
 
@@ -447,7 +423,7 @@ extern "C" void xv_engine_destroy(xv_engine* e) {
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
     if (e->ev_dz) (void)hipEventDestroy(e->ev_dz);
     for (int i = 0; i < 2; ++i) if (e->ev_w[i]) (void)hipEventDestroy(e->ev_w[i]);
-    for (int i = 0; i < 8; ++i) if (e->ev_wt[i]) (void)hipEventDestroy(e->ev_wt[i]);
+
     if (e->arena) (void)hipFree(e->arena);
     delete e;
 }
@@ -516,8 +492,6 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             Affine& a = e->L[i];
             int t_out = cur_t - a.k + 1;
             int rows = b * t_out;
-            rc = wait_weights(e, s, i);
-            if (rc) return rc;
             // the epilogue's column min/max are needed in inference too (they fix the next operand's scale)
             rc = xv_affine_forward_f16x3(s, curh, cur_stride, cur_amax, b, cur_t, a.c_pad, a.k, a.wth, a.wth_stride,
                                          e->amax + AMAX_WT + i, vptr(e, a.v_bias), a.z, a.c_out, a.c_out, a.bn_part);
@@ -552,8 +526,6 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             Affine& a = e->L[i];
             int t_out = cur_t - a.k + 1;
             int rows = b * t_out;
-            rc = wait_weights(e, s, i);
-            if (rc) return rc;
             rc = xv_affine_forward(s, cur, b, cur_t, a.c_pad, a.k, a.wt, vptr(e, a.v_bias), a.z, a.c_out, a.c_out,
                                    training ? a.bn_part : nullptr, e->ws, e->ws_bytes);
             if (rc) return rc;
@@ -569,10 +541,6 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
     if (rc) return rc;
     // segment-level layers
     Affine& l6 = e->L[5];
-    rc = wait_weights(e, s, 5);
-    if (rc) return rc;
-    rc = wait_weights(e, s, 6);
-    if (rc) return rc;
     rc = xv_affine_forward(s, e->pool, b, 1, l6.c_pad, 1, l6.wt, vptr(e, l6.v_bias), l6.z, l6.c_out, l6.c_out, nullptr, e->ws, e->ws_bytes);
     if (rc) return rc;
     rc = bn_forward(e, s, l6, b, false, l6.a);
@@ -612,8 +580,6 @@ extern "C" int xv_engine_loss_forward(xv_engine* e, void* stream, const int32_t*
     e->labels_dev = (int32_t*)labels;
     e->with_margin = with_margin;
     int rc = ensure_weights(e, s);
-    if (rc) return rc;
-    rc = wait_weights(e, s, 7);
     if (rc) return rc;
     XvGemmNT g = {};
     g.A = e->out; g.lda = e->Lout; g.a_rps = 1; g.a_pitch = 1;

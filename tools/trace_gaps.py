@@ -33,3 +33,16 @@ for r in sel:
     tot[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); cnt[k] += 1
 for k, v in tot.most_common(40):
     print("  %-46s %5.1f/step  avg %7.1f us  %7.1f us/step" % (k[:46], cnt[k] / steps, v / cnt[k] / 1e3, v / steps / 1e3))
+
+# largest idle gaps on the busiest queue: (kernel before -> kernel after), averaged per step
+mainq = max(byq, key=lambda q: sum(e - s for s, e, _ in byq[q]))
+iv = sorted(byq[mainq])
+gaps = collections.defaultdict(lambda: [0, 0])
+for (s0, e0, k0), (s1, e1, k1) in zip(iv, iv[1:]):
+    g = s1 - e0
+    if g > 0:
+        key = (k0.split("(")[0][:34], k1.split("(")[0][:34])
+        gaps[key][0] += g; gaps[key][1] += 1
+print("idle gaps on queue %s (us/step):" % mainq)
+for key, (g, n) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:22]:
+    print("  %7.1f  (%4.1f/step, avg %6.1f us)  %s -> %s" % (g / steps / 1e3, n / steps, g / n / 1e3, key[0], key[1]))
