@@ -642,34 +642,54 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, PoolGrad pg, c
 }
 
 // Same as bn_bwd_apply_kernel but dz is written as two fp16 planes [2][segs*(t+2pad)][ldd] scaled by the power of two
-// derived from *amax (xv_gemm16.hip); 8 channels (one 16-byte chunk per plane) per thread; pad rows / columns are zero.
+// derived from *amax (xv_gemm16.hip); pad rows / columns are zero.
+// Thread = one 8-channel chunk (16 B per plane) x a strip of rows: the 7 per-channel parameter vectors are loaded
+// once per thread, not once per element (they were 3/4 of the load instructions of the element-per-thread form).
+// block = 64 chunks x 4 row lanes, BAS_ROWS padded rows per block.
+#define BAS_ROWS 32
 template <bool POOLED>
-__global__ void bn_bwd_apply_split_kernel(const float* __restrict__ da, PoolGrad pg, const float* __restrict__ z, int segs, int t, int n,
-                                          const float* __restrict__ gamma, const float* __restrict__ mean,
-                                          const float* __restrict__ invstd, const float* __restrict__ scale,
-                                          const float* __restrict__ shift, const float* __restrict__ coef, int relu, int pad,
-                                          const unsigned* __restrict__ amax, unsigned short* __restrict__ dst, long ldd,
-                                          long plane_stride) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_split_kernel(const float* __restrict__ da, PoolGrad pg, const float* __restrict__ z,
+                                                                 int segs, int t, int n, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ coef, int relu, int pad,
+                                                                 const unsigned* __restrict__ amax, unsigned short* __restrict__ dst,
+                                                                 long ldd, long plane_stride) {
     const float s = xv_pow2_scale(*amax);
     const int tp = t + 2 * pad;
-    const unsigned cq = (unsigned)(ldd / 8), total = (unsigned)segs * tp * cq;      // < 2^31 (checked by the wrapper)
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const unsigned dr = i / cq;
-        int col = (int)(i - dr * cq) * 8;
-        int seg = (int)(dr / tp), u = (int)(dr - (unsigned)seg * tp) - pad;
+    const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 8;
+    const int rl = threadIdx.x >> 6;
+    if (col >= ldd) return;
+    const int total_rows = segs * tp;
+    const int r0 = blockIdx.y * BAS_ROWS, r1 = min(total_rows, r0 + BAS_ROWS);
+    f32x4 g_is[2], mu[2], is[2], sc[2], sh[2], c1[2], c2[2];
+    bool cv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = col + 4 * q;
+        cv[q] = c < n;
+        const int cc = cv[q] ? c : 0;
+        mu[q] = *(const f32x4*)(mean + cc); is[q] = *(const f32x4*)(invstd + cc);
+        sc[q] = *(const f32x4*)(scale + cc); sh[q] = *(const f32x4*)(shift + cc);
+        c1[q] = *(const f32x4*)(coef + cc); c2[q] = *(const f32x4*)(coef + n + cc);
+        g_is[q] = *(const f32x4*)(gamma + cc) * is[q];
+    }
+    int seg = r0 / tp, u = r0 - seg * tp;          // padded row r0 -> (segment, frame + pad)
+    u += rl;
+    while (u >= tp) { u -= tp; ++seg; }
+    for (int dr = r0 + rl; dr < r1; dr += 4) {
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (u >= 0 && u < t) {
-            const long r = (long)seg * t + u;
+        const int f = u - pad;
+        if (f >= 0 && f < t) {
+            const long r = (long)seg * t + f;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
+                if (!cv[q]) continue;
                 const int c = col + 4 * q;
-                if (c >= n) break;
                 f32x4 zz = *(const f32x4*)(z + r * n + c);
-                f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
-                f32x4 dd = upstream_grad<POOLED>(da, pg, r, n, c, zz, *(const f32x4*)(scale + c), *(const f32x4*)(shift + c), relu);
-                f32x4 xh = (zz - mu) * is;
-                f32x4 c1 = *(const f32x4*)(coef + c), c2 = *(const f32x4*)(coef + n + c);
-                f32x4 o = (*(const f32x4*)(gamma + c) * is) * (dd - c1 - xh * c2);
+                f32x4 dd = upstream_grad<POOLED>(da, pg, r, n, c, zz, sc[q], sh[q], relu);
+                f32x4 xh = (zz - mu[q]) * is[q];
+                f32x4 o = g_is[q] * (dd - c1[q] - xh * c2[q]);
                 v[4 * q] = o.x; v[4 * q + 1] = o.y; v[4 * q + 2] = o.z; v[4 * q + 3] = o.w;
             }
         }
@@ -684,6 +704,8 @@ __global__ void bn_bwd_apply_split_kernel(const float* __restrict__ da, PoolGrad
         }
         *(uint4*)(dst + (long)dr * ldd + col) = *(const uint4*)h;
         *(uint4*)(dst + plane_stride + (long)dr * ldd + col) = *(const uint4*)l;
+        u += 4;
+        while (u >= tp) { u -= tp; ++seg; }
     }
 }
 
@@ -735,8 +757,8 @@ static int bn_relu_backward_split_impl(hipStream_t s, const float* da, PoolGrad 
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
                        dgamma, dbeta, coef, gamma, invstd, dbias, mean, zmin, zmax, (unsigned*)dz_amax);
     XV_LAUNCH_CHECK();
-    long total = (long)segs * (t + 2 * pad) * (ldp / 8);
-    hipLaunchKernelGGL(pooled ? bn_bwd_apply_split_kernel<true> : bn_bwd_apply_split_kernel<false>, dim3(grid_for(total, 256, 8192)),
+    dim3 agrid(xv_cdiv(ldp / 8, 64), xv_cdiv(segs * (t + 2 * pad), BAS_ROWS));
+    hipLaunchKernelGGL(pooled ? bn_bwd_apply_split_kernel<true> : bn_bwd_apply_split_kernel<false>, agrid,
                        dim3(256), 0, s, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad,
                        (const unsigned*)dz_amax, (unsigned short*)dz_planes, (long)ldp, (long)plane_stride);
     XV_LAUNCH_CHECK();
