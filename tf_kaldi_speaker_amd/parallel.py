@@ -20,14 +20,15 @@ import torch
 class GradAllReduce(object):
     """Callable handed to Engine.train_step: all-reduces finished gradient slices asynchronously."""
 
-    def __init__(self, dist, world_size):
+    def __init__(self, dist, world_size, always=False):
         self.dist = dist
         self.world_size = int(world_size)
         self.grad_scale = 1.0 / float(self.world_size)
+        self.always = bool(always)       # issue the collective even on one rank (tests of the RCCL wiring on a 1-GPU box)
         self._pending = []
 
     def __call__(self, flat_slice):
-        if self.world_size == 1 or flat_slice.numel() == 0:
+        if (self.world_size == 1 and not self.always) or flat_slice.numel() == 0:
             return
         self._pending.append(self.dist.all_reduce(flat_slice, op=self.dist.ReduceOp.SUM, async_op=True))
 
