@@ -126,6 +126,17 @@ int xv_prep_add(XvPrepJobs& J, int type, const float* w, int k, int C, int O, in
 int xv_launch_weight_prep(hipStream_t s, const XvPrepJobs& J);
 int xv_launch_amax_multi(hipStream_t s, const XvAmaxJobs& J);
 
+// Segment-level BatchNorm (rows = chunks per batch, a few hundred at most) in ONE launch each way: statistics, moving
+// averages, scale/shift and the activation (forward); both reductions and dz (backward).  The three-kernel forms are
+// built for 25 k-row tensors; on 128 rows their launches and gaps were what the layer cost.  (xv_elementwise.hip)
+#define XV_BN_SMALL_MAX_ROWS 4096
+int xv_bn_small_forward(hipStream_t s, const float* z, int rows, int n, const float* gamma, const float* beta, float eps, float momentum,
+                        int unbiased_moving, float* moving_mean, float* moving_var, float* mean, float* invstd, float* scale, float* shift,
+                        int relu, float* a);
+int xv_bn_small_backward(hipStream_t s, const float* da, const float* z, int rows, int n, const float* gamma, const float* mean,
+                         const float* invstd, const float* scale, const float* shift, int relu, float* dz, float* dgamma, float* dbeta,
+                         float* dbias);
+
 // Live launch timing (xv_profile_begin/end): brackets one GEMM launch with hipEvents on its stream.
 struct XvProfScope {
     hipStream_t s; int idx;

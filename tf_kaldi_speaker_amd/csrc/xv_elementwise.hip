@@ -806,6 +806,108 @@ extern "C" int xv_bn_relu_backward_pooled_split(void* stream, const float* pool_
                                        0, dz_planes, ldp, plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes);
 }
 
+// ------------------------------------------------------------------------------------
+// small-row BatchNorm, one launch (xv_common.h).  block = 256 threads = 16 channels x 16 row lanes; fixed-order combines.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float small_reduce16(float v, float (*red)[16], int rl, int cx) {
+    __syncthreads();
+    red[rl][cx] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cx];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ z, int rows, int n, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum, int unbiased,
+                                                           float* __restrict__ mmean, float* __restrict__ mvar, float* __restrict__ mean_o,
+                                                           float* __restrict__ invstd_o, float* __restrict__ scale_o,
+                                                           float* __restrict__ shift_o, int relu, float* __restrict__ a) {
+    __shared__ float red[16][16];
+    const int cx = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    const bool cv = c < n;
+    float s = 0.f;
+    if (cv) for (int r = rl; r < rows; r += 16) s += z[(long)r * n + c];
+    const float mean = small_reduce16(s, red, rl, cx) / (float)rows;
+    float q = 0.f;
+    if (cv) for (int r = rl; r < rows; r += 16) { float d = z[(long)r * n + c] - mean; q += d * d; }
+    const float var = small_reduce16(q, red, rl, cx) / (float)rows;      // biased, two-pass (tf.nn.moments)
+    if (!cv) return;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * invstd, sh = beta[c] - mean * sc;
+    if (rl == 0) {
+        mean_o[c] = mean; invstd_o[c] = invstd; scale_o[c] = sc; shift_o[c] = sh;
+        if (mmean) {
+            float v = (unbiased && rows > 1) ? var * ((float)rows / (float)(rows - 1)) : var;
+            mmean[c] = mmean[c] * momentum + mean * (1.0f - momentum);
+            mvar[c] = mvar[c] * momentum + v * (1.0f - momentum);
+        }
+    }
+    if (a)
+        for (int r = rl; r < rows; r += 16) {
+            float y = z[(long)r * n + c] * sc + sh;
+            a[(long)r * n + c] = relu ? fmaxf(y, 0.f) : y;
+        }
+}
+
+int xv_bn_small_forward(hipStream_t s, const float* z, int rows, int n, const float* gamma, const float* beta, float eps, float momentum,
+                        int unbiased_moving, float* moving_mean, float* moving_var, float* mean, float* invstd, float* scale, float* shift,
+                        int relu, float* a) {
+    XV_REQUIRE(rows > 0 && rows <= XV_BN_SMALL_MAX_ROWS && n > 0, "bn_small_forward: bad shape (rows=%d)", rows);
+    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(xv_cdiv(n, 16)), dim3(256), 0, s, z, rows, n, gamma, beta, eps, momentum, unbiased_moving,
+                       moving_mean, moving_var, mean, invstd, scale, shift, relu, a);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ da, const float* __restrict__ z, int rows, int n,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu, float* __restrict__ dz,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ dbias) {
+    __shared__ float red[16][16];
+    const int cx = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    const bool cv = c < n;
+    float mu = 0.f, is = 0.f, sc = 0.f, sh = 0.f;
+    if (cv) { mu = mean[c]; is = invstd[c]; sc = scale[c]; sh = shift[c]; }
+    float s1 = 0.f, s2 = 0.f;
+    if (cv)
+        for (int r = rl; r < rows; r += 16) {
+            float zz = z[(long)r * n + c], dd = da[(long)r * n + c];
+            if (relu && !(zz * sc + sh > 0.f)) dd = 0.f;
+            s1 += dd;
+            s2 += dd * ((zz - mu) * is);
+        }
+    s1 = small_reduce16(s1, red, rl, cx);
+    s2 = small_reduce16(s2, red, rl, cx);
+    if (!cv) return;
+    const float c1 = s1 / (float)rows, c2 = s2 / (float)rows;
+    const float g = gamma[c] * is;
+    if (rl == 0) {
+        dbeta[c] = s1; dgamma[c] = s2;
+        if (dbias) dbias[c] = g * (s1 - c1 * (float)rows);
+    }
+    for (int r = rl; r < rows; r += 16) {
+        float zz = z[(long)r * n + c], dd = da[(long)r * n + c];
+        if (relu && !(zz * sc + sh > 0.f)) dd = 0.f;
+        dz[(long)r * n + c] = g * (dd - c1 - ((zz - mu) * is) * c2);
+    }
+}
+
+int xv_bn_small_backward(hipStream_t s, const float* da, const float* z, int rows, int n, const float* gamma, const float* mean,
+                         const float* invstd, const float* scale, const float* shift, int relu, float* dz, float* dgamma, float* dbeta,
+                         float* dbias) {
+    XV_REQUIRE(rows > 0 && rows <= XV_BN_SMALL_MAX_ROWS && n > 0, "bn_small_backward: bad shape (rows=%d)", rows);
+    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(xv_cdiv(n, 16)), dim3(256), 0, s, da, z, rows, n, gamma, mean, invstd, scale, shift, relu,
+                       dz, dgamma, dbeta, dbias);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void relu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ a, size_t count, float* __restrict__ dz) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
         dz[i] = a[i] > 0.f ? da[i] : 0.f;

@@ -376,6 +376,10 @@ int ensure_weights(xv_engine* e, hipStream_t s) {
 int bn_forward(xv_engine* e, hipStream_t s, Affine& a, int rows, bool stats_from_gemm, float* dst_a) {
     const xv_config& c = e->cfg;
     int rc;
+    if (e->training && !stats_from_gemm && rows <= XV_BN_SMALL_MAX_ROWS)      // segment-level layers: one launch
+        return xv_bn_small_forward(s, a.z, rows, a.c_out, vptr(e, a.v_gamma), vptr(e, a.v_beta), c.bn_epsilon, c.batchnorm_momentum,
+                                   a.fused_bn && c.fused_bn_unbiased_moving_var, vptr(e, a.v_mmean), vptr(e, a.v_mvar), a.mean, a.invstd,
+                                   a.scale, a.shift, a.has_relu ? 1 : 0, dst_a);
     if (e->training) {
         if (!stats_from_gemm) {
             rc = xv_col_stats(s, a.z, rows, a.c_out, a.c_out, a.bn_part);
@@ -669,6 +673,11 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
         XV_REQUIRE(&a == &e->L[4] && a.has_bn, "engine_backward: only tdnn5 takes its gradient from the pooling layer");
         rc = xv_bn_relu_backward_pooled(s, e->pool, e->d_small0, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale,
                                         a.shift, 1, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
+        if (rc) return rc;
+        dz = Z;
+    } else if (a.has_bn && pad == 0 && segs * t_out <= XV_BN_SMALL_MAX_ROWS && &a > &e->L[4]) {      // segment-level layers: one launch
+        rc = xv_bn_small_backward(s, da, a.z, segs * t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift,
+                                  a.has_relu ? 1 : 0, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias));
         if (rc) return rc;
         dz = Z;
     } else if (a.has_bn) {

@@ -299,6 +299,7 @@ __global__ void xv_splitk_reduce_kernel(const float* __restrict__ slab, int spli
 }
 
 // ---- live launch timing (bench.py roofline leg) ----------------------------------------
+#include <algorithm>
 #include <vector>
 namespace {
 struct ProfRec { hipEvent_t a, b; int kind; double flops; };
@@ -363,6 +364,9 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
         if (splits > ksteps / 4) splits = ksteps / 4;
         if (splits < 1) splits = 1;
         const long np = (long)xv_align(g.N, 4);
+        // the slabs are written and read back: beyond ~8 MB the reduce costs more than the extra workgroups buy
+        const long slab_cap = std::max<long>(8, (8L << 20) / ((long)g.M * np * (long)sizeof(float)));
+        if (splits > slab_cap) splits = (int)slab_cap;
         while (splits > 1 && (size_t)splits * g.M * np * sizeof(float) > g.ws_bytes) --splits;
     }
     if (splits == 1) {
