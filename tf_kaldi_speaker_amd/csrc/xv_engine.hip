@@ -754,9 +754,12 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
     const unsigned short* xin = li == 0 ? e->xh : e->L[li - 1].ah;
     const int xin_rows = li == 0 ? e->B * e->Tl[0] : e->L[li - 1].rows;
     const uint32_t* xin_amax = li == 0 ? e->amax + AMAX_X : e->amax + AMAX_A + (li - 1);
-    hipStream_t wst = e->concurrent ? e->side : s;
-    void* wws = e->concurrent ? e->ws_side : e->ws;
-    if (e->concurrent) {
+    // tdnn1 is the end of the chain: nothing is left on `s` to overlap with, and the side stream is still busy with
+    // tdnn2's weight gradient - its own (small) weight gradient finishes sooner in line on `s`
+    const bool conc = e->concurrent && li > 0;
+    hipStream_t wst = conc ? e->side : s;
+    void* wws = conc ? e->ws_side : e->ws;
+    if (conc) {
         rc = chain(s, e->side, e->ev_dz);
         if (rc) return rc;
     }
@@ -764,7 +767,7 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
                                seg_pitch, pad, a.o_ld, a.c_out, vptr(e, a.v_kernel), c.weight_l2_regularizer, gptr(e, a.v_kernel), wws,
                                e->ws_bytes);
     if (rc) return rc;
-    if (e->concurrent) {
+    if (conc) {
         XV_CHECK_HIP(hipEventRecord(e->ev_w[zi], e->side));
         e->w_pending[zi] = true;
     }
