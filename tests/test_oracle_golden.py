@@ -49,3 +49,15 @@ def test_lambda_schedule_values():
     assert O.margin_lambda(0, 1000, 1e-4, 5, 0) == 1000.0
     assert abs(O.margin_lambda(0, 1000, 1e-4, 5, 10000) - 1000 * 2.0 ** -5) < 1e-12
     assert O.margin_lambda(10, 1000, 1e-5, 5, 10 ** 9) == 10.0
+
+
+def test_self_attention_matches_reference_numpy_oracle():
+    """oracle.self_attention_fwd vs model/test_utils.py:compute_self_attention (tests/golden/make_attention_golden.py).
+    The reference oracle adds 1e-12 inside the sqrt where the graph (and our restatement) masks variances <= 1e-12
+    (pooling.py:160-162): identical above ~1e-9, both give 1e-6 for a constant chunk."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "attention_golden.npz"))
+    for i in range(int(g["num_cases"])):
+        value, key, query, ref = g["value_%d" % i], g["key_%d" % i], g["query_%d" % i], g["att_%d" % i]
+        att, _ = O.self_attention_fwd(value, key, query, bool(g["use_scale_%d" % i]))
+        assert att.shape == ref.shape
+        assert np.allclose(att, ref, rtol=1e-5, atol=1e-8), (i, np.abs(att - ref).max())

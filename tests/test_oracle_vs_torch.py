@@ -22,9 +22,10 @@ def torch_forward(V, x, cfg, labels, step, training=True):
     eps = 1e-3
     ep = {}
 
-    def bn(prefix, z):
-        g, b = tv["tdnn/%s_bn/gamma" % prefix], tv["tdnn/%s_bn/beta" % prefix]
-        mm, mv = tv["tdnn/%s_bn/moving_mean" % prefix], tv["tdnn/%s_bn/moving_variance" % prefix]
+    def bn(prefix, z, scope=""):
+        base = "tdnn/%s%s_bn/" % (scope, prefix)
+        g, b = tv[base + "gamma"], tv[base + "beta"]
+        mm, mv = tv[base + "moving_mean"], tv[base + "moving_variance"]
         z2 = z.reshape(-1, z.shape[-1])
         if training:
             y = F.batch_norm(z2, None, None, g, b, True, 0.0, eps)
@@ -43,8 +44,23 @@ def torch_forward(V, x, cfg, labels, step, training=True):
         ep[name] = z
         h = torch.relu(bn(prefix, z))
         ep[prefix + "_relu"] = h
-    mean = h.mean(dim=1)
-    var = ((h - mean[:, None, :]) ** 2).mean(dim=1)
+    if cfg.pooling_type == "self_attention":
+        a0, a1 = "tdnn/attention/att_key0/att_key0_dense/", "tdnn/attention/att_key1/att_key1_dense/"
+        k = torch.relu(bn("att_key0", F.linear(ep["tdnn4_relu"], tv[a0 + "kernel"].t(), tv[a0 + "bias"]), "attention/att_key0/"))
+        k = F.linear(k, tv[a1 + "kernel"].t(), tv[a1 + "bias"])
+        ep["att_key1_dense"] = k
+        if cfg.att_key_network_type == 3:
+            k = torch.tanh(k)
+        score = torch.einsum("btd,hd->bth", k, tv["tdnn/attention/query"])[:, :, 0]
+        if cfg.att_use_scale:
+            score = score / np.sqrt(k.shape[-1])
+        w = torch.softmax(score, dim=1)
+        ep["attention_weights"] = w[:, None, :]
+        mean = torch.einsum("btc,bt->bc", h, w)
+        var = torch.einsum("btc,bt->bc", (h - mean[:, None, :]) ** 2, w)
+    else:
+        mean = h.mean(dim=1)
+        var = ((h - mean[:, None, :]) ** 2).mean(dim=1)
     mask = (var <= 1e-12).double()
     var = (1 - mask) * var + mask * 1e-12
     h = torch.cat([mean, var.sqrt()], dim=1)
@@ -121,10 +137,14 @@ CASES = [
     dict(loss_func="additive_angular_margin_softmax", margin_m=0.25, lambda_gamma=1e-2, last_layer_linear=True),
     dict(loss_func="additive_margin_softmax", margin_m=0.2, feature_norm=True, feature_scaling_factor=30.0,
          last_layer_linear=True),
+    # self-attention pooling, the shipped form (nnet_conf/*_tdnn4_att.json) and its affine-key / unscaled variants
+    dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, pooling_type="self_attention",
+         att_key_num_nodes=(24, 20)),
+    dict(loss_func="softmax", pooling_type="self_attention", att_key_num_nodes=(16, 12), att_key_network_type=0, att_use_scale=False),
 ]
 
 
-@pytest.mark.parametrize("kw", CASES, ids=lambda d: d["loss_func"] + "_" + str(d.get("margin_m", "")))
+@pytest.mark.parametrize("kw", CASES, ids=lambda d: d["loss_func"] + "_" + str(d.get("margin_m", "")) + ("_att%d" % d["att_key_network_type"] if "att_key_network_type" in d else "_att" if "pooling_type" in d else ""))
 def test_full_step_forward_backward(kw):
     cfg = O.Config(feat_dim=6, num_speakers=11, num_nodes_pooling_layer=20, num_nodes_last_layer=16, **kw)
     # the layer widths 512 are fixed by tdnn.py; keep B,T small instead
@@ -144,7 +164,10 @@ def test_full_step_forward_backward(kw):
 
     assert abs(float(loss.detach()) - float(info["raw_loss"])) < 1e-10 * max(1, abs(float(loss.detach())))
     assert abs(float((loss + reg).detach()) - float(info["total_loss"])) < 1e-10 * max(1, abs(float((loss + reg).detach())))
-    for name in ("tdnn1_conv", "tdnn3_conv", "tdnn5_dense", "pooling", "tdnn6_dense", "tdnn7_dense", "output"):
+    names = ["tdnn1_conv", "tdnn3_conv", "tdnn5_dense", "pooling", "tdnn6_dense", "tdnn7_dense", "output"]
+    if cfg.pooling_type == "self_attention":
+        names += ["att_key1_dense", "attention_weights"]
+    for name in names:
         a, b = info["endpoints"][name], ep[name].detach().numpy()
         assert np.allclose(a, b, rtol=1e-9, atol=1e-11), name
     for k, v in tv.items():
