@@ -170,10 +170,13 @@ int xv_bn_relu_backward_split(void* stream, const float* da, const float* z, int
  * gradient dpool [b][2n] -  d a = dmean/t + dstd/(t*std) * (a - mean), a = relu?(z*scale + shift), zero where the
  * variance was clamped (pooling.py:28-29) - i.e. pooling backward + ReLU backward + BN backward in one pass over z.
  * rows = b*t, no segment padding. */
-int xv_bn_relu_backward_pooled(void* stream, const float* pool_out, const float* dpool, int b, int t, const float* z, int n,
+int xv_bn_relu_backward_pooled(void* stream, const float* pool_out, const float* dpool,
+                               const float* weights /* [b*t] attention weights or NULL: d a = w*(dmean + dstd/std*(a - mean)) */, int b, int t,
+                               const float* z, int n,
                                const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
                                int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes);
-int xv_bn_relu_backward_pooled_split(void* stream, const float* pool_out, const float* dpool, int b, int t, const float* z, int n,
+int xv_bn_relu_backward_pooled_split(void* stream, const float* pool_out, const float* dpool, const float* weights, int b, int t,
+                                     const float* z, int n,
                                      const float* gamma, const float* mean, const float* invstd, const float* scale,
                                      const float* shift, const float* zmin, const float* zmax, int relu, void* dz_planes, int ldp,
                                      size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
@@ -198,8 +201,27 @@ int xv_stat_pool_backward(void* stream, const float* x, const float* out, const 
 /* Statistics pooling over relu?(z*scale + shift) evaluated on the fly (tdnn5's BN + ReLU, tdnn.py:124-131, fused into
  * pooling.py:9-34): out[b] = [mean_t | std_t] of the activation, which is never written to memory. */
 int xv_stat_pool_forward_bn(void* stream, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
+                            const float* weights /* [b*t] frame weights summing to 1 per chunk (self-attention), or NULL = 1/t */,
                             float* out);
 
+
+/* ---- self-attention pooling, the shipped single-head form (model/pooling.py:37-192; nnet_conf/..._tdnn4_att.json) ----
+ * The key network's dense layers run on the frame-level GEMMs; these are the pieces around them.
+ *   score[r]   = scale * sum_c act(zk[r][c]) * query[c]        act: 0 = identity, 3 = tanh (att_key_network_type, pooling.py:84-96)
+ *   weights    = softmax over the t frames of each chunk        (pooling.py:148)
+ *   pooled     = xv_stat_pool_forward_bn(..., weights, ...)     (pooling.py:151-164)
+ * backward: d weights from the pooled statistics (the value path enters tdnn5's BN backward through
+ * xv_bn_relu_backward_pooled*'s `weights`), softmax backward, then through the score into the key layer output:
+ *   dzk[r][c] = dscore[r]*scale*query[c]*act'(zk),  dquery[c] = sum_r dscore[r]*scale*act(zk[r][c]),  dbias[c] = sum_r dzk[r][c]. */
+int xv_att_score(void* stream, const float* zk, int rows, int n, int ldz, int act, const float* query, float scale, float* score);
+int xv_softmax_segments(void* stream, const float* score, int b, int t, float* weights);
+int xv_softmax_segments_backward(void* stream, const float* weights, const float* dweights, int b, int t, float* dscore);
+int xv_att_pool_backward_weights(void* stream, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
+                                 const float* pool_out, const float* dpool, float* dweights);
+int xv_att_key_backward(void* stream, const float* zk, int rows, int n, int act, const float* query, float scale, const float* dscore,
+                        float* dzk, float* dquery, float* dbias, void* ws, size_t ws_bytes);
+/* y[i] += x[i]  (the two gradient paths into tdnn4_relu: through tdnn5 and through the attention key network) */
+int xv_add_inplace(void* stream, float* y, const float* x, size_t count);
 
 /* l2_scaling, common.py:45-58 (feature_norm:true, trainer.py:183-186). */
 int xv_l2_scaling_forward(void* stream, const float* x, int rows, int n, float factor, float* y);

@@ -320,3 +320,53 @@ def test_optimizers_and_reductions(ops):
     acc = dev(np.zeros(1))
     ops.l2_reg_loss(dev(g), 1e-2, acc)
     assert abs(float(host(acc)[0]) - 0.005 * float((g.astype(np.float64) ** 2).sum())) < 1e-4 * 0.005 * n
+
+
+@pytest.mark.parametrize("act,use_scale", [(3, True), (0, False)])
+def test_self_attention_pieces(ops, act, use_scale):
+    """The kernels around the key network's GEMMs (pooling.py:37-192, shipped single-head form) against the oracle:
+    score -> softmax over frames -> weighted statistics of relu(bn(z)) on the fly; backward: d weights, softmax backward,
+    the key-layer gradient (dzk, d query, d bias) and the value path through tdnn5's BN backward with frame weights."""
+    rs = np.random.RandomState(31 + act)
+    b, t, n, dk = 5, 37, 1500, 1500
+    z = (rs.randn(b * t, n) * 2 + 0.3).astype(np.float32)          # tdnn5 pre-BN output
+    zk = (rs.randn(b * t, dk) * 0.7).astype(np.float32)            # key layer pre-activation
+    query = (rs.randn(1, dk) * 0.1).astype(np.float32)
+    gamma, beta = (rs.rand(n) + 0.5).astype(np.float32), (0.3 * rs.randn(n)).astype(np.float32)
+    dout = rs.randn(b, 2 * n).astype(np.float32)
+    z64, zk64, q64 = z.astype(np.float64), zk.astype(np.float64), query.astype(np.float64)
+    y, cache = O.batchnorm_train_fwd(z64, gamma.astype(np.float64), beta.astype(np.float64))
+    value = np.maximum(y, 0).reshape(b, t, n)
+    key = (np.tanh(zk64) if act == 3 else zk64).reshape(b, t, dk)
+    pool_ref, pc = O.self_attention_fwd(value, key, q64, use_scale)
+    dv, dkey, dq_ref = O.self_attention_bwd(value, key, q64, pc, dout.astype(np.float64))
+    dzk_ref = dkey.reshape(b * t, dk) * ((1 - key.reshape(b * t, dk) ** 2) if act == 3 else 1.0)
+    dz_ref, dg_ref, db_ref = O.batchnorm_train_bwd(dv.reshape(b * t, n) * (y > 0), cache, gamma.astype(np.float64))
+    scale_f = 1.0 / np.sqrt(dk) if use_scale else 1.0
+
+    part = ops.col_stats(dev(z))
+    mean, invstd, sc, sh = ops.bn_finalize(part, b * t, dev(gamma), dev(beta), 1e-3, 0.99, False, None, None)
+    score = ops.att_score(dev(zk), act, dev(query), scale_f)
+    assert_close(host(score), (key.reshape(b * t, dk) @ q64[0]) * scale_f, 2e-6, 2e-5, "att score")
+    w = ops.softmax_segments(score, b, t)
+    assert_close(host(w), pc[0], 2e-6, 2e-5, "attention weights")
+    assert np.allclose(host(w).sum(axis=1), 1.0, atol=1e-5)
+    pool = ops.stat_pool_forward_bn(dev(z), b, t, sc, sh, True, weights=w)
+    assert_close(host(pool), pool_ref, 5e-6, 5e-5, "attention pooling")
+    dw = ops.att_pool_backward_weights(dev(z), b, t, sc, sh, True, pool, dev(dout))
+    dw_ref = np.einsum("btc,bc->bt", value, dout[:, :n].astype(np.float64)) + \
+        np.einsum("btc,bc->bt", (value - pc[1][:, None, :]) ** 2, dout[:, n:] * 0.5 / pc[2] * (1 - pc[3]))
+    assert_close(host(dw), dw_ref, 5e-6, 5e-5, "d weights")
+    ds = ops.softmax_segments_backward(w, dw)
+    dzk, dq, dbias = ops.att_key_backward(dev(zk), act, dev(query), scale_f, ds.reshape(-1))
+    assert_close(host(dzk), dzk_ref, 1e-5, 1e-4, "d key pre-activation")
+    assert_close(host(dq), dq_ref[0], 1e-5, 1e-4, "d query")
+    # the frame gradients of a chunk sum to zero (softmax), so for the affine key the bias gradient is 0 + rounding noise
+    assert np.abs(host(dbias) - dzk_ref.sum(axis=0)).max() <= 1e-5 * np.abs(dzk_ref).sum(axis=0).max(), "d key bias"
+    dz, dg, db, _ = ops.bn_relu_backward_pooled(pool, dev(dout), b, t, dev(z), dev(gamma), mean, invstd, sc, sh, True, weights=w)
+    assert_close(host(dz), dz_ref, 2e-5, 2e-4, "value path: tdnn5 dz")
+    assert_close(host(dg), dg_ref, 2e-5, 1e-4, "value path: dgamma")
+    assert_close(host(db), db_ref, 2e-5, 1e-4, "value path: dbeta")
+    y2 = host(dzk).copy()
+    ops._lib.call("xv_add_inplace", ops._s(), ops._p(dzk), ops._p(dzk), ops.C.c_size_t(dzk.numel()))
+    assert np.array_equal(host(dzk), 2 * y2)

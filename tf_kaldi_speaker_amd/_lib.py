@@ -97,10 +97,16 @@ SIGNATURES = {
     "xv_affine_wgrad_f16x3": (_I, [_VP, _VP, _SZ, _VP, _I, _I, _I, _I, _I, _VP, _SZ, _VP, _I, _I, _I, _I, _VP, _F, _VP, _VP, _SZ]),
     "xv_stat_pool_forward": (_I, [_VP, _VP, _I, _I, _I, _VP]),
     "xv_stat_pool_backward": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
-    "xv_stat_pool_forward_bn": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP]),
-    "xv_bn_relu_backward_pooled": (_I, [_VP, _VP, _VP, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _SZ]),
-    "xv_bn_relu_backward_pooled_split": (_I, [_VP, _VP, _VP, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _SZ, _VP,
+    "xv_stat_pool_forward_bn": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP]),
+    "xv_bn_relu_backward_pooled": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _SZ]),
+    "xv_bn_relu_backward_pooled_split": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _SZ, _VP,
                                               _VP, _VP, _VP, _VP, _SZ]),
+    "xv_att_score": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _F, _VP]),
+    "xv_softmax_segments": (_I, [_VP, _VP, _I, _I, _VP]),
+    "xv_softmax_segments_backward": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
+    "xv_att_pool_backward_weights": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP]),
+    "xv_att_key_backward": (_I, [_VP, _VP, _I, _I, _I, _VP, _F, _VP, _VP, _VP, _VP, _VP, _SZ]),
+    "xv_add_inplace": (_I, [_VP, _VP, _VP, _SZ]),
     "xv_l2_scaling_forward": (_I, [_VP, _VP, _I, _I, _F, _VP]),
     "xv_l2_scaling_backward": (_I, [_VP, _VP, _VP, _I, _I, _F, _VP]),
     "xv_loss_prep_weight": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP]),

@@ -495,11 +495,11 @@ extern "C" int xv_bn_apply(void* stream, const float* z, int rows, int n, int ld
 // Upstream gradient of a layer whose output feeds statistics pooling directly (tdnn5): instead of reading a
 // materialised d(activation), the BN backward evaluates the pooling backward (pooling.py:9-34) on the fly from the
 // pooled statistics [b][mean | std] and their gradient:  da = dmean/T + dstd/(T*std) * (a - mean),  a = relu?(z*scale+shift).
-struct PoolGrad { const float* out; const float* dout; int t; };
+struct PoolGrad { const float* out; const float* dout; int t; const float* w; };   // w: per-frame attention weights or null (1/t)
 
 __device__ __forceinline__ f32x4 pool_grad(const PoolGrad& pg, long row, int n, int col, f32x4 a) {
     const int b = (int)(row / pg.t);
-    const float invT = 1.f / (float)pg.t;
+    const float invT = pg.w ? pg.w[row] : 1.f / (float)pg.t;      // self-attention: frame weight instead of 1/T (pooling.py:148-155)
     const float sd_eps = 1e-6f;      // sqrt(1e-12): the forward clamps the variance there (pooling.py:28-29)
     const float* o = pg.out + (long)b * 2 * n;
     const float* g = pg.dout + (long)b * 2 * n;
@@ -769,7 +769,7 @@ extern "C" int xv_bn_relu_backward(void* stream, const float* da, const float* z
                                    const float* mean, const float* invstd, const float* scale, const float* shift, int relu,
                                    int pad, float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
     XV_REQUIRE(da, "bn_relu_backward: null upstream gradient");
-    PoolGrad pg = {nullptr, nullptr, 1};
+    PoolGrad pg = {nullptr, nullptr, 1, nullptr};
     return bn_relu_backward_impl((hipStream_t)stream, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, relu, pad, dz_pad, dgamma,
                                  dbeta, dbias, ws, ws_bytes);
 }
@@ -780,28 +780,30 @@ extern "C" int xv_bn_relu_backward_split(void* stream, const float* da, const fl
                                          size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
                                          size_t ws_bytes) {
     XV_REQUIRE(da, "bn_relu_backward_split: null upstream gradient");
-    PoolGrad pg = {nullptr, nullptr, 1};
+    PoolGrad pg = {nullptr, nullptr, 1, nullptr};
     return bn_relu_backward_split_impl((hipStream_t)stream, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, zmin, zmax, relu, pad,
                                        dz_planes, ldp, plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes);
 }
 
-extern "C" int xv_bn_relu_backward_pooled(void* stream, const float* pool_out, const float* dpool, int b, int t, const float* z, int n,
+extern "C" int xv_bn_relu_backward_pooled(void* stream, const float* pool_out, const float* dpool, const float* weights, int b, int t,
+                                          const float* z, int n,
                                           const float* gamma, const float* mean, const float* invstd, const float* scale,
                                           const float* shift, int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws,
                                           size_t ws_bytes) {
     XV_REQUIRE(pool_out && dpool && b > 0 && t > 0, "bn_relu_backward_pooled: bad arguments");
-    PoolGrad pg = {pool_out, dpool, t};
+    PoolGrad pg = {pool_out, dpool, t, weights};
     return bn_relu_backward_impl((hipStream_t)stream, nullptr, pg, z, b * t, 1, n, gamma, mean, invstd, scale, shift, relu, 0, dz, dgamma,
                                  dbeta, dbias, ws, ws_bytes);
 }
 
-extern "C" int xv_bn_relu_backward_pooled_split(void* stream, const float* pool_out, const float* dpool, int b, int t, const float* z, int n,
+extern "C" int xv_bn_relu_backward_pooled_split(void* stream, const float* pool_out, const float* dpool, const float* weights, int b, int t,
+                                                const float* z, int n,
                                                 const float* gamma, const float* mean, const float* invstd, const float* scale,
                                                 const float* shift, const float* zmin, const float* zmax, int relu, void* dz_planes,
                                                 int ldp, size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta,
                                                 float* dbias, void* ws, size_t ws_bytes) {
     XV_REQUIRE(pool_out && dpool && b > 0 && t > 0, "bn_relu_backward_pooled_split: bad arguments");
-    PoolGrad pg = {pool_out, dpool, t};
+    PoolGrad pg = {pool_out, dpool, t, weights};
     return bn_relu_backward_split_impl((hipStream_t)stream, nullptr, pg, z, b * t, 1, n, gamma, mean, invstd, scale, shift, zmin, zmax, relu,
                                        0, dz_planes, ldp, plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes);
 }
@@ -941,7 +943,8 @@ __device__ __forceinline__ void wf_merge(f32x4& mean, f32x4& m2, float& n, const
 // activation is never written to memory.
 template <bool BN>
 __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restrict__ x, int T, int C, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, int relu, float* __restrict__ out) {
+                                                            const float* __restrict__ shift, int relu, const float* __restrict__ wts,
+                                                            float* __restrict__ out) {
     __shared__ f32x4 s_mean[4][32], s_m2[4][32];
     __shared__ float s_n[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -963,24 +966,29 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
     };
     float n = 0.f;
     int t = fl;
+    // frame weights: 1 (statistics pooling; n counts frames) or the attention weights of this chunk (n sums them);
+    // weighted incremental mean / M2 (West), identical to Welford for unit weights
+    const float* wp = wts ? wts + (long)b * T : nullptr;
     // 4 loads in flight per lane
     for (; t + 24 < T; t += 32) {
         f32x4 v0 = act(*(const f32x4*)(xp + (long)t * C));
         f32x4 v1 = act(*(const f32x4*)(xp + (long)(t + 8) * C));
         f32x4 v2 = act(*(const f32x4*)(xp + (long)(t + 16) * C));
         f32x4 v3 = act(*(const f32x4*)(xp + (long)(t + 24) * C));
+        const float w0 = wp ? wp[t] : 1.f, w1 = wp ? wp[t + 8] : 1.f, w2 = wp ? wp[t + 16] : 1.f, w3 = wp ? wp[t + 24] : 1.f;
         f32x4 d;
-        n += 1.f; d = v0 - mean; mean += d * (1.f / n); m2 += d * (v0 - mean);
-        n += 1.f; d = v1 - mean; mean += d * (1.f / n); m2 += d * (v1 - mean);
-        n += 1.f; d = v2 - mean; mean += d * (1.f / n); m2 += d * (v2 - mean);
-        n += 1.f; d = v3 - mean; mean += d * (1.f / n); m2 += d * (v3 - mean);
+        n += w0; d = v0 - mean; if (n > 0.f) mean += d * (w0 / n); m2 += d * (v0 - mean) * w0;
+        n += w1; d = v1 - mean; if (n > 0.f) mean += d * (w1 / n); m2 += d * (v1 - mean) * w1;
+        n += w2; d = v2 - mean; if (n > 0.f) mean += d * (w2 / n); m2 += d * (v2 - mean) * w2;
+        n += w3; d = v3 - mean; if (n > 0.f) mean += d * (w3 / n); m2 += d * (v3 - mean) * w3;
     }
     for (; t < T; t += 8) {
         f32x4 v = act(*(const f32x4*)(xp + (long)t * C));
-        n += 1.f;
+        const float w = wp ? wp[t] : 1.f;
+        n += w;
         f32x4 d = v - mean;
-        mean += d * (1.f / n);
-        m2 += d * (v - mean);
+        if (n > 0.f) mean += d * (w / n);
+        m2 += d * (v - mean) * w;
     }
     // merge the two frame lanes of this wave
     f32x4 mean_b, m2_b;
@@ -999,7 +1007,7 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
     if (wave == 0 && half == 0 && cv) {
         mean = s_mean[0][qx]; m2 = s_m2[0][qx]; n = s_n[0];
         for (int w = 1; w < 4; ++w) wf_merge(mean, m2, n, s_mean[w][qx], s_m2[w][qx], s_n[w]);
-        f32x4 var = m2 * (1.f / (float)T);
+        f32x4 var = m2 * (1.f / n);      // n == T for unit weights, the sum of the attention weights (1) otherwise
         const float eps = 1e-12f;
         f32x4 sd;
         sd.x = sqrtf(var.x <= eps ? eps : var.x); sd.y = sqrtf(var.y <= eps ? eps : var.y);
@@ -1012,16 +1020,16 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
 extern "C" int xv_stat_pool_forward(void* stream, const float* x, int b, int t, int c, float* out) {
     XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0, "stat_pool_forward: bad shape (c=%d must be a multiple of 4)", c);
     hipLaunchKernelGGL(stat_pool_fwd_kernel<false>, dim3(xv_cdiv(c / 4, 32), b), dim3(256), 0, (hipStream_t)stream, x, t, c,
-                       (const float*)nullptr, (const float*)nullptr, 0, out);
+                       (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, out);
     XV_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int xv_stat_pool_forward_bn(void* stream, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
-                                       float* out) {
+                                       const float* weights, float* out) {
     XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0 && scale && shift, "stat_pool_forward_bn: bad shape (c=%d must be a multiple of 4)", c);
     hipLaunchKernelGGL(stat_pool_fwd_kernel<true>, dim3(xv_cdiv(c / 4, 32), b), dim3(256), 0, (hipStream_t)stream, z, t, c, scale, shift,
-                       relu, out);
+                       relu, weights, out);
     XV_LAUNCH_CHECK();
     return 0;
 }

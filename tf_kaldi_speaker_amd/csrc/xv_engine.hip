@@ -541,7 +541,7 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
         }
     }
     // tdnn5's BN + ReLU is applied inside the pooling reduction: its [b*t][1500] activation is never written
-    rc = xv_stat_pool_forward_bn(s, e->L[4].z, b, cur_t, e->P, e->L[4].scale, e->L[4].shift, 1, e->pool);
+    rc = xv_stat_pool_forward_bn(s, e->L[4].z, b, cur_t, e->P, e->L[4].scale, e->L[4].shift, 1, nullptr, e->pool);
     if (rc) return rc;
     // segment-level layers
     Affine& l6 = e->L[5];
@@ -671,7 +671,7 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     }
     if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
         XV_REQUIRE(&a == &e->L[4] && a.has_bn, "engine_backward: only tdnn5 takes its gradient from the pooling layer");
-        rc = xv_bn_relu_backward_pooled(s, e->pool, e->d_small0, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale,
+        rc = xv_bn_relu_backward_pooled(s, e->pool, e->d_small0, nullptr, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale,
                                         a.shift, 1, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
         if (rc) return rc;
         dz = Z;
@@ -741,7 +741,7 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
     int rc;
     if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
         XV_REQUIRE(li == 4, "engine_backward: only tdnn5 takes its gradient from the pooling layer");
-        rc = xv_bn_relu_backward_pooled_split(s, e->pool, e->d_small0, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd,
+        rc = xv_bn_relu_backward_pooled_split(s, e->pool, e->d_small0, nullptr, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd,
                                               a.scale, a.shift, a.zmin, a.zmax, 1, Z, a.o_ld, zstride, zamax, gptr(e, a.v_gamma),
                                               gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
     } else {

@@ -159,21 +159,56 @@ def stat_pool_forward(x):
     return out
 
 
-def stat_pool_forward_bn(z, b, t, scale, shift, relu=True):
-    """[b, 2c] statistics of relu?(z*scale+shift) without materialising it (z: [b*t, c])."""
+def stat_pool_forward_bn(z, b, t, scale, shift, relu=True, weights=None):
+    """[b, 2c] statistics of relu?(z*scale+shift) without materialising it (z: [b*t, c]); weights [b, t]: self-attention."""
     c = z.shape[1]
     out = _f32((b, 2 * c), z)
-    _lib.call("xv_stat_pool_forward_bn", _s(), _p(z), b, t, c, _p(scale), _p(shift), int(relu), _p(out))
+    _lib.call("xv_stat_pool_forward_bn", _s(), _p(z), b, t, c, _p(scale), _p(shift), int(relu), _p(weights), _p(out))
     return out
 
 
-def bn_relu_backward_pooled(pool_out, dpool, b, t, z, gamma, mean, invstd, scale, shift, relu=True):
+def att_score(zk, act, query, scale):
+    rows, n = zk.shape
+    score = _f32((rows,), zk)
+    _lib.call("xv_att_score", _s(), _p(zk), rows, n, n, int(act), _p(query), float(scale), _p(score))
+    return score
+
+
+def softmax_segments(score, b, t):
+    w = _f32((b, t), score)
+    _lib.call("xv_softmax_segments", _s(), _p(score), b, t, _p(w))
+    return w
+
+
+def softmax_segments_backward(w, dw):
+    b, t = w.shape
+    ds = _f32((b, t), w)
+    _lib.call("xv_softmax_segments_backward", _s(), _p(w), _p(dw), b, t, _p(ds))
+    return ds
+
+
+def att_pool_backward_weights(z, b, t, scale, shift, relu, pool_out, dpool):
+    c = z.shape[1]
+    dw = _f32((b, t), z)
+    _lib.call("xv_att_pool_backward_weights", _s(), _p(z), b, t, c, _p(scale), _p(shift), int(relu), _p(pool_out), _p(dpool), _p(dw))
+    return dw
+
+
+def att_key_backward(zk, act, query, scale, dscore):
+    rows, n = zk.shape
+    dzk, dq, db = _f32((rows, n), zk), _f32((n,), zk), _f32((n,), zk)
+    wp, wb = _ws(zk)
+    _lib.call("xv_att_key_backward", _s(), _p(zk), rows, n, int(act), _p(query), float(scale), _p(dscore), _p(dzk), _p(dq), _p(db), wp, wb)
+    return dzk, dq, db
+
+
+def bn_relu_backward_pooled(pool_out, dpool, b, t, z, gamma, mean, invstd, scale, shift, relu=True, weights=None):
     """BN(+ReLU) backward of the layer feeding statistics pooling, upstream gradient = pooling backward on the fly."""
     n = z.shape[1]
     dz = _f32((b * t, n), z)
     dgamma, dbeta, dbias = _f32((n,), z), _f32((n,), z), _f32((n,), z)
     wp, wb = _ws(z)
-    _lib.call("xv_bn_relu_backward_pooled", _s(), _p(pool_out), _p(dpool), b, t, _p(z), n, _p(gamma), _p(mean), _p(invstd), _p(scale),
+    _lib.call("xv_bn_relu_backward_pooled", _s(), _p(pool_out), _p(dpool), _p(weights), b, t, _p(z), n, _p(gamma), _p(mean), _p(invstd), _p(scale),
               _p(shift), int(relu), _p(dz), _p(dgamma), _p(dbeta), _p(dbias), wp, wb)
     return dz, dgamma, dbeta, dbias
 
@@ -303,7 +338,7 @@ def bn_relu_backward_split(da, z, segs, t, gamma, mean, invstd, scale, shift, zm
     return Planes(data, rows, ld, amax), dgamma, dbeta, dbias
 
 
-def bn_relu_backward_pooled_split(pool_out, dpool, b, t, z, gamma, mean, invstd, scale, shift, zmin, zmax, relu=True):
+def bn_relu_backward_pooled_split(pool_out, dpool, b, t, z, gamma, mean, invstd, scale, shift, zmin, zmax, relu=True, weights=None):
     n = z.shape[1]
     ld = (n + 7) // 8 * 8
     rows = b * t
@@ -311,7 +346,7 @@ def bn_relu_backward_pooled_split(pool_out, dpool, b, t, z, gamma, mean, invstd,
     amax = torch.zeros(1, dtype=torch.int32, device=z.device)
     dgamma, dbeta, dbias = _f32((n,), z), _f32((n,), z), _f32((n,), z)
     wp, wb = _ws(z)
-    _lib.call("xv_bn_relu_backward_pooled_split", _s(), _p(pool_out), _p(dpool), b, t, _p(z), n, _p(gamma), _p(mean), _p(invstd), _p(scale),
+    _lib.call("xv_bn_relu_backward_pooled_split", _s(), _p(pool_out), _p(dpool), _p(weights), b, t, _p(z), n, _p(gamma), _p(mean), _p(invstd), _p(scale),
               _p(shift), _p(zmin), _p(zmax), int(relu), _p(data), ld, C.c_size_t(rows * ld), _p(amax), _p(dgamma), _p(dbeta), _p(dbias),
               wp, wb)
     return Planes(data, rows, ld, amax), dgamma, dbeta, dbias
