@@ -288,7 +288,16 @@ typedef struct xv_config {
     int32_t max_batch;                /* capacity: chunks per step */
     int32_t max_frames;               /* capacity: frames per chunk */
     int32_t precision;                /* XV_PRECISION_*: how the tdnn1-5 contractions are evaluated */
+    int32_t pooling;                  /* XV_POOL_*: pooling_type, tdnn.py:133-138 */
+    int32_t att_key0_nodes;           /* att_key_num_nodes[0]: dense+bn+relu on tdnn4_relu (pooling.py:78-82) */
+    int32_t att_key1_nodes;           /* att_key_num_nodes[1]: the key dimension (pooling.py:84-96) */
+    int32_t att_key_type;             /* att_key_network_type of the last key layer: 0 affine, 3 affine + tanh */
+    int32_t att_use_scale;            /* att_use_scale: scores / sqrt(key dim) (pooling.py:144-145) */
 } xv_config;
+#define XV_POOL_STATISTICS 0
+/* self_attention in the shipped single-head form (nnet_conf/..._tdnn4_att.json): key network on tdnn4_relu, value = tdnn5_relu,
+ * one head, key not split, no value network, no penalty term, no post non-linearity */
+#define XV_POOL_SELF_ATTENTION 1
 /* fp32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products) */
 #define XV_PRECISION_F32 0
 /* split precision: three fp16 MFMA products of (hi,lo) pieces per fp32 product, fp32 accumulate (2^-22 relative) */

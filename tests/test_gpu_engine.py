@@ -37,6 +37,11 @@ CASES = [
          last_layer_linear=True),
     dict(loss_func="softmax", optimizer="momentum", momentum=0.9, use_nesterov=True),
     dict(loss_func="softmax", optimizer="adam"),
+    # self-attention pooling (pooling.py:37-192), the shipped form of nnet_conf/*_tdnn4_att.json with smaller key layers,
+    # and its affine-key / unscaled variant
+    dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, pooling_type="self_attention",
+         att_key_num_nodes=(300, 200)),
+    dict(loss_func="softmax", pooling_type="self_attention", att_key_num_nodes=(64, 48), att_key_network_type=0, att_use_scale=False),
 ]
 
 
@@ -79,7 +84,7 @@ def test_variable_table_matches_reference_names():
     eng.close()
 
 
-RELU_LAYERS = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5", "tdnn6", "tdnn7")
+RELU_LAYERS = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5", "att_key0", "tdnn6", "tdnn7")
 
 
 def oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x, labels, lr, step, opt_state):
@@ -134,7 +139,7 @@ def oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x, labels, lr, step, opt_st
     return newV, new_state, info
 
 
-@pytest.mark.parametrize("kw", CASES, ids=lambda d: "-".join("%s" % v for v in d.values()))
+@pytest.mark.parametrize("kw", CASES, ids=lambda d: "-".join(str(v).replace(" ", "") for v in d.values()))
 def test_train_step_matches_oracle(kw):
     B, T = 6, 40
     eng, cfg_o, V = _make(kw, B, T)
@@ -150,8 +155,11 @@ def test_train_step_matches_oracle(kw):
     raw, reg = eng.losses()
     assert abs(raw - info["raw_loss"]) <= 2e-5 * abs(info["raw_loss"]) + 1e-6
     assert abs(reg - info["reg_loss"]) <= 2e-5 * abs(info["reg_loss"])
-    for name in ("tdnn1_conv", "tdnn1_relu", "tdnn2_conv", "tdnn3_conv", "tdnn3_relu", "tdnn4_dense", "tdnn5_dense",
-                 "tdnn5_bn", "tdnn5_relu", "pooling", "tdnn6_dense", "tdnn6_relu", "tdnn7_dense", "output", "logits"):
+    names = ["tdnn1_conv", "tdnn1_relu", "tdnn2_conv", "tdnn3_conv", "tdnn3_relu", "tdnn4_dense", "tdnn5_dense",
+             "tdnn5_bn", "tdnn5_relu", "pooling", "tdnn6_dense", "tdnn6_relu", "tdnn7_dense", "output", "logits"]
+    if cfg_o.pooling_type == "self_attention":
+        names += ["att_key0_dense", "att_key0_relu", "att_key1_dense", "attention_weights"]
+    for name in names:
         ref = info["endpoints"][name]
         got = eng.endpoint(name).cpu().numpy()
         # north_star: embeddings within 1e-4 relative; measured ~1e-6..2e-5
@@ -159,6 +167,12 @@ def test_train_step_matches_oracle(kw):
     grads = eng.get_gradients()
     for name, g in grads.items():
         ref = info["grads"][name].reshape(g.shape)
+        if "att_key1_dense/bias" in name:
+            # no BN behind it: a real gradient for the tanh key, 0 + rounding noise for the affine key (the frame gradients
+            # of a chunk sum to zero through the softmax) - absolute criterion on the scale of the layer's kernel gradient
+            scale = max(np.abs(ref).max(), 1e-2 * np.abs(info["grads"][name.replace("/bias", "/kernel")]).max())
+            assert np.abs(g - ref).max() <= 1e-4 * scale, (name, np.abs(g - ref).max(), scale)
+            continue
         if name.endswith("_conv/bias") or (name.endswith("_dense/bias") and not (name.startswith("tdnn/tdnn7") and cfg_o.last_layer_no_bn)):
             # bias in front of a BatchNorm: the true gradient is exactly 0, both sides hold rounding noise
             assert np.abs(g).max() <= 1e-4 * max(1.0, np.abs(info["grads"][name.replace("/bias", "/kernel")]).max())

@@ -46,6 +46,11 @@ class XvConfig(C.Structure):
         ("max_batch", C.c_int32),
         ("max_frames", C.c_int32),
         ("precision", C.c_int32),
+        ("pooling", C.c_int32),
+        ("att_key0_nodes", C.c_int32),
+        ("att_key1_nodes", C.c_int32),
+        ("att_key_type", C.c_int32),
+        ("att_use_scale", C.c_int32),
     ]
 
 
@@ -57,6 +62,7 @@ LOSS_KINDS = {
 }
 OPTIMIZERS = {"sgd": 0, "momentum": 1, "adam": 2}
 PRECISIONS = {"f32": 0, "f16x3": 1}
+POOLINGS = {"statistics_pooling": 0, "self_attention": 1}
 
 _VP = C.c_void_p
 _SZ = C.c_size_t

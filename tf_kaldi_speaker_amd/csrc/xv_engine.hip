@@ -14,6 +14,7 @@
 //                GEMM as the forward pass (xv_gemm.hip).
 //   weights    : kernel-layout copies (transposed / tap-flipped / channel-padded) rebuilt once
 //                per optimiser step.
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -46,6 +47,10 @@ struct Affine {   // one conv/dense layer (+ optional BN, ReLU)
     int o_ld = 0;                             // plane pitch of c_out (multiple of 8)
     float *zmin = nullptr, *zmax = nullptr;
     int rows;                             // rows of the most recent forward
+    std::string scope;                    // variable scope under "tdnn/" ("" or "attention/att_key0/")
+    int in_layer = -1;                    // index of the layer whose output this one reads (-1: the features / the pooled vector)
+    int act = 0;                          // 3: tanh on the affine output (att_key_network_type 3), no BN
+    int wslot = 0, aslot = 0;             // amax slots of the weights / of the BN+ReLU output planes
 };
 
 }  // namespace
@@ -55,7 +60,12 @@ struct xv_engine {
     std::vector<Var> vars;
     size_t n_train = 0, n_all = 0, n_opt = 0;
     float *V = nullptr, *G = nullptr, *S = nullptr;   // bound buffers
-    Affine L[7];
+    Affine L[9];                          // tdnn1..7, then the attention key layers att_key0, att_key1 (self-attention pooling)
+    int NL = 7;                           // layers in use
+    bool att = false;
+    int v_query = -1;
+    float *att_score = nullptr, *att_w = nullptr, *att_dw = nullptr, *att_ds = nullptr;   // [B*T5]
+    float* bufA = nullptr;                // d tdnn4_relu through the key network, [B*T5][512]
     int v_loss_kernel = -1, v_loss_bias = -1;
     int c_pad0 = 0;
     int P = 0, Lout = 0, N = 0, ldl = 0;
@@ -100,6 +110,9 @@ namespace {
 // amax slots: 0 input x | 1..4 BN+ReLU outputs of tdnn1..4 | 8..12 weights of tdnn1..5 (both layouts) | 24,25 dz buffers
 enum { AMAX_X = 0, AMAX_A = 1, AMAX_WT = 8, AMAX_DZ = 24, AMAX_SLOTS = 32 };
 
+// frame-level layers (rows = chunks x frames): tdnn1-5 and the attention key layers; tdnn6/7 are segment level
+inline bool is_frame(int i) { return i < 5 || i >= 7; }
+
 float* carve(xv_engine* e, size_t floats) {
     size_t bytes = xv_align(floats * sizeof(float), 256);
     if (e->arena_used + bytes > e->arena_bytes) return nullptr;
@@ -131,36 +144,49 @@ void build_variables(xv_engine* e) {
     e->P = c.num_nodes_pooling_layer;
     e->Lout = c.num_nodes_last_layer;
     e->N = c.num_speakers;
-    struct Spec { const char* prefix; const char* kind; int k, cin, cout; bool bn, relu, fused; };
-    const Spec specs[7] = {
-        {"tdnn1", "conv", 5, D, 512, true, true, true},
-        {"tdnn2", "conv", 5, 512, 512, true, true, true},
-        {"tdnn3", "conv", 7, 512, 512, true, true, true},
-        {"tdnn4", "dense", 1, 512, 512, true, true, false},
-        {"tdnn5", "dense", 1, 512, e->P, true, true, false},
-        {"tdnn6", "dense", 1, 2 * e->P, 512, true, true, false},
-        {"tdnn7", "dense", 1, 512, e->Lout, !c.last_layer_no_bn, !c.last_layer_linear, false},
+    e->att = c.pooling == XV_POOL_SELF_ATTENTION;
+    e->NL = e->att ? 9 : 7;
+    struct Spec { const char* prefix; const char* kind; const char* scope; int k, cin, cout; bool bn, relu, fused; int in_layer, act; };
+    const Spec specs[9] = {
+        {"tdnn1", "conv", "", 5, D, 512, true, true, true, -1, 0},
+        {"tdnn2", "conv", "", 5, 512, 512, true, true, true, 0, 0},
+        {"tdnn3", "conv", "", 7, 512, 512, true, true, true, 1, 0},
+        {"tdnn4", "dense", "", 1, 512, 512, true, true, false, 2, 0},
+        {"tdnn5", "dense", "", 1, 512, e->P, true, true, false, 3, 0},
+        {"tdnn6", "dense", "", 1, 2 * e->P, 512, true, true, false, -1, 0},
+        {"tdnn7", "dense", "", 1, 512, e->Lout, !c.last_layer_no_bn, !c.last_layer_linear, false, 5, 0},
+        // self-attention key network (pooling.py:78-96): dense+bn+relu on tdnn4_relu, then dense (+tanh)
+        {"att_key0", "dense", "attention/att_key0/", 1, 512, c.att_key0_nodes, true, true, false, 3, 0},
+        {"att_key1", "dense", "attention/att_key1/", 1, c.att_key0_nodes, c.att_key1_nodes, false, false, false, 7, c.att_key_type},
     };
-    for (int i = 0; i < 7; ++i) {
+    // graph-construction order of the reference: tdnn1-5, the pooling layer's variables, tdnn6-7
+    const int order[9] = {0, 1, 2, 3, 4, 7, 8, 5, 6};
+    for (int oi = 0; oi < 9; ++oi) {
+        const int i = order[oi];
+        if (i >= e->NL) continue;
         Affine& a = e->L[i];
         const Spec& s = specs[i];
-        a.prefix = s.prefix; a.kind = s.kind;
+        a.prefix = s.prefix; a.kind = s.kind; a.scope = s.scope; a.in_layer = s.in_layer; a.act = s.act;
         a.k = s.k; a.c_in = s.cin; a.c_out = s.cout;
-        a.c_pad = (int)xv_align(s.cin, i == 0 ? 8 : 4);   // == c_in except for the feature layer (30 -> 32)
+        // operand pitch: 16-byte chunks of fp16 planes need multiples of 8 (feature layer 30 -> 32, att_key1 1500 -> 1504)
+        a.c_pad = (int)xv_align(s.cin, (i == 0 || (e->f16 && is_frame(i))) ? 8 : 4);
         a.o_ld = (int)xv_align(s.cout, 8);
         a.has_bn = s.bn; a.has_relu = s.relu; a.fused_bn = s.fused;
-        std::string base = std::string("tdnn/") + s.prefix + "_" + s.kind;
+        a.wslot = i < 5 ? i : i - 2;          // amax slots of the weights: tdnn1-5 -> 0..4, att_key0/1 -> 5, 6
+        a.aslot = i < 5 ? i : 4;              // BN+ReLU output planes: tdnn1-4 -> 0..3, att_key0 -> 4
+        std::string base = std::string("tdnn/") + s.scope + s.prefix + "_" + s.kind;
         if (s.k > 1) a.v_kernel = add_var(e, base + "/kernel", {1, s.k, s.cin, s.cout}, true);
         else a.v_kernel = add_var(e, base + "/kernel", {s.cin, s.cout}, true);
         a.v_bias = add_var(e, base + "/bias", {s.cout}, true);
         a.v_gamma = a.v_beta = a.v_mmean = a.v_mvar = -1;
         if (s.bn) {
-            std::string bn = std::string("tdnn/") + s.prefix + "_bn";
+            std::string bn = std::string("tdnn/") + s.scope + s.prefix + "_bn";
             a.v_gamma = add_var(e, bn + "/gamma", {s.cout}, true);
             a.v_beta = add_var(e, bn + "/beta", {s.cout}, true);
             a.v_mmean = add_var(e, bn + "/moving_mean", {s.cout}, false);
             a.v_mvar = add_var(e, bn + "/moving_variance", {s.cout}, false);
         }
+        if (i == 8) e->v_query = add_var(e, "tdnn/attention/query", {1, s.cout}, true);   // [heads, key dim], pooling.py:131
     }
     e->c_pad0 = e->L[0].c_pad;
     if (e->N > 0) {
@@ -194,9 +220,10 @@ int alloc_buffers(xv_engine* e) {
     size_t need = 0;
     auto want = [&](size_t floats) { need += xv_align(floats * sizeof(float), 256); };
     want(rows[0] * e->c_pad0);
-    for (int i = 0; i < 7; ++i) {
+    auto lrows = [&](int i) -> size_t { return i < 5 ? rows[i + 1] : (i >= 7 ? rows[5] : B); };
+    for (int i = 0; i < e->NL; ++i) {
         Affine& a = e->L[i];
-        size_t r = i < 5 ? rows[i + 1] : B;
+        size_t r = lrows(i);
         want((size_t)a.c_out * a.k * a.c_pad);                 // wt
         if (a.k > 1) want((size_t)a.c_in * a.k * a.c_out);     // wf
         want(r * a.c_out); want(r * a.c_out);                  // z, a
@@ -205,21 +232,24 @@ int alloc_buffers(xv_engine* e) {
     }
     if (e->f16) {
         want(rows[0] * e->c_pad0);                                              // xh: 2 planes of halfs == 1 float per element
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < e->NL; ++i) {
+            if (!is_frame(i)) continue;
             Affine& a = e->L[i];
             want((size_t)a.c_out * a.k * a.c_pad);                              // wth
             if (i > 0) want((size_t)a.c_in * a.k * a.o_ld);                     // wfh
-            if (i < 4) want(rows[i + 1] * a.o_ld);                              // ah
+            if (i < 4 || i == 7) want(lrows(i) * a.o_ld);                       // ah
             want(a.c_out); want(a.c_out);                                       // zmin, zmax
         }
         want(AMAX_SLOTS);
     }
+    if (e->att) { for (int j = 0; j < 4; ++j) want(rows[5]); want(rows[5] * 512); }
     want(B * 2 * e->P); want(B * e->Lout); want(B * e->Lout);
     if (e->N > 0) {
         want(B * e->ldl); want(B * e->ldl); want(B); want(B);
         want(e->N); want((size_t)e->Lout * e->ldl); want((size_t)e->N * e->Lout); want((size_t)e->Lout * e->ldl);
     }
     size_t maxc = e->P > 512 ? e->P : 512;
+    if (e->att) { maxc = std::max<size_t>(maxc, (size_t)c.att_key0_nodes); maxc = std::max<size_t>(maxc, (size_t)c.att_key1_nodes); }
     size_t bufd = rows[1] * 512;
     if (rows[5] * maxc > bufd) bufd = rows[5] * maxc;
     size_t bufz = B * (T - 8 + 8) * 512;                        // tdnn2: (T2 + 2*4) frames
@@ -233,13 +263,13 @@ int alloc_buffers(xv_engine* e) {
     want(16);
     // GEMM split slabs: weight-gradient partials dominate
     size_t ws = 0;
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < e->NL; ++i) {
         Affine& a = e->L[i];
-        size_t r = i < 5 ? rows[i + 1] : B;
+        size_t r = lrows(i);
         int M = a.k * a.c_pad, Nn = a.c_out;
         size_t s = (size_t)xv_tn_splits(M, Nn, (int)r) * M * Nn * sizeof(float);
         if (s > ws) ws = s;
-        if (e->f16 && i < 5) {
+        if (e->f16 && is_frame(i)) {
             s = (size_t)xv_tn16_splits(M, a.o_ld, (int)r) * M * a.o_ld * sizeof(float);
             if (s > ws) ws = s;
         }
@@ -252,6 +282,10 @@ int alloc_buffers(xv_engine* e) {
     }
     size_t opws = xv_op_workspace_bytes((int)rows[1], 2 * e->P, 2 * e->P);
     if (opws > ws) ws = opws;
+    if (e->att) {       // xv_att_key_backward: per-chunk partials + the column-sum workspace
+        size_t s = 2 * ((size_t)xv_cdiv(rows[5], 64) * 2 * c.att_key1_nodes * sizeof(float) + xv_op_workspace_bytes((int)rows[5], c.att_key1_nodes, c.att_key1_nodes)) + 4096;
+        if (s > ws) ws = s;
+    }
     ws = xv_align(ws, 256);
     need += 2 * ws + 8192;
     XV_CHECK_HIP(hipMalloc((void**)&e->arena, need));
@@ -260,9 +294,9 @@ int alloc_buffers(xv_engine* e) {
     e->arena_used = 0;
     // --- carve pass
     e->xpad = carve(e, rows[0] * e->c_pad0);
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < e->NL; ++i) {
         Affine& a = e->L[i];
-        size_t r = i < 5 ? rows[i + 1] : B;
+        size_t r = lrows(i);
         a.wt = carve(e, (size_t)a.c_out * a.k * a.c_pad);
         a.wf = a.k > 1 ? carve(e, (size_t)a.c_in * a.k * a.c_out) : nullptr;
         a.z = carve(e, r * a.c_out);
@@ -274,7 +308,8 @@ int alloc_buffers(xv_engine* e) {
     }
     if (e->f16) {
         e->xh = (unsigned short*)carve(e, rows[0] * e->c_pad0);
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < e->NL; ++i) {
+            if (!is_frame(i)) continue;
             Affine& a = e->L[i];
             a.wth_stride = (size_t)a.c_out * a.k * a.c_pad;
             a.wth = (unsigned short*)carve(e, a.wth_stride);
@@ -282,11 +317,15 @@ int alloc_buffers(xv_engine* e) {
                 a.wfh_stride = (size_t)a.c_in * a.k * a.o_ld;
                 a.wfh = (unsigned short*)carve(e, a.wfh_stride);
             }
-            if (i < 4) a.ah = (unsigned short*)carve(e, rows[i + 1] * a.o_ld);
+            if (i < 4 || i == 7) a.ah = (unsigned short*)carve(e, lrows(i) * a.o_ld);
             a.zmin = carve(e, a.c_out);
             a.zmax = carve(e, a.c_out);
         }
         e->amax = (uint32_t*)carve(e, AMAX_SLOTS);
+    }
+    if (e->att) {
+        e->att_score = carve(e, rows[5]); e->att_w = carve(e, rows[5]); e->att_dw = carve(e, rows[5]); e->att_ds = carve(e, rows[5]);
+        e->bufA = carve(e, rows[5] * 512);
     }
     e->pool = carve(e, B * 2 * e->P);
     e->h7_buf = carve(e, B * e->Lout);
@@ -333,14 +372,14 @@ int ensure_weights(xv_engine* e, hipStream_t s) {
     if (!e->weights_dirty) return 0;
     XvPrepJobs J = {};
     XvAmaxJobs A = {};
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < e->NL; ++i) {
         Affine& a = e->L[i];
         const float* w = vptr(e, a.v_kernel);
-        if (e->f16 && i < 5) {
+        if (e->f16 && is_frame(i)) {
             // fp16 planes scaled by the tensor's own max |w|; the forward and dgrad layouts hold the same values, so one
             // max per layer, taken on the variable itself
-            const unsigned* am = e->amax + AMAX_WT + i;
-            A.x[A.n] = w; A.count[A.n] = (size_t)a.k * a.c_in * a.c_out; A.out[A.n] = e->amax + AMAX_WT + i; A.n++;
+            const unsigned* am = e->amax + AMAX_WT + a.wslot;
+            A.x[A.n] = w; A.count[A.n] = (size_t)a.k * a.c_in * a.c_out; A.out[A.n] = e->amax + AMAX_WT + a.wslot; A.n++;
             int rc = xv_prep_add(J, XV_PREP_T16, w, a.k, a.c_in, a.c_out, a.c_pad, a.o_ld, a.wth, (long)a.wth_stride, am);
             if (rc) return rc;
             if (i > 0) {
@@ -412,6 +451,13 @@ extern "C" int xv_engine_create(const xv_config* cfg, xv_engine** out) {
         XV_REQUIRE(cfg->margin_m == 1.f || cfg->margin_m == 2.f || cfg->margin_m == 4.f, "[ERROR] m=%d is not unsupported.", (int)cfg->margin_m);
     XV_REQUIRE(!cfg->feature_norm || cfg->feature_scaling_factor > 0.f, "If feature normalization is applied, scaling factor is necessary.");
     XV_REQUIRE(cfg->precision == XV_PRECISION_F32 || cfg->precision == XV_PRECISION_F16X3, "engine_create: unknown precision %d", cfg->precision);
+    XV_REQUIRE(cfg->pooling == XV_POOL_STATISTICS || cfg->pooling == XV_POOL_SELF_ATTENTION, "Not implement pooling kind %d", cfg->pooling);
+    if (cfg->pooling == XV_POOL_SELF_ATTENTION) {
+        XV_REQUIRE(cfg->att_key0_nodes > 0 && cfg->att_key0_nodes % 4 == 0 && cfg->att_key1_nodes > 0 && cfg->att_key1_nodes % 4 == 0,
+                   "engine_create: att_key_num_nodes must be two positive multiples of 4 (got %d, %d)", cfg->att_key0_nodes, cfg->att_key1_nodes);
+        XV_REQUIRE(cfg->att_key_type == 0 || cfg->att_key_type == 3, "engine_create: att_key_network_type %d is not implemented (0 affine, 3 tanh)",
+                   cfg->att_key_type);
+    }
     xv_engine* e = new xv_engine();
     e->cfg = *cfg;
     e->f16 = cfg->precision == XV_PRECISION_F16X3;
@@ -498,9 +544,9 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             int rows = b * t_out;
             // the epilogue's column min/max are needed in inference too (they fix the next operand's scale)
             rc = xv_affine_forward_f16x3(s, curh, cur_stride, cur_amax, b, cur_t, a.c_pad, a.k, a.wth, a.wth_stride,
-                                         e->amax + AMAX_WT + i, vptr(e, a.v_bias), a.z, a.c_out, a.c_out, a.bn_part);
+                                         e->amax + AMAX_WT + a.wslot, vptr(e, a.v_bias), a.z, a.c_out, a.c_out, a.bn_part);
             if (rc) return rc;
-            uint32_t* out_amax = i < 4 ? e->amax + AMAX_A + i : nullptr;
+            uint32_t* out_amax = i < 4 ? e->amax + AMAX_A + a.aslot : nullptr;
             const xv_config& c = e->cfg;
             if (training) {
                 rc = xv_bn_finalize(s, a.bn_part, rows, a.c_out, vptr(e, a.v_gamma), vptr(e, a.v_beta), c.bn_epsilon, c.batchnorm_momentum,
@@ -522,6 +568,33 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             cur_t = t_out;
             e->Tl[i + 1] = t_out;
         }
+        if (e->att) {
+            // key network on tdnn4_relu (its planes are still there): att_key0 = dense+bn+relu -> planes, att_key1 = dense
+            const xv_config& c = e->cfg;
+            Affine &k0 = e->L[7], &k1 = e->L[8], &in = e->L[3];
+            const int rows = b * cur_t;
+            uint32_t* k0_amax = e->amax + AMAX_A + k0.aslot;
+            rc = xv_affine_forward_f16x3(s, in.ah, (size_t)rows * in.o_ld, e->amax + AMAX_A + in.aslot, rows, 1, k0.c_pad, 1, k0.wth,
+                                         k0.wth_stride, e->amax + AMAX_WT + k0.wslot, vptr(e, k0.v_bias), k0.z, k0.c_out, k0.c_out, k0.bn_part);
+            if (rc) return rc;
+            if (training) {
+                rc = xv_bn_finalize(s, k0.bn_part, rows, k0.c_out, vptr(e, k0.v_gamma), vptr(e, k0.v_beta), c.bn_epsilon, c.batchnorm_momentum,
+                                    0, vptr(e, k0.v_mmean), vptr(e, k0.v_mvar), k0.mean, k0.invstd, k0.scale, k0.shift, k0.zmin, k0.zmax,
+                                    k0_amax, 1);
+            } else {
+                rc = xv_bn_inference_scale(s, k0.c_out, vptr(e, k0.v_gamma), vptr(e, k0.v_beta), vptr(e, k0.v_mmean), vptr(e, k0.v_mvar),
+                                           c.bn_epsilon, k0.scale, k0.shift);
+                if (rc) return rc;
+                rc = xv_bn_output_range(s, k0.bn_part, rows, k0.c_out, k0.scale, k0.shift, 1, k0.zmin, k0.zmax, k0_amax);
+            }
+            if (rc) return rc;
+            rc = xv_bn_apply_split(s, k0.z, rows, k0.c_out, k0.c_out, k0.scale, k0.shift, 1, k0_amax, k0.ah, k0.o_ld, (size_t)rows * k0.o_ld);
+            if (rc) return rc;
+            rc = xv_affine_forward_f16x3(s, k0.ah, (size_t)rows * k0.o_ld, k0_amax, rows, 1, k1.c_pad, 1, k1.wth, k1.wth_stride,
+                                         e->amax + AMAX_WT + k1.wslot, vptr(e, k1.v_bias), k1.z, k1.c_out, k1.c_out, nullptr);
+            if (rc) return rc;
+            k0.rows = k1.rows = rows;
+        }
     } else {
         rc = xv_pad_channels(s, features, b * t, e->cfg.feat_dim, e->xpad, e->c_pad0);
         if (rc) return rc;
@@ -539,9 +612,33 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             cur = a.a; cur_t = t_out;
             e->Tl[i + 1] = t_out;
         }
+        if (e->att) {
+            Affine &k0 = e->L[7], &k1 = e->L[8];
+            const int rows = b * cur_t;
+            rc = xv_affine_forward(s, e->L[3].a, rows, 1, k0.c_pad, 1, k0.wt, vptr(e, k0.v_bias), k0.z, k0.c_out, k0.c_out,
+                                   training ? k0.bn_part : nullptr, e->ws, e->ws_bytes);
+            if (rc) return rc;
+            rc = bn_forward(e, s, k0, rows, true, k0.a);
+            if (rc) return rc;
+            rc = xv_affine_forward(s, k0.a, rows, 1, k1.c_pad, 1, k1.wt, vptr(e, k1.v_bias), k1.z, k1.c_out, k1.c_out, nullptr, e->ws,
+                                   e->ws_bytes);
+            if (rc) return rc;
+            k0.rows = k1.rows = rows;
+        }
+    }
+    const float* frame_w = nullptr;
+    if (e->att) {
+        // scores = key.query (/ sqrt(dk)), weights = softmax over the frames of each chunk (pooling.py:134-148)
+        Affine& k1 = e->L[8];
+        const float scale = e->cfg.att_use_scale ? 1.0f / sqrtf((float)k1.c_out) : 1.0f;
+        rc = xv_att_score(s, k1.z, b * cur_t, k1.c_out, k1.c_out, k1.act, vptr(e, e->v_query), scale, e->att_score);
+        if (rc) return rc;
+        rc = xv_softmax_segments(s, e->att_score, b, cur_t, e->att_w);
+        if (rc) return rc;
+        frame_w = e->att_w;
     }
     // tdnn5's BN + ReLU is applied inside the pooling reduction: its [b*t][1500] activation is never written
-    rc = xv_stat_pool_forward_bn(s, e->L[4].z, b, cur_t, e->P, e->L[4].scale, e->L[4].shift, 1, nullptr, e->pool);
+    rc = xv_stat_pool_forward_bn(s, e->L[4].z, b, cur_t, e->P, e->L[4].scale, e->L[4].shift, 1, frame_w, e->pool);
     if (rc) return rc;
     // segment-level layers
     Affine& l6 = e->L[5];
@@ -614,7 +711,7 @@ extern "C" int xv_engine_loss_forward(xv_engine* e, void* stream, const int32_t*
 static int compute_reg_loss(xv_engine* e, hipStream_t s) {
     const xv_config& c = e->cfg;
     XV_CHECK_HIP(hipMemsetAsync(e->scalars + 1, 0, sizeof(float), s));
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < e->NL; ++i) {
         int rc = xv_l2_reg_loss(s, vptr(e, e->L[i].v_kernel), e->vars[e->L[i].v_kernel].count, c.weight_l2_regularizer, e->scalars + 1);
         if (rc) return rc;
     }
@@ -661,7 +758,8 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     const int t_out = t_in - a.k + 1;
     const int pad = (dx && a.k > 1) ? a.k - 1 : 0;
     int rc;
-    if (e->f16 && &a <= &e->L[4]) return layer_backward_f16(e, s, (int)(&a - &e->L[0]), da, segs, t_in, dx);
+    const int lidx = (int)(&a - &e->L[0]);
+    if (e->f16 && is_frame(lidx)) return layer_backward_f16(e, s, lidx, da, segs, t_in, dx);
     const float* dz = nullptr;
     const int zi = e->zcur;
     float* Z = e->bufZ[zi];
@@ -671,11 +769,11 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     }
     if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
         XV_REQUIRE(&a == &e->L[4] && a.has_bn, "engine_backward: only tdnn5 takes its gradient from the pooling layer");
-        rc = xv_bn_relu_backward_pooled(s, e->pool, e->d_small0, nullptr, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale,
+        rc = xv_bn_relu_backward_pooled(s, e->pool, e->d_small0, e->att ? e->att_w : nullptr, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale,
                                         a.shift, 1, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
         if (rc) return rc;
         dz = Z;
-    } else if (a.has_bn && pad == 0 && segs * t_out <= XV_BN_SMALL_MAX_ROWS && &a > &e->L[4]) {      // segment-level layers: one launch
+    } else if (a.has_bn && pad == 0 && segs * t_out <= XV_BN_SMALL_MAX_ROWS && !is_frame(lidx)) {      // segment-level layers: one launch
         rc = xv_bn_small_backward(s, da, a.z, segs * t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift,
                                   a.has_relu ? 1 : 0, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias));
         if (rc) return rc;
@@ -741,19 +839,28 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
     int rc;
     if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
         XV_REQUIRE(li == 4, "engine_backward: only tdnn5 takes its gradient from the pooling layer");
-        rc = xv_bn_relu_backward_pooled_split(s, e->pool, e->d_small0, nullptr, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd,
+        rc = xv_bn_relu_backward_pooled_split(s, e->pool, e->d_small0, e->att ? e->att_w : nullptr, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd,
                                               a.scale, a.shift, a.zmin, a.zmax, 1, Z, a.o_ld, zstride, zamax, gptr(e, a.v_gamma),
                                               gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
+    } else if (!a.has_bn) {      // att_key1: `da` already is dz (fp32): planes + the bias gradient straight from it
+        XV_REQUIRE(pad == 0 && !a.has_relu, "engine_backward: a frame layer without BN is the attention key layer");
+        XV_CHECK_HIP(hipMemsetAsync(zamax, 0, sizeof(uint32_t), s));
+        rc = xv_amax(s, da, (size_t)segs * t_out * a.c_out, zamax);
+        if (rc) return rc;
+        rc = xv_split_planes(s, da, segs * t_out, a.c_out, a.c_out, Z, a.o_ld, zstride, zamax);
+        if (rc) return rc;
+        rc = xv_colsum(s, da, segs * t_out, a.c_out, a.c_out, gptr(e, a.v_bias), e->ws, e->ws_bytes);
     } else {
         rc = xv_bn_relu_backward_split(s, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift, a.zmin,
                                        a.zmax, 1, pad, Z, a.o_ld, zstride, zamax, gptr(e, a.v_gamma), gptr(e, a.v_beta),
                                        gptr(e, a.v_bias), e->ws, e->ws_bytes);
     }
     if (rc) return rc;
-    // operand planes of this layer's input: the feature planes for tdnn1, the previous layer's BN+ReLU planes otherwise
-    const unsigned short* xin = li == 0 ? e->xh : e->L[li - 1].ah;
-    const int xin_rows = li == 0 ? e->B * e->Tl[0] : e->L[li - 1].rows;
-    const uint32_t* xin_amax = li == 0 ? e->amax + AMAX_X : e->amax + AMAX_A + (li - 1);
+    // operand planes of this layer's input: the feature planes for tdnn1, the producing layer's BN+ReLU planes otherwise
+    const int in = a.in_layer;
+    const unsigned short* xin = in < 0 ? e->xh : e->L[in].ah;
+    const int xin_rows = in < 0 ? e->B * e->Tl[0] : e->L[in].rows;
+    const uint32_t* xin_amax = in < 0 ? e->amax + AMAX_X : e->amax + AMAX_A + e->L[in].aslot;
     // tdnn1 is the end of the chain: nothing is left on `s` to overlap with, and the side stream is still busy with
     // tdnn2's weight gradient - its own (small) weight gradient finishes sooner in line on `s`
     const bool conc = e->concurrent && li > 0;
@@ -773,7 +880,7 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
     }
     e->zcur ^= 1;
     if (dx) {
-        rc = xv_affine_dgrad_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WT + li, dx, a.c_in);
+        rc = xv_affine_dgrad_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WT + a.wslot, dx, a.c_in);
         if (rc) return rc;
     }
     return 0;
@@ -849,7 +956,33 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
         if (stage == 0) { rc = join_side(e, s); if (rc) return rc; }
     }
     if (stage == -1 || stage == 1) {
+        if (e->att) {
+            // through the attention weights into the key network (pooling.py:134-155): d weights from the pooled statistics,
+            // softmax backward, then att_key1 (dense [+ tanh]) and att_key0 (dense + bn + relu) down to tdnn4_relu (bufA)
+            Affine &k0 = e->L[7], &k1 = e->L[8];
+            const int rows = b * e->Tl[5];
+            const float scale = c.att_use_scale ? 1.0f / sqrtf((float)k1.c_out) : 1.0f;
+            rc = xv_att_pool_backward_weights(s, e->L[4].z, b, e->Tl[5], e->P, e->L[4].scale, e->L[4].shift, 1, e->pool, e->d_small0, e->att_dw);
+            if (rc) return rc;
+            rc = xv_softmax_segments_backward(s, e->att_w, e->att_dw, b, e->Tl[5], e->att_ds);
+            if (rc) return rc;
+            // dzk (fp32): in split precision the fp32 dz buffers are otherwise unused; in fp32 it is the dz ping-pong buffer
+            float* dzk = e->bufZ[e->f16 ? 0 : e->zcur];
+            if (!e->f16 && e->w_pending[e->zcur]) {
+                XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_w[e->zcur], 0));
+                e->w_pending[e->zcur] = false;
+            }
+            rc = xv_att_key_backward(s, k1.z, rows, k1.c_out, k1.act, vptr(e, e->v_query), scale, e->att_ds, dzk, gptr(e, e->v_query), nullptr,
+                                     e->ws, e->ws_bytes);
+            if (rc) return rc;
+            rc = layer_backward(e, s, k1, dzk, k0.a, rows, 1, e->bufD, nullptr);      // -> d att_key0_relu (bufD)
+            if (rc) return rc;
+            rc = layer_backward(e, s, k0, e->bufD, e->L[3].a, rows, 1, e->bufA, nullptr);  // -> d tdnn4_relu through the keys (bufA)
+            if (rc) return rc;
+        }
         rc = layer_backward(e, s, e->L[4], nullptr, e->L[3].a, b * e->Tl[5], 1, e->bufD, nullptr);   // tdnn5 (da = pooling backward) -> d a4
+        if (rc) return rc;
+        if (e->att) rc = xv_add_inplace(s, e->bufD, e->bufA, (size_t)b * e->Tl[5] * 512);                // the two paths into tdnn4_relu
         if (rc) return rc;
         rc = layer_backward(e, s, e->L[3], e->bufD, e->L[2].a, b * e->Tl[4], 1, e->bufD, nullptr);   // tdnn4
         if (rc) return rc;
@@ -924,11 +1057,11 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
     XV_REQUIRE(e->B > 0, "engine_endpoint: run forward first");
     std::string n(name);
     auto set = [&](float* p, int r, int c, int l) { *ptr = p; *rows = r; *cols = c; *ld = l; return 0; };
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < e->NL; ++i) {
         Affine& a = e->L[i];
         if (n == a.prefix + "_" + a.kind) return set(a.z, a.rows, a.c_out, a.c_out);
         if (n == a.prefix + "_relu" && a.has_relu) {
-            if ((e->f16 && i < 4) || i == 4) {     // not materialised on the hot path (fp16 planes / fused into pooling): rebuild on demand
+            if ((e->f16 && (i < 4 || i == 7)) || i == 4) {     // not materialised on the hot path (fp16 planes / fused into pooling): rebuild on demand
                 int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 1, a.a, a.c_out);
                 if (rc) return rc;
             }
@@ -952,6 +1085,7 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
         return set(e->bufD, e->B * e->Tl[5], e->P, e->P);
     }
     if (n == "debug:dpool") return set(e->d_small0, e->B, 2 * e->P, 2 * e->P);
+    if (n == "attention_weights" && e->att) return set(e->att_w, e->B, e->Tl[5], e->Tl[5]);     // [b, heads = 1, frames]
     if (n == "pooling") return set(e->pool, e->B, 2 * e->P, 2 * e->P);
     if (n == "output") return set(e->out, e->B, e->Lout, e->Lout);
     if (n == "logits" && e->N > 0) return set(e->logits, e->B, e->N, e->ldl);

@@ -13,10 +13,10 @@ import torch
 
 try:
     from . import _lib
-    from ._lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, PRECISIONS, XV_BWD_STAGES
+    from ._lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, PRECISIONS, POOLINGS, XV_BWD_STAGES
 except ImportError:      # drop-in layout: PYTHONPATH=$TF_KALDI_ROOT makes these top-level modules
     import _lib
-    from _lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, PRECISIONS, XV_BWD_STAGES
+    from _lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, PRECISIONS, POOLINGS, XV_BWD_STAGES
 
 
 # How tdnn1-5's contractions are evaluated unless make_config(precision=...) / $XV_PRECISION says otherwise.
@@ -41,7 +41,10 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
                 last_layer_no_bn=False, last_layer_linear=False, feature_norm=False, feature_scaling_factor=1.0,
                 weight_l2_regularizer=1e-2, output_weight_l2_regularizer=None, batchnorm_momentum=0.99,
                 bn_epsilon=1e-3, fused_bn_unbiased_moving_var=True, optimizer="sgd", momentum=0.9, use_nesterov=False,
-                clip_gradient_norm=0.0, max_batch=128, max_frames=400, precision=None):
+                clip_gradient_norm=0.0, max_batch=128, max_frames=400, precision=None, pooling_type="statistics_pooling",
+                att_key_num_nodes=(1500, 1500), att_key_network_type=3, att_use_scale=True):
+    if pooling_type not in POOLINGS:
+        raise NotImplementedError("Not implement %s pooling" % pooling_type)
     if loss_func not in LOSS_KINDS:
         raise NotImplementedError("Not implement %s loss" % loss_func)
     if optimizer not in OPTIMIZERS:
@@ -75,6 +78,16 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
     c.precision = PRECISIONS[precision]
+    c.pooling = POOLINGS[pooling_type]
+    if pooling_type == "self_attention":
+        # the shipped single-head form (nnet_conf/*_tdnn4_att.json): two key layers on tdnn4_relu, value = tdnn5_relu
+        if len(att_key_num_nodes) != 2:
+            raise NotImplementedError("self_attention: att_key_num_nodes must have two entries (dense+bn+relu, then the key layer)")
+        if int(att_key_network_type) not in (0, 3):
+            raise NotImplementedError("self_attention: att_key_network_type %r is not implemented (0 affine, 3 tanh)" % att_key_network_type)
+        c.att_key0_nodes, c.att_key1_nodes = int(att_key_num_nodes[0]), int(att_key_num_nodes[1])
+        c.att_key_type = int(att_key_network_type)
+        c.att_use_scale = int(bool(att_use_scale))
     return c
 
 

@@ -37,8 +37,32 @@ def check_params(params):
         raise NotImplementedError("network_relu_type %s is not implemented (no shipped config uses it)" % params.network_relu_type)
     if "num_nodes_pooling_layer" not in params.dict:
         params.dict["num_nodes_pooling_layer"] = 1500
-    if params.pooling_type != "statistics_pooling":
-        if params.pooling_type in ("self_attention", "ghost_vlad"):
+    if params.pooling_type == "self_attention":
+        # model/pooling.py:37-192 in the form the shipped attention config uses; everything else the function offers
+        # (value network, several heads, split keys, penalty term, post non-linearity) is refused by name
+        d = params.dict
+        unsupported = []
+        if d.get("att_key_input") != "tdnn4_relu":
+            unsupported.append("att_key_input=%r (tdnn4_relu)" % d.get("att_key_input"))
+        if d.get("att_value_input") != "tdnn5_relu":
+            unsupported.append("att_value_input=%r (tdnn5_relu)" % d.get("att_value_input"))
+        if len(d.get("att_value_num_nodes", [])) != 0:
+            unsupported.append("att_value_num_nodes (no value network)")
+        if len(d.get("att_key_num_nodes", [])) != 2:
+            unsupported.append("att_key_num_nodes (two key layers)")
+        if int(d.get("att_key_network_type", -1)) not in (0, 3):
+            unsupported.append("att_key_network_type=%r (0 or 3)" % d.get("att_key_network_type"))
+        if int(d.get("att_num_heads", 1)) != 1 or d.get("att_split_key", False):
+            unsupported.append("att_num_heads / att_split_key (one head)")
+        if float(d.get("att_penalty_term", 0) or 0) != 0.0:
+            unsupported.append("att_penalty_term (0)")
+        if d.get("att_apply_nonlinear", False):
+            unsupported.append("att_apply_nonlinear (false)")
+        if unsupported:
+            raise NotImplementedError("self_attention on the MI355X engine supports the shipped single-head form only; not: "
+                                      + ", ".join(unsupported))
+    elif params.pooling_type != "statistics_pooling":
+        if params.pooling_type == "ghost_vlad":
             raise NotImplementedError("Not implement %s pooling on the MI355X engine yet" % params.pooling_type)
         raise NotImplementedError("Not implement %s pooling" % params.pooling_type)
     if "num_nodes_last_layer" not in params.dict:
@@ -61,7 +85,11 @@ def engine_config(params, dim, num_speakers=0, loss_type="softmax", max_batch=12
               momentum=float(d.get("momentum", 0.0) or 0.0), use_nesterov=bool(d.get("use_nesterov", False)),
               clip_gradient_norm=float(d["clip_gradient_norm"]) if d.get("clip_gradient", False) else 0.0,
               max_batch=max_batch, max_frames=max_frames,
-              precision=d.get("precision", None))      # engine extension: "f16x3" (default) | "f32"; absent from reference configs
+              precision=d.get("precision", None),      # engine extension: "f16x3" (default) | "f32"; absent from reference configs
+              pooling_type=d["pooling_type"])
+    if d["pooling_type"] == "self_attention":
+        kw.update(att_key_num_nodes=tuple(d["att_key_num_nodes"]), att_key_network_type=int(d["att_key_network_type"]),
+                  att_use_scale=bool(d.get("att_use_scale", False)))
     if d.get("feature_norm", False):
         assert "feature_scaling_factor" in d, "If feature normalization is applied, scaling factor is necessary."
     prefix = {"asoftmax": "asoftmax", "additive_margin_softmax": "amsoftmax", "additive_angular_margin_softmax": "arcsoftmax"}.get(loss_type)
