@@ -90,6 +90,54 @@ def test_trainer_api_roundtrip(tmp_path):
     tr2.close()
 
 
+ATT_KEYS = {   # the attention block of egs/voxceleb/v1/nnet_conf/tdnn_amsoftmax_m0.20_linear_bn_1e-2_tdnn4_att.json:17-28 (key widths shrunk)
+    "pooling_type": "self_attention", "att_key_input": "tdnn4_relu", "att_key_num_nodes": [96, 64], "att_key_network_type": 3,
+    "att_value_input": "tdnn5_relu", "att_value_num_nodes": [], "att_value_network_type": 0, "att_apply_nonlinear": False,
+    "att_use_scale": True, "att_num_heads": 1, "att_split_key": False, "att_penalty_term": 0,
+}
+
+
+def test_trainer_with_self_attention_pooling(tmp_path):
+    """The shipped attention configuration through the Trainer: train one epoch, checkpoint round trip, embeddings of a fresh
+    predict-only Trainer against the oracle in inference mode; unsupported attention options are refused by name."""
+    from tf_kaldi_speaker_amd.misc.utils import Params
+    from tf_kaldi_speaker_amd.model.trainer import Trainer
+    data, spklist, mats = make_data_dir(str(tmp_path / "train"), num_spk=6, utts_per_spk=3, min_frames=60, max_frames=110)
+    cfg = dict(CONFIG, **ATT_KEYS)
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps(cfg))
+    params = Params(str(cfg_path))
+    model = str(tmp_path / "exp")
+    os.makedirs(os.path.join(model, "nnet"))
+    tr = Trainer(params, model)
+    tr.build("train", dim=30, loss_type=params.loss_func, num_speakers=6)
+    names = list(tr.engine.table)
+    assert "tdnn/attention/att_key0/att_key0_dense/kernel" in names and "tdnn/attention/query" in names
+    assert names.index("tdnn/attention/query") < names.index("tdnn/tdnn6_dense/kernel")      # graph order of the reference
+    before = tr.engine.get_variables()
+    tr.train(data, spklist, 0.01)
+    after = tr.engine.get_variables()
+    for k in ("tdnn/attention/att_key1/att_key1_dense/kernel", "tdnn/attention/query", "tdnn/attention/att_key0/att_key0_bn/moving_mean"):
+        assert np.abs(after[k] - before[k]).max() > 0, k
+    p2 = Params(str(cfg_path))
+    tr2 = Trainer(p2, model, single_cpu=True)
+    tr2.build("predict", dim=30)
+    feat = next(iter(mats.values()))
+    e1 = tr2.predict(feat)
+    V = {k: v.astype(np.float64) for k, v in after.items()}
+    cfg_o = O.Config(feat_dim=30, num_speakers=6, loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True,
+                     pooling_type="self_attention", att_key_num_nodes=(96, 64))
+    _, ep, _ = O.tdnn_forward(V, feat[None].astype(np.float64), cfg_o, False)
+    ref = ep["tdnn6_dense"][0]
+    assert np.abs(e1 - ref).max() / np.abs(ref).max() < 1e-4
+    tr.close()
+    tr2.close()
+    bad = dict(cfg, att_num_heads=4)
+    (tmp_path / "bad.json").write_text(json.dumps(bad))
+    with pytest.raises(NotImplementedError, match="att_num_heads"):
+        Trainer(Params(str(tmp_path / "bad.json")), model).build("train", dim=30, loss_type="additive_margin_softmax", num_speakers=6)
+
+
 def test_drivers_as_run_sh_calls_them(tmp_path):
     """python nnet/lib/train.py ... ; make_checkpoint.py ; extract.py with PYTHONPATH=$TF_KALDI_ROOT (run_train_nnet.sh:30,64)."""
     data, spklist, mats = make_data_dir(str(tmp_path / "train"), num_spk=6, utts_per_spk=3, min_frames=60, max_frames=110)

@@ -21,7 +21,10 @@ _GRAPH = {"engine": None, "key": None}
 
 ENDPOINT_ORDER = ["tdnn1_conv", "tdnn1_bn", "tdnn1_relu", "tdnn2_conv", "tdnn2_bn", "tdnn2_relu",
                   "tdnn3_conv", "tdnn3_bn", "tdnn3_relu", "tdnn4_dense", "tdnn4_bn", "tdnn4_relu",
-                  "tdnn5_dense", "tdnn5_bn", "tdnn5_relu", "pooling", "tdnn6_dense", "tdnn6_bn", "tdnn6_relu",
+                  "tdnn5_dense", "tdnn5_bn", "tdnn5_relu",
+                  # self_attention only (pooling.py:78-149); absent names are skipped for statistics pooling
+                  "att_key0_dense", "att_key0_bn", "att_key0_relu", "att_key1_dense", "attention_weights",
+                  "pooling", "tdnn6_dense", "tdnn6_bn", "tdnn6_relu",
                   "tdnn7_dense", "tdnn7_bn", "tdnn7_relu"]
 
 
