@@ -63,11 +63,14 @@ def pmc_traffic(kind):
     return None
 
 
-def step_flops(b, t, d, n):
-    """2*M*K*N per contraction, backward = 2x forward."""
+def step_flops(b, t, d, n, attention=False):
+    """2*M*K*N per contraction, backward = 2x forward (attention = shape S4: the key network
+    512 -> 1500 -> 1500 of nnet_conf/*_tdnn4_att.json on the T-14 frames)."""
     t1, t2, t3 = t - 4, t - 8, t - 14
     fwd = 2.0 * b * (t1 * 5 * d * 512 + t2 * 2560 * 512 + t3 * 3584 * 512 + t3 * 512 * 512 + t3 * 512 * 1500)
     fwd += 2.0 * b * (3000 * 512 + 512 * 512 + 512 * n)
+    if attention:
+        fwd += 2.0 * b * t3 * (512 * 1500 + 1500 * 1500)
     return fwd, 3.0 * fwd
 
 
@@ -120,6 +123,8 @@ def main():
     ap.add_argument("--frames", default=str(T), help="frames per chunk: N (default %d = shape S1) or LO:HI = a length drawn per step "
                     "from a seeded stream, as the reference's loader does (SURVEY 8d shape S3)" % T)
     ap.add_argument("--chunks", type=int, default=B, help="chunks per GPU per step (default %d)" % B)
+    ap.add_argument("--attention", action="store_true", help="self-attention pooling of nnet_conf/*_tdnn4_att.json instead of "
+                    "statistics pooling (SURVEY 8d shape S4, BASELINE configs[3])")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=None,
                     help="frame-level GEMM arithmetic (default: the engine's default, env XV_PRECISION)")
     args = ap.parse_args()
@@ -151,7 +156,8 @@ def main():
 
     cfg = E.make_config(D, NSPK, loss_func="additive_margin_softmax", margin_m=0.2, lambda_min=0.0, lambda_base=1000.0,
                         lambda_gamma=1e-4, lambda_power=5.0, last_layer_linear=True, weight_l2_regularizer=1e-2,
-                        batchnorm_momentum=0.99, optimizer="sgd", max_batch=chunks, max_frames=t_hi, precision=args.precision)
+                        batchnorm_momentum=0.99, optimizer="sgd", max_batch=chunks, max_frames=t_hi, precision=args.precision,
+                        pooling_type="self_attention" if args.attention else "statistics_pooling")
     precision = {v: k for k, v in _lib.PRECISIONS.items()}[int(cfg.precision)]
     eng = E.Engine(cfg, device=str(dev))
     eng.init_variables(seed=0)       # identical replicas on every rank
@@ -217,7 +223,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * chunks * args.steps / elapsed
         t_mean = float(np.mean([ts[(args.warmup + i) % nb] for i in range(args.steps)]))
-        fl_steps = [step_flops(chunks, ts[(args.warmup + i) % nb], D, NSPK) for i in range(args.steps)]
+        fl_steps = [step_flops(chunks, ts[(args.warmup + i) % nb], D, NSPK, args.attention) for i in range(args.steps)]
         fwd_flops, total_flops = float(np.mean([f[0] for f in fl_steps])), float(np.mean([f[1] for f in fl_steps]))
         by_steps = float(np.mean([step_bytes(chunks, ts[(args.warmup + i) % nb], D, NSPK) for i in range(args.steps)]))
         dom = int(np.argmax([ms[k] for k in range(NKINDS)]))
@@ -242,9 +248,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if precision == "f32" else "f32 (frame-level GEMMs as 3 fp16-plane MFMA products, fp32 accumulate; fp32-level results)",
             "data": "synthetic",
-            "config": {"workload": "TDNN x-vector (tdnn.py 5 frame + 2 segment layers, stat pooling) + AM-Softmax m=0.2, "
+            "config": {"workload": "TDNN x-vector (tdnn.py 5 frame + 2 segment layers, %s) + AM-Softmax m=0.2, "
                                    "full optimiser step (fwd+bwd+L2+SGD%s), %d chunks/GPU x %s frames x %d-dim, %d speakers"
-                                   % ("+RCCL all-reduce" if world > 1 else "", chunks, args.frames, D, NSPK),
+                                   % ("self-attention pooling 512-1500-1500 keys" if args.attention else "stat pooling",
+                                      "+RCCL all-reduce" if world > 1 else "", chunks, args.frames, D, NSPK),
                        "chunks_per_gpu": chunks, "frames": t_lo if t_lo == t_hi else [t_lo, t_hi], "mean_frames": t_mean,
                        "feat_dim": D, "num_speakers": NSPK,
                        "precision": precision, "parallelism": "dp%d" % world},
