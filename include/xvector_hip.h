@@ -205,6 +205,18 @@ int xv_stat_pool_forward_bn(void* stream, const float* z, int b, int t, int c, c
                             float* out);
 
 
+/* ---- auxiliary losses (model/loss.py:985-1036; shipped in nnet_conf/..._r0.01.json and ..._mhe0.01.json) ----
+ * ring loss: lambda * mean((||x|| - r)^2), r a trainable scalar ("softmax_ringloss/r").  Adds the value to *loss_accum,
+ * lambda*2*(||x||-r)/rows to dnorm_accum[row] (what xv_add_norm_grad turns into d x) and writes d r.
+ * MHE: lambda / (mean_{b,n}(2 - 2 wn[:,y_b].wn[:,n]) + 1e-6) on the column-normalised weights wn [c][ldn]; xv_mhe_loss adds the value
+ * and leaves [g | u[c] | v[c]] in coef (1 + 2c floats) and the label histogram in counts (n ints); xv_mhe_add_grad adds
+ * g*(u + counts[n]*v) to the gradient w.r.t. wn (before xv_loss_weight_backward). */
+int xv_ring_loss(void* stream, const float* x, int rows, int n, int ldx, const float* r, float lambda, float* loss_accum,
+                 float* dnorm_accum, float* dr);
+int xv_mhe_loss(void* stream, const float* wn, int c, int n, int ldn, const int32_t* labels, int rows, float lambda, float* loss_accum,
+                float* coef, int32_t* counts);
+int xv_mhe_add_grad(void* stream, float* dwn, int c, int n, int ldn, const float* coef, const int32_t* counts);
+
 /* ---- self-attention pooling, the shipped single-head form (model/pooling.py:37-192; nnet_conf/..._tdnn4_att.json) ----
  * The key network's dense layers run on the frame-level GEMMs; these are the pieces around them.
  *   score[r]   = scale * sum_c act(zk[r][c]) * query[c]        act: 0 = identity, 3 = tanh (att_key_network_type, pooling.py:84-96)
@@ -293,6 +305,11 @@ typedef struct xv_config {
     int32_t att_key1_nodes;           /* att_key_num_nodes[1]: the key dimension (pooling.py:84-96) */
     int32_t att_key_type;             /* att_key_network_type of the last key layer: 0 affine, 3 affine + tanh */
     int32_t att_use_scale;            /* att_use_scale: scores / sqrt(key dim) (pooling.py:144-145) */
+    int32_t aux_ring;                 /* "ring_loss" in aux_loss_func (loss.py:1003-1017); adds the variable softmax_ringloss/r */
+    float ring_loss_init;             /* initial r (set by the host initialiser; the engine does not read it) */
+    float ring_loss_lambda;
+    int32_t aux_mhe;                  /* "mhe_loss" in aux_loss_func (loss.py:1018-1033); margin losses only (normalised weights) */
+    float mhe_lambda;
 } xv_config;
 #define XV_POOL_STATISTICS 0
 /* self_attention in the shipped single-head form (nnet_conf/..._tdnn4_att.json): key network on tdnn4_relu, value = tdnn5_relu,

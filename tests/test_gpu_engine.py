@@ -42,6 +42,9 @@ CASES = [
     dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, pooling_type="self_attention",
          att_key_num_nodes=(300, 200)),
     dict(loss_func="softmax", pooling_type="self_attention", att_key_num_nodes=(64, 48), att_key_network_type=0, att_use_scale=False),
+    # auxiliary losses (loss.py:985-1036) as in nnet_conf/*_r0.01.json and *_mhe0.01.json, stronger weights to make them count
+    dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, aux_loss_func=("ring_loss", "mhe_loss"),
+         ring_loss_init=3.0, ring_loss_lambda=0.05, mhe_lambda=0.05),
 ]
 
 

@@ -61,3 +61,15 @@ def test_self_attention_matches_reference_numpy_oracle():
         att, _ = O.self_attention_fwd(value, key, query, bool(g["use_scale_%d" % i]))
         assert att.shape == ref.shape
         assert np.allclose(att, ref, rtol=1e-5, atol=1e-8), (i, np.abs(att - ref).max())
+
+
+def test_auxiliary_losses_match_reference_numpy_oracles():
+    """oracle.ring_loss / mhe_loss vs model/test_utils.py:855-884 (tests/golden/make_aux_golden.py).  The graph (and the
+    restatement) adds 1e-6 to the mean distance of MHE (loss.py:1028), the NumPy oracle does not: 1e-6 relative."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "aux_golden.npz"))
+    for i in range(int(g["num_cases"])):
+        lam = float(g["lambda_%d" % i])
+        ring, _ = O.ring_loss(g["features_%d" % i], float(g["r_%d" % i]), lam)
+        assert np.isclose(ring, float(g["ring_%d" % i]), rtol=1e-12)
+        mhe, _ = O.mhe_loss(g["w_%d" % i], g["labels_%d" % i], lam)
+        assert np.isclose(mhe, float(g["mhe_%d" % i]), rtol=5e-6), (mhe, float(g["mhe_%d" % i]))

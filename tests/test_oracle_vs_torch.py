@@ -117,6 +117,12 @@ def torch_forward(V, x, cfg, labels, step, training=True):
             delta[idx, lab] = phi * fn - sel
             updated = (1 - fa) * logits + fa * (logits + delta)
             loss = F.cross_entropy(updated, lab)
+    for aux in cfg.aux_loss_func:
+        if aux == "ring_loss":
+            loss = loss + cfg.ring_loss_lambda * ((h.norm(dim=1) - tv["softmax_ringloss/r"]) ** 2).mean()
+        else:
+            wn2 = W * torch.rsqrt(torch.clamp((W * W).sum(dim=0, keepdim=True), min=1e-12))
+            loss = loss + cfg.mhe_lambda / ((2.0 - 2.0 * (wn2.t()[lab] @ wn2)).mean() + 1e-6)
     reg = 0
     for k, v in tv.items():
         if k.endswith("/kernel"):
@@ -141,10 +147,13 @@ CASES = [
     dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, pooling_type="self_attention",
          att_key_num_nodes=(24, 20)),
     dict(loss_func="softmax", pooling_type="self_attention", att_key_num_nodes=(16, 12), att_key_network_type=0, att_use_scale=False),
+    # auxiliary losses of the shipped *_r0.01.json / *_mhe0.01.json configs (loss.py:985-1036)
+    dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, aux_loss_func=("ring_loss", "mhe_loss"),
+         ring_loss_init=3.0, ring_loss_lambda=0.05, mhe_lambda=0.05),
 ]
 
 
-@pytest.mark.parametrize("kw", CASES, ids=lambda d: d["loss_func"] + "_" + str(d.get("margin_m", "")) + ("_att%d" % d["att_key_network_type"] if "att_key_network_type" in d else "_att" if "pooling_type" in d else ""))
+@pytest.mark.parametrize("kw", CASES, ids=lambda d: d["loss_func"] + "_" + str(d.get("margin_m", "")) + ("_att%d" % d["att_key_network_type"] if "att_key_network_type" in d else "_att" if "pooling_type" in d else "") + ("_aux" if "aux_loss_func" in d else ""))
 def test_full_step_forward_backward(kw):
     cfg = O.Config(feat_dim=6, num_speakers=11, num_nodes_pooling_layer=20, num_nodes_last_layer=16, **kw)
     # the layer widths 512 are fixed by tdnn.py; keep B,T small instead

@@ -51,6 +51,11 @@ class XvConfig(C.Structure):
         ("att_key1_nodes", C.c_int32),
         ("att_key_type", C.c_int32),
         ("att_use_scale", C.c_int32),
+        ("aux_ring", C.c_int32),
+        ("ring_loss_init", C.c_float),
+        ("ring_loss_lambda", C.c_float),
+        ("aux_mhe", C.c_int32),
+        ("mhe_lambda", C.c_float),
     ]
 
 
@@ -107,6 +112,9 @@ SIGNATURES = {
     "xv_bn_relu_backward_pooled": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _SZ]),
     "xv_bn_relu_backward_pooled_split": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _SZ, _VP,
                                               _VP, _VP, _VP, _VP, _SZ]),
+    "xv_ring_loss": (_I, [_VP, _VP, _I, _I, _I, _VP, _F, _VP, _VP, _VP]),
+    "xv_mhe_loss": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _F, _VP, _VP, _VP]),
+    "xv_mhe_add_grad": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP]),
     "xv_att_score": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _F, _VP]),
     "xv_softmax_segments": (_I, [_VP, _VP, _I, _I, _VP]),
     "xv_softmax_segments_backward": (_I, [_VP, _VP, _VP, _I, _I, _VP]),

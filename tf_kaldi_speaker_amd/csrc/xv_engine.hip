@@ -66,7 +66,9 @@ struct xv_engine {
     int v_query = -1;
     float *att_score = nullptr, *att_w = nullptr, *att_dw = nullptr, *att_ds = nullptr;   // [B*T5]
     float* bufA = nullptr;                // d tdnn4_relu through the key network, [B*T5][512]
-    int v_loss_kernel = -1, v_loss_bias = -1;
+    int v_loss_kernel = -1, v_loss_bias = -1, v_ring = -1;
+    float* mhe_coef = nullptr;            // [1 + 2*Lout]: g, u, v of the MHE auxiliary loss
+    int32_t* mhe_counts = nullptr;        // [N] label histogram
     int c_pad0 = 0;
     int P = 0, Lout = 0, N = 0, ldl = 0;
     // device arena
@@ -192,6 +194,7 @@ void build_variables(xv_engine* e) {
     if (e->N > 0) {
         e->v_loss_kernel = add_var(e, "softmax/output/kernel", {e->Lout, e->N}, true);
         if (c.loss_kind == XV_LOSS_SOFTMAX) e->v_loss_bias = add_var(e, "softmax/output/bias", {e->N}, true);
+        if (c.aux_ring) e->v_ring = add_var(e, "softmax_ringloss/r", {}, true);      // scalar, loss.py:1008-1011
     }
     // offsets: trainable section first (graph order), then non-trainable; 16-byte aligned starts
     size_t off = 0;
@@ -244,6 +247,7 @@ int alloc_buffers(xv_engine* e) {
     }
     if (e->att) { for (int j = 0; j < 4; ++j) want(rows[5]); want(rows[5] * 512); }
     want(B * 2 * e->P); want(B * e->Lout); want(B * e->Lout);
+    if (e->N > 0 && c.aux_mhe) { want(1 + 2 * (size_t)e->Lout); want(e->N); }
     if (e->N > 0) {
         want(B * e->ldl); want(B * e->ldl); want(B); want(B);
         want(e->N); want((size_t)e->Lout * e->ldl); want((size_t)e->N * e->Lout); want((size_t)e->Lout * e->ldl);
@@ -330,6 +334,10 @@ int alloc_buffers(xv_engine* e) {
     e->pool = carve(e, B * 2 * e->P);
     e->h7_buf = carve(e, B * e->Lout);
     e->out_buf = carve(e, B * e->Lout);
+    if (e->N > 0 && c.aux_mhe) {
+        e->mhe_coef = carve(e, 1 + 2 * (size_t)e->Lout);
+        e->mhe_counts = (int32_t*)carve(e, e->N);
+    }
     if (e->N > 0) {
         e->logits = carve(e, B * e->ldl); e->dlogits = carve(e, B * e->ldl);
         e->dnorm = carve(e, B); e->row_loss = carve(e, B);
@@ -458,6 +466,8 @@ extern "C" int xv_engine_create(const xv_config* cfg, xv_engine** out) {
         XV_REQUIRE(cfg->att_key_type == 0 || cfg->att_key_type == 3, "engine_create: att_key_network_type %d is not implemented (0 affine, 3 tanh)",
                    cfg->att_key_type);
     }
+    XV_REQUIRE(!cfg->aux_mhe || cfg->num_speakers == 0 || cfg->loss_kind != XV_LOSS_SOFTMAX,
+               "engine_create: mhe_loss needs a loss with normalised speaker weights (asoftmax / additive margin losses)");
     xv_engine* e = new xv_engine();
     e->cfg = *cfg;
     e->f16 = cfg->precision == XV_PRECISION_F16X3;
@@ -701,6 +711,15 @@ extern "C" int xv_engine_loss_forward(xv_engine* e, void* stream, const int32_t*
     rc = xv_margin_softmax_rows(s, kind, e->logits, b, e->N, e->ldl, e->out, e->Lout, labels, m, e->lambda, e->dlogits, e->dnorm,
                                 e->row_loss, e->scalars + 0);
     if (rc) return rc;
+    // auxiliary losses are part of the training loss only (trainer.py:279-289 clears aux_loss_func for validation)
+    if (with_margin && c.aux_ring) {
+        rc = xv_ring_loss(s, e->out, b, e->Lout, e->Lout, vptr(e, e->v_ring), c.ring_loss_lambda, e->scalars + 0, e->dnorm, e->scalars + 3);
+        if (rc) return rc;
+    }
+    if (with_margin && c.aux_mhe) {
+        rc = xv_mhe_loss(s, e->wn, e->Lout, e->N, e->ldl, labels, b, c.mhe_lambda, e->scalars + 0, e->mhe_coef, e->mhe_counts);
+        if (rc) return rc;
+    }
     e->reg_valid = false;
     return 0;
 }
@@ -908,6 +927,11 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
         if (rc) return rc;
         rc = xv_add_norm_grad(s, e->out, e->dnorm, b, e->Lout, e->d_small0);
         if (rc) return rc;
+        if (e->v_ring >= 0) {      // d r of the ring loss was evaluated with the loss (0 when the auxiliary loss was off)
+            rc = e->with_margin ? xv_copy_2d(s, gptr(e, e->v_ring), 1, e->scalars + 3, 1, 1, 1) : 0;
+            if (!e->with_margin) XV_CHECK_HIP(hipMemsetAsync(gptr(e, e->v_ring), 0, sizeof(float), s));
+            if (rc) return rc;
+        }
         // d wn = out^T . dlogits and the gradient through l2_normalize: on the side stream (only reads
         // dlogits / out / wn, which the main chain never rewrites during backward)
         {
@@ -927,6 +951,10 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
             if (rc) return rc;
             rc = xv_launch_wgrad_reduce(ss, w.P, w.splits, 1, e->Lout, e->Lout, e->ldl, e->ldl, nullptr, 0, 0.f, e->dwn, e->ldl);
             if (rc) return rc;
+            if (e->with_margin && c.aux_mhe) {
+                rc = xv_mhe_add_grad(ss, e->dwn, e->Lout, e->N, e->ldl, e->mhe_coef, e->mhe_counts);
+                if (rc) return rc;
+            }
             float ol2 = c.output_weight_l2_regularizer >= 0.f ? c.output_weight_l2_regularizer : c.weight_l2_regularizer;
             rc = xv_loss_weight_backward(ss, e->dwn, e->ldl, e->wn, e->ldl, e->inv_norm, vptr(e, e->v_loss_kernel), e->Lout, e->N,
                                          c.loss_kind != XV_LOSS_SOFTMAX, ol2, gptr(e, e->v_loss_kernel), e->ws_side, e->ws_bytes);

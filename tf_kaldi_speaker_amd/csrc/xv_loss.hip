@@ -281,3 +281,111 @@ extern "C" int xv_loss_weight_backward(void* stream, const float* dwn, int lddwn
     XV_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------
+// auxiliary losses (model/loss.py:985-1036; shipped in *_r0.01.json and *_mhe0.01.json)
+// ------------------------------------------------------------------------------------
+// ring loss: lambda * mean((||x|| - r)^2), r a trainable scalar.  One workgroup, rows walked in a fixed order:
+// adds the loss to *loss_accum, lambda*2*(||x|| - r)/rows to dnorm[row] (the gradient w.r.t. ||x|| that
+// xv_add_norm_grad turns into d x) and writes d r.
+__global__ __launch_bounds__(256) void ring_loss_kernel(const float* __restrict__ x, int rows, int n, long ldx, const float* __restrict__ r,
+                                                        float lambda, float* __restrict__ loss_accum, float* __restrict__ dnorm,
+                                                        float* __restrict__ dr) {
+    __shared__ float s_sq[4], s_d[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float rr = *r;
+    float sq = 0.f, sd = 0.f;
+    for (int row = wave; row < rows; row += 4) {
+        const float* xr = x + (long)row * ldx;
+        float ss = 0.f;
+        for (int c = lane; c < n; c += 64) ss += xr[c] * xr[c];
+        ss = wave_sum_f(ss);
+        const float diff = sqrtf(ss) - rr;
+        sq += diff * diff;
+        sd += diff;
+        if (lane == 0) dnorm[row] += lambda * 2.0f * diff / (float)rows;
+    }
+    if (lane == 0) { s_sq[wave] = sq; s_d[wave] = sd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tq = (s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3]), td = (s_d[0] + s_d[1]) + (s_d[2] + s_d[3]);
+        *loss_accum += lambda * tq / (float)rows;
+        *dr = -lambda * 2.0f * td / (float)rows;
+    }
+}
+
+extern "C" int xv_ring_loss(void* stream, const float* x, int rows, int n, int ldx, const float* r, float lambda, float* loss_accum,
+                            float* dnorm_accum, float* dr) {
+    XV_REQUIRE(x && r && loss_accum && dnorm_accum && dr && rows > 0 && n > 0 && ldx >= n, "ring_loss: bad arguments");
+    hipLaunchKernelGGL(ring_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, rows, n, (long)ldx, r, lambda, loss_accum,
+                       dnorm_accum, dr);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// MHE on the column-normalised speaker weights wn [c][ldn]:  M = mean_{b,n}(2 - 2 wn[:,y_b].wn[:,n]) = 2 - 2 u.v/(B N),
+// u = sum_b wn[:,y_b], v = sum_n wn[:,n];  loss = lambda / (M + 1e-6);  d loss / d wn[:,n] = g (u + cnt_n v),
+// g = 2 lambda / ((M + 1e-6)^2 B N), cnt_n = #{b : y_b = n}.   coef = [g | u[c] | v[c]], counts = int32 [n].
+__global__ void mhe_counts_kernel(const int* __restrict__ labels, int rows, int n, int* __restrict__ counts) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) counts[i] = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < rows; b += blockDim.x) atomicAdd(counts + labels[b], 1);
+}
+__global__ __launch_bounds__(256) void mhe_uv_kernel(const float* __restrict__ wn, int n, long ldn, const int* __restrict__ labels, int rows,
+                                                     float* __restrict__ coef, int c_total) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const float* w = wn + (long)c * ldn;
+    float v = 0.f, u = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) v += w[i];
+    for (int b = threadIdx.x; b < rows; b += 256) u += w[labels[b]];
+    v = block_sum(v, red);
+    u = block_sum(u, red);
+    if (threadIdx.x == 0) { coef[1 + c] = u; coef[1 + c_total + c] = v; }
+}
+__global__ __launch_bounds__(256) void mhe_finalize_kernel(float* __restrict__ coef, int c_total, int rows, int n, float lambda,
+                                                           float* __restrict__ loss_accum) {
+    __shared__ float red[4];
+    float d = 0.f;
+    for (int c = threadIdx.x; c < c_total; c += 256) d += coef[1 + c] * coef[1 + c_total + c];
+    d = block_sum(d, red);
+    if (threadIdx.x == 0) {
+        const float bn = (float)rows * (float)n;
+        const float M = 2.0f - 2.0f * d / bn + 1e-6f;
+        *loss_accum += lambda / M;
+        coef[0] = 2.0f * lambda / (M * M * bn);
+    }
+}
+__global__ void mhe_add_grad_kernel(float* __restrict__ dwn, int c_total, int n, long ldn, const float* __restrict__ coef,
+                                    const int* __restrict__ counts) {
+    const float g = coef[0];
+    const long total = (long)c_total * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i / n), j = (int)(i - (long)c * n);
+        dwn[(long)c * ldn + j] += g * (coef[1 + c] + (float)counts[j] * coef[1 + c_total + c]);
+    }
+}
+
+extern "C" int xv_mhe_loss(void* stream, const float* wn, int c, int n, int ldn, const int32_t* labels, int rows, float lambda,
+                           float* loss_accum, float* coef, int32_t* counts) {
+    XV_REQUIRE(wn && labels && loss_accum && coef && counts && c > 0 && n > 0 && ldn >= n && rows > 0, "mhe_loss: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mhe_counts_kernel, dim3(1), dim3(1024), 0, s, (const int*)labels, rows, n, (int*)counts);
+    XV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mhe_uv_kernel, dim3(c), dim3(256), 0, s, wn, n, (long)ldn, (const int*)labels, rows, coef, c);
+    XV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mhe_finalize_kernel, dim3(1), dim3(256), 0, s, coef, c, rows, n, lambda, loss_accum);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xv_mhe_add_grad(void* stream, float* dwn, int c, int n, int ldn, const float* coef, const int32_t* counts) {
+    XV_REQUIRE(dwn && coef && counts && c > 0 && n > 0 && ldn >= n, "mhe_add_grad: bad arguments");
+    long total = (long)c * n;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mhe_add_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dwn, c, n, (long)ldn, coef, (const int*)counts);
+    XV_LAUNCH_CHECK();
+    return 0;
+}

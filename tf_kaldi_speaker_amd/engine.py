@@ -42,7 +42,8 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
                 weight_l2_regularizer=1e-2, output_weight_l2_regularizer=None, batchnorm_momentum=0.99,
                 bn_epsilon=1e-3, fused_bn_unbiased_moving_var=True, optimizer="sgd", momentum=0.9, use_nesterov=False,
                 clip_gradient_norm=0.0, max_batch=128, max_frames=400, precision=None, pooling_type="statistics_pooling",
-                att_key_num_nodes=(1500, 1500), att_key_network_type=3, att_use_scale=True):
+                att_key_num_nodes=(1500, 1500), att_key_network_type=3, att_use_scale=True, aux_loss_func=(), ring_loss_init=20.0,
+                ring_loss_lambda=0.01, mhe_lambda=0.01):
     if pooling_type not in POOLINGS:
         raise NotImplementedError("Not implement %s pooling" % pooling_type)
     if loss_func not in LOSS_KINDS:
@@ -78,6 +79,13 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
     c.precision = PRECISIONS[precision]
+    for aux in aux_loss_func or ():
+        if aux not in ("ring_loss", "mhe_loss"):
+            raise NotImplementedError("Unsupported loss function %s" % aux)
+    c.aux_ring = int("ring_loss" in (aux_loss_func or ()))
+    c.ring_loss_init, c.ring_loss_lambda = float(ring_loss_init), float(ring_loss_lambda)
+    c.aux_mhe = int("mhe_loss" in (aux_loss_func or ()))
+    c.mhe_lambda = float(mhe_lambda)
     c.pooling = POOLINGS[pooling_type]
     if pooling_type == "self_attention":
         # the shipped single-head form (nnet_conf/*_tdnn4_att.json): two key layers on tdnn4_relu, value = tdnn5_relu
@@ -181,6 +189,10 @@ class Engine(object):
                     fan_in, fan_out = shape
                 lim = np.sqrt(6.0 / (fan_in + fan_out))
                 vals[name] = rs.uniform(-lim, lim, size=shape).astype(np.float32)
+            elif name == "softmax_ringloss/r":
+                vals[name] = np.full(shape, self.config.ring_loss_init, np.float32)
+            elif leaf == "query":      # truncated_normal(stddev=0.1), pooling.py:131-132
+                vals[name] = np.clip(rs.randn(*shape) * 0.1, -0.2, 0.2).astype(np.float32)
             elif leaf in ("gamma", "moving_variance"):
                 vals[name] = np.ones(shape, np.float32)
             else:

@@ -90,6 +90,12 @@ def engine_config(params, dim, num_speakers=0, loss_type="softmax", max_batch=12
               max_batch=max_batch, max_frames=max_frames,
               precision=d.get("precision", None),      # engine extension: "f16x3" (default) | "f32"; absent from reference configs
               pooling_type=d["pooling_type"])
+    if num_speakers and d.get("aux_loss_func"):      # loss.py:985-1036; every loss function adds them (loss.py:40,161,249,347)
+        kw.update(aux_loss_func=tuple(d["aux_loss_func"]))
+        if "ring_loss" in d["aux_loss_func"]:
+            kw.update(ring_loss_init=float(d["ring_loss_init"]), ring_loss_lambda=float(d["ring_loss_lambda"]))
+        if "mhe_loss" in d["aux_loss_func"]:
+            kw.update(mhe_lambda=float(d["mhe_lambda"]))
     if d["pooling_type"] == "self_attention":
         kw.update(att_key_num_nodes=tuple(d["att_key_num_nodes"]), att_key_network_type=int(d["att_key_network_type"]),
                   att_use_scale=bool(d.get("att_use_scale", False)))
