@@ -34,7 +34,7 @@ def get_variable(name, shape, reuse, init="xavier"):
         if reuse is None or reuse is False:
             raise ValueError("Variable %s already exists, disallowed. Did you mean to set reuse=True?" % name)
         v = _VARIABLES[name]
-        assert tuple(v.shape) == tuple(shape), "variable %s has shape %s, requested %s" % (name, tuple(v.shape), shape)
+        assert tuple(v.shape) == (tuple(shape) or (1,)), "variable %s has shape %s, requested %s" % (name, tuple(v.shape), shape)
         return v
     if reuse is True:
         raise ValueError("Variable %s does not exist, or was not created with get_variable()." % name)
@@ -42,6 +42,8 @@ def get_variable(name, shape, reuse, init="xavier"):
     if init == "xavier":                         # tf.contrib.layers.xavier_initializer(): uniform, loss.py:100-102
         lim = np.sqrt(6.0 / (shape[0] + shape[1]))
         val = rs.uniform(-lim, lim, size=shape).astype(np.float32)
+    elif isinstance(init, float):                # constant initialiser (ring loss r, loss.py:1009-1011)
+        val = np.full(shape if shape else (1,), init, np.float32)
     else:
         val = np.zeros(shape, np.float32)
     _VARIABLES[name] = to_device(val)
@@ -79,9 +81,19 @@ def _run(kind, features, labels, num_outputs, params, reuse_variables, name, m, 
     endpoints = OrderedDict()
     endpoints["logits"] = logits[:, :num_outputs]
     endpoints["labels"] = y
-    if "aux_loss_func" in params.dict and params.dict["aux_loss_func"]:
-        raise NotImplementedError("aux_loss_func (ring / MHE, loss.py:985) is not implemented yet (SURVEY.md 8f-4)")
-    return loss[0], endpoints
+    total = loss[0]
+    for aux in params.dict.get("aux_loss_func") or []:      # loss.py:985-1036, added by every loss function (loss.py:40,161,249,347)
+        if aux == "ring_loss":
+            r = get_variable(name + "_ringloss/r", (), reuse_variables, init=float(params.ring_loss_init))
+            total = total + ops.ring_loss(x, r, float(params.ring_loss_lambda))
+            endpoints["ring_loss_r"] = r
+        elif aux == "mhe_loss":
+            wn_unit = wn if kind != 0 else ops.loss_prep_weight(w, True)[1]      # MHE normalises the weights itself (loss.py:1026)
+            total = total + ops.mhe_loss(wn_unit, num_outputs, y, float(params.mhe_lambda))
+            endpoints["w"] = w
+        else:
+            raise NotImplementedError("Unsupported loss function %s" % aux)
+    return total, endpoints
 
 
 def softmax(features, labels, num_outputs, params, is_training=None, reuse_variables=None, name="softmax"):

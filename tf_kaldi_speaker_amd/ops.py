@@ -266,6 +266,23 @@ def loss_weight_backward(dwn, wn, inv, w, normalize, l2_scale):
     return dw
 
 
+def ring_loss(x, r, lam):
+    """lam * mean((||x|| - r)^2) as a device scalar (loss.py:1003-1017)."""
+    rows, n = x.shape
+    out, dn, dr = _f32((1,), x).zero_(), _f32((rows,), x).zero_(), _f32((1,), x)
+    _lib.call("xv_ring_loss", _s(), _p(x), rows, n, n, _p(r), float(lam), _p(out), _p(dn), _p(dr))
+    return out[0]
+
+
+def mhe_loss(wn, n, labels, lam):
+    """lam / (mean_{b,n}(2 - 2 wn[:,y_b].wn[:,n]) + 1e-6) on column-normalised weights wn [c, ldn] (loss.py:1018-1033)."""
+    c, ldn = wn.shape
+    out, coef = _f32((1,), wn).zero_(), _f32((1 + 2 * c,), wn)
+    counts = torch.empty(n, dtype=torch.int32, device=wn.device)
+    _lib.call("xv_mhe_loss", _s(), _p(wn), c, n, ldn, _p(labels), labels.shape[0], float(lam), _p(out), _p(coef), _p(counts))
+    return out[0]
+
+
 def l2_reg_loss(w, scale, accum):
     _lib.call("xv_l2_reg_loss", _s(), _p(w), C.c_size_t(w.numel()), float(scale), _p(accum))
 
