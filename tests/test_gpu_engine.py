@@ -299,3 +299,17 @@ def test_full_size_properties():
     pool = eng.endpoint("pooling").cpu().numpy()
     assert pool.shape == (128, 3000) and (pool[:, 1500:] > 0).all()
     eng.close()
+
+
+def test_out_of_range_label_poisons_the_loss_instead_of_faulting():
+    eng, cfg_o, V = _make(dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True), 4, 30)
+    rs = np.random.RandomState(0)
+    x = rs.randn(4, 30, 30).astype(np.float32)
+    eng.forward(x, True)
+    eng.loss(np.array([1, 2, cfg_o.num_speakers + 5, -3], np.int32), 0, True)
+    raw, _ = eng.losses()
+    assert np.isnan(raw)
+    eng.loss(np.array([1, 2, 3, 4], np.int32), 0, True)
+    raw, _ = eng.losses()
+    assert np.isfinite(raw)
+    eng.close()

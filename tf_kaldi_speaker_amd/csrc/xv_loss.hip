@@ -94,7 +94,10 @@ __global__ __launch_bounds__(256) void margin_softmax_rows_kernel(int kind, cons
     const int r = blockIdx.x, tid = threadIdx.x;
     const float* lr = logits + (long)r * ldl;
     float* gr = dlogits + (long)r * ldl;
-    const int y = labels[r];
+    // a label outside [0, N) is a caller error (TF raises / yields NaN): keep the memory accesses in range and poison the loss
+    const int y_raw = labels[r];
+    const bool bad_label = y_raw < 0 || y_raw >= N;
+    const int y = bad_label ? 0 : y_raw;
     const bool margin = (kind != XV_LOSS_SOFTMAX) && !(kind == XV_LOSS_ASOFTMAX && m == 1.0f);
     float fa = 0.f, fs = 1.f;
     float ss = 0.f;
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void margin_softmax_rows_kernel(int kind, cons
         gr[j] = g;
     }
     if (tid == 0) {
-        row_loss[r] = lse - uy;
+        row_loss[r] = bad_label ? NAN : lse - uy;
         float py = expf(uy - lse);
         dnorm[r] = margin ? s_dn * (py - 1.f) * inv_rows : 0.f;
     }
@@ -330,7 +333,10 @@ extern "C" int xv_ring_loss(void* stream, const float* x, int rows, int n, int l
 __global__ void mhe_counts_kernel(const int* __restrict__ labels, int rows, int n, int* __restrict__ counts) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) counts[i] = 0;
     __syncthreads();
-    for (int b = threadIdx.x; b < rows; b += blockDim.x) atomicAdd(counts + labels[b], 1);
+    for (int b = threadIdx.x; b < rows; b += blockDim.x) {
+        const int y = labels[b];
+        if (y >= 0 && y < n) atomicAdd(counts + y, 1);      // out-of-range labels already poison the main loss with NaN
+    }
 }
 __global__ __launch_bounds__(256) void mhe_uv_kernel(const float* __restrict__ wn, int n, long ldn, const int* __restrict__ labels, int rows,
                                                      float* __restrict__ coef, int c_total) {
@@ -339,7 +345,10 @@ __global__ __launch_bounds__(256) void mhe_uv_kernel(const float* __restrict__ w
     const float* w = wn + (long)c * ldn;
     float v = 0.f, u = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) v += w[i];
-    for (int b = threadIdx.x; b < rows; b += 256) u += w[labels[b]];
+    for (int b = threadIdx.x; b < rows; b += 256) {
+        const int y = labels[b];
+        if (y >= 0 && y < n) u += w[y];
+    }
     v = block_sum(v, red);
     u = block_sum(u, red);
     if (threadIdx.x == 0) { coef[1 + c] = u; coef[1 + c_total + c] = v; }
