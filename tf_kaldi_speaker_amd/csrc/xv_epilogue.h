@@ -72,6 +72,68 @@ __device__ __forceinline__ void xv_tile_stats_epilogue(const f32x16 (&acc)[2][NB
     }
 }
 
+// The same statistics for a tile held as 4 x 4 v_mfma_f32_16x16x32 accumulators per wave (4 waves, 2 x 2, 64 x 64 each):
+// lane l owns column l & 15 of block b and rows (l >> 4) * 4 + j of block a.
+__device__ __forceinline__ void xv_tile_stats_epilogue16(const f32x4 (&acc)[4][4], float* red /* >= 1024 floats of LDS, free */, int tid, int wr,
+                                                         int wc, int lane, int m0, int n0, int M, int N, int tile_m, int tiles_m,
+                                                         float* __restrict__ part) {
+    float* r_sum = red;          // [2][128]
+    float* r_m2 = red + 256;
+    float* r_min = red + 512;
+    float* r_max = red + 768;
+    const int lc = lane & 15, lg = lane >> 4;
+    const int cnt = min(XV_TILE_M, M - m0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        float v = 0.f, mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = m0 + wr * 64 + a * 16 + lg * 4 + j < M;
+                const float x = acc[a][b][j];
+                v += ok ? x : 0.f;
+                mn = ok ? fminf(mn, x) : mn;
+                mx = ok ? fmaxf(mx, x) : mx;
+            }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        mn = fminf(mn, __shfl_xor(mn, 16)); mn = fminf(mn, __shfl_xor(mn, 32));
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (lg == 0) {
+            const int col = wc * 64 + b * 16 + lc;
+            r_sum[wr * 128 + col] = v; r_min[wr * 128 + col] = mn; r_max[wr * 128 + col] = mx;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int col = wc * 64 + b * 16 + lc;
+        const float mean = (r_sum[col] + r_sum[128 + col]) / (float)cnt;
+        float v = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = acc[a][b][j] - mean;
+                v += (m0 + wr * 64 + a * 16 + lg * 4 + j < M) ? d * d : 0.f;
+            }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if (lg == 0) r_m2[wr * 128 + col] = v;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        int n = n0 + tid;
+        if (n < N) {
+            const long plane = (long)tiles_m * N;
+            const long o = (long)tile_m * N + n;
+            part[o] = r_sum[tid] + r_sum[128 + tid];
+            part[plane + o] = r_m2[tid] + r_m2[128 + tid];
+            part[2 * plane + o] = fminf(r_min[tid], r_min[128 + tid]);
+            part[3 * plane + o] = fmaxf(r_max[tid], r_max[128 + tid]);
+        }
+    }
+}
+
 // power-of-two scale that brings a tensor with max |x| = amax (given as the uint bits of a non-negative
 // float) to [2^12, 2^13): exact to apply and to undo, 3 bits of headroom below the fp16 maximum.
 __device__ __forceinline__ float xv_pow2_scale(unsigned amax_bits) {

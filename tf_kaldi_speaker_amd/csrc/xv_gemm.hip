@@ -109,11 +109,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
     for (int i = 0; i < NT_RPT; ++i) {
         int row = NT_RPI * (NT_RPT * wave + i) + lrow;
         ksrc[i] = ((lpos ^ NT_SWZ(row)) << 2);
-#if defined(XV_ABL) && (XV_ABL & 64)
-        // timing-only: fetch full 128-B lines (8 rows x 128 B per instruction) instead of 16 rows x 64 B
-        row = NT_RPI * (NT_RPT * wave + i) + (lane >> 3);
-        ksrc[i] = (lane & 7) << 2;
-#endif
         int m = m0 + row;
         av[i] = m < p.M;
         int mm = av[i] ? m : 0;
@@ -129,11 +124,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
     auto gstage = [&](int kt, int buf) {
         float* sa = smem + buf * (2 * BM * NT_PITCH) + NT_RPI * NT_RPT * uwave * NT_PITCH;
         float* sb = sa + BM * NT_PITCH;
-#if defined(XV_ABL) && (XV_ABL & 64)
-        const int k0 = k_begin + ((kt * BK) & ~31);
-#else
         const int k0 = k_begin + kt * BK;
-#endif
 #pragma unroll
         for (int i = 0; i < NT_RPT; ++i) {
             const int k = k0 + ksrc[i];
@@ -201,44 +192,25 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-#ifdef XV_STAGGER
-    // de-phase co-resident workgroups (they start together and would hit their barrier / staging
-    // phases together, idling the MFMA pipe): 0..3 quarter K-steps of sleep by workgroup id
-    for (int d = (blockIdx.x * 2654435761u >> 13) & 3; d > 0; --d) __builtin_amdgcn_s_sleep(XV_STAGGER);
-#endif
     if (nk > 0) NT_STAGE_FIRST();
     __syncthreads();
 
     const int a_off = (wr * 64 + li) * NT_PITCH;
     const int b_off = (wc * 64 + li) * NT_PITCH;
     const int fsw = NT_SWZ(li);     // rows wr*64 + a*32 + li share f(li): the offsets are multiples of 16
-#ifndef XV_ABL
-#define XV_ABL 0
-#endif
-    // XV_ABL (timing-only ablation builds, wrong results): 1 = no global loads / LDS staging in the loop,
-    // 2 = no LDS fragment reads, 3 = neither (MFMA + barrier only), 4 = 3 without the barrier
-    f32x4 cf = {1.f, 2.f, 3.f, 4.f};
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (!(XV_ABL & 1) && kt + 1 < nk) NT_STAGE_NEXT(kt, buf);
+        if (kt + 1 < nk) NT_STAGE_NEXT(kt, buf);
         const float* sa = smem + buf * (2 * BM * NT_PITCH);
         const float* sb = sa + BM * NT_PITCH;
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 af[2], bf[2];
             const int pos = (((2 * q + lh) ^ fsw) << 2);
-            if (XV_ABL & 2) {
-                asm volatile("" : "+v"(cf));
-                af[0] = cf; af[1] = cf; bf[0] = cf; bf[1] = cf;
-            } else {
             af[0] = *(const f32x4*)(sa + a_off + pos);
             af[1] = *(const f32x4*)(sa + a_off + 32 * NT_PITCH + pos);
             bf[0] = *(const f32x4*)(sb + b_off + pos);
             bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
-            }
-#ifdef XV_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[0][e], acc[0][0], 0, 0, 0);
@@ -246,15 +218,9 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[0][e], acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[1][e], acc[1][1], 0, 0, 0);
             }
-#ifdef XV_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
-        if (!(XV_ABL & 1) && kt + 1 < nk) NT_COMMIT(buf);
-        if (XV_ABL & 32) {              // timing-only: barrier WITHOUT waiting for the DMA (wrong results)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        } else if (XV_ABL != 4 && XV_ABL != 7) __syncthreads();
+        if (kt + 1 < nk) NT_COMMIT(buf);
+        __syncthreads();
     }
 
     // ---- epilogue

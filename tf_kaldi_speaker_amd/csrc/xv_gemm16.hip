@@ -206,7 +206,17 @@ struct NT16Args {
 #define WN16 (XV16_WAVES / 2)          // waves along N
 #define NB16 (4 / WN16)                // 32-column accumulator blocks per wave
 #define BK16 XV16_BK
+#ifndef XV16_MFMA16
+#define XV16_MFMA16 0    // 1: v_mfma_f32_16x16x32_f16 in the generic NT kernel (4 x 4 accumulator blocks per wave), BK = 32 and 4 waves only
+#endif
+#if XV16_MFMA16
+// 16x16x32 operands: lane l reads row l & 15, 16-byte chunk l >> 4 of a 64-byte row.  A ds_read_b128 lane group then holds
+// row quads q = (row >> 2) & 3 with chunks {q0:c, q3:c, q1:c^1, q2:c^1}; chunk ^= f(q), f = (0, 2, 3, 1), maps them to four distinct
+// 4-bank columns in every group (conflict-free); the same involution is applied to the LDS-DMA source chunk.
+#define SWZ16(row) ((0x78 >> (2 * (((row) >> 2) & 3))) & 3)
+#else
 #define SWZ16(row) (BK16 == 64 ? (((row) >> 1) & 7) : BK16 == 32 ? (((row) >> 2) & 3) : 0)
+#endif
 #define CQ16 (BK16 / 8)
 #define PLANE_HALFS (128 * BK16)
 #define BUF_HALFS (4 * PLANE_HALFS)
@@ -260,6 +270,62 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
         }
     };
 
+#if XV16_MFMA16
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lc = lane & 15, lg = lane >> 4;
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ra = wr * 64 + q * 16 + lc, rb = wc * 64 + q * 16 + lc;
+        a_off[q] = ra * BK16 + ((lg ^ SWZ16(ra)) << 3);
+        b_off[q] = rb * BK16 + ((lg ^ SWZ16(rb)) << 3);
+    }
+    if (nk > 0) gstage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
+        const u16* base = smem + buf * BUF_HALFS;
+        f32x4 af[2][4], bf[2][4];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                af[pl][q] = *(const f32x4*)(base + pl * PLANE_HALFS + a_off[q]);
+                bf[pl][q] = *(const f32x4*)(base + (2 + pl) * PLANE_HALFS + b_off[q]);
+            }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+#define MM(i, j) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i][a]), __builtin_bit_cast(f16x8, bf[j][b]), acc[a][b], 0, 0, 0)
+                MM(0, 1); MM(1, 0); MM(0, 0);
+#undef MM
+            }
+        __syncthreads();
+    }
+    const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = n0 + wc * 64 + b * 16 + lc;
+        const float bias_v = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = m0 + wr * 64 + a * 16 + lg * 4 + jj;
+                const float v = acc[a][b][jj] * out_scale + bias_v;
+                acc[a][b][jj] = v;
+                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = v;
+            }
+    }
+    if (STATS) xv_tile_stats_epilogue16(acc, (float*)smem, tid, wr, wc, lane, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
+}
+#else
     f32x16 acc[2][NB16];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -334,6 +400,7 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
         }
     if (STATS) xv_tile_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Context-window ("conv") form of the NT kernel: K = taps x C with A row (m, tap j) = x row xrow(m) + j.
