@@ -188,6 +188,18 @@ int xv_affine_forward_f16x3(void* stream, const void* x_planes, size_t x_plane_s
                             const float* bias, float* z, int o, int ldz, float* bn_part);
 int xv_affine_dgrad_f16x3(void* stream, const void* dz_planes, size_t dz_plane_stride, const uint32_t* dz_amax, int segs, int t_out,
                           int o_ld, int k, const void* wf_planes, size_t wf_plane_stride, const uint32_t* wf_amax, float* dx, int c);
+/* The same with the BN-backward reductions of the layer that owns dx fused into the epilogue: dx is d(relu(bn(z_below)));
+ * part [ceil(rows/128)][3][c] = per-tile sum dd | sum dd*xhat | max |dd| with dd = dx masked by the ReLU - what the first pass of
+ * xv_bn_relu_backward_split would compute by re-reading dx and z_below.  Feed it to xv_bn_relu_backward_split_from_part. */
+int xv_affine_dgrad_bnstats_f16x3(void* stream, const void* dz_planes, size_t dz_plane_stride, const uint32_t* dz_amax, int segs, int t_out,
+                                  int o_ld, int k, const void* wf_planes, size_t wf_plane_stride, const uint32_t* wf_amax, float* dx, int c,
+                                  const float* z_below, const float* scale, const float* shift, const float* mean, const float* invstd,
+                                  float* part);
+int xv_bn_relu_backward_split_from_part(void* stream, const float* part, int chunks, const float* da, const float* z, int segs, int t, int n,
+                                        const float* gamma, const float* mean, const float* invstd, const float* scale,
+                                        const float* shift, const float* zmin, const float* zmax, int pad, void* dz_planes, int ldp,
+                                        size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
+                                        size_t ws_bytes);
 int xv_affine_wgrad_f16x3(void* stream, const void* x_planes, size_t x_plane_stride, const uint32_t* x_amax, int segs, int t_in,
                           int c_ld, int k, int c, const void* dz_planes, size_t dz_plane_stride, const uint32_t* dz_amax,
                           int dz_seg_pitch, int dz_row0, int o_ld, int o, const float* kernel, float l2_scale, float* dkernel,

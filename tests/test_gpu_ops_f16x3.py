@@ -153,3 +153,38 @@ def test_pooling_fused_into_bn_split(ops):
     assert_close(rec[:, :n], dz_ref, 2e-5, 2e-4, "pooled split dz")
     assert_close(host(dg), dg_ref, 2e-5, 1e-4, "pooled split dgamma")
     assert_close(host(db), db_ref, 2e-5, 1e-4, "pooled split dbeta")
+
+
+@pytest.mark.parametrize("segs,t_out,k", [(5, 57, 5), (3, 300, 1)])
+def test_dgrad_epilogue_produces_the_bn_backward_partials(ops, segs, t_out, k):
+    """xv_affine_dgrad_bnstats_f16x3: dx identical to the plain data gradient, partials = the sums the BN backward needs
+    (sum dd, sum dd*xhat, max |dd| per 128-row tile), checked against float64 on the kernel's own dx."""
+    rs = np.random.RandomState(k)
+    c, o = 512, 512
+    rows = segs * (t_out + k - 1)
+    kern = (rs.randn(k, c, o) / np.sqrt(k * c)).astype(np.float32)
+    pad = k - 1
+    dzp_host = np.zeros((segs, t_out + 2 * pad, o), np.float32)
+    dzp_host[:, pad:pad + t_out] = (rs.randn(segs, t_out, o) * 1e-3).astype(np.float32)
+    dzp = ops.split_planes(dev(dzp_host.reshape(-1, o)))
+    wf = ops.prep_weight_dgrad(dev(kern)) if k > 1 else dev(kern[0])
+    wfp = ops.split_planes(wf)
+    z = (rs.randn(rows, c) * 2 + 0.3).astype(np.float32)                       # pre-BN output of the layer that owns dx
+    gamma, beta = (rs.rand(c) + 0.5).astype(np.float32), (0.3 * rs.randn(c)).astype(np.float32)
+    part_z = ops.col_stats(dev(z))
+    mean, invstd, scale, shift, zmin, zmax, _ = ops.bn_finalize(part_z, rows, dev(gamma), dev(beta), 1e-3, 0.99, False, None, None,
+                                                                with_range=True)
+    dx_plain = ops.affine_dgrad_f16x3(dzp, segs, t_out, k, wfp, c)
+    dx, part = ops.affine_dgrad_bnstats_f16x3(dzp, segs, t_out, k, wfp, c, dev(z), scale, shift, mean, invstd)
+    assert torch.equal(dx, dx_plain)
+    dxh, zh = host(dx), z.astype(np.float64)
+    sc, sh, mu, istd = host(scale), host(shift), host(mean), host(invstd)
+    dd = dxh * ((zh * sc + sh) > 0)
+    xh = (zh - mu) * istd
+    p = host(part)
+    tiles = (rows + 127) // 128
+    for t in range(tiles):
+        r = slice(128 * t, min(rows, 128 * t + 128))
+        assert_close(p[t, 0], dd[r].sum(axis=0), 2e-5, 2e-4, "sum dd tile %d" % t)
+        assert_close(p[t, 1], (dd[r] * xh[r]).sum(axis=0), 2e-5, 2e-4, "sum dd*xhat tile %d" % t)
+        assert_close(p[t, 2], np.abs(dd[r]).max(axis=0), 1e-6, 1e-6, "max |dd| tile %d" % t)

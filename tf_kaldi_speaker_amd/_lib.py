@@ -105,6 +105,9 @@ SIGNATURES = {
                                        _VP, _VP, _SZ]),
     "xv_affine_forward_f16x3": (_I, [_VP, _VP, _SZ, _VP, _I, _I, _I, _I, _VP, _SZ, _VP, _VP, _VP, _I, _I, _VP]),
     "xv_affine_dgrad_f16x3": (_I, [_VP, _VP, _SZ, _VP, _I, _I, _I, _I, _VP, _SZ, _VP, _VP, _I]),
+    "xv_affine_dgrad_bnstats_f16x3": (_I, [_VP, _VP, _SZ, _VP, _I, _I, _I, _I, _VP, _SZ, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "xv_bn_relu_backward_split_from_part": (_I, [_VP, _VP, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _SZ,
+                                                 _VP, _VP, _VP, _VP, _VP, _SZ]),
     "xv_affine_wgrad_f16x3": (_I, [_VP, _VP, _SZ, _VP, _I, _I, _I, _I, _I, _VP, _SZ, _VP, _I, _I, _I, _I, _VP, _F, _VP, _VP, _SZ]),
     "xv_stat_pool_forward": (_I, [_VP, _VP, _I, _I, _I, _VP]),
     "xv_stat_pool_backward": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),

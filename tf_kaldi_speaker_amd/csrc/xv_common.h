@@ -93,6 +93,9 @@ struct XvGemm16NT {
     const float* bias;
     float* bn_part;                       // optional [4][tiles_m][N]
     const unsigned* a_amax; const unsigned* b_amax;   // device: float bits of the operands' max |x| (scale source)
+    // optional data-gradient epilogue (xv_epilogue.h XvBwdStats): C is d a of a BN+ReLU layer whose pre-BN tensor is bwd_z [M][N]
+    const float* bwd_z; const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_invstd;
+    float* bwd_part;                      // [tiles_m][3][N]
 };
 int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g);
 struct XvGemm16TN {

@@ -739,21 +739,25 @@ static int bn_relu_backward_split_impl(hipStream_t s, const float* da, PoolGrad 
                                        const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
                                        const float* zmin, const float* zmax, int relu, int pad, void* dz_planes, int ldp,
                                        size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
-                                       size_t ws_bytes) {
+                                       size_t ws_bytes, const float* ext_part = nullptr, int ext_chunks = 0) {
     XV_REQUIRE(segs > 0 && t > 0 && n > 0 && n % 4 == 0 && pad >= 0, "bn_relu_backward_split: bad shape (n=%d must be a multiple of 4)", n);
     XV_REQUIRE(ldp % 8 == 0 && ldp >= n && plane_stride % 8 == 0 && zmin && zmax && dz_amax, "bn_relu_backward_split: bad plane arguments");
     XV_REQUIRE((long)segs * (t + 2 * pad) * (ldp / 8) < (1L << 31), "bn_relu_backward_split: tensor too large for 32-bit indexing");
     const int rows = segs * t;
-    const int chunks = xv_cdiv(rows, BB_ROWS);
-    size_t need = ((size_t)chunks * 3 * n + 2 * n) * sizeof(float);
+    // the reduction partials either come from the data-gradient GEMM's epilogue (ext_part, one chunk per 128-row tile) or
+    // are computed here from (da, z)
+    const int chunks = ext_part ? ext_chunks : xv_cdiv(rows, BB_ROWS);
+    size_t need = ((size_t)(ext_part ? 0 : chunks) * 3 * n + 2 * n) * sizeof(float);
     XV_REQUIRE(need <= ws_bytes, "bn_relu_backward_split: workspace too small (%zu > %zu)", need, ws_bytes);
-    float* part = (float*)ws;
-    float* coef = part + (size_t)chunks * 3 * n;
+    float* part = ext_part ? const_cast<float*>(ext_part) : (float*)ws;
+    float* coef = ext_part ? (float*)ws : part + (size_t)chunks * 3 * n;
     const bool pooled = pg.out != nullptr;
     XV_CHECK_HIP(hipMemsetAsync(dz_amax, 0, sizeof(uint32_t), s));
-    hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
-                       da, pg, z, rows, n, mean, invstd, scale, shift, relu, part);
-    XV_LAUNCH_CHECK();
+    if (!ext_part) {
+        hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
+                           da, pg, z, rows, n, mean, invstd, scale, shift, relu, part);
+        XV_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
                        dgamma, dbeta, coef, gamma, invstd, dbias, mean, zmin, zmax, (unsigned*)dz_amax);
     XV_LAUNCH_CHECK();
@@ -783,6 +787,19 @@ extern "C" int xv_bn_relu_backward_split(void* stream, const float* da, const fl
     PoolGrad pg = {nullptr, nullptr, 1, nullptr};
     return bn_relu_backward_split_impl((hipStream_t)stream, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, zmin, zmax, relu, pad,
                                        dz_planes, ldp, plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes);
+}
+
+// xv_bn_relu_backward_split with the reduction partials already produced by xv_affine_dgrad_bnstats_f16x3 (the pass over
+// (da, z) that computes them is skipped): part [chunks][3][n], chunks = ceil(rows / 128), ReLU layers, pad as usual.
+extern "C" int xv_bn_relu_backward_split_from_part(void* stream, const float* part, int chunks, const float* da, const float* z, int segs,
+                                                   int t, int n, const float* gamma, const float* mean, const float* invstd,
+                                                   const float* scale, const float* shift, const float* zmin, const float* zmax, int pad,
+                                                   void* dz_planes, int ldp, size_t plane_stride, uint32_t* dz_amax, float* dgamma,
+                                                   float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
+    XV_REQUIRE(da && part && chunks == xv_cdiv(segs * t, XV_TILE_M), "bn_relu_backward_split_from_part: one chunk per 128-row tile expected");
+    PoolGrad pg = {nullptr, nullptr, 1, nullptr};
+    return bn_relu_backward_split_impl((hipStream_t)stream, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, zmin, zmax, 1, pad,
+                                       dz_planes, ldp, plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes, part, chunks);
 }
 
 extern "C" int xv_bn_relu_backward_pooled(void* stream, const float* pool_out, const float* dpool, const float* weights, int b, int t,

@@ -66,6 +66,8 @@ struct xv_engine {
     int v_query = -1;
     float *att_score = nullptr, *att_w = nullptr, *att_dw = nullptr, *att_ds = nullptr;   // [B*T5]
     float* bufA = nullptr;                // d tdnn4_relu through the key network, [B*T5][512]
+    float* bwd_part = nullptr;            // BN-backward reduction partials written by a data-gradient GEMM epilogue
+    int bwd_part_layer = -1, bwd_part_chunks = 0;   // ... for this layer's BN backward (-1: none pending)
     int v_loss_kernel = -1, v_loss_bias = -1, v_ring = -1;
     float* mhe_coef = nullptr;            // [1 + 2*Lout]: g, u, v of the MHE auxiliary loss
     int32_t* mhe_counts = nullptr;        // [N] label histogram
@@ -261,6 +263,7 @@ int alloc_buffers(xv_engine* e) {
     if (rows[5] * maxc > bufz) bufz = rows[5] * maxc;
     if (rows[1] * 512 > bufz) bufz = rows[1] * 512;
     want(bufd); want(bufz); want(bufz);
+    if (e->f16) want((size_t)xv_cdiv(rows[1], XV_TILE_M) * 3 * maxc);
     const size_t dzh_halfs = xv_align(B * (T + 12) * (size_t)xv_align(maxc, 8), 8);
     if (e->f16) { want(dzh_halfs); want(dzh_halfs); }
     want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512)); want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512));
@@ -349,6 +352,7 @@ int alloc_buffers(xv_engine* e) {
     e->bufD = carve(e, bufd);
     e->bufZ[0] = carve(e, bufz);
     e->bufZ[1] = carve(e, bufz);
+    if (e->f16) e->bwd_part = carve(e, (size_t)xv_cdiv(rows[1], XV_TILE_M) * 3 * maxc);
     if (e->f16) {
         e->dzh_halfs = dzh_halfs;
         e->dzh[0] = (unsigned short*)carve(e, dzh_halfs);
@@ -869,11 +873,17 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
         rc = xv_split_planes(s, da, segs * t_out, a.c_out, a.c_out, Z, a.o_ld, zstride, zamax);
         if (rc) return rc;
         rc = xv_colsum(s, da, segs * t_out, a.c_out, a.c_out, gptr(e, a.v_bias), e->ws, e->ws_bytes);
+    } else if (e->bwd_part_layer == li && e->bwd_part_chunks == xv_cdiv(segs * t_out, XV_TILE_M)) {
+        // the GEMM that produced `da` already reduced it against this layer's z (xv_affine_dgrad_bnstats_f16x3)
+        rc = xv_bn_relu_backward_split_from_part(s, e->bwd_part, e->bwd_part_chunks, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean,
+                                                 a.invstd, a.scale, a.shift, a.zmin, a.zmax, pad, Z, a.o_ld, zstride, zamax,
+                                                 gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
     } else {
         rc = xv_bn_relu_backward_split(s, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift, a.zmin,
                                        a.zmax, 1, pad, Z, a.o_ld, zstride, zamax, gptr(e, a.v_gamma), gptr(e, a.v_beta),
                                        gptr(e, a.v_bias), e->ws, e->ws_bytes);
     }
+    e->bwd_part_layer = -1;
     if (rc) return rc;
     // operand planes of this layer's input: the feature planes for tdnn1, the producing layer's BN+ReLU planes otherwise
     const int in = a.in_layer;
@@ -899,7 +909,21 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
     }
     e->zcur ^= 1;
     if (dx) {
-        rc = xv_affine_dgrad_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WT + a.wslot, dx, a.c_in);
+        // dx is d(relu(bn(z))) of the producing layer: fold that layer's BN-backward reductions into this GEMM's epilogue - unless
+        // dx is only one of two contributions (tdnn4_relu also feeds the attention key network)
+        // [measured] off by default: the epilogue's extra z-tile reads cost each data-gradient GEMM 50-60 us at S1, the
+        // reduce kernels they replace 37 us each (3.17 vs 3.03 ms/step); XV_FUSE_BWD_STATS=1 turns it on for experiments
+        static const bool fuse_env = getenv("XV_FUSE_BWD_STATS") && getenv("XV_FUSE_BWD_STATS")[0] == '1';
+        const bool fuse = fuse_env && in >= 0 && is_frame(in) && e->L[in].has_bn && e->L[in].has_relu && !(e->att && in == 3) && e->bwd_part;
+        if (fuse) {
+            Affine& p = e->L[in];
+            rc = xv_affine_dgrad_bnstats_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WT + a.wslot, dx,
+                                               a.c_in, p.z, p.scale, p.shift, p.mean, p.invstd, e->bwd_part);
+            e->bwd_part_layer = in;
+            e->bwd_part_chunks = xv_cdiv(segs * (t_out + a.k - 1), XV_TILE_M);
+        } else {
+            rc = xv_affine_dgrad_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WT + a.wslot, dx, a.c_in);
+        }
         if (rc) return rc;
     }
     return 0;

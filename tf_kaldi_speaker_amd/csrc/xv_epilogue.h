@@ -72,6 +72,61 @@ __device__ __forceinline__ void xv_tile_stats_epilogue(const f32x16 (&acc)[2][NB
     }
 }
 
+// Data-gradient epilogue: the tile in `acc` is d a (the gradient w.r.t. a BN+ReLU output); together with the matching
+// tile of that layer's pre-BN tensor z it yields the per-tile partials of the BN backward reductions
+//   part[tile_m][0][n] = sum_rows dd,   [1] = sum_rows dd * xhat,   [2] = max_rows |dd|,     dd = (z*scale+shift > 0) ? d a : 0,
+// i.e. what bn_bwd_reduce_kernel computes from memory - without re-reading d a (xv_elementwise.hip consumes the partials).
+struct XvBwdStats { const float* z; const float* scale; const float* shift; const float* mean; const float* invstd; float* part; };
+
+template <int NB>
+__device__ __forceinline__ void xv_tile_bwd_stats_epilogue(const f32x16 (&acc)[2][NB], float* red /* >= 768 floats of LDS, free */, int tid,
+                                                           int wr, int wc, int li, int lh, int m0, int n0, int M, int N, int tile_m,
+                                                           const XvBwdStats& q) {
+    float* r1 = red;             // [2][128]
+    float* r2 = red + 256;
+    float* r3 = red + 512;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int col = (wc * NB + b) * 32 + li, n = n0 + col;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (n < N) {
+            const float sc = q.scale[n], sh = q.shift[n], mu = q.mean[n], is = q.invstd[n];
+            // unconditional loads (row index clamped) issued as one batch: a predicated load compiles to a branch + vmcnt(0),
+            // i.e. 32 serialised memory round trips per column block
+            float zz[2][16];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    zz[a][r] = q.z[(long)min(m, M - 1) * N + n];
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float dd = (m < M && zz[a][r] * sc + sh > 0.f) ? acc[a][b][r] : 0.f;
+                    s1 += dd;
+                    s2 += dd * ((zz[a][r] - mu) * is);
+                    s3 = fmaxf(s3, fabsf(dd));
+                }
+        }
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 = fmaxf(s3, __shfl_xor(s3, 32));
+        if (lh == 0) { r1[wr * 128 + col] = s1; r2[wr * 128 + col] = s2; r3[wr * 128 + col] = s3; }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int n = n0 + tid;
+        if (n < N) {
+            float* o = q.part + (long)tile_m * 3 * N + n;
+            o[0] = r1[tid] + r1[128 + tid];
+            o[N] = r2[tid] + r2[128 + tid];
+            o[2 * N] = fmaxf(r3[tid], r3[128 + tid]);
+        }
+    }
+}
+
 // The same statistics for a tile held as 4 x 4 v_mfma_f32_16x16x32 accumulators per wave (4 waves, 2 x 2, 64 x 64 each):
 // lane l owns column l & 15 of block b and rows (l >> 4) * 4 + j of block a.
 __device__ __forceinline__ void xv_tile_stats_epilogue16(const f32x4 (&acc)[4][4], float* red /* >= 1024 floats of LDS, free */, int tid, int wr,

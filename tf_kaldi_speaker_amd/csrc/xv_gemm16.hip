@@ -188,6 +188,7 @@ struct NT16Args {
     float* part;
     const unsigned* a_amax; const unsigned* b_amax;
     const u16* zero;
+    XvBwdStats bwd;         // EPI == 2 only
 };
 
 #ifndef XV16_ABL
@@ -221,7 +222,7 @@ struct NT16Args {
 #define PLANE_HALFS (128 * BK16)
 #define BUF_HALFS (4 * PLANE_HALFS)
 
-template <bool STATS>
+template <int EPI>      // 0: plain, 1: + forward BN statistics of the tile, 2: + BN backward reductions (data gradient)
 __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel(NT16Args p) {
     constexpr int RPI = 64 / CQ16;                 // tile rows per LDS-DMA wave-instruction (16)
     constexpr int IPW = 128 / RPI / XV16_WAVES;    // DMA instructions per wave per plane per operand
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
                 if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = v;
             }
     }
-    if (STATS) xv_tile_stats_epilogue16(acc, (float*)smem, tid, wr, wc, lane, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
+    if (EPI == 1) xv_tile_stats_epilogue16(acc, (float*)smem, tid, wr, wc, lane, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
 }
 #else
     f32x16 acc[2][NB16];
@@ -398,7 +399,8 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
                 if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = v;
             }
         }
-    if (STATS) xv_tile_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
+    if (EPI == 1) xv_tile_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
+    if (EPI == 2) xv_tile_bwd_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.bwd);
 }
 #endif
 
@@ -427,7 +429,7 @@ struct NT16ConvArgs {
     long a_rows;               // rows of the A planes (reads beyond are zero)
 };
 
-template <bool STATS>
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_conv_kernel(NT16ConvArgs q) {
     const NT16Args& p = q.g;
     __shared__ __attribute__((aligned(16))) u16 smem[2 * CONV_ABUF + 2 * CONV_BBUF];
@@ -565,7 +567,8 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_conv_kernel(NT16ConvArgs 
                 if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = v;
             }
         }
-    if (STATS) xv_tile_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
+    if (EPI == 1) xv_tile_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
+    if (EPI == 2) xv_tile_bwd_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.bwd);
 }
 
 #ifndef XV16_CONV
@@ -597,6 +600,11 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
     p.C = g.C; p.ldc = g.ldc; p.M = g.M; p.N = g.N; p.K = (int)xv_align(g.K, 8);
     p.tiles_m = xv_cdiv(g.M, 128); p.tiles_n = xv_cdiv(g.N, 128);
     p.bias = g.bias; p.part = g.bn_part; p.a_amax = g.a_amax; p.b_amax = g.b_amax; p.zero = g_zero16;
+    const bool bwd = g.bwd_part != nullptr;
+    XV_REQUIRE(!(bwd && g.bn_part), "gemm16_nt: one epilogue at a time");
+    XV_REQUIRE(!bwd || (g.bwd_z && g.bwd_scale && g.bwd_shift && g.bwd_mean && g.bwd_invstd && !XV16_MFMA16 && XV16_WAVES == 4),
+               "gemm16_nt: incomplete BN-backward epilogue arguments");
+    p.bwd = XvBwdStats{g.bwd_z, g.bwd_scale, g.bwd_shift, g.bwd_mean, g.bwd_invstd, g.bwd_part};
     dim3 grid(p.tiles_m * p.tiles_n);
     XvProfScope prof(s, g.bn_part ? 3 : 4, 2.0 * g.M * g.N * g.K);
     int taps = 0;
@@ -604,13 +612,15 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
         NT16ConvArgs q;
         q.g = p; q.taps = taps; q.chunks = (int)(g.lda / 32);
         q.a_rows = (long)xv_cdiv(g.M, g.a_rps) * g.a_pitch;
-        if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_conv_kernel<true>, grid, dim3(256), 0, s, q);
-        else hipLaunchKernelGGL(xv_gemm16_nt_conv_kernel<false>, grid, dim3(256), 0, s, q);
+        if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_conv_kernel<1>, grid, dim3(256), 0, s, q);
+        else if (bwd) hipLaunchKernelGGL(xv_gemm16_nt_conv_kernel<2>, grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL(xv_gemm16_nt_conv_kernel<0>, grid, dim3(256), 0, s, q);
         XV_LAUNCH_CHECK();
         return 0;
     }
-    if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_kernel<true>, grid, dim3(64 * XV16_WAVES), 0, s, p);
-    else hipLaunchKernelGGL(xv_gemm16_nt_kernel<false>, grid, dim3(64 * XV16_WAVES), 0, s, p);
+    if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_kernel<1>, grid, dim3(64 * XV16_WAVES), 0, s, p);
+    else if (bwd) hipLaunchKernelGGL(xv_gemm16_nt_kernel<2>, grid, dim3(64 * XV16_WAVES), 0, s, p);
+    else hipLaunchKernelGGL(xv_gemm16_nt_kernel<0>, grid, dim3(64 * XV16_WAVES), 0, s, p);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -800,6 +810,23 @@ extern "C" int xv_affine_dgrad_f16x3(void* stream, const void* dz_planes, size_t
     g.Bt = wf_planes; g.ldb = (long)k * o_ld; g.b_plane = (long)wf_plane_stride;
     g.C = dx; g.ldc = c; g.M = segs * (t_out + k - 1); g.N = c; g.K = k * o_ld;
     g.a_amax = dz_amax; g.b_amax = wf_amax;
+    return xv_launch_gemm16_nt((hipStream_t)stream, g);
+}
+
+// xv_affine_dgrad_f16x3 whose epilogue also produces the per-tile partials of the BN backward of the layer that owns dx
+// (dx = d a of a BN+ReLU layer with pre-BN output z_below [rows][c]): part [ceil(rows/128)][3][c] = sum dd | sum dd*xhat | max |dd|.
+extern "C" int xv_affine_dgrad_bnstats_f16x3(void* stream, const void* dz_planes, size_t dz_plane_stride, const uint32_t* dz_amax, int segs,
+                                             int t_out, int o_ld, int k, const void* wf_planes, size_t wf_plane_stride,
+                                             const uint32_t* wf_amax, float* dx, int c, const float* z_below, const float* scale,
+                                             const float* shift, const float* mean, const float* invstd, float* part) {
+    XV_REQUIRE(segs > 0 && k >= 1 && t_out >= 1 && o_ld > 0 && c > 0, "affine_dgrad_bnstats_f16x3: bad shape");
+    XV_REQUIRE(z_below && scale && shift && mean && invstd && part, "affine_dgrad_bnstats_f16x3: null BN argument");
+    XvGemm16NT g = {};
+    g.A = dz_planes; g.lda = o_ld; g.a_plane = (long)dz_plane_stride; g.a_rps = t_out + k - 1; g.a_pitch = t_out + 2 * (k - 1);
+    g.Bt = wf_planes; g.ldb = (long)k * o_ld; g.b_plane = (long)wf_plane_stride;
+    g.C = dx; g.ldc = c; g.M = segs * (t_out + k - 1); g.N = c; g.K = k * o_ld;
+    g.a_amax = dz_amax; g.b_amax = wf_amax;
+    g.bwd_z = z_below; g.bwd_scale = scale; g.bwd_shift = shift; g.bwd_mean = mean; g.bwd_invstd = invstd; g.bwd_part = part;
     return xv_launch_gemm16_nt((hipStream_t)stream, g);
 }
 

@@ -386,6 +386,16 @@ def affine_dgrad_f16x3(dzp, segs, t_out, k, wfp, c):
     return dx
 
 
+def affine_dgrad_bnstats_f16x3(dzp, segs, t_out, k, wfp, c, z_below, scale, shift, mean, invstd):
+    """affine_dgrad_f16x3 + the per-tile BN-backward partials [ceil(rows/128), 3, c] of the layer that owns dx."""
+    rows = segs * (t_out + k - 1)
+    dx = torch.empty((rows, c), dtype=torch.float32, device=dzp.data.device)
+    part = torch.empty(((rows + TILE_M - 1) // TILE_M, 3, c), dtype=torch.float32, device=dx.device)
+    _lib.call("xv_affine_dgrad_bnstats_f16x3", _s(), _p(dzp.data), C.c_size_t(dzp.stride), _p(dzp.amax), segs, t_out, dzp.ld, k, _p(wfp.data),
+              C.c_size_t(wfp.stride), _p(wfp.amax), _p(dx), c, _p(z_below), _p(scale), _p(shift), _p(mean), _p(invstd), _p(part))
+    return dx, part
+
+
 def affine_wgrad_f16x3(xp, segs, t_in, k, c, dzp, dz_seg_pitch, dz_row0, o, kernel, l2_scale):
     dk = torch.empty((k, c, o), dtype=torch.float32, device=xp.data.device)
     wp, wb = _ws(dk)
