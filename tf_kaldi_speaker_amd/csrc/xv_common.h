@@ -140,6 +140,16 @@ int xv_bn_small_backward(hipStream_t s, const float* da, const float* z, int row
                          const float* invstd, const float* scale, const float* shift, int relu, float* dz, float* dgamma, float* dbeta,
                          float* dbias);
 
+// Engine-internal form of xv_bn_relu_backward_split / _pooled_split / _split_from_part: the upstream gradient is `da`, or the
+// (weighted) pooling backward of (pool_out, dpool) when pool_out != null; ext_part: reductions already done by a GEMM epilogue;
+// zero_amax = false: *dz_amax was zeroed by the caller (one memset per backward pass instead of one per layer).
+struct XvBnBwdSplit { const float* da; const float* pool_out; const float* dpool; const float* weights; int pool_t;
+                      const float* ext_part; int ext_chunks; bool zero_amax; };
+int xv_bn_relu_backward_split_ex(hipStream_t s, const XvBnBwdSplit& x, const float* z, int segs, int t, int n, const float* gamma,
+                                 const float* mean, const float* invstd, const float* scale, const float* shift, const float* zmin,
+                                 const float* zmax, int relu, int pad, void* dz_planes, int ldp, size_t plane_stride, uint32_t* dz_amax,
+                                 float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes);
+
 // Live launch timing (xv_profile_begin/end): brackets one GEMM launch with hipEvents on its stream.
 struct XvProfScope {
     hipStream_t s; int idx;

@@ -739,7 +739,7 @@ static int bn_relu_backward_split_impl(hipStream_t s, const float* da, PoolGrad 
                                        const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
                                        const float* zmin, const float* zmax, int relu, int pad, void* dz_planes, int ldp,
                                        size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
-                                       size_t ws_bytes, const float* ext_part = nullptr, int ext_chunks = 0) {
+                                       size_t ws_bytes, const float* ext_part = nullptr, int ext_chunks = 0, bool zero_amax = true) {
     XV_REQUIRE(segs > 0 && t > 0 && n > 0 && n % 4 == 0 && pad >= 0, "bn_relu_backward_split: bad shape (n=%d must be a multiple of 4)", n);
     XV_REQUIRE(ldp % 8 == 0 && ldp >= n && plane_stride % 8 == 0 && zmin && zmax && dz_amax, "bn_relu_backward_split: bad plane arguments");
     XV_REQUIRE((long)segs * (t + 2 * pad) * (ldp / 8) < (1L << 31), "bn_relu_backward_split: tensor too large for 32-bit indexing");
@@ -752,7 +752,7 @@ static int bn_relu_backward_split_impl(hipStream_t s, const float* da, PoolGrad 
     float* part = ext_part ? const_cast<float*>(ext_part) : (float*)ws;
     float* coef = ext_part ? (float*)ws : part + (size_t)chunks * 3 * n;
     const bool pooled = pg.out != nullptr;
-    XV_CHECK_HIP(hipMemsetAsync(dz_amax, 0, sizeof(uint32_t), s));
+    if (zero_amax) XV_CHECK_HIP(hipMemsetAsync(dz_amax, 0, sizeof(uint32_t), s));
     if (!ext_part) {
         hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
                            da, pg, z, rows, n, mean, invstd, scale, shift, relu, part);
@@ -787,6 +787,16 @@ extern "C" int xv_bn_relu_backward_split(void* stream, const float* da, const fl
     PoolGrad pg = {nullptr, nullptr, 1, nullptr};
     return bn_relu_backward_split_impl((hipStream_t)stream, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, zmin, zmax, relu, pad,
                                        dz_planes, ldp, plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes);
+}
+
+// engine-internal form of the three public variants (xv_common.h)
+int xv_bn_relu_backward_split_ex(hipStream_t s, const XvBnBwdSplit& x, const float* z, int segs, int t, int n, const float* gamma,
+                                 const float* mean, const float* invstd, const float* scale, const float* shift, const float* zmin,
+                                 const float* zmax, int relu, int pad, void* dz_planes, int ldp, size_t plane_stride, uint32_t* dz_amax,
+                                 float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
+    PoolGrad pg = {x.pool_out, x.dpool, x.pool_out ? x.pool_t : 1, x.weights};
+    return bn_relu_backward_split_impl(s, x.da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, zmin, zmax, relu, pad, dz_planes, ldp,
+                                       plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes, x.ext_part, x.ext_chunks, x.zero_amax);
 }
 
 // xv_bn_relu_backward_split with the reduction partials already produced by xv_affine_dgrad_bnstats_f16x3 (the pass over

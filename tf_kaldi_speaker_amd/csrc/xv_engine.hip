@@ -111,7 +111,8 @@ struct xv_engine {
 
 namespace {
 
-// amax slots: 0 input x | 1..4 BN+ReLU outputs of tdnn1..4 | 8..12 weights of tdnn1..5 (both layouts) | 24,25 dz buffers
+// amax slots: 0 input x | 1..5 BN+ReLU outputs of tdnn1..4, att_key0 | 8..14 weights of tdnn1..5, att_key0/1 (both layouts) |
+// 24..30 dz of tdnn1..5, att_key0/1 (one slot per layer: zeroed once per backward pass, not once per layer)
 enum { AMAX_X = 0, AMAX_A = 1, AMAX_WT = 8, AMAX_DZ = 24, AMAX_SLOTS = 32 };
 
 // frame-level layers (rows = chunks x frames): tdnn1-5 and the attention key layers; tdnn6/7 are segment level
@@ -851,7 +852,7 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
     const int pad = (dx && a.k > 1) ? a.k - 1 : 0;
     const int zi = e->zcur;
     unsigned short* Z = e->dzh[zi];
-    uint32_t* zamax = e->amax + AMAX_DZ + zi;
+    uint32_t* zamax = e->amax + AMAX_DZ + a.wslot;
     if (e->w_pending[zi]) {
         XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_w[zi], 0));
         e->w_pending[zi] = false;
@@ -860,28 +861,27 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
     const size_t zstride = (size_t)segs * seg_pitch * a.o_ld;
     XV_REQUIRE(zstride <= e->dzh_halfs, "engine_backward: dz plane buffer too small");
     int rc;
-    if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
-        XV_REQUIRE(li == 4, "engine_backward: only tdnn5 takes its gradient from the pooling layer");
-        rc = xv_bn_relu_backward_pooled_split(s, e->pool, e->d_small0, e->att ? e->att_w : nullptr, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd,
-                                              a.scale, a.shift, a.zmin, a.zmax, 1, Z, a.o_ld, zstride, zamax, gptr(e, a.v_gamma),
-                                              gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
-    } else if (!a.has_bn) {      // att_key1: `da` already is dz (fp32): planes + the bias gradient straight from it
+    if (da && !a.has_bn) {      // att_key1: `da` already is dz (fp32): planes + the bias gradient straight from it
         XV_REQUIRE(pad == 0 && !a.has_relu, "engine_backward: a frame layer without BN is the attention key layer");
-        XV_CHECK_HIP(hipMemsetAsync(zamax, 0, sizeof(uint32_t), s));
         rc = xv_amax(s, da, (size_t)segs * t_out * a.c_out, zamax);
         if (rc) return rc;
         rc = xv_split_planes(s, da, segs * t_out, a.c_out, a.c_out, Z, a.o_ld, zstride, zamax);
         if (rc) return rc;
         rc = xv_colsum(s, da, segs * t_out, a.c_out, a.c_out, gptr(e, a.v_bias), e->ws, e->ws_bytes);
-    } else if (e->bwd_part_layer == li && e->bwd_part_chunks == xv_cdiv(segs * t_out, XV_TILE_M)) {
-        // the GEMM that produced `da` already reduced it against this layer's z (xv_affine_dgrad_bnstats_f16x3)
-        rc = xv_bn_relu_backward_split_from_part(s, e->bwd_part, e->bwd_part_chunks, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean,
-                                                 a.invstd, a.scale, a.shift, a.zmin, a.zmax, pad, Z, a.o_ld, zstride, zamax,
-                                                 gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
     } else {
-        rc = xv_bn_relu_backward_split(s, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift, a.zmin,
-                                       a.zmax, 1, pad, Z, a.o_ld, zstride, zamax, gptr(e, a.v_gamma), gptr(e, a.v_beta),
-                                       gptr(e, a.v_bias), e->ws, e->ws_bytes);
+        XvBnBwdSplit x = {};
+        x.da = da;
+        x.zero_amax = false;           // the dz slots were zeroed at the start of this backward pass
+        if (!da) {       // tdnn5: the upstream gradient is the (attention-weighted) pooling backward of (pool, d pool)
+            XV_REQUIRE(li == 4, "engine_backward: only tdnn5 takes its gradient from the pooling layer");
+            x.pool_out = e->pool; x.dpool = e->d_small0; x.pool_t = e->Tl[5]; x.weights = e->att ? e->att_w : nullptr;
+        } else if (e->bwd_part_layer == li && e->bwd_part_chunks == xv_cdiv(segs * t_out, XV_TILE_M)) {
+            // the GEMM that produced `da` already reduced it against this layer's z (xv_affine_dgrad_bnstats_f16x3)
+            x.ext_part = e->bwd_part; x.ext_chunks = e->bwd_part_chunks;
+        }
+        rc = xv_bn_relu_backward_split_ex(s, x, a.z, da ? segs : e->B * e->Tl[5], da ? t_out : 1, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd,
+                                          a.scale, a.shift, a.zmin, a.zmax, 1, pad, Z, a.o_ld, zstride, zamax, gptr(e, a.v_gamma),
+                                          gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
     }
     e->bwd_part_layer = -1;
     if (rc) return rc;
@@ -940,6 +940,7 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
     const int b = e->B;
     int rc;
     if (stage == -1 || stage == 0) {
+        if (e->f16) XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_DZ, 0, 8 * sizeof(uint32_t), s));   // every layer's dz scale slot
         // d out = dlogits . wn^T   (pad column of both is zero, so K = ldl is exact)
         XvGemmNT g = {};
         g.A = e->dlogits; g.lda = e->ldl; g.a_rps = 1; g.a_pitch = 1;
