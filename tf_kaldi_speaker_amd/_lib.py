@@ -168,6 +168,10 @@ def load():
         raise XvError(
             "HIP extension %s is missing - build it with `make -C %s` (hipcc, gfx950). "
             "There is no CPU fallback." % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever HIP runtime is mapped first serves the whole
+    # process: if this library came first it would bind the system runtime and torch's CUDA initialisation would then find
+    # "no ROCm-capable device".  Importing torch first makes both share torch's runtime (device buffers are torch's anyway).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError here == ABI mismatch: fail loudly
