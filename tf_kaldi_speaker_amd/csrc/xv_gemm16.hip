@@ -211,10 +211,11 @@ struct NT16Args {
 #define XV16_MFMA16 0    // 1: v_mfma_f32_16x16x32_f16 in the generic NT kernel (4 x 4 accumulator blocks per wave), BK = 32 and 4 waves only
 #endif
 #if XV16_MFMA16
-// 16x16x32 operands: lane l reads row l & 15, 16-byte chunk l >> 4 of a 64-byte row.  A ds_read_b128 lane group then holds
-// row quads q = (row >> 2) & 3 with chunks {q0:c, q3:c, q1:c^1, q2:c^1}; chunk ^= f(q), f = (0, 2, 3, 1), maps them to four distinct
-// 4-bank columns in every group (conflict-free); the same involution is applied to the LDS-DMA source chunk.
-#define SWZ16(row) ((0x78 >> (2 * (((row) >> 2) & 3))) & 3)
+// 16x16x32 operands: lane l reads row base + (l & 15), 16-byte chunk l >> 4 of a 64-byte row.  chunk ^= 2 * ((row >> 2) & 1) puts the
+// 16 lanes of every ds_read_b128 lane group on 16 distinct 4-bank columns for ANY base row (exhaustive check over the four
+// lane groups and all 16 alignments; a context-window read shifts the rows by the tap) - the same involution is applied to the
+// LDS-DMA source chunk.
+#define SWZ16(row) ((((row) >> 2) & 1) << 1)
 #else
 #define SWZ16(row) (BK16 == 64 ? (((row) >> 1) & 7) : BK16 == 32 ? (((row) >> 2) & 3) : 0)
 #endif
