@@ -138,6 +138,56 @@ def test_trainer_with_self_attention_pooling(tmp_path):
         Trainer(Params(str(tmp_path / "bad.json")), model).build("train", dim=30, loss_type="additive_margin_softmax", num_speakers=6)
 
 
+def test_finetuning_helpers(tmp_path):
+    """noupdate_var_list / set_trainable_variables / get_finetune_model / train_tune_lr / insight (trainer.py:379-403, 522-590, 728-920)."""
+    from tf_kaldi_speaker_amd.misc.utils import Params
+    from tf_kaldi_speaker_amd.model.trainer import Trainer
+    data, spklist, mats = make_data_dir(str(tmp_path / "train"), num_spk=6, utts_per_spk=3, min_frames=60, max_frames=110)
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps(dict(CONFIG, optimizer="momentum", momentum=0.9)))
+    model = str(tmp_path / "exp")
+    os.makedirs(os.path.join(model, "nnet"))
+    # pre-train one epoch
+    tr = Trainer(Params(str(cfg_path)), model)
+    tr.build("train", dim=30, loss_type="additive_margin_softmax", num_speakers=6)
+    tr.train(data, spklist, 0.01)
+    pre = tr.engine.get_variables()
+    tr.close()
+    # fine-tune: a new speaker set (softmax layer re-initialised), tdnn1-3 frozen incl. their BN statistics
+    tr = Trainer(Params(str(cfg_path)), model)
+    tr.build("train", dim=30, loss_type="additive_margin_softmax", num_speakers=6, noupdate_var_list=["tdnn1", "tdnn2", "tdnn3"])
+    tr.build("valid", dim=30, loss_type="additive_margin_softmax", num_speakers=6)
+    tr.get_finetune_model(["softmax"])
+    start = tr.engine.get_variables()
+    nnet = os.path.join(model, "nnet")
+    assert os.path.isfile(os.path.join(nnet, "model-0.npz")) and any(f.endswith(".bak") for f in os.listdir(nnet))
+    assert np.array_equal(start["tdnn/tdnn2_conv/kernel"], pre["tdnn/tdnn2_conv/kernel"])
+    assert not np.array_equal(start["softmax/output/kernel"], pre["softmax/output/kernel"])
+    tr.train(data, spklist, 0.01)
+    after = tr.engine.get_variables()
+    for k in after:
+        frozen = any(s in k for s in ("tdnn1", "tdnn2", "tdnn3"))
+        changed = not np.array_equal(after[k], start[k])
+        if frozen:
+            assert not changed, k                                   # values AND moving statistics untouched
+        elif k.endswith(("kernel", "gamma", "beta", "moving_mean")):
+            assert changed, k
+    # set_trainable_variables: only the loss layer from now on (BN statistics keep moving)
+    tr.set_trainable_variables(["softmax"])
+    tr.train(data, spklist, 0.01)
+    last = tr.engine.get_variables()
+    assert np.array_equal(last["tdnn/tdnn5_dense/kernel"], after["tdnn/tdnn5_dense/kernel"])
+    assert not np.array_equal(last["softmax/output/kernel"], after["softmax/output/kernel"])
+    assert not np.array_equal(last["tdnn/tdnn5_bn/moving_mean"], after["tdnn/tdnn5_bn/moving_mean"])
+    tr.set_trainable_variables(None)
+    loss, emb, labels = tr.insight(data, spklist, output_embeddings=True)
+    assert np.isfinite(loss) and emb.shape[0] == labels.shape[0]
+    tr.train_tune_lr(data, spklist, tune_period=2, tune_times=3)
+    lines = open(os.path.join(nnet, "learning_rate_tuning")).read().strip().split("\n")
+    assert len(lines) == 3 and lines[0].split()[0] == "0" and abs(float(lines[1].split()[1]) - 1.15e-5) < 1e-6
+    tr.close()
+
+
 def test_drivers_as_run_sh_calls_them(tmp_path):
     """python nnet/lib/train.py ... ; make_checkpoint.py ; extract.py with PYTHONPATH=$TF_KALDI_ROOT (run_train_nnet.sh:30,64)."""
     data, spklist, mats = make_data_dir(str(tmp_path / "train"), num_spk=6, utts_per_spk=3, min_frames=60, max_frames=110)

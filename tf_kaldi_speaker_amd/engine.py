@@ -264,12 +264,42 @@ class Engine(object):
         _lib.check(self.lib.xv_copy_2d(_stream(), _ptr(out), cols.value, p, ld.value, rows.value, cols.value), "xv_copy_2d")
         return out
 
+    # ---- fine-tuning: variables the optimiser must not touch (trainer.py:379-403 noupdate_var_list, :728-773 set_trainable_variables)
+    def set_update_filter(self, frozen_names=()):
+        """frozen_names: variable names (trainable ones: never updated; BN moving statistics: their UPDATE_OPS are skipped).
+        Implemented on the flat buffers: frozen trainables (and their momentum / Adam slots - TF does not create the update op at
+        all) are saved before the optimiser step and put back after it, their gradient slices are zeroed first so that a global-norm
+        clip sees what TF's restricted var_list sees; frozen moving statistics are restored after the training forward pass."""
+        frozen = [n for n in frozen_names if n in self.table]
+        grad_ranges, stat_ranges = [], []
+        for n in frozen:
+            shape, off, trainable = self.table[n]
+            cnt = int(np.prod(shape)) if len(shape) else 1
+            (grad_ranges if trainable else stat_ranges).append((off, off + cnt))
+
+        def merge(r):
+            out = []
+            for b, e in sorted(r):
+                if out and b <= out[-1][1] + 3:          # variables start on 4-float boundaries
+                    out[-1] = (out[-1][0], max(out[-1][1], e))
+                else:
+                    out.append((b, e))
+            return out
+        self._frozen_grads, self._frozen_stats = merge(grad_ranges), merge(stat_ranges)
+        self.frozen_names = tuple(frozen)
+
     def train_step(self, features, labels, lr, global_step, allreduce=None, fetch_losses=False):
         """One sess.run(train_op) (trainer.py:505-508).  `allreduce(tensor_slice)` - if given - is
         called after each backward stage on the finished slice of the flat gradient buffer.
         fetch_losses: also return (raw_loss, regularization_loss) evaluated on the PRE-update
         weights, as the reference's logging fetch does (trainer.py:485-499); this synchronises."""
+        frozen_stats = getattr(self, "_frozen_stats", None)
+        if frozen_stats:
+            keep = [self.variables[b:e].clone() for b, e in frozen_stats]
         self.forward(features, True)
+        if frozen_stats:
+            for (b, e), v in zip(frozen_stats, keep):
+                self.variables[b:e].copy_(v)
         self.loss(labels, global_step, True)
         if allreduce is None:
             self.backward(-1)
@@ -281,6 +311,18 @@ class Engine(object):
                 allreduce(self.grads[b:e])
             allreduce.wait()
             grad_scale = allreduce.grad_scale
+        frozen = getattr(self, "_frozen_grads", None) or ()
+        saved = []
+        for b, e in frozen:
+            self.grads[b:e].zero_()
+            slots = [self.opt_state[k * self.n_train + b:k * self.n_train + e] for k in range(self.n_opt // max(self.n_train, 1))]
+            saved.append((self.variables[b:e].clone(), [t.clone() for t in slots]))
         out = self.losses() if fetch_losses else None
         self.apply(lr, grad_scale)
+        for (b, e), (v, slots) in zip(frozen, saved):
+            self.variables[b:e].copy_(v)
+            for k, t in enumerate(slots):
+                self.opt_state[k * self.n_train + b:k * self.n_train + e].copy_(t)
+        if frozen:
+            _lib.check(self.lib.xv_engine_invalidate_weights(self.h), "xv_engine_invalidate_weights")
         return out

@@ -142,13 +142,12 @@ class Trainer(object):
         self.engine = self._make_engine(self.num_speakers, self.loss_type, nb, nt, keep=values)
         if self.engine.opt_state.numel() == opt.numel():
             self.engine.opt_state.copy_(opt)
+        self._apply_update_filter()
         self.engine.update_count = cnt
 
     # ------------------------------------------------------------------ build
     def build(self, mode, dim, loss_type=None, num_speakers=None, noupdate_var_list=None):
         assert (mode == "train" or mode == "valid" or mode == "predict")
-        if noupdate_var_list is not None:
-            raise NotImplementedError("fine-tuning with noupdate_var_list is outside the hot path (SURVEY.md section 2, item 6)")
         check_params(self.params)
         self.dim = int(dim)
         if mode == "predict":
@@ -190,6 +189,16 @@ class Trainer(object):
         self.embeddings = "output"          # valid embeddings = endpoints["output"], trainer.py:308
         self.modes.add(mode)
         self.is_built = True
+        if mode == "train" and noupdate_var_list is not None:
+            # fine-tuning (trainer.py:379-403): variables - and BN UPDATE_OPS - whose name contains one of the strings are left alone
+            self._frozen = [n for n in self.engine.table if substring_in_list(n, noupdate_var_list)]
+            for n in self.engine.table:
+                log.info("[Info] Var %s will not be updated" % n if n in self._frozen else "[Info] Train %s" % n)
+        self._apply_update_filter()
+
+    def _apply_update_filter(self):
+        if self.engine is not None:
+            self.engine.set_update_filter(getattr(self, "_frozen", None) or ())
 
     # ------------------------------------------------------------------ checkpoints
     def save(self, step):
@@ -351,6 +360,7 @@ class Trainer(object):
                 self._ensure_capacity(features.shape[0], features.shape[1])
                 self.engine.forward(features, False)
                 self.engine.loss(labels, curr_step, with_margin=False)
+                self._last_valid_labels = np.asarray(labels)
                 total += self.engine.raw_loss()
                 num_batches += 1
         finally:
@@ -384,15 +394,97 @@ class Trainer(object):
             emb = np.squeeze(emb, axis=0)
         return emb
 
-    # ------------------------------------------------------------------ research tooling of the reference: not on the hot path
-    def train_tune_lr(self, *a, **k):
-        raise NotImplementedError("train_tune_lr is research tooling outside the hot path (SURVEY.md section 2, item 6)")
+    # ------------------------------------------------------------------ fine-tuning / diagnostics (trainer.py:522-590, 728-920)
+    def set_trainable_variables(self, variable_list=None):
+        """Only the trainable variables whose name contains one of the strings are optimised (None: all).  BN moving statistics
+        keep updating (trainer.py:728-773)."""
+        assert "train" in self.modes, "call build('train', ...) first"
+        if variable_list is None:
+            log.info("[Info] Add all trainable variables to the optimizer.")
+            self._frozen = []
+        else:
+            self._frozen = []
+            for n, (_, _, trainable) in self.engine.table.items():
+                if not trainable:
+                    continue
+                if substring_in_list(n, variable_list):
+                    log.info("[Info] Add %s to trainable list" % n)
+                else:
+                    self._frozen.append(n)
+        self._apply_update_filter()
 
-    def set_trainable_variables(self, *a, **k):
-        raise NotImplementedError("fine-tuning helpers are outside the hot path (SURVEY.md section 2, item 6)")
+    def get_finetune_model(self, excluded_list):
+        """Start from the pre-trained checkpoint in the model directory; variables whose name contains a string of `excluded_list`
+        keep their default initialisation.  The pre-trained files are backed up (`.bak`) and the result is saved as step 0
+        (trainer.py:775-819)."""
+        assert self.engine is not None, "call build(...) first"
+        self.engine.init_variables(seed=int(self.params.dict.get("seed", 0)))
+        fresh = self.engine.get_variables()
+        current, _ = read_checkpoint_state(self.model)
+        if not current:
+            sys.exit("Failed to find a checkpoint in {}".format(self.model))
+        path = os.path.join(self.model, os.path.basename(current) + ".npz")
+        data = np.load(path)
+        values = {}
+        for name in self.engine.table:
+            if substring_in_list(name, excluded_list):
+                log.info("[Info] Ignore %s when loading the checkpoint" % name)
+                values[name] = fresh[name]
+            elif name in data.files and tuple(data[name].shape) == tuple(fresh[name].shape):
+                values[name] = data[name]
+            else:
+                sys.exit("Checkpoint %s lacks variable %s (exclude it to re-initialise it)" % (path, name))
+        self.engine.set_variables(values)
+        self.engine.opt_state.zero_()
+        self.engine.update_count = 0
+        import glob
+        import shutil
+        for filename in glob.glob(os.path.join(self.model, os.path.basename(current)) + "*"):
+            if not filename.endswith(".bak"):
+                shutil.copyfile(filename, filename + ".bak")
+        self.save(0)
+        self.is_loaded = True
 
-    def get_finetune_model(self, *a, **k):
-        raise NotImplementedError("fine-tuning helpers are outside the hot path (SURVEY.md section 2, item 6)")
+    def train_tune_lr(self, data, spklist, tune_period=100, aux_data=None, tune_times=100):
+        """Learning-rate range test (trainer.py:522-590): lr = 1e-5 * 1.15^(step // tune_period), global_step fed as 0, the
+        (step, lr, total loss) of the first step of every period written to <model>/learning_rate_tuning."""
+        assert "train" in self.modes, "call build('train', ...) first"
+        p = self.params
+        self.engine.init_variables(seed=int(p.dict.get("seed", 0)))
+        if os.path.isfile(os.path.join(self.model, "checkpoint")):
+            self.load()
+        queue_cls = KaldiDataRandomQueue if os.environ.get("XV_LOADER", "native") == "python" else NativeRandomQueue
+        loader = queue_cls(data, spklist, num_parallel=p.num_parallel_datasets, max_qsize=p.max_queue_size,
+                           num_speakers=p.num_speakers_per_batch, num_segments=p.num_segments_per_speaker,
+                           min_len=p.min_segment_len, max_len=p.max_segment_len, shuffle=True)
+        loader.start()
+        init_learning_rate, factor = 1e-5, 1.15
+        os.makedirs(self.model, exist_ok=True)
+        try:
+            with open(os.path.join(self.model, "learning_rate_tuning"), "w") as fp_lr:
+                for step in range(int(tune_period) * int(tune_times)):
+                    lr = init_learning_rate * (factor ** (step // tune_period))
+                    start_time = time.time()
+                    features, labels = loader.fetch()
+                    self._ensure_capacity(features.shape[0], features.shape[1])
+                    first = step % tune_period == 0
+                    losses = self.engine.train_step(features, labels, lr, 0, fetch_losses=first)
+                    if first:
+                        raw, reg = losses
+                        log.info("Epoch: step: %2d, time: %.4f s/step, lr: %f, raw loss: %f, total loss: %f"
+                                 % (step, time.time() - start_time, lr, raw, raw + reg))
+                        fp_lr.write("%d %f %f\n" % (step, lr, raw + reg))
+        finally:
+            loader.stop()
 
-    def insight(self, *a, **k):
-        raise NotImplementedError("insight() is debug tooling outside the hot path")
+    def insight(self, data, spklist, batch_type="softmax", output_embeddings=False, aux_data=None):
+        """The reference's debugging pass (trainer.py:821-920) without its pdb breakpoint: validation loss, optional embeddings /
+        labels in file order, and the accuracy of the last validation batch in the log."""
+        loss, emb, labels = self.valid(data, spklist, batch_type=batch_type, output_embeddings=output_embeddings, aux_data=aux_data)
+        try:
+            logits = self.engine.endpoint("logits").cpu().numpy()
+            lab = self._last_valid_labels
+            log.info("Acc: %f" % (float(np.sum(np.argmax(logits[:, :self.num_speakers], axis=1) == lab)) / float(lab.shape[0])))
+        except Exception:
+            pass
+        return loss, emb, labels
