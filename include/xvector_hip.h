@@ -231,7 +231,7 @@ int xv_mhe_add_grad(void* stream, float* dwn, int c, int n, int ldn, const float
 
 /* ---- self-attention pooling, the shipped single-head form (model/pooling.py:37-192; nnet_conf/..._tdnn4_att.json) ----
  * The key network's dense layers run on the frame-level GEMMs; these are the pieces around them.
- *   score[r]   = scale * sum_c act(zk[r][c]) * query[c]        act: 0 = identity, 3 = tanh (att_key_network_type, pooling.py:84-96)
+ *   score[r]   = scale * sum_c act(zk[r][c]) * query[c]        act: 0 = identity, 1 = relu, 3 = tanh (att_key_network_type, pooling.py:84-96)
  *   weights    = softmax over the t frames of each chunk        (pooling.py:148)
  *   pooled     = xv_stat_pool_forward_bn(..., weights, ...)     (pooling.py:151-164)
  * backward: d weights from the pooled statistics (the value path enters tdnn5's BN backward through
@@ -315,7 +315,7 @@ typedef struct xv_config {
     int32_t pooling;                  /* XV_POOL_*: pooling_type, tdnn.py:133-138 */
     int32_t att_key0_nodes;           /* att_key_num_nodes[0]: dense+bn+relu on tdnn4_relu (pooling.py:78-82) */
     int32_t att_key1_nodes;           /* att_key_num_nodes[1]: the key dimension (pooling.py:84-96) */
-    int32_t att_key_type;             /* att_key_network_type of the last key layer: 0 affine, 3 affine + tanh */
+    int32_t att_key_type;             /* att_key_network_type of the last key layer: 0 affine, 1 + relu, 2 + bn + relu, 3 + tanh */
     int32_t att_use_scale;            /* att_use_scale: scores / sqrt(key dim) (pooling.py:144-145) */
     int32_t aux_ring;                 /* "ring_loss" in aux_loss_func (loss.py:1003-1017); adds the variable softmax_ringloss/r */
     float ring_loss_init;             /* initial r (set by the host initialiser; the engine does not read it) */

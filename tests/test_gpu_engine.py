@@ -42,6 +42,8 @@ CASES = [
     dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, pooling_type="self_attention",
          att_key_num_nodes=(300, 200)),
     dict(loss_func="softmax", pooling_type="self_attention", att_key_num_nodes=(64, 48), att_key_network_type=0, att_use_scale=False),
+    dict(loss_func="softmax", pooling_type="self_attention", att_key_num_nodes=(64, 48), att_key_network_type=1),      # fisher *_att_2.json
+    dict(loss_func="softmax", pooling_type="self_attention", att_key_num_nodes=(64, 48), att_key_network_type=2),      # fisher *_att_3.json
     # auxiliary losses (loss.py:985-1036) as in nnet_conf/*_r0.01.json and *_mhe0.01.json, stronger weights to make them count
     dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, aux_loss_func=("ring_loss", "mhe_loss"),
          ring_loss_init=3.0, ring_loss_lambda=0.05, mhe_lambda=0.05),
@@ -87,7 +89,7 @@ def test_variable_table_matches_reference_names():
     eng.close()
 
 
-RELU_LAYERS = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5", "att_key0", "tdnn6", "tdnn7")
+RELU_LAYERS = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5", "att_key0", "att_key1", "tdnn6", "tdnn7")
 
 
 def oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x, labels, lr, step, opt_state):
@@ -110,7 +112,7 @@ def oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x, labels, lr, step, opt_st
         got = eng.endpoint(key).cpu().numpy().reshape(ep[key].shape)
         flips = (got > 0) != (ep[key] > 0)
         assert flips.mean() < 1e-4, (key, flips.mean())
-        pre = ep[prefix + "_bn"]
+        pre = ep[prefix + "_bn"] if prefix + "_bn" in ep else ep[prefix + "_dense"]       # att_key1 with a plain ReLU (type 1)
         assert np.all(np.abs(pre[flips]) < 2e-5 * max(1.0, np.abs(pre).max())), key
         ep_gpu[key] = got.astype(np.float64)
     raw_loss, logits, dfeat, Gl = O.loss_forward_backward(V, cfg_o, feats, labels, step)

@@ -51,6 +51,10 @@ def torch_forward(V, x, cfg, labels, step, training=True):
         ep["att_key1_dense"] = k
         if cfg.att_key_network_type == 3:
             k = torch.tanh(k)
+        elif cfg.att_key_network_type == 1:
+            k = torch.relu(k)
+        elif cfg.att_key_network_type == 2:
+            k = torch.relu(bn("att_key1", k, "attention/att_key1/"))
         score = torch.einsum("btd,hd->bth", k, tv["tdnn/attention/query"])[:, :, 0]
         if cfg.att_use_scale:
             score = score / np.sqrt(k.shape[-1])
@@ -147,6 +151,8 @@ CASES = [
     dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, pooling_type="self_attention",
          att_key_num_nodes=(24, 20)),
     dict(loss_func="softmax", pooling_type="self_attention", att_key_num_nodes=(16, 12), att_key_network_type=0, att_use_scale=False),
+    dict(loss_func="softmax", pooling_type="self_attention", att_key_num_nodes=(16, 12), att_key_network_type=1),
+    dict(loss_func="softmax", pooling_type="self_attention", att_key_num_nodes=(16, 12), att_key_network_type=2),
     # auxiliary losses of the shipped *_r0.01.json / *_mhe0.01.json configs (loss.py:985-1036)
     dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, aux_loss_func=("ring_loss", "mhe_loss"),
          ring_loss_init=3.0, ring_loss_lambda=0.05, mhe_lambda=0.05),

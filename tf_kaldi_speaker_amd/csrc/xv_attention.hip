@@ -21,7 +21,9 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
-__device__ __forceinline__ float key_act(float z, int act) { return act == 3 ? tanhf(z) : z; }
+// att_key_network_type of the last key layer (pooling.py:84-96): 0 affine, 1 affine + relu, 3 affine + tanh
+// (2 = affine + bn + relu runs through the BN kernels; these functions then see its output with act = 0)
+__device__ __forceinline__ float key_act(float z, int act) { return act == 3 ? tanhf(z) : (act == 1 ? fmaxf(z, 0.f) : z); }
 
 // score[r] = scale * sum_c act(zk[r][c]) * q[c]; block = 4 waves = 4 rows
 __global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict__ zk, int rows, int n, long ldz, int act,
@@ -122,6 +124,9 @@ __global__ __launch_bounds__(256) void att_key_bwd_kernel(const float* __restric
             if (act == 3) {
                 k.x = tanhf(zz.x); k.y = tanhf(zz.y); k.z = tanhf(zz.z); k.w = tanhf(zz.w);
                 dk = dk - k * k;
+            } else if (act == 1) {
+                dk.x = zz.x > 0.f ? 1.f : 0.f; dk.y = zz.y > 0.f ? 1.f : 0.f; dk.z = zz.z > 0.f ? 1.f : 0.f; dk.w = zz.w > 0.f ? 1.f : 0.f;
+                k = k * dk;
             }
             const float d = ds[r];
             f32x4 dz = qq * d * dk;
@@ -150,7 +155,7 @@ __global__ void add_inplace_kernel(float* __restrict__ y, const float* __restric
 
 extern "C" int xv_att_score(void* stream, const float* zk, int rows, int n, int ldz, int act, const float* query, float scale,
                             float* score) {
-    XV_REQUIRE(zk && query && score && rows > 0 && n > 0 && ldz >= n && (act == 0 || act == 3), "att_score: bad arguments (act=%d)", act);
+    XV_REQUIRE(zk && query && score && rows > 0 && n > 0 && ldz >= n && (act == 0 || act == 1 || act == 3), "att_score: bad arguments (act=%d)", act);
     hipLaunchKernelGGL(att_score_kernel, dim3(xv_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, zk, rows, n, (long)ldz, act, query,
                        scale, score);
     XV_LAUNCH_CHECK();
@@ -182,7 +187,7 @@ extern "C" int xv_att_pool_backward_weights(void* stream, const float* z, int b,
 
 extern "C" int xv_att_key_backward(void* stream, const float* zk, int rows, int n, int act, const float* query, float scale,
                                    const float* dscore, float* dzk, float* dquery, float* dbias, void* ws, size_t ws_bytes) {
-    XV_REQUIRE(zk && query && dscore && dzk && dquery && rows > 0 && n > 0 && n % 4 == 0 && (act == 0 || act == 3),
+    XV_REQUIRE(zk && query && dscore && dzk && dquery && rows > 0 && n > 0 && n % 4 == 0 && (act == 0 || act == 1 || act == 3),
                "att_key_backward: bad arguments (n=%d must be a multiple of 4)", n);
     const int chunks = xv_cdiv(rows, AKB_ROWS);
     const size_t part_bytes = (size_t)chunks * 2 * n * sizeof(float);

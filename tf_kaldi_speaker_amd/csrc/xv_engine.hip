@@ -162,7 +162,9 @@ void build_variables(xv_engine* e) {
         {"tdnn7", "dense", "", 1, 512, e->Lout, !c.last_layer_no_bn, !c.last_layer_linear, false, 5, 0},
         // self-attention key network (pooling.py:78-96): dense+bn+relu on tdnn4_relu, then dense (+tanh)
         {"att_key0", "dense", "attention/att_key0/", 1, 512, c.att_key0_nodes, true, true, false, 3, 0},
-        {"att_key1", "dense", "attention/att_key1/", 1, c.att_key0_nodes, c.att_key1_nodes, false, false, false, 7, c.att_key_type},
+        // last key layer (att_key_network_type): 0 affine, 1 + relu, 3 + tanh as an activation inside the score kernels; 2 = + bn + relu
+        {"att_key1", "dense", "attention/att_key1/", 1, c.att_key0_nodes, c.att_key1_nodes, c.att_key_type == 2, c.att_key_type == 2, false, 7,
+         c.att_key_type == 2 ? 0 : c.att_key_type},
     };
     // graph-construction order of the reference: tdnn1-5, the pooling layer's variables, tdnn6-7
     const int order[9] = {0, 1, 2, 3, 4, 7, 8, 5, 6};
@@ -468,8 +470,7 @@ extern "C" int xv_engine_create(const xv_config* cfg, xv_engine** out) {
     if (cfg->pooling == XV_POOL_SELF_ATTENTION) {
         XV_REQUIRE(cfg->att_key0_nodes > 0 && cfg->att_key0_nodes % 4 == 0 && cfg->att_key1_nodes > 0 && cfg->att_key1_nodes % 4 == 0,
                    "engine_create: att_key_num_nodes must be two positive multiples of 4 (got %d, %d)", cfg->att_key0_nodes, cfg->att_key1_nodes);
-        XV_REQUIRE(cfg->att_key_type == 0 || cfg->att_key_type == 3, "engine_create: att_key_network_type %d is not implemented (0 affine, 3 tanh)",
-                   cfg->att_key_type);
+        XV_REQUIRE(cfg->att_key_type >= 0 && cfg->att_key_type <= 3, "engine_create: att_key_network_type %d is not one of 0..3", cfg->att_key_type);
     }
     XV_REQUIRE(!cfg->aux_mhe || cfg->num_speakers == 0 || cfg->loss_kind != XV_LOSS_SOFTMAX,
                "engine_create: mhe_loss needs a loss with normalised speaker weights (asoftmax / additive margin losses)");
@@ -606,8 +607,22 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             rc = xv_bn_apply_split(s, k0.z, rows, k0.c_out, k0.c_out, k0.scale, k0.shift, 1, k0_amax, k0.ah, k0.o_ld, (size_t)rows * k0.o_ld);
             if (rc) return rc;
             rc = xv_affine_forward_f16x3(s, k0.ah, (size_t)rows * k0.o_ld, k0_amax, rows, 1, k1.c_pad, 1, k1.wth, k1.wth_stride,
-                                         e->amax + AMAX_WT + k1.wslot, vptr(e, k1.v_bias), k1.z, k1.c_out, k1.c_out, nullptr);
+                                         e->amax + AMAX_WT + k1.wslot, vptr(e, k1.v_bias), k1.z, k1.c_out, k1.c_out,
+                                         k1.has_bn ? k1.bn_part : nullptr);
             if (rc) return rc;
+            if (k1.has_bn) {      // att_key_network_type 2: the key is relu(bn(.)), kept in fp32 for the score (no GEMM consumes it)
+                if (training) {
+                    rc = xv_bn_finalize(s, k1.bn_part, rows, k1.c_out, vptr(e, k1.v_gamma), vptr(e, k1.v_beta), c.bn_epsilon,
+                                        c.batchnorm_momentum, 0, vptr(e, k1.v_mmean), vptr(e, k1.v_mvar), k1.mean, k1.invstd, k1.scale,
+                                        k1.shift, k1.zmin, k1.zmax, nullptr, 1);
+                } else {
+                    rc = xv_bn_inference_scale(s, k1.c_out, vptr(e, k1.v_gamma), vptr(e, k1.v_beta), vptr(e, k1.v_mmean), vptr(e, k1.v_mvar),
+                                               c.bn_epsilon, k1.scale, k1.shift);
+                }
+                if (rc) return rc;
+                rc = xv_bn_apply(s, k1.z, rows, k1.c_out, k1.c_out, k1.scale, k1.shift, 1, k1.a, k1.c_out);
+                if (rc) return rc;
+            }
             k0.rows = k1.rows = rows;
         }
     } else {
@@ -635,9 +650,13 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             if (rc) return rc;
             rc = bn_forward(e, s, k0, rows, true, k0.a);
             if (rc) return rc;
-            rc = xv_affine_forward(s, k0.a, rows, 1, k1.c_pad, 1, k1.wt, vptr(e, k1.v_bias), k1.z, k1.c_out, k1.c_out, nullptr, e->ws,
-                                   e->ws_bytes);
+            rc = xv_affine_forward(s, k0.a, rows, 1, k1.c_pad, 1, k1.wt, vptr(e, k1.v_bias), k1.z, k1.c_out, k1.c_out,
+                                   (k1.has_bn && training) ? k1.bn_part : nullptr, e->ws, e->ws_bytes);
             if (rc) return rc;
+            if (k1.has_bn) {
+                rc = bn_forward(e, s, k1, rows, true, k1.a);
+                if (rc) return rc;
+            }
             k0.rows = k1.rows = rows;
         }
     }
@@ -646,7 +665,7 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
         // scores = key.query (/ sqrt(dk)), weights = softmax over the frames of each chunk (pooling.py:134-148)
         Affine& k1 = e->L[8];
         const float scale = e->cfg.att_use_scale ? 1.0f / sqrtf((float)k1.c_out) : 1.0f;
-        rc = xv_att_score(s, k1.z, b * cur_t, k1.c_out, k1.c_out, k1.act, vptr(e, e->v_query), scale, e->att_score);
+        rc = xv_att_score(s, k1.has_bn ? k1.a : k1.z, b * cur_t, k1.c_out, k1.c_out, k1.act, vptr(e, e->v_query), scale, e->att_score);
         if (rc) return rc;
         rc = xv_softmax_segments(s, e->att_score, b, cur_t, e->att_w);
         if (rc) return rc;
@@ -1025,8 +1044,9 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
                 XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_w[e->zcur], 0));
                 e->w_pending[e->zcur] = false;
             }
-            rc = xv_att_key_backward(s, k1.z, rows, k1.c_out, k1.act, vptr(e, e->v_query), scale, e->att_ds, dzk, gptr(e, e->v_query), nullptr,
-                                     e->ws, e->ws_bytes);
+            // with a BN+ReLU key layer (type 2) this is d key (act = 0 on its output) and layer_backward does the BN/ReLU part
+            rc = xv_att_key_backward(s, k1.has_bn ? k1.a : k1.z, rows, k1.c_out, k1.act, vptr(e, e->v_query), scale, e->att_ds, dzk,
+                                     gptr(e, e->v_query), nullptr, e->ws, e->ws_bytes);
             if (rc) return rc;
             rc = layer_backward(e, s, k1, dzk, k0.a, rows, 1, e->bufD, nullptr);      // -> d att_key0_relu (bufD)
             if (rc) return rc;
@@ -1139,6 +1159,12 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
     }
     if (n == "debug:dpool") return set(e->d_small0, e->B, 2 * e->P, 2 * e->P);
     if (n == "attention_weights" && e->att) return set(e->att_w, e->B, e->Tl[5], e->Tl[5]);     // [b, heads = 1, frames]
+    if (n == "att_key1_relu" && e->att && e->L[8].act == 1) {      // relu key (type 1) lives inside the score kernels: rebuild on demand
+        Affine& k1 = e->L[8];
+        int rc = xv_relu_backward(e->last_stream, k1.z, k1.z, (size_t)k1.rows * k1.c_out, e->bufZ[0]);      // z > 0 ? z : 0
+        if (rc) return rc;
+        return set(e->bufZ[0], k1.rows, k1.c_out, k1.c_out);
+    }
     if (n == "pooling") return set(e->pool, e->B, 2 * e->P, 2 * e->P);
     if (n == "output") return set(e->out, e->B, e->Lout, e->Lout);
     if (n == "logits" && e->N > 0) return set(e->logits, e->B, e->N, e->ldl);

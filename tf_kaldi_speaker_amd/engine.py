@@ -91,8 +91,8 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
         # the shipped single-head form (nnet_conf/*_tdnn4_att.json): two key layers on tdnn4_relu, value = tdnn5_relu
         if len(att_key_num_nodes) != 2:
             raise NotImplementedError("self_attention: att_key_num_nodes must have two entries (dense+bn+relu, then the key layer)")
-        if int(att_key_network_type) not in (0, 3):
-            raise NotImplementedError("self_attention: att_key_network_type %r is not implemented (0 affine, 3 tanh)" % att_key_network_type)
+        if int(att_key_network_type) not in (0, 1, 2, 3):
+            raise NotImplementedError("self_attention: att_key_network_type %r is not one of 0..3 (pooling.py:84-96)" % att_key_network_type)
         c.att_key0_nodes, c.att_key1_nodes = int(att_key_num_nodes[0]), int(att_key_num_nodes[1])
         c.att_key_type = int(att_key_network_type)
         c.att_use_scale = int(bool(att_use_scale))

@@ -23,7 +23,7 @@ ENDPOINT_ORDER = ["tdnn1_conv", "tdnn1_bn", "tdnn1_relu", "tdnn2_conv", "tdnn2_b
                   "tdnn3_conv", "tdnn3_bn", "tdnn3_relu", "tdnn4_dense", "tdnn4_bn", "tdnn4_relu",
                   "tdnn5_dense", "tdnn5_bn", "tdnn5_relu",
                   # self_attention only (pooling.py:78-149); absent names are skipped for statistics pooling
-                  "att_key0_dense", "att_key0_bn", "att_key0_relu", "att_key1_dense", "attention_weights",
+                  "att_key0_dense", "att_key0_bn", "att_key0_relu", "att_key1_dense", "att_key1_bn", "att_key1_relu", "attention_weights",
                   "pooling", "tdnn6_dense", "tdnn6_bn", "tdnn6_relu",
                   "tdnn7_dense", "tdnn7_bn", "tdnn7_relu"]
 
@@ -53,8 +53,8 @@ def check_params(params):
             unsupported.append("att_value_num_nodes (no value network)")
         if len(d.get("att_key_num_nodes", [])) != 2:
             unsupported.append("att_key_num_nodes (two key layers)")
-        if int(d.get("att_key_network_type", -1)) not in (0, 3):
-            unsupported.append("att_key_network_type=%r (0 or 3)" % d.get("att_key_network_type"))
+        if int(d.get("att_key_network_type", -1)) not in (0, 1, 2, 3):
+            unsupported.append("att_key_network_type=%r (0..3)" % d.get("att_key_network_type"))
         if int(d.get("att_num_heads", 1)) != 1 or d.get("att_split_key", False):
             unsupported.append("att_num_heads / att_split_key (one head)")
         if float(d.get("att_penalty_term", 0) or 0) != 0.0:
