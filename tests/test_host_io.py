@@ -190,3 +190,26 @@ def test_cos_pairwise_eer():
     assert 0.35 < rand_eer < 0.65
     # subsampling path (> max_num_embeddings) keeps working with an integer stride (py2 '/' in the reference)
     assert 0.0 <= U.compute_cos_pairwise_eer(emb.copy(), labels, max_num_embeddings=30) < 0.2
+
+
+def test_every_shipped_single_task_config_builds_an_engine_config():
+    """All 81 single-task nnet_conf/*.json of the reference (voxceleb, sre, fisher recipes) map onto an engine configuration:
+    4 loss families, statistics / self-attention pooling (key types 0-3), ring / MHE auxiliary losses, sgd / momentum.
+    Needs the reference checkout (build container only); the 10 multitask configs (no network_type) are out of scope."""
+    import glob
+    ref = "/root/reference/egs"
+    if not os.path.isdir(ref):
+        pytest.skip("reference checkout not present")
+    from tf_kaldi_speaker_amd.misc.utils import Params
+    from tf_kaldi_speaker_amd.model.tdnn import engine_config
+    files = sorted(glob.glob(os.path.join(ref, "*", "*", "nnet_conf", "*.json")))
+    assert len(files) >= 90
+    n = 0
+    for f in files:
+        p = Params(f)
+        if "network_type" not in p.dict:
+            continue
+        cfg = engine_config(p, 30, 100, p.dict["loss_func"], 64, 400)
+        assert cfg.feat_dim == 30 and cfg.num_speakers == 100
+        n += 1
+    assert n == 81
