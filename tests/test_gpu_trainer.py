@@ -233,3 +233,29 @@ def test_drivers_as_run_sh_calls_them(tmp_path):
         embs.append(ep["tdnn6_dense"][0]); lens.append(n)
     ref = (np.array(embs) * np.array(lens)[:, None]).sum(0) / sum(lens)
     assert np.abs(out["long"] - ref).max() / np.abs(ref).max() < 1e-4
+    # fine-tuning drivers (finetune.py, train_lr_learning.py in its fine-tuning form, train_insight.py): a new loss layer on the frozen
+    # tdnn1-3 of the model trained above
+    ft_cfg = dict(CONFIG, num_epochs=1, noupdate_var_list=["tdnn1", "tdnn2", "tdnn3"], noload_var_list=["softmax"])
+    ft_path = tmp_path / "finetune.json"
+    ft_path.write_text(json.dumps(ft_cfg))
+    ft_model = str(tmp_path / "exp_ft")
+    os.makedirs(ft_model)
+    r = subprocess.run([sys.executable, os.path.join(lib, "finetune.py"), "--checkpoint", "last", "--config", str(ft_path), data, spklist, vdata,
+                        vspk, model, ft_model], env=env, cwd=lib, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "In the beginning: Valid EER" in r.stderr
+    ft = np.load(os.path.join(ft_model, "nnet", "model-6.npz"))
+    assert np.array_equal(ft["tdnn/tdnn2_conv/kernel"], ck["tdnn/tdnn2_conv/kernel"])              # frozen
+    assert np.array_equal(ft["tdnn/tdnn1_bn/moving_mean"], ck["tdnn/tdnn1_bn/moving_mean"])          # its BN update op too
+    assert not np.array_equal(ft["tdnn/tdnn5_dense/kernel"], ck["tdnn/tdnn5_dense/kernel"])
+    assert not np.array_equal(ft["softmax/output/kernel"], ck["softmax/output/kernel"])
+    tune_model = str(tmp_path / "exp_tune")
+    os.makedirs(tune_model)
+    r = subprocess.run([sys.executable, os.path.join(lib, "finetune_lr_learning.py"), "--tune_period", "1", "--checkpoint", "last", "--config",
+                        str(ft_path), data, spklist, vdata, vspk, model, tune_model], env=dict(env, XV_TUNE_TIMES="3"), cwd=lib,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(open(os.path.join(tune_model, "nnet", "learning_rate_tuning")).read().strip().split("\n")) == 3
+    r = subprocess.run([sys.executable, os.path.join(lib, "train_insight.py"), vdata, vspk, ft_model], env=env, cwd=lib, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "EER:" in r.stderr, r.stderr[-3000:]

@@ -173,6 +173,48 @@ def get_checkpoint(model, checkpoint="-1"):
     return path
 
 
+def get_pretrain_model(pretrain_model, target_model, checkpoint="-1"):
+    """Copy one checkpoint of a pre-trained model into `target_model` as step 0 and point the index at it (reference
+    utils.py:126-182).  checkpoint: "last", an explicit step, or -1 = best by valid_loss."""
+    if not os.path.isfile(os.path.join(pretrain_model, "checkpoint")):
+        sys.exit("[ERROR] Cannot find checkpoint in %s." % pretrain_model)
+    current, all_paths = read_checkpoint_state(pretrain_model)
+    if not current:
+        sys.exit("[ERROR] Cannot read checkpoint %s." % os.path.join(pretrain_model, "checkpoint"))
+    steps = sorted(int(c.rsplit("-", 1)[1]) for c in all_paths)
+    if checkpoint == "last":
+        log.info("Load the last saved model.")
+        checkpoint = steps[-1]
+    else:
+        checkpoint = int(checkpoint)
+        if checkpoint == -1:
+            log.info("Load the best model according to valid_loss")
+            min_epoch, min_loss = -1, 1e10
+            with open(os.path.join(pretrain_model, "valid_loss")) as f:
+                for line in f:
+                    if not line.strip():
+                        continue
+                    epoch, loss = line.split(" ")[:2]
+                    if float(loss) < min_loss:
+                        min_loss, min_epoch = float(loss), int(epoch)
+            params = Params(os.path.join(pretrain_model, "config.json"))
+            checkpoint = (min_epoch + 1) * params.num_steps_per_epoch
+    assert checkpoint in steps, "The checkpoint %d not in the model directory" % checkpoint
+    stem = os.path.basename(current).rsplit("-", 1)[0]
+    src = os.path.join(pretrain_model, "%s-%d" % (stem, checkpoint))
+    log.info("Copy the pre-trained model %s as the fine-tuned initialization" % src)
+    os.makedirs(target_model, exist_ok=True)
+    import glob
+    import shutil
+    for filename in glob.glob(src + ".*"):
+        ext = filename[len(src):]
+        if ext.endswith(".bak"):
+            continue
+        shutil.copyfile(filename, os.path.join(target_model, stem + "-0" + ext))
+    path = os.path.join(target_model, stem + "-0")
+    write_checkpoint_state(target_model, path, [path])
+
+
 def compute_cos_pairwise_eer(embeddings, labels, max_num_embeddings=1000):
     """Pairwise cosine EER (reference utils.py:273-312): L2-normalise, subsample to <= max_num_embeddings
     with an integer stride, score all pairs i<j, EER = root of 1 - x - tpr(x) on the ROC curve."""

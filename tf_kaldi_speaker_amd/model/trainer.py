@@ -445,11 +445,13 @@ class Trainer(object):
         self.save(0)
         self.is_loaded = True
 
-    def train_tune_lr(self, data, spklist, tune_period=100, aux_data=None, tune_times=100):
+    def train_tune_lr(self, data, spklist, tune_period=100, aux_data=None, tune_times=None):
         """Learning-rate range test (trainer.py:522-590): lr = 1e-5 * 1.15^(step // tune_period), global_step fed as 0, the
         (step, lr, total loss) of the first step of every period written to <model>/learning_rate_tuning."""
         assert "train" in self.modes, "call build('train', ...) first"
         p = self.params
+        if tune_times is None:      # the reference hard-codes 100 learning rates (trainer.py:556); XV_TUNE_TIMES shortens a smoke run
+            tune_times = int(os.environ.get("XV_TUNE_TIMES", "100"))
         self.engine.init_variables(seed=int(p.dict.get("seed", 0)))
         if os.path.isfile(os.path.join(self.model, "checkpoint")):
             self.load()

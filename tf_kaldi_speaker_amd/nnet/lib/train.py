@@ -34,9 +34,15 @@ parser.add_argument("model", type=str, help="The output model directory.")
 
 
 def main():
+    run(parser.parse_args())
+
+
+def run(args, finetune=False):
+    """The epoch loop shared by train.py and finetune.py (reference finetune.py:36-175 is train.py plus: the pre-trained
+    checkpoint copied in as step 0, params.noupdate_var_list frozen, params.noload_var_list re-initialised, an evaluation
+    before the first epoch).  args.model is the (fine-tuned) model directory."""
     logging.basicConfig(level=logging.INFO, format="%(levelname)s:%(name)s:%(message)s")
     log = logging.getLogger("tf_kaldi_speaker_amd")
-    args = parser.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     dist = None
@@ -63,6 +69,12 @@ def main():
         step = int(next(re.finditer(r"(\d+)(?!.*\d)", os.path.basename(current))).group(0))
         start_epoch = int(step / params.num_steps_per_epoch)
     else:
+        if finetune and rank == 0:
+            # the pre-trained model becomes step 0 of the new directory: "just like an initialized model" (finetune.py:60-66)
+            from misc.utils import get_pretrain_model
+            get_pretrain_model(os.path.join(args.pretrain_model, "nnet"), model_dir, args.checkpoint)
+        if finetune and dist is not None:
+            dist.barrier()
         start_epoch = 0
 
     learning_rate = params.learning_rate
@@ -90,13 +102,23 @@ def main():
         min_valid_loss = load_valid_loss(os.path.join(model_dir, "valid_loss"))
 
     trainer = Trainer(params, args.model)
-    trainer.build("train", dim=dim, loss_type=params.loss_func, num_speakers=num_total_train_speakers)
+    trainer.build("train", dim=dim, loss_type=params.loss_func, num_speakers=num_total_train_speakers,
+                  noupdate_var_list=params.noupdate_var_list if finetune else None)
     trainer.build("valid", dim=dim, loss_type=params.loss_func, num_speakers=num_total_train_speakers)
 
     if "early_stop_epochs" not in params.dict:
-        params.dict["early_stop_epochs"] = 10
+        params.dict["early_stop_epochs"] = 5 if finetune else 10      # finetune.py:117 / train.py:101
     if "min_learning_rate" not in params.dict:
         params.dict["min_learning_rate"] = 1e-5
+
+    if finetune and start_epoch == 0:
+        if rank == 0:
+            trainer.get_finetune_model(params.noload_var_list)
+            valid_loss, valid_embeddings, valid_labels = trainer.valid(args.valid_dir, args.valid_spklist,
+                                                                       batch_type=params.batch_type, output_embeddings=True)
+            log.info("In the beginning: Valid EER: %f" % compute_cos_pairwise_eer(valid_embeddings, valid_labels))
+        if dist is not None:
+            dist.barrier()
 
     for epoch in range(start_epoch, params.num_epochs):
         trainer.train(args.train_dir, args.train_spklist, learning_rate_array[epoch])
