@@ -83,8 +83,9 @@ struct xv_engine {
     float *bufD = nullptr, *bufZ[2] = {nullptr, nullptr}, *d_small0 = nullptr, *d_small1 = nullptr;
     // second stream: weight gradients run beside the data-gradient chain (they only share dz)
     hipStream_t side = nullptr;
-    hipEvent_t ev_dz = nullptr, ev_w[2] = {nullptr, nullptr};
+    hipEvent_t ev_dz = nullptr, ev_w[2] = {nullptr, nullptr}, ev_lw = nullptr;
     bool w_pending[2] = {false, false};
+    bool lw_pending = false;      // the loss head's weight gradient (side stream) - it reads no dz buffer, so it has its own event
     bool concurrent = true;
     int zcur = 0;
     void* ws_side = nullptr;
@@ -378,6 +379,7 @@ int alloc_buffers(xv_engine* e) {
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_dz, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_w[0], hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_w[1], hipEventDisableTiming));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lw, hipEventDisableTiming));
     return 0;
 }
 
@@ -489,6 +491,7 @@ extern "C" void xv_engine_destroy(xv_engine* e) {
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
     if (e->ev_dz) (void)hipEventDestroy(e->ev_dz);
     for (int i = 0; i < 2; ++i) if (e->ev_w[i]) (void)hipEventDestroy(e->ev_w[i]);
+    if (e->ev_lw) (void)hipEventDestroy(e->ev_lw);
 
     if (e->arena) (void)hipFree(e->arena);
     delete e;
@@ -783,6 +786,10 @@ int join_side(xv_engine* e, hipStream_t s) {
             XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_w[i], 0));
             e->w_pending[i] = false;
         }
+    if (e->lw_pending) {
+        XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_lw, 0));
+        e->lw_pending = false;
+    }
     return 0;
 }
 
@@ -1007,10 +1014,10 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
                 rc = xv_colsum(ss, e->dlogits, b, e->N, e->ldl, gptr(e, e->v_loss_bias), e->ws_side, e->ws_bytes);
                 if (rc) return rc;
             }
-            // tracked through ev_w[zcur^1]'s slot so join_side() covers it (the side stream is in-order)
+            // its own event: tying it to a dz buffer's slot made the next-but-one layer wait ~50 us for it for nothing
             if (e->concurrent) {
-                XV_CHECK_HIP(hipEventRecord(e->ev_w[e->zcur ^ 1], ss));
-                e->w_pending[e->zcur ^ 1] = true;
+                XV_CHECK_HIP(hipEventRecord(e->ev_lw, ss));
+                e->lw_pending = true;
             }
         }
         const float* d = e->d_small0;
