@@ -50,6 +50,9 @@ int xv_device_count(void);
  * xv_profile_end synchronises the recorded events and returns, per kind, the number of launches,
  * their summed duration in ms and their summed algorithmic FLOPs (2*M*N*K each). */
 int xv_profile_begin(int max_launches);
+/* Same, restricted to the kinds whose bit is set in kind_mask (bit k = kind k): an event pair costs a few
+ * microseconds of queue time per launch, so bench.py's timed region brackets only the dominant kernel. */
+int xv_profile_begin_kinds(int max_launches, uint32_t kind_mask);
 #define XV_PROFILE_KINDS 6
 int xv_profile_end(int64_t launches[XV_PROFILE_KINDS], double ms[XV_PROFILE_KINDS], double flops[XV_PROFILE_KINDS]);
 

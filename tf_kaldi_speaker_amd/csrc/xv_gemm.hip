@@ -270,13 +270,14 @@ __global__ void xv_splitk_reduce_kernel(const float* __restrict__ slab, int spli
 namespace {
 struct ProfRec { hipEvent_t a, b; int kind; double flops; };
 bool g_prof_on = false;
+uint32_t g_prof_mask = ~0u;
 std::vector<ProfRec> g_prof;
 size_t g_prof_cap = 0;
 std::vector<hipEvent_t> g_prof_events;   // pool, two per record slot
 }  // namespace
 
 XvProfScope::XvProfScope(hipStream_t st, int kind, double flops) : s(st), idx(-1) {
-    if (!g_prof_on || g_prof.size() >= g_prof_cap) return;
+    if (!g_prof_on || !((g_prof_mask >> kind) & 1u) || g_prof.size() >= g_prof_cap) return;
     idx = (int)g_prof.size();
     ProfRec r = {g_prof_events[2 * idx], g_prof_events[2 * idx + 1], kind, flops};
     g_prof.push_back(r);
@@ -284,8 +285,11 @@ XvProfScope::XvProfScope(hipStream_t st, int kind, double flops) : s(st), idx(-1
 }
 XvProfScope::~XvProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, s); }
 
-extern "C" int xv_profile_begin(int max_launches) {
+extern "C" int xv_profile_begin(int max_launches) { return xv_profile_begin_kinds(max_launches, ~0u); }
+
+extern "C" int xv_profile_begin_kinds(int max_launches, uint32_t kind_mask) {
     XV_REQUIRE(max_launches > 0, "profile_begin: max_launches must be positive");
+    g_prof_mask = kind_mask;
     while (g_prof_events.size() < (size_t)2 * max_launches) {
         hipEvent_t ev;
         XV_CHECK_HIP(hipEventCreate(&ev));
