@@ -83,11 +83,13 @@ struct xv_engine {
     float *bufD = nullptr, *bufZ[2] = {nullptr, nullptr}, *d_small0 = nullptr, *d_small1 = nullptr;
     // second stream: weight gradients run beside the data-gradient chain (they only share dz)
     hipStream_t side = nullptr;
-    hipEvent_t ev_dz = nullptr, ev_w[2] = {nullptr, nullptr}, ev_lw = nullptr;
-    bool w_pending[2] = {false, false};
+    hipEvent_t ev_dz = nullptr, ev_lw = nullptr;
+    // dz ping-pong state.  ring 0: the frame-level layers' dz (fp16 planes `dzh` in split precision) and, in fp32, every
+    // layer's dz (`bufZ`); ring 1 (split precision only): the fp32 dz of the segment-level layers and the attention key
+    // gradient in `bufZ` - its own ring, so a frame layer never waits for a segment layer's weight gradient
+    struct ZRing { int cur = 0; bool pending[2] = {false, false}; hipEvent_t ev[2] = {nullptr, nullptr}; } zr[2];
     bool lw_pending = false;      // the loss head's weight gradient (side stream) - it reads no dz buffer, so it has its own event
     bool concurrent = true;
-    int zcur = 0;
     void* ws_side = nullptr;
     float *scalars = nullptr;   // [0] raw loss, [1] reg loss, [2] grad sumsq
     // split precision state
@@ -377,8 +379,8 @@ int alloc_buffers(xv_engine* e) {
         XV_CHECK_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
     }
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_dz, hipEventDisableTiming));
-    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_w[0], hipEventDisableTiming));
-    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_w[1], hipEventDisableTiming));
+    for (int r = 0; r < 2; ++r)
+        for (int i = 0; i < 2; ++i) XV_CHECK_HIP(hipEventCreateWithFlags(&e->zr[r].ev[i], hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lw, hipEventDisableTiming));
     return 0;
 }
@@ -490,7 +492,8 @@ extern "C" void xv_engine_destroy(xv_engine* e) {
     if (!e) return;
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
     if (e->ev_dz) (void)hipEventDestroy(e->ev_dz);
-    for (int i = 0; i < 2; ++i) if (e->ev_w[i]) (void)hipEventDestroy(e->ev_w[i]);
+    for (int r = 0; r < 2; ++r)
+        for (int i = 0; i < 2; ++i) if (e->zr[r].ev[i]) (void)hipEventDestroy(e->zr[r].ev[i]);
     if (e->ev_lw) (void)hipEventDestroy(e->ev_lw);
 
     if (e->arena) (void)hipFree(e->arena);
@@ -781,11 +784,12 @@ int chain(hipStream_t signaller, hipStream_t waiter, hipEvent_t ev) {
 
 // All weight-gradient work enqueued on the side stream so far becomes visible to `s`.
 int join_side(xv_engine* e, hipStream_t s) {
-    for (int i = 0; i < 2; ++i)
-        if (e->w_pending[i]) {
-            XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_w[i], 0));
-            e->w_pending[i] = false;
-        }
+    for (int r = 0; r < 2; ++r)
+        for (int i = 0; i < 2; ++i)
+            if (e->zr[r].pending[i]) {
+                XV_CHECK_HIP(hipStreamWaitEvent(s, e->zr[r].ev[i], 0));
+                e->zr[r].pending[i] = false;
+            }
     if (e->lw_pending) {
         XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_lw, 0));
         e->lw_pending = false;
@@ -799,7 +803,7 @@ int join_side(xv_engine* e, hipStream_t s) {
 // The weight/bias gradient only shares dz with the data-gradient chain, so it is enqueued on the
 // side stream: its workgroups fill the CUs that the tail of the data-gradient GEMM (and the small
 // BN kernels of the next layer) leave idle.  dz ping-pongs between two buffers; a buffer is rewritten
-// only after the weight gradient that read it has finished (ev_w).
+// only after the weight gradient that read it has finished (ZRing).
 int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int segs, int t_in, float* dx);
 
 int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, const float* x, int segs, int t_in, float* dx,
@@ -811,11 +815,12 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     const int lidx = (int)(&a - &e->L[0]);
     if (e->f16 && is_frame(lidx)) return layer_backward_f16(e, s, lidx, da, segs, t_in, dx);
     const float* dz = nullptr;
-    const int zi = e->zcur;
+    xv_engine::ZRing& zr = e->zr[e->f16 ? 1 : 0];
+    const int zi = zr.cur;
     float* Z = e->bufZ[zi];
-    if (e->w_pending[zi]) {                       // WAR: the weight gradient two layers up read this buffer
-        XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_w[zi], 0));
-        e->w_pending[zi] = false;
+    if (zr.pending[zi]) {                       // WAR: the weight gradient two layers up read this buffer
+        XV_CHECK_HIP(hipStreamWaitEvent(s, zr.ev[zi], 0));
+        zr.pending[zi] = false;
     }
     if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
         XV_REQUIRE(&a == &e->L[4] && a.has_bn, "engine_backward: only tdnn5 takes its gradient from the pooling layer");
@@ -856,10 +861,10 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
         if (rc) return rc;
     }
     if (concurrent) {
-        XV_CHECK_HIP(hipEventRecord(e->ev_w[zi], e->side));
-        e->w_pending[zi] = true;
+        XV_CHECK_HIP(hipEventRecord(zr.ev[zi], e->side));
+        zr.pending[zi] = true;
     }
-    if (dz == Z) e->zcur ^= 1;
+    if (dz == Z) zr.cur ^= 1;
     if (dx) {
         const float* wf = a.k > 1 ? a.wf : vptr(e, a.v_kernel);
         rc = xv_affine_dgrad(s, dz, segs, t_out, a.c_out, a.k, wf, dx, a.c_in, e->ws, e->ws_bytes);
@@ -876,12 +881,13 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
     const xv_config& c = e->cfg;
     const int t_out = t_in - a.k + 1;
     const int pad = (dx && a.k > 1) ? a.k - 1 : 0;
-    const int zi = e->zcur;
+    xv_engine::ZRing& zr = e->zr[0];
+    const int zi = zr.cur;
     unsigned short* Z = e->dzh[zi];
     uint32_t* zamax = e->amax + AMAX_DZ + a.wslot;
-    if (e->w_pending[zi]) {
-        XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_w[zi], 0));
-        e->w_pending[zi] = false;
+    if (zr.pending[zi]) {
+        XV_CHECK_HIP(hipStreamWaitEvent(s, zr.ev[zi], 0));
+        zr.pending[zi] = false;
     }
     const int seg_pitch = t_out + 2 * pad;
     const size_t zstride = (size_t)segs * seg_pitch * a.o_ld;
@@ -930,10 +936,10 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
                                e->ws_bytes);
     if (rc) return rc;
     if (conc) {
-        XV_CHECK_HIP(hipEventRecord(e->ev_w[zi], e->side));
-        e->w_pending[zi] = true;
+        XV_CHECK_HIP(hipEventRecord(zr.ev[zi], e->side));
+        zr.pending[zi] = true;
     }
-    e->zcur ^= 1;
+    zr.cur ^= 1;
     if (dx) {
         // dx is d(relu(bn(z))) of the producing layer: fold that layer's BN-backward reductions into this GEMM's epilogue - unless
         // dx is only one of two contributions (tdnn4_relu also feeds the attention key network)
@@ -1045,11 +1051,14 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
             if (rc) return rc;
             rc = xv_softmax_segments_backward(s, e->att_w, e->att_dw, b, e->Tl[5], e->att_ds);
             if (rc) return rc;
-            // dzk (fp32): in split precision the fp32 dz buffers are otherwise unused; in fp32 it is the dz ping-pong buffer
-            float* dzk = e->bufZ[e->f16 ? 0 : e->zcur];
-            if (!e->f16 && e->w_pending[e->zcur]) {
-                XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_w[e->zcur], 0));
-                e->w_pending[e->zcur] = false;
+            // dzk (fp32) takes the current slot of the fp32 dz ring: a segment-level weight gradient (side stream) may still be
+            // reading it.  In split precision its consumer (key1's plane split) runs on `s`, so the slot is not flipped; in
+            // fp32 layer_backward() below recognises it as the ring's buffer (dz == Z) and flips the ring itself
+            xv_engine::ZRing& zrk = e->zr[e->f16 ? 1 : 0];
+            float* dzk = e->bufZ[zrk.cur];
+            if (zrk.pending[zrk.cur]) {
+                XV_CHECK_HIP(hipStreamWaitEvent(s, zrk.ev[zrk.cur], 0));
+                zrk.pending[zrk.cur] = false;
             }
             // with a BN+ReLU key layer (type 2) this is d key (act = 0 on its output) and layer_backward does the BN/ReLU part
             rc = xv_att_key_backward(s, k1.has_bn ? k1.a : k1.z, rows, k1.c_out, k1.act, vptr(e, e->v_query), scale, e->att_ds, dzk,
