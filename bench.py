@@ -10,8 +10,10 @@ fp32, plain SGD + L2 - one "step" = forward + loss + backward (+ gradient all-re
 + update on synthetic features already resident in HBM.  Weak scaling: 128 chunks per GPU.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
-dominant kernel (live hipEvent timing of every MFMA GEMM launch inside the timed region) and, at
-N = 1, `cpu_baseline` = the NumPy oracle's train_step timed on this box's host cores.
+dominant kernel (its launches are bracketed by hipEvents on their stream inside the timed region; an
+untimed probe pass brackets every MFMA GEMM kind for the per-kernel table) and, at N = 1,
+`cpu_baseline` = the NumPy oracle's train_step timed on this box's host cores (all cores, plus a
+single-thread row).
 """
 import argparse
 import ctypes as C
@@ -109,9 +111,26 @@ def cpu_baseline(seconds_budget=25.0):
         if time.time() - t0 > seconds_budget * 0.5 or n >= 8:
             break
     dt = time.time() - t0
-    return {"value": round(cb * n / dt, 2), "unit": "chunks/s", "cores": int(threads), "kind": "port",
-            "sample": "oracle (NumPy/OpenBLAS fp32 port, this repo) train_step, %d chunks x %d frames x %d-dim, %d speakers, %d steps in %.1f s"
-                      % (cb, T, D, NSPK, n, dt)}
+    out = {"value": round(cb * n / dt, 2), "unit": "chunks/s", "cores": int(threads), "kind": "port",
+           "sample": "oracle (NumPy/OpenBLAS fp32 port, this repo) train_step, %d chunks x %d frames x %d-dim, %d speakers, %d steps in %.1f s"
+                     % (cb, T, D, NSPK, n, dt)}
+    # single-thread row (comparable to the reference's single_cpu extraction mode)
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            t0 = time.time()
+            n1 = 0
+            while True:
+                V, state, _ = O.train_step(V, state, cfg, x, y, 0.01, n + n1 + 1)
+                n1 += 1
+                if time.time() - t0 > seconds_budget * 0.4 or n1 >= 4:
+                    break
+            dt1 = time.time() - t0
+        out["single_thread"] = {"value": round(cb * n1 / dt1, 2), "unit": "chunks/s", "cores": 1,
+                                "sample": "same workload, BLAS limited to 1 thread, %d steps in %.1f s" % (n1, dt1)}
+    except Exception as exc:      # threadpoolctl missing: the all-cores row stands alone
+        out["single_thread"] = {"value": None, "note": "not measured (%s)" % type(exc).__name__}
+    return out
 
 
 def main():
