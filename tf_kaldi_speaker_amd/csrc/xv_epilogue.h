@@ -59,7 +59,7 @@ __device__ __forceinline__ void xv_tile_stats_epilogue(const f32x16 (&acc)[2][NB
         if (lh == 0) r_m2[wr * 128 + col] = v;
     }
     __syncthreads();
-    if (tid < 128) {
+    if (tid < 128 && m0 < M) {       // (a 256-row workgroup's lower half may lie entirely below the last row)
         int n = n0 + tid;
         if (n < N) {
             const long plane = (long)tiles_m * N;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void xv_tile_bwd_stats_epilogue(const f32x16 (&acc)[2
         if (lh == 0) { r1[wr * 128 + col] = s1; r2[wr * 128 + col] = s2; r3[wr * 128 + col] = s3; }
     }
     __syncthreads();
-    if (tid < 128) {
+    if (tid < 128 && m0 < M) {
         const int n = n0 + tid;
         if (n < N) {
             float* o = q.part + (long)tile_m * 3 * N + n;

@@ -415,27 +415,39 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
 // x rows are fetched in `taps` slices, one per K-step, so every step issues about the same number of LDS-DMAs
 // (5 per wave instead of 8 for taps = 5).  Rows of one tile may straddle segments: aoff(q) = xrow(m0+q) - xrow(m0)
 // grows by (pitch - rps) at every crossing; the launcher falls back to the generic kernel when the rows of a
-// tile do not fit the CONV_AR-row image.
-// LDS: A 2 x 2 planes x 160 rows x 64 B = 40 KB, B 2 x 2 planes x 128 x 64 B = 32 KB: two workgroups per CU.
+// tile do not fit the (BM + 32)-row image.
+// LDS (128-row tile): A 2 x 2 planes x 160 rows x 64 B = 40 KB, B 2 x 2 planes x 128 x 64 B = 32 KB: two workgroups per CU.
 // ---------------------------------------------------------------------------------------------
-#define CONV_AR 160                                  // x rows per A image (128 + halo)
-#define CONV_APLANE (CONV_AR * 32)                   // halfs per A plane image
-#define CONV_ABUF (2 * CONV_APLANE)
 #define CONV_BPLANE (128 * 32)
 #define CONV_BBUF (2 * CONV_BPLANE)
 
 struct NT16ConvArgs {
-    NT16Args g;
+    NT16Args g;                // tiles_m counts BM-row tiles (BM = 64 * WR)
     int taps, chunks;          // K = taps * C, chunks = C / 32
     long a_rows;               // rows of the A planes (reads beyond are zero)
 };
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void xv_gemm16_nt_conv_kernel(NT16ConvArgs q) {
+// WR = row-waves per workgroup: 2 -> 128-row tile, 4 waves, 72 KB LDS, two workgroups per CU;
+//                               4 -> 256-row tile, 8 waves, 104 KB LDS, one workgroup per CU: the weight tile staged per
+//                                    K-step serves twice the rows (staging is the largest non-MFMA cost of this kernel).
+template <int WR> struct ConvGeom {
+    static constexpr int BM = 64 * WR;
+    static constexpr int NW = 2 * WR;                 // waves
+    static constexpr int AR = BM + 32;                // x rows per A image (tile + halo)
+    static constexpr int APLANE = AR * 32;            // halfs per A plane image
+    static constexpr int ABUF = 2 * APLANE;
+    static constexpr int NG = AR / 16;                // 16-row DMA groups per plane
+    static constexpr int BG = 8 / NW;                 // weight-tile DMA groups per wave
+    static constexpr int LDS_HALFS = 2 * ABUF + 2 * CONV_BBUF;
+};
+
+template <int EPI, int WR>
+__global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16ConvArgs q) {
+    typedef ConvGeom<WR> G;
     const NT16Args& p = q.g;
-    __shared__ __attribute__((aligned(16))) u16 smem[2 * CONV_ABUF + 2 * CONV_BBUF];
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* const sA = smem;
-    u16* const sB = smem + 2 * CONV_ABUF;
+    u16* const sB = smem + 2 * G::ABUF;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_conv_kernel(NT16ConvArgs 
     const int li = lane & 31, lh = lane >> 5;
     const int t = xcd_swizzle16(blockIdx.x, gridDim.x);
     const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
-    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int m0 = tile_m * G::BM, n0 = tile_n * 128;
     const int taps = q.taps, nc = q.chunks;
     const long C = p.lda;
 
@@ -460,39 +472,39 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_conv_kernel(NT16ConvArgs 
 
     // DMA lane geometry: one wave-instruction = 16 image rows x 64 B; lane -> row l>>2, 16-byte chunk l&3 (source chunk swizzled)
     const int drow = lane >> 2, dchunk = lane & 3;
-    // B: rows 32*wave + 16*i + drow of the weight tile
-    long boff[2];
-    bool bv[2];
-    int bsrc[2];
+    // B: rows 16*(BG*wave + i) + drow of the weight tile
+    long boff[G::BG];
+    bool bv[G::BG];
+    int bsrc[G::BG];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = 16 * (2 * wave + i) + drow;
+    for (int i = 0; i < G::BG; ++i) {
+        const int row = 16 * (G::BG * wave + i) + drow;
         bsrc[i] = (dchunk ^ ((row >> 2) & 3)) << 3;
         int n = n0 + row;
         bv[i] = n < p.N;
         boff[i] = (long)(bv[i] ? n : 0) * p.ldb;
     }
     auto stage_b = [&](int cc, int j, int buf) {
-        u16* base = sB + buf * CONV_BBUF + 32 * uwave * 32;
+        u16* base = sB + buf * CONV_BBUF + 16 * G::BG * uwave * 32;
         const long k0 = (long)j * C + cc * 32;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < G::BG; ++i)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
                 const u16* pb = bv[i] ? p.Bt + pl * p.b_plane + boff[i] + k0 + bsrc[i] : p.zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + pl * CONV_BPLANE + 16 * i * 32), 16, 0, 0);
             }
     };
-    // A: 10 row groups x 2 planes = 20 wave-instructions per chunk, id = plane*10 + group; slice `part` of `nparts`
-    // hands ids part*4 + wave + s*4*nparts to this wave.
+    // A: NG row groups x 2 planes wave-instructions per chunk, id = plane*NG + group; slice `part` of `nparts`
+    // hands ids part*NW + wave + s*NW*nparts to this wave.
     auto stage_a = [&](int cc, int buf, int part, int nparts) {
-        for (int id = part * 4 + uwave; id < 20; id += 4 * nparts) {
-            const int pl = id >= 10 ? 1 : 0, grp = id - 10 * pl;
+        for (int id = part * G::NW + uwave; id < 2 * G::NG; id += G::NW * nparts) {
+            const int pl = id >= G::NG ? 1 : 0, grp = id - G::NG * pl;
             const int row = 16 * grp + drow;
             const long xr = xr0 + row;
             const int src = (dchunk ^ ((row >> 2) & 3)) << 3;
             const u16* pa = xr < q.a_rows ? p.A + pl * p.a_plane + xr * C + cc * 32 + src : p.zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(sA + buf * CONV_ABUF + pl * CONV_APLANE + 16 * grp * 32), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(sA + buf * G::ABUF + pl * G::APLANE + 16 * grp * 32), 16, 0, 0);
         }
     };
 
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_conv_kernel(NT16ConvArgs 
     __syncthreads();
     int st = 0;
     for (int cc = 0; cc < nc; ++cc) {
-        const u16* abase = sA + (cc & 1) * CONV_ABUF;
+        const u16* abase = sA + (cc & 1) * G::ABUF;
         for (int j = 0; j < taps; ++j, ++st) {
             // prefetch: next step's weight tile, and this step's slice of the next chunk's x rows
 #if !(XV16_ABL & 16)
@@ -530,8 +542,8 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_conv_kernel(NT16ConvArgs 
                 f32x4 af[2][2], bf[2][2];
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
-                    af[pl][0] = *(const f32x4*)(abase + pl * CONV_APLANE + r0 * 32 + ((c ^ asw0) << 3));
-                    af[pl][1] = *(const f32x4*)(abase + pl * CONV_APLANE + r1 * 32 + ((c ^ asw1) << 3));
+                    af[pl][0] = *(const f32x4*)(abase + pl * G::APLANE + r0 * 32 + ((c ^ asw0) << 3));
+                    af[pl][1] = *(const f32x4*)(abase + pl * G::APLANE + r1 * 32 + ((c ^ asw1) << 3));
                     bf[pl][0] = *(const f32x4*)(bbase + pl * CONV_BPLANE + b_row + ((c ^ bsw) << 3));
                     bf[pl][1] = *(const f32x4*)(bbase + pl * CONV_BPLANE + b_row + 32 * 32 + ((c ^ bsw) << 3));
                 }
@@ -568,25 +580,61 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_nt_conv_kernel(NT16ConvArgs 
                 if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = v;
             }
         }
-    if (EPI == 1) xv_tile_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
-    if (EPI == 2) xv_tile_bwd_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.bwd);
+    // the statistics epilogues work on 128-row tiles: each group of 4 waves is one (own scratch, same barriers)
+    const int half = wr >> 1;
+    const int tiles128 = (p.M + 127) / 128;
+    float* red = (float*)smem + half * 1024;
+    if (EPI == 1)
+        xv_tile_stats_epilogue(acc, red, tid & 255, wr & 1, wc, li, lh, m0 + 128 * half, n0, p.M, p.N, (WR / 2) * tile_m + half, tiles128, p.part);
+    if (EPI == 2)
+        xv_tile_bwd_stats_epilogue(acc, red, tid & 255, wr & 1, wc, li, lh, m0 + 128 * half, n0, p.M, p.N, (WR / 2) * tile_m + half, p.bwd);
 }
 
 #ifndef XV16_CONV
 #define XV16_CONV 1
 #endif
 
-// Does the context-window kernel apply?  K = taps*lda with whole 32-channel chunks, and the x rows of any 128-row tile
-// (one extra (pitch - rps) per segment crossing, plus the taps) fit the A image.
-static bool conv_form_applies(const XvGemm16NT& g, int* taps_out) {
+// Does the context-window kernel apply?  K = taps*lda with whole 32-channel chunks, and the x rows of any BM-row tile
+// (one extra (pitch - rps) per segment crossing, plus the taps) fit the A image of BM + 32 rows.
+static bool conv_form_applies(const XvGemm16NT& g, int bm, int* taps_out) {
     if (!XV16_CONV || XV16_WAVES != 4 || g.lda % 32 != 0 || g.K % g.lda != 0) return false;
     const int taps = (int)(g.K / g.lda);
     if (taps < 2 || g.a_pitch < g.a_rps) return false;
-    const long crossings = 127 / g.a_rps + 1;
-    const long span = 127 + (long)(g.a_pitch - g.a_rps) * crossings + (taps - 1);
-    if (span >= CONV_AR) return false;
+    const long crossings = (bm - 1) / g.a_rps + 1;
+    const long span = (bm - 1) + (long)(g.a_pitch - g.a_rps) * crossings + (taps - 1);
+    if (span >= bm + 32) return false;
     *taps_out = taps;
     return true;
+}
+
+// [measured] 256-row tiles (XV_CONV_WR=4) are 5-7 % slower at S1 (tdnn2/3 forward 270 vs 291 TF): 384 one-per-CU
+// workgroups on 256 CUs leave half the chip idle for the second round, which costs more than the halved weight-tile
+// staging saves.  128-row tiles stay the default.
+#ifndef XV16_CONV_WR
+#define XV16_CONV_WR 2
+#endif
+
+template <int WR>
+static int launch_conv(hipStream_t s, const XvGemm16NT& g, NT16Args p, int taps, bool bwd) {
+    typedef ConvGeom<WR> G;
+    NT16ConvArgs q;
+    p.tiles_m = xv_cdiv(g.M, G::BM);
+    q.g = p; q.taps = taps; q.chunks = (int)(g.lda / 32);
+    q.a_rows = (long)xv_cdiv(g.M, g.a_rps) * g.a_pitch;
+    const size_t lds = (size_t)G::LDS_HALFS * sizeof(u16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        XV_CHECK_HIP(hipFuncSetAttribute((const void*)xv_gemm16_nt_conv_kernel<0, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        XV_CHECK_HIP(hipFuncSetAttribute((const void*)xv_gemm16_nt_conv_kernel<1, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        XV_CHECK_HIP(hipFuncSetAttribute((const void*)xv_gemm16_nt_conv_kernel<2, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n), block(128 * WR);
+    if (g.bn_part) hipLaunchKernelGGL((xv_gemm16_nt_conv_kernel<1, WR>), grid, block, lds, s, q);
+    else if (bwd) hipLaunchKernelGGL((xv_gemm16_nt_conv_kernel<2, WR>), grid, block, lds, s, q);
+    else hipLaunchKernelGGL((xv_gemm16_nt_conv_kernel<0, WR>), grid, block, lds, s, q);
+    XV_LAUNCH_CHECK();
+    return 0;
 }
 
 int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
@@ -609,16 +657,10 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
     dim3 grid(p.tiles_m * p.tiles_n);
     XvProfScope prof(s, g.bn_part ? 3 : 4, 2.0 * g.M * g.N * g.K);
     int taps = 0;
-    if (conv_form_applies(g, &taps)) {
-        NT16ConvArgs q;
-        q.g = p; q.taps = taps; q.chunks = (int)(g.lda / 32);
-        q.a_rows = (long)xv_cdiv(g.M, g.a_rps) * g.a_pitch;
-        if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_conv_kernel<1>, grid, dim3(256), 0, s, q);
-        else if (bwd) hipLaunchKernelGGL(xv_gemm16_nt_conv_kernel<2>, grid, dim3(256), 0, s, q);
-        else hipLaunchKernelGGL(xv_gemm16_nt_conv_kernel<0>, grid, dim3(256), 0, s, q);
-        XV_LAUNCH_CHECK();
-        return 0;
-    }
+    static const int conv_wr = getenv("XV_CONV_WR") ? atoi(getenv("XV_CONV_WR")) : XV16_CONV_WR;
+    // 256-row tiles need enough of them to cover the chip once per CU
+    if (conv_wr == 4 && g.M >= 256 * 64 && conv_form_applies(g, 256, &taps)) return launch_conv<4>(s, g, p, taps, bwd);
+    if (conv_form_applies(g, 128, &taps)) return launch_conv<2>(s, g, p, taps, bwd);
     if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_kernel<1>, grid, dim3(64 * XV16_WAVES), 0, s, p);
     else if (bwd) hipLaunchKernelGGL(xv_gemm16_nt_kernel<2>, grid, dim3(64 * XV16_WAVES), 0, s, p);
     else hipLaunchKernelGGL(xv_gemm16_nt_kernel<0>, grid, dim3(64 * XV16_WAVES), 0, s, p);
