@@ -188,3 +188,19 @@ def test_dgrad_epilogue_produces_the_bn_backward_partials(ops, segs, t_out, k):
         assert_close(p[t, 0], dd[r].sum(axis=0), 2e-5, 2e-4, "sum dd tile %d" % t)
         assert_close(p[t, 1], (dd[r] * xh[r]).sum(axis=0), 2e-5, 2e-4, "sum dd*xhat tile %d" % t)
         assert_close(p[t, 2], np.abs(dd[r]).max(axis=0), 1e-6, 1e-6, "max |dd| tile %d" % t)
+
+
+def test_context_window_kernel_256_row_tiles():
+    """The 256-row-tile build of the context-window kernel (XV_CONV_WR=4, off by default because it measured slower at
+    S1) stays parity-clean: rerun the affine cases and the fused-statistics test with it forced.  The switch is read once
+    per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, XV_CONV_WR="4")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_ops_f16x3.py"),
+                        "-k", "test_affine_forward_dgrad_wgrad_f16x3 or test_dgrad_epilogue"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout

@@ -657,9 +657,11 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
     dim3 grid(p.tiles_m * p.tiles_n);
     XvProfScope prof(s, g.bn_part ? 3 : 4, 2.0 * g.M * g.N * g.K);
     int taps = 0;
-    static const int conv_wr = getenv("XV_CONV_WR") ? atoi(getenv("XV_CONV_WR")) : XV16_CONV_WR;
-    // 256-row tiles need enough of them to cover the chip once per CU
-    if (conv_wr == 4 && g.M >= 256 * 64 && conv_form_applies(g, 256, &taps)) return launch_conv<4>(s, g, p, taps, bwd);
+    // XV_CONV_WR=4 (experiments, tests) forces 256-row tiles wherever they apply; as a build default they would be
+    // limited to problems with at least one tile per CU
+    static const int conv_wr_env = getenv("XV_CONV_WR") ? atoi(getenv("XV_CONV_WR")) : 0;
+    const bool wr4 = conv_wr_env ? conv_wr_env == 4 : (XV16_CONV_WR == 4 && g.M >= 256 * 256);
+    if (wr4 && conv_form_applies(g, 256, &taps)) return launch_conv<4>(s, g, p, taps, bwd);
     if (conv_form_applies(g, 128, &taps)) return launch_conv<2>(s, g, p, taps, bwd);
     if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_kernel<1>, grid, dim3(64 * XV16_WAVES), 0, s, p);
     else if (bwd) hipLaunchKernelGGL(xv_gemm16_nt_kernel<2>, grid, dim3(64 * XV16_WAVES), 0, s, p);
