@@ -12,8 +12,8 @@ fp32, plain SGD + L2 - one "step" = forward + loss + backward (+ gradient all-re
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
 dominant kernel (its launches are bracketed by hipEvents on their stream inside the timed region; an
 untimed probe pass brackets every MFMA GEMM kind for the per-kernel table) and, at N = 1,
-`cpu_baseline` = the NumPy oracle's train_step timed on this box's host cores (all cores, plus a
-single-thread row).
+`cpu_baseline` = the NumPy oracle's train_step timed on this box's host cores (all cores, 16 and 1
+BLAS threads; the fastest is `value`).
 """
 import argparse
 import ctypes as C
@@ -88,12 +88,16 @@ def step_bytes(b, t, d, n):
 
 
 def cpu_baseline(seconds_budget=25.0):
-    """The oracle (a NumPy port of the reference arithmetic, NOT TensorFlow) on the host cores."""
+    """The oracle (a NumPy port of the reference arithmetic, NOT TensorFlow) on the host cores.  The port is dominated by
+    NumPy element-wise passes, and OpenBLAS on every core of a large host can be slower than on one, so three BLAS thread
+    counts are timed (all cores, 16, 1 - SURVEY.md section 8d asks for the single-thread and the all-cores rows) and
+    `value` is the fastest of them, with `cores` = the threads it used."""
     from oracle import xvector_oracle as O
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
+        threadpool_limits = None
         threads = os.cpu_count() or 1
     cb = 16
     cfg = O.Config(feat_dim=D, num_speakers=NSPK, loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True)
@@ -103,34 +107,29 @@ def cpu_baseline(seconds_budget=25.0):
     y = rs.randint(0, NSPK, cb)
     state = {}
     V, state, _ = O.train_step(V, state, cfg, x, y, 0.01, 0)      # warm-up (BLAS thread pool, page faults)
-    t0 = time.time()
-    n = 0
-    while True:
-        V, state, _ = O.train_step(V, state, cfg, x, y, 0.01, n + 1)
-        n += 1
-        if time.time() - t0 > seconds_budget * 0.5 or n >= 8:
-            break
-    dt = time.time() - t0
-    out = {"value": round(cb * n / dt, 2), "unit": "chunks/s", "cores": int(threads), "kind": "port",
-           "sample": "oracle (NumPy/OpenBLAS fp32 port, this repo) train_step, %d chunks x %d frames x %d-dim, %d speakers, %d steps in %.1f s"
-                     % (cb, T, D, NSPK, n, dt)}
-    # single-thread row (comparable to the reference's single_cpu extraction mode)
-    try:
-        from threadpoolctl import threadpool_limits
-        with threadpool_limits(limits=1):
+    counts = [threads] if threadpool_limits is None else sorted({threads, min(threads, 16), 1}, reverse=True)
+    rows, step = [], 1
+    for nt in counts:
+        import contextlib
+        ctx = threadpool_limits(limits=nt) if threadpool_limits is not None else contextlib.nullcontext()
+        with ctx:
+            V, state, _ = O.train_step(V, state, cfg, x, y, 0.01, step)      # settle the pool at this size
+            step += 1
             t0 = time.time()
-            n1 = 0
+            n = 0
             while True:
-                V, state, _ = O.train_step(V, state, cfg, x, y, 0.01, n + n1 + 1)
-                n1 += 1
-                if time.time() - t0 > seconds_budget * 0.4 or n1 >= 4:
+                V, state, _ = O.train_step(V, state, cfg, x, y, 0.01, step)
+                step += 1
+                n += 1
+                if time.time() - t0 > seconds_budget / (2.0 * len(counts)) or n >= 6:
                     break
-            dt1 = time.time() - t0
-        out["single_thread"] = {"value": round(cb * n1 / dt1, 2), "unit": "chunks/s", "cores": 1,
-                                "sample": "same workload, BLAS limited to 1 thread, %d steps in %.1f s" % (n1, dt1)}
-    except Exception as exc:      # threadpoolctl missing: the all-cores row stands alone
-        out["single_thread"] = {"value": None, "note": "not measured (%s)" % type(exc).__name__}
-    return out
+            dt = time.time() - t0
+        rows.append({"cores": int(nt), "value": round(cb * n / dt, 2), "steps": n, "seconds": round(dt, 1)})
+    best = max(rows, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "chunks/s", "cores": best["cores"], "kind": "port",
+            "sample": "oracle (NumPy/OpenBLAS fp32 port, this repo) train_step, %d chunks x %d frames x %d-dim, %d speakers, %d steps in %.1f s "
+                      "(fastest of the BLAS thread counts in `rows`)" % (cb, T, D, NSPK, best["steps"], best["seconds"]),
+            "rows": rows}
 
 
 def main():
