@@ -15,7 +15,7 @@ def timeit(fn, n=20, warm=3):
     return a.elapsed_time(b) / n * 1e3   # us
 
 
-B = 128
+B = int(os.environ.get("XV_B", "128"))
 rs = np.random.RandomState(0)
 ZERO = float(os.environ.get('XV_DATA_SCALE', '1'))
 def rnd(*s): return torch.from_numpy((rs.randn(*s) * ZERO).astype(np.float32)).cuda()
