@@ -213,3 +213,41 @@ def test_every_shipped_single_task_config_builds_an_engine_config():
         assert cfg.feat_dim == 30 and cfg.num_speakers == 100
         n += 1
     assert n == 81
+
+
+def test_sample_validset_spk2utt_rules(tmp_path):
+    """misc/tools/sample_validset_spk2utt.py (run.sh:179): speakers with >= n+2 utterances first, n utterances each, one
+    utterance of every speaker always left for training, output in spk2utt format."""
+    from tf_kaldi_speaker_amd.misc.tools.sample_validset_spk2utt import main, read_spk2utt, sample_validset
+    import io
+    import random
+    from contextlib import redirect_stdout
+    lines = ["spk%02d %s" % (i, " ".join("spk%02d-u%d" % (i, j) for j in range(n))) for i, n in enumerate([12, 9, 7, 3, 2, 1, 15, 5])]
+    p = tmp_path / "spk2utt"
+    p.write_text("\n".join(lines) + "\n")
+    speakers = read_spk2utt(str(p))
+    assert len(speakers) == 8 and speakers[3] == ("spk03", ["spk03-u0", "spk03-u1", "spk03-u2"])
+    all_utts = dict(speakers)
+    for seed in range(20):
+        got = sample_validset(speakers, 4, 5, random.Random(seed))
+        assert len(got) == 4 and len({s for s, _ in got}) == 4
+        for spk, utts in got:
+            assert len(all_utts[spk]) >= 7          # four speakers have >= 5 + 2 utterances: only those are drawn
+            assert len(utts) == 5 and len(set(utts)) == 5 and set(utts) <= set(all_utts[spk])
+    # more held-out speakers than rich ones: topped up with small speakers, which keep one utterance for training
+    got = dict(sample_validset(speakers, 6, 5, random.Random(1)))
+    assert len(got) == 6 and {"spk00", "spk01", "spk02", "spk06"} <= set(got)
+    for spk, utts in got.items():
+        n = len(all_utts[spk])
+        assert len(utts) == (5 if n > 5 else n - 1)
+    with pytest.raises(ValueError):
+        sample_validset(speakers, 9, 5, random.Random(0))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        main(["2", "3", str(p), "--seed", "7"])
+    out = [l.split() for l in buf.getvalue().strip().splitlines()]
+    assert len(out) == 2 and all(len(l) == 4 and all(u.startswith(l[0] + "-") for u in l[1:]) for l in out)
+    buf2 = io.StringIO()
+    with redirect_stdout(buf2):
+        main(["2", "3", str(p), "--seed", "7"])
+    assert buf2.getvalue() == buf.getvalue()
