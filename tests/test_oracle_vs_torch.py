@@ -22,6 +22,14 @@ def torch_forward(V, x, cfg, labels, step, training=True):
     eps = 1e-3
     ep = {}
 
+    def act(prefix, y, scope=""):
+        """network_relu_type (tdnn.py:24-30): relu | tf.nn.leaky_relu (alpha 0.2) | prelu = relu(x) + alpha (x - |x|) / 2."""
+        if cfg.network_relu_type == "lrelu":
+            return F.leaky_relu(y, 0.2)
+        if cfg.network_relu_type == "prelu":
+            return torch.relu(y) + tv["tdnn/%s%s_relu/alpha" % (scope, prefix)] * (y - y.abs()) * 0.5
+        return torch.relu(y)
+
     def bn(prefix, z, scope=""):
         base = "tdnn/%s%s_bn/" % (scope, prefix)
         g, b = tv[base + "gamma"], tv[base + "beta"]
@@ -42,19 +50,20 @@ def torch_forward(V, x, cfg, labels, step, training=True):
         else:
             z = F.linear(h, K.t(), b)
         ep[name] = z
-        h = torch.relu(bn(prefix, z))
+        h = act(prefix, bn(prefix, z))
         ep[prefix + "_relu"] = h
     if cfg.pooling_type == "self_attention":
         a0, a1 = "tdnn/attention/att_key0/att_key0_dense/", "tdnn/attention/att_key1/att_key1_dense/"
-        k = torch.relu(bn("att_key0", F.linear(ep["tdnn4_relu"], tv[a0 + "kernel"].t(), tv[a0 + "bias"]), "attention/att_key0/"))
+        k = act("att_key0", bn("att_key0", F.linear(ep["tdnn4_relu"], tv[a0 + "kernel"].t(), tv[a0 + "bias"]), "attention/att_key0/"),
+                "attention/att_key0/")
         k = F.linear(k, tv[a1 + "kernel"].t(), tv[a1 + "bias"])
         ep["att_key1_dense"] = k
         if cfg.att_key_network_type == 3:
             k = torch.tanh(k)
         elif cfg.att_key_network_type == 1:
-            k = torch.relu(k)
+            k = act("att_key1", k, "attention/att_key1/")
         elif cfg.att_key_network_type == 2:
-            k = torch.relu(bn("att_key1", k, "attention/att_key1/"))
+            k = act("att_key1", bn("att_key1", k, "attention/att_key1/"), "attention/att_key1/")
         score = torch.einsum("btd,hd->bth", k, tv["tdnn/attention/query"])[:, :, 0]
         if cfg.att_use_scale:
             score = score / np.sqrt(k.shape[-1])
@@ -71,14 +80,14 @@ def torch_forward(V, x, cfg, labels, step, training=True):
     ep["pooling"] = h
     z = F.linear(h, tv["tdnn/tdnn6_dense/kernel"].t(), tv["tdnn/tdnn6_dense/bias"])
     ep["tdnn6_dense"] = z
-    h = torch.relu(bn("tdnn6", z))
+    h = act("tdnn6", bn("tdnn6", z))
     z = F.linear(h, tv["tdnn/tdnn7_dense/kernel"].t(), tv["tdnn/tdnn7_dense/bias"])
     ep["tdnn7_dense"] = z
     h = z
     if not cfg.last_layer_no_bn:
         h = bn("tdnn7", h)
     if not cfg.last_layer_linear:
-        h = torch.relu(h)
+        h = act("tdnn7", h)
     if cfg.feature_norm:
         ss = (h * h).sum(dim=-1, keepdim=True)
         h = h * torch.rsqrt(torch.clamp(ss, min=1e-12)) * cfg.feature_scaling_factor
@@ -156,17 +165,23 @@ CASES = [
     # auxiliary losses of the shipped *_r0.01.json / *_mhe0.01.json configs (loss.py:985-1036)
     dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, aux_loss_func=("ring_loss", "mhe_loss"),
          ring_loss_init=3.0, ring_loss_lambda=0.05, mhe_lambda=0.05),
+    # network_relu_type variants (tdnn.py:24-30) incl. the relu'd last layer and the attention key networks
+    dict(loss_func="softmax", network_relu_type="lrelu"),
+    dict(loss_func="softmax", network_relu_type="prelu", last_layer_no_bn=True),
+    dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, network_relu_type="prelu",
+         pooling_type="self_attention", att_key_num_nodes=(16, 12), att_key_network_type=1),
+    dict(loss_func="softmax", network_relu_type="lrelu", pooling_type="self_attention", att_key_num_nodes=(16, 12), att_key_network_type=2),
 ]
 
 
-@pytest.mark.parametrize("kw", CASES, ids=lambda d: d["loss_func"] + "_" + str(d.get("margin_m", "")) + ("_att%d" % d["att_key_network_type"] if "att_key_network_type" in d else "_att" if "pooling_type" in d else "") + ("_aux" if "aux_loss_func" in d else ""))
+@pytest.mark.parametrize("kw", CASES, ids=lambda d: d["loss_func"] + "_" + str(d.get("margin_m", "")) + ("_att%d" % d["att_key_network_type"] if "att_key_network_type" in d else "_att" if "pooling_type" in d else "") + ("_aux" if "aux_loss_func" in d else "") + ("_" + d["network_relu_type"] if "network_relu_type" in d else ""))
 def test_full_step_forward_backward(kw):
     cfg = O.Config(feat_dim=6, num_speakers=11, num_nodes_pooling_layer=20, num_nodes_last_layer=16, **kw)
     # the layer widths 512 are fixed by tdnn.py; keep B,T small instead
     V = O.init_variables(cfg, seed=3, dtype=np.float64)
     rs = np.random.RandomState(7)
     for k in V:   # perturb BN params / biases so every gradient path is exercised
-        if k.endswith(("gamma", "beta", "bias")):
+        if k.endswith(("gamma", "beta", "bias", "alpha")):
             V[k] = V[k] + 0.1 * rs.randn(*V[k].shape)
     B, T = 5, 22
     x = rs.randn(B, T, cfg.feat_dim)
