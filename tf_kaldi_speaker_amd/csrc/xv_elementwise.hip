@@ -497,30 +497,38 @@ extern "C" int xv_bn_apply(void* stream, const float* z, int rows, int n, int ld
 // pooled statistics [b][mean | std] and their gradient:  da = dmean/T + dstd/(T*std) * (a - mean),  a = relu?(z*scale+shift).
 struct PoolGrad { const float* out; const float* dout; int t; const float* w; };   // w: per-frame attention weights or null (1/t)
 
-__device__ __forceinline__ f32x4 pool_grad(const PoolGrad& pg, long row, int n, int col, f32x4 a) {
-    const int b = (int)(row / pg.t);
-    const float invT = pg.w ? pg.w[row] : 1.f / (float)pg.t;      // self-attention: frame weight instead of 1/T (pooling.py:148-155)
+// The pooled statistics of chunk b at one channel quad, in the form the per-element formula needs: they change only when
+// the row loop crosses into the next chunk, so the kernels reload them there instead of once per element (4 vector loads,
+// 4 divisions and an integer division by T per 16 bytes of z before).
+struct PoolCoef { f32x4 mean, dm, q; };      // q = dstd / std (0 where the forward clamped the variance)
+__device__ __forceinline__ PoolCoef pool_coef(const PoolGrad& pg, int b, int n, int col) {
     const float sd_eps = 1e-6f;      // sqrt(1e-12): the forward clamps the variance there (pooling.py:28-29)
     const float* o = pg.out + (long)b * 2 * n;
     const float* g = pg.dout + (long)b * 2 * n;
-    f32x4 mean = *(const f32x4*)(o + col), sd = *(const f32x4*)(o + n + col);
-    f32x4 dm = *(const f32x4*)(g + col), ds = *(const f32x4*)(g + n + col);
-    f32x4 k;
-    k.x = sd.x <= sd_eps ? 0.f : ds.x / sd.x * invT; k.y = sd.y <= sd_eps ? 0.f : ds.y / sd.y * invT;
-    k.z = sd.z <= sd_eps ? 0.f : ds.z / sd.z * invT; k.w = sd.w <= sd_eps ? 0.f : ds.w / sd.w * invT;
-    return dm * invT + k * (a - mean);
+    PoolCoef pc;
+    pc.mean = *(const f32x4*)(o + col);
+    pc.dm = *(const f32x4*)(g + col);
+    const f32x4 sd = *(const f32x4*)(o + n + col), ds = *(const f32x4*)(g + n + col);
+    pc.q.x = sd.x <= sd_eps ? 0.f : ds.x / sd.x; pc.q.y = sd.y <= sd_eps ? 0.f : ds.y / sd.y;
+    pc.q.z = sd.z <= sd_eps ? 0.f : ds.z / sd.z; pc.q.w = sd.w <= sd_eps ? 0.f : ds.w / sd.w;
+    return pc;
 }
+// da = dmean * w + (dstd / std * w) * (a - mean), w = 1/T or the frame's attention weight (pooling.py:148-155)
+__device__ __forceinline__ f32x4 pool_grad(const PoolCoef& pc, float invT, f32x4 a) {
+    return pc.dm * invT + (pc.q * invT) * (a - pc.mean);
+}
+__device__ __forceinline__ float pool_frame_weight(const PoolGrad& pg, long row) { return pg.w ? pg.w[row] : 1.f / (float)pg.t; }
 
 // masked upstream gradient of one channel quad: POOLED ? pooling backward on the fly : da, zeroed where the ReLU was off
 template <bool POOLED>
-__device__ __forceinline__ f32x4 upstream_grad(const float* __restrict__ da, const PoolGrad& pg, long r, int n, int col, f32x4 zz,
-                                               f32x4 sc, f32x4 sh, int relu) {
+__device__ __forceinline__ f32x4 upstream_grad(const float* __restrict__ da, const PoolCoef& pc, float invT, long r, int n, int col,
+                                               f32x4 zz, f32x4 sc, f32x4 sh, int relu) {
     f32x4 y = zz * sc + sh;
     f32x4 dd;
     if (POOLED) {
         f32x4 a = y;
         if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-        dd = pool_grad(pg, r, n, col, a);
+        dd = pool_grad(pc, invT, a);
     } else {
         dd = *(const f32x4*)(da + r * n + col);
     }
@@ -548,9 +556,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (col < n) {
         f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
         f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
+        PoolCoef pc = {};
+        int pb = -1, b_end = 0;           // chunk whose statistics are in pc; its first row beyond
+        float invT = 0.f;
         for (int r = r0 + rl; r < r1; r += 4) {
+            if (POOLED) {
+                if (r >= b_end) { pb = r / pg.t; b_end = (pb + 1) * pg.t; pc = pool_coef(pg, pb, n, col); }
+                invT = pool_frame_weight(pg, r);
+            }
             f32x4 zz = *(const f32x4*)(z + (long)r * n + col);
-            f32x4 dd = upstream_grad<POOLED>(da, pg, (long)r, n, col, zz, sc, sh, relu);
+            f32x4 dd = upstream_grad<POOLED>(da, pc, invT, (long)r, n, col, zz, sc, sh, relu);
             f32x4 xh = (zz - mu) * is;
             s1 += dd;
             s2 += dd * xh;
@@ -632,7 +647,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, PoolGrad pg, c
             long r = (long)seg * t + u;
             f32x4 zz = *(const f32x4*)(z + r * n + col);
             f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
-            f32x4 dd = upstream_grad<POOLED>(da, pg, r, n, col, zz, *(const f32x4*)(scale + col), *(const f32x4*)(shift + col), relu);
+            PoolCoef pc = {};
+            float invT = 0.f;
+            if (POOLED) { pc = pool_coef(pg, (int)((unsigned)r / (unsigned)pg.t), n, col); invT = pool_frame_weight(pg, r); }
+            f32x4 dd = upstream_grad<POOLED>(da, pc, invT, r, n, col, zz, *(const f32x4*)(scale + col), *(const f32x4*)(shift + col), relu);
             f32x4 xh = (zz - mu) * is;
             f32x4 c1 = *(const f32x4*)(coef + col), c2 = *(const f32x4*)(coef + n + col);
             out = (*(const f32x4*)(gamma + col) * is) * (dd - c1 - xh * c2);
@@ -677,17 +695,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split_kernel(const float* __
     int seg = r0 / tp, u = r0 - seg * tp;          // padded row r0 -> (segment, frame + pad)
     u += rl;
     while (u >= tp) { u -= tp; ++seg; }
+    PoolCoef pc[2] = {};
+    int b_end = 0;                                 // first row beyond the chunk whose statistics are in pc
+    float invT = 0.f;
     for (int dr = r0 + rl; dr < r1; dr += 4) {
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int f = u - pad;
         if (f >= 0 && f < t) {
             const long r = (long)seg * t + f;
+            if (POOLED) {
+                if (r >= b_end) {
+                    const int pb = (int)r / pg.t;
+                    b_end = (pb + 1) * pg.t;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) pc[q] = pool_coef(pg, pb, n, cv[q] ? col + 4 * q : 0);
+                }
+                invT = pool_frame_weight(pg, r);
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 if (!cv[q]) continue;
                 const int c = col + 4 * q;
                 f32x4 zz = *(const f32x4*)(z + r * n + c);
-                f32x4 dd = upstream_grad<POOLED>(da, pg, r, n, c, zz, sc[q], sh[q], relu);
+                f32x4 dd = upstream_grad<POOLED>(da, pc[q], invT, r, n, c, zz, sc[q], sh[q], relu);
                 f32x4 xh = (zz - mu[q]) * is[q];
                 f32x4 o = g_is[q] * (dd - c1[q] - xh * c2[q]);
                 v[4 * q] = o.x; v[4 * q + 1] = o.y; v[4 * q + 2] = o.z; v[4 * q + 3] = o.w;
