@@ -362,6 +362,12 @@ int xv_engine_forward(xv_engine* e, void* stream, const float* features, int b, 
 #define XV_BWD_STAGES 4
 int xv_engine_loss_forward(xv_engine* e, void* stream, const int32_t* labels, int global_step, int with_margin);
 int xv_engine_backward(xv_engine* e, void* stream, int stage);
+/* Staged backward without the join at the end of stages 0..2: `stream` does not wait for the engine's weight-gradient stream,
+ * so the next stage's data-gradient chain keeps overlapping it.  The slice of stage k is complete on any stream that called
+ * xv_engine_stage_wait(e, that_stream, k) - typically the communication stream the slice's all-reduce is enqueued on.  The last
+ * stage joins on `stream` as xv_engine_backward does (xv_engine_apply may follow on `stream`). */
+int xv_engine_backward_async(xv_engine* e, void* stream, int stage);
+int xv_engine_stage_wait(xv_engine* e, void* waiter_stream, int stage);
 /* [begin,end) float range of the gradient buffer completed by backward stage `stage`. */
 int xv_engine_stage_grad_range(const xv_engine* e, int stage, size_t* begin, size_t* end);
 /* optimiser step on the bound buffers (after the gradient all-reduce). t = 1-based update count. */

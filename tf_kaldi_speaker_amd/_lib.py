@@ -147,6 +147,8 @@ SIGNATURES = {
     "xv_engine_forward": (_I, [_VP, _VP, _VP, _I, _I, _I]),
     "xv_engine_loss_forward": (_I, [_VP, _VP, _VP, _I, _I]),
     "xv_engine_backward": (_I, [_VP, _VP, _I]),
+    "xv_engine_backward_async": (_I, [_VP, _VP, _I]),
+    "xv_engine_stage_wait": (_I, [_VP, _VP, _I]),
     "xv_engine_stage_grad_range": (_I, [_VP, _I, C.POINTER(_SZ), C.POINTER(_SZ)]),
     "xv_engine_apply": (_I, [_VP, _VP, _F, _F, _I]),
     "xv_engine_loss_ptrs": (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),

@@ -84,6 +84,8 @@ struct xv_engine {
     // second stream: weight gradients run beside the data-gradient chain (they only share dz)
     hipStream_t side = nullptr;
     hipEvent_t ev_dz = nullptr, ev_lw = nullptr;
+    hipEvent_t ev_stage[XV_BWD_STAGES][2] = {};   // [stage][0 main, 1 side]: that stage's gradients are complete (backward_async)
+    bool stage_side[XV_BWD_STAGES] = {};          // the side-stream event of the stage was recorded
     // dz ping-pong state.  ring 0: the frame-level layers' dz (fp16 planes `dzh` in split precision) and, in fp32, every
     // layer's dz (`bufZ`); ring 1 (split precision only): the fp32 dz of the segment-level layers and the attention key
     // gradient in `bufZ` - its own ring, so a frame layer never waits for a segment layer's weight gradient
@@ -382,6 +384,8 @@ int alloc_buffers(xv_engine* e) {
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < 2; ++i) XV_CHECK_HIP(hipEventCreateWithFlags(&e->zr[r].ev[i], hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lw, hipEventDisableTiming));
+    for (int k = 0; k < XV_BWD_STAGES; ++k)
+        for (int j = 0; j < 2; ++j) XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_stage[k][j], hipEventDisableTiming));
     return 0;
 }
 
@@ -495,6 +499,8 @@ extern "C" void xv_engine_destroy(xv_engine* e) {
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < 2; ++i) if (e->zr[r].ev[i]) (void)hipEventDestroy(e->zr[r].ev[i]);
     if (e->ev_lw) (void)hipEventDestroy(e->ev_lw);
+    for (int k = 0; k < XV_BWD_STAGES; ++k)
+        for (int j = 0; j < 2; ++j) if (e->ev_stage[k][j]) (void)hipEventDestroy(e->ev_stage[k][j]);
 
     if (e->arena) (void)hipFree(e->arena);
     delete e;
@@ -963,7 +969,39 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
 
 }  // namespace
 
-extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
+namespace {
+// End of a backward stage.  Joining: `s` waits for the side stream, so the stage's gradients are complete on `s` (a collective
+// enqueued on `s` next sees them) - but `s` then also stalls until the weight gradients have drained, which costs the overlap
+// of the next stage's data-gradient chain with them (0.2 ms/step at S1).  Deferred: both streams only record an event; whoever
+// consumes the slice waits for the pair (xv_engine_stage_wait) on its own stream.
+int end_stage(xv_engine* e, hipStream_t s, int stage, bool defer) {
+    if (!defer || stage == XV_BWD_STAGES - 1) return join_side(e, s);
+    XV_CHECK_HIP(hipEventRecord(e->ev_stage[stage][0], s));
+    e->stage_side[stage] = e->concurrent && e->side;
+    if (e->stage_side[stage]) XV_CHECK_HIP(hipEventRecord(e->ev_stage[stage][1], e->side));
+    return 0;
+}
+int engine_backward(xv_engine* e, void* stream, int stage, bool defer);
+}  // namespace
+
+extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) { return engine_backward(e, stream, stage, false); }
+
+extern "C" int xv_engine_backward_async(xv_engine* e, void* stream, int stage) {
+    XV_REQUIRE(stage >= 0 && stage < XV_BWD_STAGES, "engine_backward_async: stage %d is not one of 0..%d", stage, XV_BWD_STAGES - 1);
+    return engine_backward(e, stream, stage, true);
+}
+
+extern "C" int xv_engine_stage_wait(xv_engine* e, void* waiter_stream, int stage) {
+    XV_REQUIRE(e && stage >= 0 && stage < XV_BWD_STAGES, "engine_stage_wait: bad arguments");
+    if (stage == XV_BWD_STAGES - 1) return 0;      // the last stage joins on the caller's stream itself
+    hipStream_t w = (hipStream_t)waiter_stream;
+    XV_CHECK_HIP(hipStreamWaitEvent(w, e->ev_stage[stage][0], 0));
+    if (e->stage_side[stage]) XV_CHECK_HIP(hipStreamWaitEvent(w, e->ev_stage[stage][1], 0));
+    return 0;
+}
+
+namespace {
+int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
     XV_REQUIRE(e && e->V && e->G, "engine_backward: gradient buffer not bound");
     XV_REQUIRE(e->training && e->labels_dev, "engine_backward: needs a training forward + loss_forward first");
     XV_REQUIRE(stage >= -1 && stage < XV_BWD_STAGES, "engine_backward: bad stage %d", stage);
@@ -1038,7 +1076,7 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
         if (rc) return rc;
         rc = layer_backward(e, s, e->L[5], e->bufD, e->pool, b, 1, e->d_small0, nullptr);
         if (rc) return rc;
-        if (stage == 0) { rc = join_side(e, s); if (rc) return rc; }
+        if (stage == 0) { rc = end_stage(e, s, 0, defer); if (rc) return rc; }
     }
     if (stage == -1 || stage == 1) {
         if (e->att) {
@@ -1075,12 +1113,12 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
         if (rc) return rc;
         rc = layer_backward(e, s, e->L[3], e->bufD, e->L[2].a, b * e->Tl[4], 1, e->bufD, nullptr);   // tdnn4
         if (rc) return rc;
-        if (stage == 1) { rc = join_side(e, s); if (rc) return rc; }
+        if (stage == 1) { rc = end_stage(e, s, 1, defer); if (rc) return rc; }
     }
     if (stage == -1 || stage == 2) {
         rc = layer_backward(e, s, e->L[2], e->bufD, e->L[1].a, b, e->Tl[2], e->bufD, nullptr);        // tdnn3 -> d a2
         if (rc) return rc;
-        if (stage == 2) { rc = join_side(e, s); if (rc) return rc; }
+        if (stage == 2) { rc = end_stage(e, s, 2, defer); if (rc) return rc; }
     }
     if (stage == -1 || stage == 3) {
         rc = layer_backward(e, s, e->L[1], e->bufD, e->L[0].a, b, e->Tl[1], e->bufD, nullptr);        // tdnn2 -> d a1
@@ -1092,6 +1130,7 @@ extern "C" int xv_engine_backward(xv_engine* e, void* stream, int stage) {
     }
     return 0;
 }
+}  // namespace
 
 extern "C" int xv_engine_stage_grad_range(const xv_engine* e, int stage, size_t* begin, size_t* end) {
     XV_REQUIRE(e && stage >= 0 && stage < XV_BWD_STAGES && begin && end, "stage_grad_range: bad arguments");

@@ -227,6 +227,14 @@ class Engine(object):
     def backward(self, stage=-1):
         _lib.check(self.lib.xv_engine_backward(self.h, _stream(), int(stage)), "xv_engine_backward")
 
+    def backward_async(self, stage):
+        """Stage `stage` of the backward pass without the end-of-stage join: the current stream keeps overlapping the weight
+        gradients; stage_wait(stage, stream) orders a consumer stream behind the finished slice."""
+        _lib.check(self.lib.xv_engine_backward_async(self.h, _stream(), int(stage)), "xv_engine_backward_async")
+
+    def stage_wait(self, stage, stream_ptr):
+        _lib.check(self.lib.xv_engine_stage_wait(self.h, C.c_void_p(int(stream_ptr)), int(stage)), "xv_engine_stage_wait")
+
     def stage_grad_range(self, stage):
         b, e = C.c_size_t(), C.c_size_t()
         _lib.check(self.lib.xv_engine_stage_grad_range(self.h, int(stage), C.byref(b), C.byref(e)))
@@ -306,9 +314,9 @@ class Engine(object):
             grad_scale = 1.0
         else:
             for st in range(XV_BWD_STAGES):
-                self.backward(st)
+                self.backward_async(st)
                 b, e = self.stage_grad_range(st)
-                allreduce(self.grads[b:e])
+                allreduce(self.grads[b:e], ready=lambda stream_ptr, st=st: self.stage_wait(st, stream_ptr))
             allreduce.wait()
             grad_scale = allreduce.grad_scale
         frozen = getattr(self, "_frozen_grads", None) or ()
