@@ -50,13 +50,13 @@ CASES = [
 ]
 
 
-def _make(kw, B, T, N=37, P=1500, seed=0, max_batch=None, max_frames=None):
+def _make(kw, B, T, N=37, P=1500, seed=0, max_batch=None, max_frames=None, D=30, L=512):
     from tf_kaldi_speaker_amd import engine as E
     kw = dict(kw)
-    cfg_o = O.Config(feat_dim=30, num_speakers=N, num_nodes_pooling_layer=P, **kw)
+    cfg_o = O.Config(feat_dim=D, num_speakers=N, num_nodes_pooling_layer=P, num_nodes_last_layer=L, **kw)
     ekw = dict(kw)
     ekw.pop("loss_func", None)
-    c = E.make_config(30, N, loss_func=kw.get("loss_func", "softmax"), num_nodes_pooling_layer=P,
+    c = E.make_config(D, N, loss_func=kw.get("loss_func", "softmax"), num_nodes_pooling_layer=P, num_nodes_last_layer=L,
                       max_batch=max_batch or B, max_frames=max_frames or T, **ekw)
     eng = E.Engine(c)
     V = O.init_variables(cfg_o, seed=seed, dtype=np.float64)
@@ -146,10 +146,31 @@ def oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x, labels, lr, step, opt_st
 
 @pytest.mark.parametrize("kw", CASES, ids=lambda d: "-".join(str(v).replace(" ", "") for v in d.values()))
 def test_train_step_matches_oracle(kw):
-    B, T = 6, 40
-    eng, cfg_o, V = _make(kw, B, T)
+    _check_train_step(kw, 6, 40)
+
+
+# feature / layer widths of the other shipped recipes and ragged everything: 23-dim MFCCs (egs/sre, egs/fisher: not a multiple
+# of 4 - padded to 24 / 32 channels inside), 40-dim, pooling layers of 600 / 3000 nodes, a 256-node last layer, odd batch,
+# frame and speaker counts (but at least 4 rows per BatchNorm: with 2 the normalised values are +-1/sqrt(1 + eps/var) and a
+# rounding-level difference of two nearly equal pre-activations is amplified past any fixed tolerance)
+ODD_DIMS = [
+    dict(D=23, P=600, L=256, N=101, B=3, T=33, kw=dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True)),
+    dict(D=40, P=3000, L=512, N=53, B=5, T=27, kw=dict(loss_func="softmax")),
+    dict(D=23, P=1500, L=128, N=19, B=4, T=22, kw=dict(loss_func="asoftmax", margin_m=2, lambda_min=5, lambda_gamma=1e-3,
+                                                         last_layer_linear=True, pooling_type="self_attention",
+                                                         att_key_num_nodes=(100, 60))),
+]
+
+
+@pytest.mark.parametrize("c", ODD_DIMS, ids=lambda c: "D%d-P%d-L%d-N%d-B%d-T%d" % (c["D"], c["P"], c["L"], c["N"], c["B"], c["T"]))
+def test_train_step_matches_oracle_odd_dimensions(c):
+    _check_train_step(c["kw"], c["B"], c["T"], N=c["N"], P=c["P"], D=c["D"], L=c["L"])
+
+
+def _check_train_step(kw, B, T, **dims):
+    eng, cfg_o, V = _make(kw, B, T, **dims)
     rs = np.random.RandomState(42)
-    x = rs.randn(B, T, 30).astype(np.float32)
+    x = rs.randn(B, T, cfg_o.feat_dim).astype(np.float32)
     labels = rs.randint(0, cfg_o.num_speakers, B).astype(np.int32)
     step, lr = 1234, 0.05
 
@@ -199,7 +220,10 @@ def test_train_step_matches_oracle(kw):
             # pinned on identical inputs in test_gpu_ops.py::test_optimizers_and_reductions.
             gref = np.abs(info["grads"][name].reshape(v.shape))
             diff = diff[gref >= 1e-3 * gref.max()]
-        assert diff.max() / denom <= 2e-5, (name, diff.max() / denom)
+        # 2e-5 of the variable, plus - for plain SGD - what the gradient tolerance above (1e-4 of its max) admits through lr*g
+        # (tiny batches have gradients that are large against the weights)
+        slack = lr * 1e-4 * np.abs(info["grads"][name]).max() if (cfg_o.optimizer == "sgd" and name in info["grads"]) else 0.0
+        assert diff.max() <= 2e-5 * denom + slack, (name, diff.max() / denom)
     eng.close()
 
 
