@@ -50,7 +50,7 @@ CASES = [
 ]
 
 
-def _make(kw, B, T, N=37, P=1500, seed=0, max_batch=None, max_frames=None, D=30, L=512):
+def _make(kw, B, T, N=37, P=1500, seed=0, max_batch=None, max_frames=None, D=30, L=512, engine_cfg=None):
     from tf_kaldi_speaker_amd import engine as E
     kw = dict(kw)
     cfg_o = O.Config(feat_dim=D, num_speakers=N, num_nodes_pooling_layer=P, num_nodes_last_layer=L, **kw)
@@ -58,7 +58,7 @@ def _make(kw, B, T, N=37, P=1500, seed=0, max_batch=None, max_frames=None, D=30,
     ekw.pop("loss_func", None)
     c = E.make_config(D, N, loss_func=kw.get("loss_func", "softmax"), num_nodes_pooling_layer=P, num_nodes_last_layer=L,
                       max_batch=max_batch or B, max_frames=max_frames or T, **ekw)
-    eng = E.Engine(c)
+    eng = E.Engine(engine_cfg if engine_cfg is not None else c)       # engine_cfg: built by the product's own Params mapping
     V = O.init_variables(cfg_o, seed=seed, dtype=np.float64)
     rs = np.random.RandomState(seed + 100)
     for k in V:   # move BN parameters / biases / moving stats off their trivial init
@@ -167,6 +167,59 @@ def test_train_step_matches_oracle_odd_dimensions(c):
     _check_train_step(c["kw"], c["B"], c["T"], N=c["N"], P=c["P"], D=c["D"], L=c["L"])
 
 
+def _shipped_combinations():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shipped_config_switches.json")
+    return json.load(open(path))
+
+
+def _oracle_kw_from_params(d):
+    """The test's own reading of a config's hot-path keys in the oracle's vocabulary - independent of
+    model/tdnn.py::engine_config, which builds the engine side from the same dict."""
+    kw = dict(loss_func=d["loss_func"], last_layer_no_bn=bool(d.get("last_layer_no_bn", False)),
+              last_layer_linear=bool(d.get("last_layer_linear", False)), feature_norm=bool(d.get("feature_norm", False)),
+              weight_l2_regularizer=d["weight_l2_regularizer"], batchnorm_momentum=d["batchnorm_momentum"],
+              optimizer=d.get("optimizer", "sgd"), pooling_type=d["pooling_type"])
+    if kw["feature_norm"]:
+        kw["feature_scaling_factor"] = d["feature_scaling_factor"]
+    if kw["optimizer"] == "momentum":
+        kw.update(momentum=d["momentum"], use_nesterov=bool(d.get("use_nesterov", False)))
+    prefix = {"asoftmax": "asoftmax", "additive_margin_softmax": "amsoftmax", "additive_angular_margin_softmax": "arcsoftmax"}.get(d["loss_func"])
+    if prefix:
+        kw.update(margin_m=d[prefix + "_m"], lambda_min=d[prefix + "_lambda_min"], lambda_base=d[prefix + "_lambda_base"],
+                  lambda_gamma=d[prefix + "_lambda_gamma"], lambda_power=d[prefix + "_lambda_power"])
+    if d["pooling_type"] == "self_attention":
+        kw.update(att_key_num_nodes=tuple(d["att_key_num_nodes"]), att_key_network_type=d["att_key_network_type"],
+                  att_use_scale=bool(d.get("att_use_scale", False)))
+    if d.get("aux_loss_func"):
+        kw["aux_loss_func"] = tuple(d["aux_loss_func"])
+        for k in ("ring_loss_init", "ring_loss_lambda", "mhe_lambda"):
+            if k in d:
+                kw[k] = d[k]
+    return kw
+
+
+@pytest.mark.parametrize("combo", _shipped_combinations(), ids=lambda c: c["example"].split("/", 1)[1].replace("/nnet_conf/", ":").replace(".json", ""))
+def test_every_shipped_switch_combination_steps_like_the_oracle(combo, tmp_path):
+    """One full parity step (loss, endpoints, every gradient, update) for each of the 59 distinct combinations of hot-path switches
+    among the reference's 81 single-task nnet_conf/*.json (tests/golden/make_config_switches.py), with the engine configured
+    by the product's own Params -> engine mapping."""
+    import json
+    from tf_kaldi_speaker_amd.misc.utils import Params
+    from tf_kaldi_speaker_amd.model.tdnn import engine_config
+    d = dict(combo["params"])
+    f = tmp_path / "config.json"
+    f.write_text(json.dumps(d))
+    params = Params(str(f))
+    B, T, N, D = 4, 24, 13, 30
+    if d.get("clip_gradient", False):
+        pytest.skip("clip_gradient is false in every shipped config; covered by test_gpu_ops")
+    cfg = engine_config(params, D, N, d["loss_func"], B, T)
+    kw = _oracle_kw_from_params(params.dict)
+    _check_train_step(kw, B, T, N=N, P=params.dict["num_nodes_pooling_layer"], D=D, L=params.dict["num_nodes_last_layer"], engine_cfg=cfg)
+
+
 def _check_train_step(kw, B, T, **dims):
     eng, cfg_o, V = _make(kw, B, T, **dims)
     rs = np.random.RandomState(42)
@@ -220,9 +273,11 @@ def _check_train_step(kw, B, T, **dims):
             # pinned on identical inputs in test_gpu_ops.py::test_optimizers_and_reductions.
             gref = np.abs(info["grads"][name].reshape(v.shape))
             diff = diff[gref >= 1e-3 * gref.max()]
-        # 2e-5 of the variable, plus - for plain SGD - what the gradient tolerance above (1e-4 of its max) admits through lr*g
+        # 2e-5 of the variable, plus - for SGD and the first momentum step - what the gradient tolerance above (1e-4 of its max) admits through lr*g
         # (tiny batches have gradients that are large against the weights)
-        slack = lr * 1e-4 * np.abs(info["grads"][name]).max() if (cfg_o.optimizer == "sgd" and name in info["grads"]) else 0.0
+        slack = 0.0
+        if cfg_o.optimizer in ("sgd", "momentum") and name in info["grads"]:      # first momentum step: lr*g, lr*(1+m)*g with nesterov
+            slack = lr * (1.0 + (cfg_o.momentum if cfg_o.optimizer == "momentum" else 0.0)) * 1e-4 * np.abs(info["grads"][name]).max()
         assert diff.max() <= 2e-5 * denom + slack, (name, diff.max() / denom)
     eng.close()
 
