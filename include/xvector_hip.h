@@ -365,7 +365,8 @@ int xv_engine_backward(xv_engine* e, void* stream, int stage);
 /* Staged backward without the join at the end of stages 0..2: `stream` does not wait for the engine's weight-gradient stream,
  * so the next stage's data-gradient chain keeps overlapping it.  The slice of stage k is complete on any stream that called
  * xv_engine_stage_wait(e, that_stream, k) - typically the communication stream the slice's all-reduce is enqueued on.  The last
- * stage joins on `stream` as xv_engine_backward does (xv_engine_apply may follow on `stream`). */
+ * stage joins on `stream` as xv_engine_backward does (xv_engine_apply may follow on `stream`); a different consumer stream
+ * still has to call xv_engine_stage_wait for it. */
 int xv_engine_backward_async(xv_engine* e, void* stream, int stage);
 int xv_engine_stage_wait(xv_engine* e, void* waiter_stream, int stage);
 /* [begin,end) float range of the gradient buffer completed by backward stage `stage`. */

@@ -66,3 +66,75 @@ def test_bench_under_torch_distributed_run():
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 1000 and line["scaling"] == "weak" and "roofline" in line
+
+
+TWO_RANK_WORKER = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from tf_kaldi_speaker_amd import engine as E
+from tf_kaldi_speaker_amd.parallel import GradAllReduce, broadcast_variables
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                       # both ranks share the one GPU of the box; RCCL refuses that, gloo stages through the host
+dist.init_process_group("gloo", rank=rank, world_size=world)
+B, T, N, D, lr, steps = 8, 60, 29, 30, 0.05, 2
+kw = dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, max_batch=B, max_frames=T)
+def batch(r, step):
+    rs = np.random.RandomState(100 * r + step)
+    return rs.randn(B, T, D).astype(np.float32), rs.randint(0, N, B).astype(np.int32)
+eng = E.Engine(E.make_config(D, N, **kw), device="cuda:0")
+eng.init_variables(seed=rank)                  # deliberately different: the broadcast must make the replicas equal
+broadcast_variables(dist, eng.variables, 0)
+v0 = eng.variables.clone()
+ar = GradAllReduce(dist, world)
+for step in range(steps):
+    x, y = batch(rank, step)
+    eng.train_step(x, y, lr, step, allreduce=ar)
+torch.cuda.synchronize()
+mine = eng.variables[:eng.n_train].cpu().numpy().copy()
+gathered = [torch.zeros(eng.n_train) for _ in range(world)]
+dist.all_gather(gathered, torch.from_numpy(mine))
+res = {"rank": rank, "replicas_identical": bool(all(np.array_equal(g.numpy(), mine) for g in gathered))}
+if rank == 0:
+    # reference on one engine: per step, the gradients of both ranks' batches from the same weights, summed, update with 1/world.
+    # BN moving statistics are per rank by design, so they follow rank 0's batch only.
+    ref = E.Engine(E.make_config(D, N, **kw), device="cuda:0")
+    ref.variables.copy_(v0)
+    ref.lib.xv_engine_invalidate_weights(ref.h)
+    for step in range(steps):
+        keep = ref.variables.clone()
+        total = None
+        for r in (1, 0):                       # rank 0's batch last: its BN moving-average update is the one that stays
+            ref.variables.copy_(keep); ref.lib.xv_engine_invalidate_weights(ref.h)
+            x, y = batch(r, step)
+            ref.forward(x, True); ref.loss(y, step, True); ref.backward(-1)
+            g = ref.grads.clone()
+            total = g if total is None else total + g
+        ref.grads.copy_(total)
+        ref.apply(lr, 1.0 / world)
+    torch.cuda.synchronize()
+    want = ref.variables[:ref.n_train].cpu().numpy()
+    res["max_diff_vs_single_engine"] = float(np.abs(want - mine).max())
+    res["moved"] = float(np.abs(mine - v0[:eng.n_train].cpu().numpy()).max())
+    ref.close()
+eng.close()
+dist.barrier(); dist.destroy_process_group()
+json.dump(res, open(os.path.join(sys.argv[1], "rank%%d.json" %% rank), "w"))      # (stdout of the two ranks may interleave)
+"""
+
+
+def test_two_ranks_sharing_the_gpu_average_gradients_like_one_engine(tmp_path):
+    """World size 2 for real: two processes, each with its own engine and its own minibatch, on the one GPU of the box
+    (gloo carries the device tensors; the 8-GPU RCCL runs are the driver's).  After two steps the replicas are bit-identical
+    and equal the single-engine computation that sums both batches' gradients and applies them with 1/world."""
+    script = tmp_path / "worker2.py"
+    script.write_text(TWO_RANK_WORKER % ROOT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), str(script), str(tmp_path)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    assert len(lines) == 2 and all(l["replicas_identical"] for l in lines), lines
+    r0 = [l for l in lines if l["rank"] == 0][0]
+    assert r0["moved"] > 1e-4 and r0["max_diff_vs_single_engine"] == 0.0, r0

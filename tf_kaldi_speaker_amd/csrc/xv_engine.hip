@@ -975,9 +975,14 @@ namespace {
 // of the next stage's data-gradient chain with them (0.2 ms/step at S1).  Deferred: both streams only record an event; whoever
 // consumes the slice waits for the pair (xv_engine_stage_wait) on its own stream.
 int end_stage(xv_engine* e, hipStream_t s, int stage, bool defer) {
-    if (!defer || stage == XV_BWD_STAGES - 1) return join_side(e, s);
+    if (!defer) return join_side(e, s);
+    const bool last = stage == XV_BWD_STAGES - 1;
+    if (last) {                       // the optimiser step follows on `s`: join here, the event on `s` then covers both streams
+        int rc = join_side(e, s);
+        if (rc) return rc;
+    }
     XV_CHECK_HIP(hipEventRecord(e->ev_stage[stage][0], s));
-    e->stage_side[stage] = e->concurrent && e->side;
+    e->stage_side[stage] = !last && e->concurrent && e->side;
     if (e->stage_side[stage]) XV_CHECK_HIP(hipEventRecord(e->ev_stage[stage][1], e->side));
     return 0;
 }
@@ -993,7 +998,6 @@ extern "C" int xv_engine_backward_async(xv_engine* e, void* stream, int stage) {
 
 extern "C" int xv_engine_stage_wait(xv_engine* e, void* waiter_stream, int stage) {
     XV_REQUIRE(e && stage >= 0 && stage < XV_BWD_STAGES, "engine_stage_wait: bad arguments");
-    if (stage == XV_BWD_STAGES - 1) return 0;      // the last stage joins on the caller's stream itself
     hipStream_t w = (hipStream_t)waiter_stream;
     XV_CHECK_HIP(hipStreamWaitEvent(w, e->ev_stage[stage][0], 0));
     if (e->stage_side[stage]) XV_CHECK_HIP(hipStreamWaitEvent(w, e->ev_stage[stage][1], 0));
@@ -1125,7 +1129,7 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
         if (rc) return rc;
         rc = layer_backward(e, s, e->L[0], e->bufD, e->xpad, b, e->Tl[0], nullptr, nullptr);           // tdnn1
         if (rc) return rc;
-        rc = join_side(e, s);       // end of the backward pass: every gradient is visible to `stream`
+        rc = end_stage(e, s, XV_BWD_STAGES - 1, defer);       // end of the backward pass: every gradient is visible to `stream`
         if (rc) return rc;
     }
     return 0;
