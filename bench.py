@@ -154,14 +154,21 @@ def main():
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # XV_BENCH_SHARE_GPU=1 (tests on a 1-GPU box): ranks share the visible devices round-robin and talk over gloo - RCCL refuses
+    # two ranks on one device.  The measured path is the same code; the numbers of such a run mean nothing.
+    share = os.environ.get("XV_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     chunks = args.chunks
     if ":" in args.frames:

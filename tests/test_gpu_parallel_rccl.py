@@ -138,3 +138,18 @@ def test_two_ranks_sharing_the_gpu_average_gradients_like_one_engine(tmp_path):
     assert len(lines) == 2 and all(l["replicas_identical"] for l in lines), lines
     r0 = [l for l in lines if l["rank"] == 0][0]
     assert r0["moved"] > 1e-4 and r0["max_diff_vs_single_engine"] == 0.0, r0
+
+
+def test_bench_two_ranks_sharing_the_gpu():
+    """bench.py's N > 1 path end to end (barriers, max-over-ranks timing, staged all-reduce, rank-0 JSON line) with two ranks
+    on the one GPU of the box over gloo (XV_BENCH_SHARE_GPU=1); the value itself is meaningless here."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", XV_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                       # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 100 and line["scaling"] == "weak" and line["config"]["parallelism"] == "dp2"
+    assert "cpu_baseline" not in line and np.isfinite(line["loss"])
