@@ -154,9 +154,9 @@ def main():
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    # XV_BENCH_SHARE_GPU=1 (tests on a 1-GPU box): ranks share the visible devices round-robin and talk over gloo - RCCL refuses
+    # XV_SHARE_GPU=1 (tests on a 1-GPU box): ranks share the visible devices round-robin and talk over gloo - RCCL refuses
     # two ranks on one device.  The measured path is the same code; the numbers of such a run mean nothing.
-    share = os.environ.get("XV_BENCH_SHARE_GPU") == "1"
+    share = os.environ.get("XV_SHARE_GPU") == "1"
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)

@@ -142,8 +142,8 @@ def test_two_ranks_sharing_the_gpu_average_gradients_like_one_engine(tmp_path):
 
 def test_bench_two_ranks_sharing_the_gpu():
     """bench.py's N > 1 path end to end (barriers, max-over-ranks timing, staged all-reduce, rank-0 JSON line) with two ranks
-    on the one GPU of the box over gloo (XV_BENCH_SHARE_GPU=1); the value itself is meaningless here."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", XV_BENCH_SHARE_GPU="1")
+    on the one GPU of the box over gloo (XV_SHARE_GPU=1); the value itself is meaningless here."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", XV_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29500 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)

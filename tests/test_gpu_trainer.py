@@ -259,3 +259,31 @@ def test_drivers_as_run_sh_calls_them(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(lib, "train_insight.py"), vdata, vspk, ft_model], env=env, cwd=lib, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "EER:" in r.stderr, r.stderr[-3000:]
+
+
+def test_train_driver_with_two_ranks_sharing_the_gpu(tmp_path, xv_precision):
+    """nnet/lib/train.py under torch.distributed.run with WORLD_SIZE=2 (both ranks on the one GPU of the box, gloo transport:
+    XV_SHARE_GPU=1): rank 0 snapshots the config, every rank draws its own batches, gradients are averaged, the LR / stop
+    decision is broadcast, BN moving statistics are averaged into the checkpoint rank 0 writes, and the next epoch resumes
+    from it on both ranks."""
+    if xv_precision == "f32":
+        pytest.skip("one precision is enough for the process wiring")
+    data, spklist, _ = make_data_dir(str(tmp_path / "train"), num_spk=6, utts_per_spk=3, min_frames=60, max_frames=110)
+    vdata, vspk, _ = make_data_dir(str(tmp_path / "valid"), num_spk=6, utts_per_spk=2, min_frames=60, max_frames=110, seed=5)
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps(CONFIG))
+    model = str(tmp_path / "exp")
+    os.makedirs(model)
+    env = dict(os.environ, TF_KALDI_ROOT=PKG, PYTHONPATH=PKG, XV_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29300 + os.getpid() % 150), os.path.join(PKG, "nnet", "lib", "train.py"), "--config", str(cfg_path),
+           data, spklist, vdata, vspk, model]
+    r = subprocess.run(cmd, env=env, cwd=PKG, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    nnet = os.path.join(model, "nnet")
+    lr_lines = open(os.path.join(nnet, "learning_rate")).read().strip().split("\n")
+    vl_lines = open(os.path.join(nnet, "valid_loss")).read().strip().split("\n")
+    assert len(lr_lines) == 3 and lr_lines[0].startswith("0 0.0100") and len(vl_lines) == 2
+    ck = np.load(os.path.join(nnet, "model-12.npz"))         # 2 epochs x 6 steps per rank: the step count is per rank
+    assert all(np.isfinite(ck[k]).all() for k in ck.files)
+    assert float(np.abs(ck["tdnn/tdnn1_bn/moving_mean"]).max()) > 0

@@ -195,3 +195,23 @@ def check(rc, what=""):
 def call(name, *args):
     """Call an int-returning entry point and raise XvError on failure."""
     check(getattr(load(), name)(*args), name)
+
+
+def share_gpu():
+    """XV_SHARE_GPU=1 (tests of the multi-rank paths on a 1-GPU box): ranks are spread round-robin over the visible devices and
+    talk over gloo, which carries device tensors through the host - RCCL refuses two ranks on one device."""
+    return os.environ.get("XV_SHARE_GPU") == "1"
+
+
+def local_device_index():
+    """HIP device of this rank: LOCAL_RANK, modulo the device count in XV_SHARE_GPU mode."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if share_gpu():
+        import torch
+        return local_rank % max(torch.cuda.device_count(), 1)
+    return local_rank
+
+
+def dist_backend():
+    return "gloo" if share_gpu() else "nccl"
+

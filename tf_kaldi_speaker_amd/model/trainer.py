@@ -25,6 +25,7 @@ import torch
 
 try:
     from .. import engine as E
+    from .. import _lib
     from ..parallel import GradAllReduce, average_bn_statistics, broadcast_variables
     from ..dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, DataOutOfRange
     from ..dataset.native_loader import NativeRandomQueue
@@ -33,6 +34,7 @@ try:
     from . import loss as _loss
 except (ImportError, ValueError):      # drop-in layout: PYTHONPATH=$TF_KALDI_ROOT
     import engine as E
+    import _lib
     from parallel import GradAllReduce, average_bn_statistics, broadcast_variables
     from dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, DataOutOfRange
     from dataset.native_loader import NativeRandomQueue
@@ -95,7 +97,7 @@ class Trainer(object):
         self.is_built = False
         self.is_loaded = False
         self.modes = set()
-        self.device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = "cuda:%d" % _lib.local_device_index()
 
     # ------------------------------------------------------------------ lifecycle
     def _close_engine(self):

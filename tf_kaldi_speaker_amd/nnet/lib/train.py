@@ -49,9 +49,10 @@ def run(args, finetune=False):
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        import _lib                                        # $TF_KALDI_ROOT/_lib.py (PYTHONPATH=$TF_KALDI_ROOT)
+        torch.cuda.set_device(_lib.local_device_index())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group(_lib.dist_backend())      # "nccl" (= RCCL); gloo only in the XV_SHARE_GPU test mode
     if rank == 0:
         params = save_codes_and_config(args.cont, args.model, args.config)
     if dist is not None:
