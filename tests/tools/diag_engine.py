@@ -2,7 +2,7 @@
 engine against the float64 oracle for one small training step."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import xvector_oracle as O
 from tests.test_gpu_engine import _make, rel_err
 
