@@ -394,3 +394,54 @@ def test_out_of_range_label_poisons_the_loss_instead_of_faulting():
     raw, _ = eng.losses()
     assert np.isfinite(raw)
     eng.close()
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e3, 1e-3], ids=["x1", "x1e3", "x1e-3"])
+def test_full_size_split_precision_agrees_with_fp32_mfma(scale, xv_precision):
+    """BASELINE shape S1 at full size, where the oracle's backward is too slow: the split-precision path against the fp32-input
+    MFMA path (itself pinned to the fp64 oracle at small sizes) from identical variables and inputs - reductions over 25 k rows,
+    7351 speakers and per-tensor power-of-two scales only show their worst case here.  Features scaled by 1e3 / 1e-3 move
+    every operand range of the first layers (BatchNorm brings the rest back).
+
+    Forward quantities must agree to rounding.  Gradients cannot be held to that at this size: the ReLU pattern is part of the
+    gradient, and rounding-level differences flip a handful of the 12 M frame-level and 65 k segment-level ReLU bits - one flipped
+    bit in the 128-row tdnn6 moves its weight gradient by ~1e-3 (Frobenius), near-constant tdnn5 channels enter the pooling
+    gradient with 1/std.  (Diagnosed on the box: the fp32 path against itself on features perturbed by 1e-7 relative noise
+    shows the same 1e-3 ... 2e-2 differences; where no bit flips the two precisions agree to 5e-6.)  So the gradient check is a
+    yardstick comparison - no worse than a few times what that perturbation does - plus a gross-error bound; the rounding-level
+    gradient parity lives in the oracle tests above, which evaluate the oracle on the GPU's own ReLU pattern.
+    """
+    if xv_precision == "f32":
+        pytest.skip("compares the two precisions itself")
+    from tf_kaldi_speaker_amd import engine as E
+    rs = np.random.RandomState(3)
+    x = (rs.randn(128, 200, 30) * scale).astype(np.float32)
+    x[5, 17, 3] = 40.0 * scale                                  # an outlier sets the input plane scale
+    x_noise = (x * (1.0 + 1e-7 * rs.randn(*x.shape))).astype(np.float32)
+    labels = rs.randint(0, 7351, 128).astype(np.int32)
+
+    def run(prec, xin):
+        eng = E.Engine(E.make_config(30, 7351, loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True,
+                                     max_batch=128, max_frames=200, precision=prec))
+        eng.init_variables(seed=1)
+        eng.forward(xin, True)
+        eng.loss(labels, 1000, True)
+        eng.backward(-1)
+        raw, reg = eng.losses()
+        res = (raw, reg, eng.endpoint("tdnn6_dense").cpu().numpy(), eng.endpoint("tdnn5_bn").cpu().numpy()[:4096],
+               {k: v.copy() for k, v in eng.get_gradients().items()})
+        eng.close()
+        return res
+
+    a, b, y = run("f32", x), run("f16x3", x), run("f32", x_noise)
+    assert abs(a[0] - b[0]) <= 2e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 2e-6 * abs(a[1]), (a[0], b[0])
+    assert rel_err(b[2], a[2]) <= 2e-5 and rel_err(b[3], a[3]) <= 2e-5, (rel_err(b[2], a[2]), rel_err(b[3], a[3]))
+    for k in a[4]:
+        if k.endswith("/bias") and not k.startswith("softmax"):
+            continue
+        # Frobenius-relative: a flipped ReLU bit moves one row's outer product, the maximum over entries is all noise
+        fro = lambda g: np.linalg.norm((g - a[4][k]).astype(np.float64)) / np.linalg.norm(a[4][k].astype(np.float64))
+        err, yard = fro(b[4][k]), fro(y[4][k])
+        assert err <= 5.0 * yard + 5e-3, (k, err, yard)
+        if k.startswith(("tdnn/tdnn7", "softmax")):          # behind the last ReLU: no pattern to flip
+            assert rel_err(b[4][k], a[4][k]) <= 5e-5, (k, rel_err(b[4][k], a[4][k]))
