@@ -333,6 +333,54 @@ def test_inference_mode_embeddings_variable_length():
     eng.close()
 
 
+def test_inference_mode_long_utterances():
+    """extract.py's shapes: one 10 000-frame utterance (its default --chunk-size, the longest single forward) and a stack of
+    equal-length chunks of a split utterance (B = 3 x 5 000), attention-pooled as well.  The fp64 oracle needs minutes for
+    these, so the long forward is tied to the oracle-checked short one by size-independent properties: with moving statistics
+    every frame-level output row depends only on its own context window (valid convolutions), so rows of the long forward
+    equal rows of 700-frame windows cut from it; pooling and tdnn6 are then re-derived in fp64 from the fetched tdnn5 output;
+    and a chunk's embedding does not depend on what else is in the batch."""
+    rs = np.random.RandomState(11)
+    relu = lambda v: np.maximum(v, 0)
+    for kw in (dict(loss_func="softmax"), dict(loss_func="softmax", pooling_type="self_attention", att_key_num_nodes=(200, 120))):
+        eng, cfg_o, V = _make(kw, 1, 50, max_batch=3, max_frames=10000)
+        att = "pooling_type" in kw
+        T = 10000
+        x = rs.randn(1, T, 30).astype(np.float32)
+        eng.forward(x, False)
+        z5 = eng.endpoint("tdnn5_bn").cpu().numpy().astype(np.float64)            # [T-14, 1500]
+        pool = eng.endpoint("pooling").cpu().numpy()[0]
+        emb = eng.endpoint("tdnn6_dense").cpu().numpy()[0]
+        w = eng.endpoint("attention_weights").cpu().numpy().reshape(-1).astype(np.float64) if att else np.full(T - 14, 1.0 / (T - 14))
+        assert z5.shape == (T - 14, 1500) and abs(w.sum() - 1.0) < 1e-5
+        a5 = relu(z5)
+        mean = (a5 * w[:, None]).sum(0)
+        var = (((a5 - mean) ** 2) * w[:, None]).sum(0)
+        ref_pool = np.concatenate([mean, np.sqrt(np.where(var <= 1e-12, 1e-12, var))])
+        assert rel_err(pool, ref_pool) <= 1e-5, rel_err(pool, ref_pool)
+        ref_emb = ref_pool @ V["tdnn/tdnn6_dense/kernel"] + V["tdnn/tdnn6_dense/bias"]
+        assert rel_err(emb, ref_emb) <= 1e-5, rel_err(emb, ref_emb)
+        for s0 in (0, 4321, T - 700):                                              # windows: rows s0 .. s0+685 of the long forward
+            eng.forward(x[:, s0:s0 + 700], False)
+            zw = eng.endpoint("tdnn5_bn").cpu().numpy()
+            assert rel_err(zw, z5[s0:s0 + 686]) <= 2e-6, (s0, rel_err(zw, z5[s0:s0 + 686]))
+        # the 700-frame window itself against the oracle (the anchor of the chain)
+        _, ep, _ = O.tdnn_forward(V, x[:, :700].astype(np.float64), cfg_o, False)
+        eng.forward(x[:, :700], False)
+        for name in ("tdnn5_bn", "pooling", "tdnn6_dense"):
+            got = eng.endpoint(name).cpu().numpy()
+            assert rel_err(got, ep[name].reshape(got.shape)) <= 5e-5, (name, rel_err(got, ep[name].reshape(got.shape)))
+        # three 5 000-frame chunks in one batch == each alone
+        xb = rs.randn(3, 5000, 30).astype(np.float32)
+        eng.forward(xb, False)
+        stacked = eng.endpoint("tdnn6_dense").cpu().numpy()
+        for i in range(3):
+            eng.forward(xb[i:i + 1], False)
+            alone = eng.endpoint("tdnn6_dense").cpu().numpy()[0]
+            assert rel_err(stacked[i], alone) <= 2e-6, (i, rel_err(stacked[i], alone))
+        eng.close()
+
+
 def test_valid_mode_zeroes_margin():
     """build('valid') forces asoftmax_m=1 / amsoftmax_m=0 / arcsoftmax_m=0 (trainer.py:261-271)."""
     kw = dict(loss_func="additive_angular_margin_softmax", margin_m=0.3, lambda_gamma=1.0, last_layer_linear=True)
