@@ -287,3 +287,41 @@ def test_train_driver_with_two_ranks_sharing_the_gpu(tmp_path, xv_precision):
     ck = np.load(os.path.join(nnet, "model-12.npz"))         # 2 epochs x 6 steps per rank: the step count is per rank
     assert all(np.isfinite(ck[k]).all() for k in ck.files)
     assert float(np.abs(ck["tdnn/tdnn1_bn/moving_mean"]).max()) > 0
+
+
+@pytest.mark.parametrize("optimizer", ["momentum", "adam"])
+def test_resume_from_checkpoint_is_bit_identical(tmp_path, optimizer):
+    """Four optimiser steps in one go == two steps, save, a fresh Trainer that loads the checkpoint, two more steps: variables,
+    BN moving statistics, optimiser slots and (for Adam) the update count all travel through the checkpoint."""
+    from tf_kaldi_speaker_amd.misc.utils import Params
+    from tf_kaldi_speaker_amd.model.trainer import Trainer
+    cfg = dict(CONFIG, optimizer=optimizer, momentum=0.9, use_nesterov=(optimizer == "momentum"))
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps(cfg))
+    rs = np.random.RandomState(4)
+    batches = [(rs.randn(6, 40 + 3 * i, 30).astype(np.float32), rs.randint(0, 6, 6).astype(np.int32)) for i in range(4)]
+
+    def trainer(model):
+        os.makedirs(os.path.join(model, "nnet"), exist_ok=True)
+        tr = Trainer(Params(str(cfg_path)), model)
+        tr.build("train", dim=30, loss_type=cfg["loss_func"], num_speakers=6)
+        return tr
+
+    a = trainer(str(tmp_path / "a"))
+    assert a.train_batches(iter(batches), 0.02, 0, num_steps=4) == 4
+    want = a.engine.variables.cpu().numpy().copy()
+    want_opt = a.engine.opt_state.cpu().numpy().copy()
+    v_init = None
+    a.close()
+
+    b = trainer(str(tmp_path / "b"))
+    assert b.train_batches(iter(batches[:2]), 0.02, 0, num_steps=2) == 2
+    b.save(2)
+    b.close()
+    c = trainer(str(tmp_path / "b"))
+    assert c.load() == 2
+    assert c.train_batches(iter(batches[2:]), 0.02, 2, num_steps=2) == 4
+    got = c.engine.variables.cpu().numpy()
+    got_opt = c.engine.opt_state.cpu().numpy()
+    assert np.array_equal(got, want) and np.array_equal(got_opt, want_opt) and np.abs(want_opt).max() > 0
+    c.close()
