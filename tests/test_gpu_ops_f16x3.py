@@ -176,7 +176,9 @@ def test_dgrad_epilogue_produces_the_bn_backward_partials(ops, segs, t_out, k):
                                                                 with_range=True)
     dx_plain = ops.affine_dgrad_f16x3(dzp, segs, t_out, k, wfp, c)
     dx, part = ops.affine_dgrad_bnstats_f16x3(dzp, segs, t_out, k, wfp, c, dev(z), scale, shift, mean, invstd)
-    assert torch.equal(dx, dx_plain)
+    # same products, possibly another accumulation grouping (the plain launch may take the 16x16x32 context-window kernel, the
+    # epilogue launch the 32x32x16 one): equal to fp32 rounding, not bit for bit
+    assert float((dx - dx_plain).abs().max()) <= 2e-6 * float(dx_plain.abs().max())
     dxh, zh = host(dx), z.astype(np.float64)
     sc, sh, mu, istd = host(scale), host(shift), host(mean), host(invstd)
     dd = dxh * ((zh * sc + sh) > 0)

@@ -176,7 +176,7 @@ __device__ __forceinline__ void xv_tile_stats_epilogue16(const f32x4 (&acc)[4][4
         if (lg == 0) r_m2[wr * 128 + col] = v;
     }
     __syncthreads();
-    if (tid < 128) {
+    if (tid < 128 && m0 < M) {
         int n = n0 + tid;
         if (n < N) {
             const long plane = (long)tiles_m * N;

@@ -441,6 +441,19 @@ template <int WR> struct ConvGeom {
     static constexpr int LDS_HALFS = 2 * ABUF + 2 * CONV_BBUF;
 };
 
+// XV16_CONV_MFMA16=1: v_mfma_f32_16x16x32_f16 (one instruction spans the whole 32-channel K-step; 4 x 4 accumulator blocks of
+// 16 x 16 per wave) instead of v_mfma_f32_32x32x16_f16.  The 16-byte chunk swizzle changes with the fragment shape: the
+// 16-lane groups of a ds_read_b128 must land on distinct bank columns for any tap offset (see SWZ16 above).
+// [measured] tdnn2 / tdnn3 at S1: forward 236 -> 218 us / 309 -> 300 us, data gradient 242 -> 234 us / 286 -> 270 us (+3 ... +8 %).
+#ifndef XV16_CONV_MFMA16
+#define XV16_CONV_MFMA16 1
+#endif
+#if XV16_CONV_MFMA16
+#define CONV_SWZ(row) ((((row) >> 2) & 1) << 1)
+#else
+#define CONV_SWZ(row) (((row) >> 2) & 3)
+#endif
+
 template <int EPI, int WR>
 __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16ConvArgs q) {
     typedef ConvGeom<WR> G;
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
 #pragma unroll
     for (int i = 0; i < G::BG; ++i) {
         const int row = 16 * (G::BG * wave + i) + drow;
-        bsrc[i] = (dchunk ^ ((row >> 2) & 3)) << 3;
+        bsrc[i] = (dchunk ^ CONV_SWZ(row)) << 3;
         int n = n0 + row;
         bv[i] = n < p.N;
         boff[i] = (long)(bv[i] ? n : 0) * p.ldb;
@@ -502,12 +515,84 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
             const int pl = id >= G::NG ? 1 : 0, grp = id - G::NG * pl;
             const int row = 16 * grp + drow;
             const long xr = xr0 + row;
-            const int src = (dchunk ^ ((row >> 2) & 3)) << 3;
+            const int src = (dchunk ^ CONV_SWZ(row)) << 3;
             const u16* pa = xr < q.a_rows ? p.A + pl * p.a_plane + xr * C + cc * 32 + src : p.zero;
             __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(sA + buf * G::ABUF + pl * G::APLANE + 16 * grp * 32), 16, 0, 0);
         }
     };
 
+#if XV16_CONV_MFMA16
+    // (EPI == 2, the BN-backward epilogue, exists for the 32x32x16 accumulator layout only: the launcher refuses it in this build)
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lc = lane & 15, lg = lane >> 4;                 // fragment row / 8-channel chunk of this lane
+    int arow16[4], b_off[4];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        arow16[qd] = (int)(xrow(m0 + wr * 64 + qd * 16 + lc) - xr0);
+        const int rb = wc * 64 + qd * 16 + lc;
+        b_off[qd] = rb * 32 + ((lg ^ CONV_SWZ(rb)) << 3);
+    }
+    stage_a(0, 0, 0, 1);
+    stage_b(0, 0, 0);
+    __syncthreads();
+    int st = 0;
+    for (int cc = 0; cc < nc; ++cc) {
+        const u16* abase = sA + (cc & 1) * G::ABUF;
+        for (int j = 0; j < taps; ++j, ++st) {
+            if (j + 1 < taps) stage_b(cc, j + 1, (st + 1) & 1);
+            else if (cc + 1 < nc) stage_b(cc + 1, 0, (st + 1) & 1);
+            if (cc + 1 < nc) stage_a(cc + 1, (cc + 1) & 1, j, taps);
+            const u16* bbase = sB + (st & 1) * CONV_BBUF;
+            f32x4 af[2][4], bf[2][4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int ra = arow16[qd] + j;
+                const int ao = ra * 32 + ((lg ^ CONV_SWZ(ra)) << 3);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    af[pl][qd] = *(const f32x4*)(abase + pl * G::APLANE + ao);
+                    bf[pl][qd] = *(const f32x4*)(bbase + pl * CONV_BPLANE + b_off[qd]);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+#define MM(i, jj) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i][a]), __builtin_bit_cast(f16x8, bf[jj][b]), acc[a][b], 0, 0, 0)
+                    MM(0, 1); MM(1, 0); MM(0, 0);
+#undef MM
+                }
+            __syncthreads();
+        }
+    }
+    const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = n0 + wc * 64 + b * 16 + lc;
+        const float bias_v = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = m0 + wr * 64 + a * 16 + lg * 4 + jj;
+                const float v = acc[a][b][jj] * out_scale + bias_v;
+                acc[a][b][jj] = v;
+                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = v;
+            }
+    }
+    {
+        const int half = wr >> 1;
+        const int tiles128 = (p.M + 127) / 128;
+        float* red = (float*)smem + half * 1024;
+        if (EPI == 1)
+            xv_tile_stats_epilogue16(acc, red, tid & 255, wr & 1, wc, lane, m0 + 128 * half, n0, p.M, p.N, (WR / 2) * tile_m + half, tiles128, p.part);
+    }
+    (void)li; (void)lh;
+#else
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -588,6 +673,7 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
         xv_tile_stats_epilogue(acc, red, tid & 255, wr & 1, wc, li, lh, m0 + 128 * half, n0, p.M, p.N, (WR / 2) * tile_m + half, tiles128, p.part);
     if (EPI == 2)
         xv_tile_bwd_stats_epilogue(acc, red, tid & 255, wr & 1, wc, li, lh, m0 + 128 * half, n0, p.M, p.N, (WR / 2) * tile_m + half, p.bwd);
+#endif
 }
 
 #ifndef XV16_CONV
@@ -661,8 +747,11 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
     // limited to problems with at least one tile per CU
     static const int conv_wr_env = getenv("XV_CONV_WR") ? atoi(getenv("XV_CONV_WR")) : 0;
     const bool wr4 = conv_wr_env ? conv_wr_env == 4 : (XV16_CONV_WR == 4 && g.M >= 256 * 256);
-    if (wr4 && conv_form_applies(g, 256, &taps)) return launch_conv<4>(s, g, p, taps, bwd);
-    if (conv_form_applies(g, 128, &taps)) return launch_conv<2>(s, g, p, taps, bwd);
+    // the BN-backward epilogue (an off-by-default experiment) is written for the 32x32x16 accumulator layout: with the 16x16x32
+    // build of the context-window kernel such a launch takes the generic kernel
+    const bool conv_ok = !(bwd && XV16_CONV_MFMA16);
+    if (conv_ok && wr4 && conv_form_applies(g, 256, &taps)) return launch_conv<4>(s, g, p, taps, bwd);
+    if (conv_ok && conv_form_applies(g, 128, &taps)) return launch_conv<2>(s, g, p, taps, bwd);
     if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_kernel<1>, grid, dim3(64 * XV16_WAVES), 0, s, p);
     else if (bwd) hipLaunchKernelGGL(xv_gemm16_nt_kernel<2>, grid, dim3(64 * XV16_WAVES), 0, s, p);
     else hipLaunchKernelGGL(xv_gemm16_nt_kernel<0>, grid, dim3(64 * XV16_WAVES), 0, s, p);
