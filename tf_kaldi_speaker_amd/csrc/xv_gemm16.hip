@@ -767,6 +767,10 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
 // Rows are 256 B = one full bank row apart, so the 32-byte column blocks are XOR-swizzled by the row
 // (block ^= 2*(row&3)) on the DMA source address and on the read address: conflict-free.
 // ---------------------------------------------------------------------------------------------
+#ifndef XV16_TN_MFMA16
+#define XV16_TN_MFMA16 1      // v_mfma_f32_16x16x32_f16 (0: v_mfma_f32_32x32x16_f16)
+#endif
+
 struct TN16Args {
     const u16* A; long lda; long a_plane; int a_pitch;
     const u16* B; long ldb; long b_plane; int b_pitch;
@@ -798,7 +802,13 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
 
     // DMA: one wave-instruction = 4 image rows x 256 B; lane -> row l>>4, 16-byte chunk position l&15
     const int drow = lane >> 4, dpos = lane & 15;
+#if XV16_TN_MFMA16
+    // 16x16x32: the four 16-lane groups of a transposed read sit on rows 8g + {0..3} (+4) of one 32-byte column block; the block
+    // position is XOR-ed with 2*(row&3) ^ ((row>>3)&1) so that the 8 (group, row) pairs of each half-wave take 8 distinct blocks
+    const int scol = (((((dpos >> 1) ^ (2 * drow) ^ (wave & 1)) << 1) | (dpos & 1))) * 8;    // rows 8*wave + 4*i + drow: (row>>3)&1 = wave&1
+#else
     const int scol = (((((dpos >> 1) ^ (2 * drow)) << 1) | (dpos & 1))) * 8;    // source column (16-bit elements)
+#endif
     const bool a_cv = (m0 + scol) < p.M, b_cv = (n0 + scol) < p.N;
     auto gstage = [&](int kt, int buf) {
         u16* base = smem + buf * BH;
@@ -823,6 +833,67 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
         }
     };
 
+#if XV16_TN_MFMA16
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // transposed-read lane geometry: 16-lane group lg = lane>>4 = k group (rows 8*lg .. 8*lg+7 of the stage), the 16 lanes of a group
+    // cover 4 rows x 16 columns (lane t ends up with column t of the 4 rows)
+    const int lc = lane & 15, lg = lane >> 4;
+    const int tq = lc >> 2, tp = lc & 3;
+    auto tr_off = [&](int cb /* 16-column block 0..7 */, int rbase /* 0 | 4 */) {
+        const int r = 8 * lg + rbase + tq;
+        return r * 128 + ((cb ^ (2 * (r & 3)) ^ ((r >> 3) & 1)) << 4) + tp * 4;
+    };
+    typedef __attribute__((address_space(3))) s16x4* ltr_t;
+    if (nk > 0) gstage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
+        const u16* base = smem + buf * BH;
+        s16x8 af[2][4], bf[2][4];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const u16* ia = base + pl * PH;
+                const u16* ib = base + (2 + pl) * PH;
+                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(ia + tr_off(4 * wr + qd, 0)));
+                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(ia + tr_off(4 * wr + qd, 4)));
+                s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(ib + tr_off(4 * wc + qd, 0)));
+                s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(ib + tr_off(4 * wc + qd, 4)));
+                af[pl][qd] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bf[pl][qd] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+#define MM(i, j) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i][a]), __builtin_bit_cast(f16x8, bf[j][b]), acc[a][b], 0, 0, 0)
+                MM(0, 1); MM(1, 0); MM(0, 0);
+#undef MM
+            }
+        __syncthreads();
+    }
+    const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
+    float* P = p.P + (long)split * p.M * p.N;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int n = n0 + wc * 64 + b * 16 + lc;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = m0 + wr * 64 + a * 16 + lg * 4 + jj;
+                if (m < p.M && n < p.N) P[(long)m * p.N + n] = acc[a][b][jj] * out_scale;
+            }
+        }
+    (void)li; (void)lh;
+}
+#else
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -888,6 +959,7 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
             }
         }
 }
+#endif
 
 int xv_tn16_splits(int M, int N, int R) {
     int tiles = xv_cdiv(M, 128) * xv_cdiv(N, 128);
