@@ -3,7 +3,8 @@
 // accuracy.
 //
 //   x * s = h + l + eps,   h = fp16(x*s),  l = fp16(x*s - h),   |eps| <= 2^-22 |x*s|
-//   a.b  ~=  (ha.hb + ha.lb + la.hb) / (sa*sb)      three v_mfma_f32_32x32x16_f16 per 16-deep block, fp32 accumulate
+//   a.b  ~=  (ha.hb + ha.lb + la.hb) / (sa*sb)      three fp16 MFMAs per block, fp32 accumulate: v_mfma_f32_16x16x32_f16 in the
+//                                                   context-window and weight-gradient kernels, v_mfma_f32_32x32x16_f16 in the generic one
 //
 // s is a power of two per tensor (exact to apply and undo) chosen from the tensor's max |x| so that
 // max |x*s| lies in [2^12, 2^13): 3 bits below the fp16 maximum, and the low piece of every element that
@@ -11,7 +12,7 @@
 // BN+ReLU from the GEMM epilogue's column min/max; a bound for the BN backward; a reduction for inputs and
 // weights) and travels as the uint bits of a float in device memory - no host round trip.
 // Measured on MI355X (tools/gemm16_proto.py): max error vs float64 5e-7..8e-7 of the output scale (fp32-input MFMA:
-// 1.7e-7), 2.0-2.7x the speed of the fp32-input MFMA kernels of xv_gemm.hip.
+// 1.7e-7), 2.6-3.0x the speed of the fp32-input MFMA kernels of xv_gemm.hip.
 //
 // Plane layout: [2][rows][ld] 16-bit, channel axis contiguous, ld a multiple of 8 (16-byte chunks), zero padded.
 // The spliced (context-window) row map of xv_gemm.hip applies unchanged to both kernels.
