@@ -6,14 +6,20 @@
 
 Workload (BASELINE.json configs[1], SURVEY.md section 8d shape S1): standard 5-layer TDNN
 x-vector + AM-Softmax (m = 0.2), 128 chunks x 200 frames x 30-dim MFCC per GPU, 7351 speakers,
-fp32, plain SGD + L2 - one "step" = forward + loss + backward (+ gradient all-reduce for N > 1)
+plain SGD + L2 - one "step" = forward + loss + backward (+ gradient all-reduce for N > 1)
 + update on synthetic features already resident in HBM.  Weak scaling: 128 chunks per GPU.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
-dominant kernel (its launches are bracketed by hipEvents on their stream inside the timed region; an
-untimed probe pass brackets every MFMA GEMM kind for the per-kernel table) and, at N = 1,
-`cpu_baseline` = the NumPy oracle's train_step timed on this box's host cores (all cores, 16 and 1
-BLAS threads; the fastest is `value`).
+Prints ONE JSON line on rank 0 (contract in the task statement).  The headline (`value`, `ms_per_step`,
+`roofline`, `dtype` "f32") is the engine's default arithmetic: fp32 operands on the fp32-input MFMA, the
+reference's own dtype.  At N = 1 the same run then times the opt-in split-precision mode (`precision:
+"f16x3"`: every fp32 operand as two fp16 planes, three fp16 MFMA products per fp32 product, fp32
+accumulate) for the same K steps and reports it separately under `"f16x3"` with its own roofline; an
+`e2e` leg repeats the headline with the host->device copy of each feature batch inside the timed
+region; `cpu_baseline` = the NumPy oracle's fp32 train_step on the full 128-chunk batch on this box's
+host cores (1 thread and the faster multi-thread settings).  `roofline` is for the dominant kernel: its
+launches are bracketed by hipEvents on their stream inside the timed region; an untimed probe pass
+brackets every MFMA GEMM kind for the per-kernel table.  At N > 1 `comm` carries, per rank, the RCCL
+world size and the all-reduce time of every gradient slice (events on the communication stream).
 """
 import argparse
 import ctypes as C
@@ -87,49 +93,201 @@ def step_bytes(b, t, d, n):
     return 5.0 * S + 2.0 * 4.0 * b * t * d + 5.0 * P
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (a NumPy port of the reference arithmetic, NOT TensorFlow) on the host cores.  The port is dominated by
-    NumPy element-wise passes, and OpenBLAS on every core of a large host can be slower than on one, so three BLAS thread
-    counts are timed (all cores, 16, 1 - SURVEY.md section 8d asks for the single-thread and the all-cores rows) and
-    `value` is the fastest of them, with `cores` = the threads it used."""
+def cpu_baseline(seconds_budget=70.0):
+    """The oracle (a NumPy port of the reference arithmetic, NOT TensorFlow) on the host cores: ONE fp32 train_step of the
+    full S1 batch (128 chunks x 200 frames, 7351 speakers) per BLAS thread count - 1 thread (comparable to the reference's
+    single_cpu mode, trainer.py:46-50), then 8 / 16 / 32 threads as far as the box has them and the budget allows (the port is
+    dominated by NumPy element-wise passes and OpenBLAS on every core of a large host is slower than on a few, so "all
+    cores" is not the best row).  `value` is the fastest row, `cores` the threads it used."""
     from oracle import xvector_oracle as O
     try:
-        from threadpoolctl import threadpool_info, threadpool_limits
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        from threadpoolctl import threadpool_limits
     except Exception:
         threadpool_limits = None
-        threads = os.cpu_count() or 1
-    cb = 16
+    ncpu = os.cpu_count() or 1
     cfg = O.Config(feat_dim=D, num_speakers=NSPK, loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True)
     V = O.init_variables(cfg, seed=0, dtype=np.float32)
     rs = np.random.RandomState(0)
-    x = rs.randn(cb, T, D).astype(np.float32)
-    y = rs.randint(0, NSPK, cb)
-    state = {}
-    V, state, _ = O.train_step(V, state, cfg, x, y, 0.01, 0)      # warm-up (BLAS thread pool, page faults)
-    counts = [threads] if threadpool_limits is None else sorted({threads, min(threads, 16), 1}, reverse=True)
-    rows, step = [], 1
+    x = rs.randn(B, T, D).astype(np.float32)
+    y = rs.randint(0, NSPK, B)
+    O.train_step(V, {}, cfg, x[:8], y[:8], 0.01, 0)      # warm-up (BLAS thread pool, allocator)
+    counts = [1] if threadpool_limits is None else sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu)})
+    rows, t_start = [], time.time()
+    import contextlib
     for nt in counts:
-        import contextlib
+        if rows and time.time() - t_start + rows[-1]["seconds"] > seconds_budget:
+            break
         ctx = threadpool_limits(limits=nt) if threadpool_limits is not None else contextlib.nullcontext()
         with ctx:
-            V, state, _ = O.train_step(V, state, cfg, x, y, 0.01, step)      # settle the pool at this size
-            step += 1
             t0 = time.time()
-            n = 0
-            while True:
-                V, state, _ = O.train_step(V, state, cfg, x, y, 0.01, step)
-                step += 1
-                n += 1
-                if time.time() - t0 > seconds_budget / (2.0 * len(counts)) or n >= 6:
-                    break
+            O.train_step(V, {}, cfg, x, y, 0.01, 1)
             dt = time.time() - t0
-        rows.append({"cores": int(nt), "value": round(cb * n / dt, 2), "steps": n, "seconds": round(dt, 1)})
+        rows.append({"cores": int(nt), "value": round(B / dt, 2), "steps": 1, "seconds": round(dt, 2)})
     best = max(rows, key=lambda r: r["value"])
-    return {"value": best["value"], "unit": "chunks/s", "cores": best["cores"], "kind": "port",
-            "sample": "oracle (NumPy/OpenBLAS fp32 port, this repo) train_step, %d chunks x %d frames x %d-dim, %d speakers, %d steps in %.1f s "
-                      "(fastest of the BLAS thread counts in `rows`)" % (cb, T, D, NSPK, best["steps"], best["seconds"]),
+    return {"value": best["value"], "unit": "chunks/s", "cores": best["cores"], "kind": "port", "host_cpus": ncpu,
+            "sample": "oracle (NumPy/OpenBLAS fp32 port of the reference arithmetic, this repo - not TensorFlow) train_step, one step of the "
+                      "benchmark batch (%d chunks x %d frames x %d-dim, %d speakers) per BLAS thread count in `rows`; fastest row = `value`"
+                      % (B, T, D, NSPK),
             "rows": rows}
+
+
+def _profile_table(lib, _lib, which):
+    cnt = (C.c_int64 * NKINDS)()
+    ms = (C.c_double * NKINDS)()
+    fl = (C.c_double * NKINDS)()
+    _lib.check(lib.xv_profile_end(cnt, ms, fl), "xv_profile_end(%s)" % which)
+    return [int(c) for c in cnt], [float(m) for m in ms], [float(f) for f in fl]
+
+
+def run_mode(precision, args, dev, rank, world, dist, chunks, t_lo, t_hi, h2d=False, light=False):
+    """Build an engine in `precision`, warm up, then time EXACTLY args.steps optimiser steps between barrier +
+    synchronize brackets.  h2d: every step first copies its feature / label batch from pinned host memory on the compute
+    stream (the reference boundary hands host arrays).  light: skip the probe / isolated passes (e2e leg)."""
+    from tf_kaldi_speaker_amd import _lib, engine as E
+    from tf_kaldi_speaker_amd.parallel import GradAllReduce
+    lib = _lib.load()
+    cfg = E.make_config(D, NSPK, loss_func="additive_margin_softmax", margin_m=0.2, lambda_min=0.0, lambda_base=1000.0,
+                        lambda_gamma=1e-4, lambda_power=5.0, last_layer_linear=True, weight_l2_regularizer=1e-2,
+                        batchnorm_momentum=0.99, optimizer="sgd", max_batch=chunks, max_frames=t_hi, precision=precision,
+                        pooling_type="self_attention" if args.attention else "statistics_pooling")
+    eng = E.Engine(cfg, device=str(dev))
+    eng.init_variables(seed=0)       # identical replicas on every rank
+    rs = np.random.RandomState(1000 + rank)
+    nb = 4 if t_lo == t_hi else 16   # rotate a few batches (variable length: 16 seeded draws of T)
+    ts = [int(rs.randint(t_lo, t_hi + 1)) for _ in range(nb)]
+    hx = [torch.from_numpy(rs.randn(chunks, ts[i], D).astype(np.float32)) for i in range(nb)]
+    hy = [torch.from_numpy(rs.randint(0, NSPK, chunks).astype(np.int32)) for _ in range(nb)]
+    if h2d:
+        hx, hy = [t.pin_memory() for t in hx], [t.pin_memory() for t in hy]
+        dx = [torch.empty_like(hx[i], device=dev) for i in range(2)] if t_lo == t_hi else None
+        dy = [torch.empty_like(hy[0], device=dev) for _ in range(2)]
+    else:
+        xs, ys = [t.to(dev) for t in hx], [t.to(dev) for t in hy]
+    allreduce = GradAllReduce(dist, world, timing=True) if world > 1 else None
+    lr = 0.01
+
+    def one_step(i):
+        j = i % nb
+        if h2d:      # double-buffered device staging; the copy is stream-ordered in front of the step that consumes it
+            xd = dx[i % 2] if dx is not None else torch.empty_like(hx[j], device=dev)
+            xd.copy_(hx[j], non_blocking=True)
+            dy[i % 2].copy_(hy[j], non_blocking=True)
+            eng.train_step(xd, dy[i % 2], lr, i, allreduce=allreduce)
+        else:
+            eng.train_step(xs[j], ys[j], lr, i, allreduce=allreduce)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    launches_per_step = 96
+    res = {"precision": precision, "ts": ts, "nb": nb}
+    step0 = args.warmup
+    if not light:
+        # Probe pass (untimed, every GEMM kind bracketed): finds the dominant kernel and fills the per-kind table.
+        # An event pair costs a few microseconds of queue time per launch (~0.12 ms/step over the ~54 GEMM launches),
+        # so the timed region below brackets the dominant kind only.
+        probe_steps = 3
+        _lib.check(lib.xv_profile_begin(int(probe_steps * launches_per_step)), "xv_profile_begin")
+        for i in range(probe_steps):
+            one_step(step0 + i)
+        torch.cuda.synchronize()
+        res["probe"] = _profile_table(lib, _lib, "probe") + (probe_steps,)
+        dom = int(np.argmax(res["probe"][1]))
+        res["dom"] = dom
+        fence()
+        _lib.check(lib.xv_profile_begin_kinds(int(args.steps * launches_per_step), 1 << dom), "xv_profile_begin_kinds")
+    if allreduce is not None:
+        allreduce.reset_timing()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(step0 + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if not light:
+        res["timed"] = _profile_table(lib, _lib, "timed")
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    res["elapsed"] = elapsed
+    res["comm"] = allreduce.timing_report() if allreduce is not None else None
+    if not light:
+        # Untimed extra pass with the side stream off: the weight-gradient launches of the timed region run
+        # concurrently with data-gradient launches, so their in-region durations include time shared with
+        # another kernel.  This pass times every GEMM launch alone (kernel quality in isolation).
+        iso_steps = 5
+        _lib.check(lib.xv_engine_set_concurrency(eng.h, 0))
+        one_step(step0 + args.steps)
+        torch.cuda.synchronize()
+        _lib.check(lib.xv_profile_begin(int(iso_steps * launches_per_step)), "xv_profile_begin")
+        for i in range(iso_steps):
+            one_step(step0 + args.steps + 1 + i)
+        torch.cuda.synchronize()
+        res["iso"] = _profile_table(lib, _lib, "isolated") + (iso_steps,)
+        _lib.check(lib.xv_engine_set_concurrency(eng.h, 1))
+    raw, reg = eng.losses()
+    if not np.isfinite(raw):
+        sys.exit("bench.py: loss is not finite (%r)" % raw)
+    res["loss"] = raw
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+    return res
+
+
+def summarize(res, args, world, chunks):
+    """value / ms_per_step / roofline / per-kernel table of one timed mode."""
+    ts, nb = res["ts"], res["nb"]
+    steps_t = [ts[(args.warmup + i) % nb] for i in range(args.steps)]
+    ms_per_step = res["elapsed"] / args.steps * 1e3
+    fl_steps = [step_flops(chunks, t, D, NSPK, args.attention) for t in steps_t]
+    total_flops = float(np.mean([f[1] for f in fl_steps]))
+    by_steps = float(np.mean([step_bytes(chunks, t, D, NSPK) for t in steps_t]))
+    out = {"value": round(world * chunks * args.steps / res["elapsed"], 1), "ms_per_step": round(ms_per_step, 4),
+           "mean_frames": float(np.mean(steps_t)), "loss": round(res["loss"], 5)}
+    if "dom" in res:
+        dom = res["dom"]
+        pcnt, pms, pfl, probe_steps = res["probe"]
+        cnt, ms, fl = res["timed"]
+        icnt, ims, ifl, iso_steps = res["iso"]
+        peak = KIND_PEAK[dom]
+        kernels = []
+        for k in range(NKINDS):
+            if pcnt[k]:     # probe pass: same schedule as the timed region, every kind bracketed
+                kernels.append({"kernel": KIND_NAMES[k], "launches_per_step": pcnt[k] // probe_steps, "avg_ms": round(pms[k] / pcnt[k], 5),
+                                "tflops": round(pfl[k] / (pms[k] * 1e-3) / 1e12, 2), "frac_of_peak": round(pfl[k] / (pms[k] * 1e-3) / 1e12 / KIND_PEAK[k], 4),
+                                "share_of_step": round(pms[k] / probe_steps / ms_per_step, 4),
+                                "isolated_tflops": round(ifl[k] / (ims[k] * 1e-3) / 1e12, 2) if icnt[k] else None})
+        achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": round(achieved, 2), "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom),
+            "peak_note": ("dense fp32-input MFMA peak (MI355X_MICROARCH.md: 157.3 TF)" if dom < 3 else
+                          "algorithmic peak of the f16x3 scheme = dense fp16 MFMA peak (16 x 157.3 TF) / 3 products; "
+                          "achieved counts algorithmic 2*M*N*K once, executed MFMA FLOPs are 3x that"),
+            "achieved_vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic_unit": "bytes/launch past L2 (rocprofv3 PMC, profiles/)",
+            "avg_launch_ms": round(ms[dom] / cnt[dom], 4), "launches": int(cnt[dom]),
+            "algorithmic_flops_per_launch": fl[dom] / cnt[dom],
+            "note": "weight-gradient launches (side stream) overlap data-gradient launches in the timed region; "
+                    "`isolated_*` = same kernel timed alone in an extra untimed pass of %d steps" % iso_steps,
+            "isolated_achieved": round(ifl[dom] / (ims[dom] * 1e-3) / 1e12, 2),
+            "isolated_frac": round(ifl[dom] / (ims[dom] * 1e-3) / 1e12 / peak, 4)}
+        out["kernels"] = kernels
+    out["step_flops"] = {"algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
+                         "whole_step_tflops": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
+                         "whole_step_frac_of_f32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                         "whole_step_frac_of_f16x3_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)}
+    out["step_bytes"] = {"algorithmic_mb_per_step": round(by_steps / 1e6, 1),
+                         "whole_step_gbs": round(by_steps / (ms_per_step * 1e-3) / 1e9, 1),
+                         "whole_step_frac_of_hbm_peak": round(by_steps / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+    return out
 
 
 def main():
@@ -143,8 +301,10 @@ def main():
     ap.add_argument("--chunks", type=int, default=B, help="chunks per GPU per step (default %d)" % B)
     ap.add_argument("--attention", action="store_true", help="self-attention pooling of nnet_conf/*_tdnn4_att.json instead of "
                     "statistics pooling (SURVEY 8d shape S4, BASELINE configs[3])")
-    ap.add_argument("--precision", choices=["f32", "f16x3"], default=None,
-                    help="frame-level GEMM arithmetic (default: the engine's default, env XV_PRECISION)")
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
+                    help="arithmetic of the headline (default f32 = the engine's default); at one GPU the other mode is timed as well "
+                         "and reported separately unless --single-mode")
+    ap.add_argument("--single-mode", action="store_true", help="time only --precision (no second mode, no e2e leg)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,157 +335,75 @@ def main():
         t_lo, t_hi = [int(v) for v in args.frames.split(":")]
     else:
         t_lo = t_hi = int(args.frames)
-    from tf_kaldi_speaker_amd import _lib, engine as E
-    from tf_kaldi_speaker_amd.parallel import GradAllReduce
-    lib = _lib.load()
-
-    cfg = E.make_config(D, NSPK, loss_func="additive_margin_softmax", margin_m=0.2, lambda_min=0.0, lambda_base=1000.0,
-                        lambda_gamma=1e-4, lambda_power=5.0, last_layer_linear=True, weight_l2_regularizer=1e-2,
-                        batchnorm_momentum=0.99, optimizer="sgd", max_batch=chunks, max_frames=t_hi, precision=args.precision,
-                        pooling_type="self_attention" if args.attention else "statistics_pooling")
-    precision = {v: k for k, v in _lib.PRECISIONS.items()}[int(cfg.precision)]
-    eng = E.Engine(cfg, device=str(dev))
-    eng.init_variables(seed=0)       # identical replicas on every rank
-    rs = np.random.RandomState(1000 + rank)
-    nb = 4 if t_lo == t_hi else 16   # rotate a few resident batches (variable length: 16 seeded draws of T)
-    ts = [int(rs.randint(t_lo, t_hi + 1)) for _ in range(nb)]
-    xs = [torch.from_numpy(rs.randn(chunks, ts[i], D).astype(np.float32)).to(dev) for i in range(nb)]
-    ys = [torch.from_numpy(rs.randint(0, NSPK, chunks).astype(np.int32)).to(dev) for _ in range(nb)]
-    allreduce = GradAllReduce(dist, world) if world > 1 else None
-    lr = 0.01
-
-    def one_step(i):
-        eng.train_step(xs[i % nb], ys[i % nb], lr, i, allreduce=allreduce)
-
     if world > 1 and t_lo != t_hi:
         sys.exit("bench.py: variable-length batches are a single-GPU diagnostic (ranks would draw different T)")
 
-    for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    launches_per_step = 64
-    # Probe pass (untimed, every GEMM kind bracketed): finds the dominant kernel and fills the per-kind table.
-    # An event pair costs a few microseconds of queue time per launch (~0.12 ms/step over the ~54 GEMM launches),
-    # so the timed region below brackets the dominant kind only.
-    probe_steps = 3
-    _lib.check(lib.xv_profile_begin(int(probe_steps * launches_per_step)), "xv_profile_begin")
-    for i in range(probe_steps):
-        one_step(args.warmup + i)
-    torch.cuda.synchronize()
-    pcnt = (C.c_int64 * NKINDS)()
-    pms = (C.c_double * NKINDS)()
-    pfl = (C.c_double * NKINDS)()
-    _lib.check(lib.xv_profile_end(pcnt, pms, pfl), "xv_profile_end")
-    dom = int(np.argmax([pms[k] for k in range(NKINDS)]))
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    _lib.check(lib.xv_profile_begin_kinds(int(args.steps * launches_per_step), 1 << dom), "xv_profile_begin_kinds")
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    cnt = (C.c_int64 * NKINDS)()
-    ms = (C.c_double * NKINDS)()
-    fl = (C.c_double * NKINDS)()
-    _lib.check(lib.xv_profile_end(cnt, ms, fl), "xv_profile_end")
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    # Untimed extra pass with the side stream off: the weight-gradient launches of the timed region run
-    # concurrently with data-gradient launches, so their in-region durations include time shared with
-    # another kernel.  This pass times every GEMM launch alone (kernel quality in isolation).
-    iso_steps = 5
-    _lib.check(lib.xv_engine_set_concurrency(eng.h, 0))
-    one_step(args.warmup + args.steps)
-    torch.cuda.synchronize()
-    _lib.check(lib.xv_profile_begin(int(iso_steps * launches_per_step)), "xv_profile_begin")
-    for i in range(iso_steps):
-        one_step(args.warmup + args.steps + 1 + i)
-    torch.cuda.synchronize()
-    icnt = (C.c_int64 * NKINDS)()
-    ims = (C.c_double * NKINDS)()
-    ifl = (C.c_double * NKINDS)()
-    _lib.check(lib.xv_profile_end(icnt, ims, ifl), "xv_profile_end")
-    _lib.check(lib.xv_engine_set_concurrency(eng.h, 1))
-    raw, reg = eng.losses()
-    if not np.isfinite(raw):
-        sys.exit("bench.py: loss is not finite (%r)" % raw)
+    head = run_mode(args.precision, args, dev, rank, world, dist, chunks, t_lo, t_hi)
+    other, e2e = None, None
+    if world == 1 and not args.single_mode:
+        other = run_mode("f16x3" if args.precision == "f32" else "f32", args, dev, rank, world, dist, chunks, t_lo, t_hi)
+        e2e = run_mode(args.precision, args, dev, rank, world, dist, chunks, t_lo, t_hi, h2d=True, light=True)
+
+    comm_all = None
+    if dist is not None:       # per-rank communication report, gathered on every rank (collective), printed by rank 0
+        try:
+            mine = {"rank": rank, "backend": dist.get_backend(), "world_size": dist.get_world_size(), "device": torch.cuda.get_device_name(dev),
+                    "report": head["comm"]}
+            comm_all = [None] * world
+            dist.all_gather_object(comm_all, mine)
+        except Exception as exc:       # the report must never cost the bench line
+            comm_all = [{"rank": rank, "error": repr(exc)}]
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * chunks * args.steps / elapsed
-        t_mean = float(np.mean([ts[(args.warmup + i) % nb] for i in range(args.steps)]))
-        fl_steps = [step_flops(chunks, ts[(args.warmup + i) % nb], D, NSPK, args.attention) for i in range(args.steps)]
-        fwd_flops, total_flops = float(np.mean([f[0] for f in fl_steps])), float(np.mean([f[1] for f in fl_steps]))
-        by_steps = float(np.mean([step_bytes(chunks, ts[(args.warmup + i) % nb], D, NSPK) for i in range(args.steps)]))
-        peak = KIND_PEAK[dom]
-        kernels = []
-        for k in range(NKINDS):
-            if pcnt[k]:     # probe pass: same schedule as the timed region, every kind bracketed
-                kernels.append({"kernel": KIND_NAMES[k], "launches_per_step": int(pcnt[k]) // probe_steps, "avg_ms": pms[k] / pcnt[k],
-                                "tflops": pfl[k] / (pms[k] * 1e-3) / 1e12, "share_of_step": pms[k] / probe_steps / ms_per_step,
-                                "isolated_tflops": ifl[k] / (ims[k] * 1e-3) / 1e12 if icnt[k] else None})
-        achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12
+        DT = {"f32": "f32",
+              "f16x3": "f16x3 (fp32 tensors; frame-level GEMM operands split into 2 fp16 planes = 22-bit significands, 3 fp16 MFMA products per "
+                       "fp32 product, fp32 accumulate - opt-in, narrower operands than the reference's fp32)"}
+        hs = summarize(head, args, world, chunks)
         out = {
             "metric": "utterance-chunks/sec (%s-frame x 30-dim)" % (args.frames.replace(":", "-")),
-            "value": round(value, 1),
+            "value": hs["value"],
             "unit": "chunks/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step": hs["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if precision == "f32" else "f32 (frame-level GEMMs as 3 fp16-plane MFMA products, fp32 accumulate; fp32-level results)",
+            "dtype": DT[args.precision],
             "data": "synthetic",
             "config": {"workload": "TDNN x-vector (tdnn.py 5 frame + 2 segment layers, %s) + AM-Softmax m=0.2, "
                                    "full optimiser step (fwd+bwd+L2+SGD%s), %d chunks/GPU x %s frames x %d-dim, %d speakers"
                                    % ("self-attention pooling 512-1500-1500 keys" if args.attention else "stat pooling",
                                       "+RCCL all-reduce" if world > 1 else "", chunks, args.frames, D, NSPK),
-                       "chunks_per_gpu": chunks, "frames": t_lo if t_lo == t_hi else [t_lo, t_hi], "mean_frames": t_mean,
-                       "feat_dim": D, "num_speakers": NSPK,
-                       "precision": precision, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": round(achieved, 2), "peak": round(peak, 1),
-                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom),
-                         "peak_note": ("dense fp32-input MFMA peak" if dom < 3 else
-                                       "algorithmic peak of the f16x3 scheme = dense fp16 MFMA peak (16 x 157.3 TF) / 3 products; "
-                                       "achieved counts algorithmic 2*M*N*K once, executed MFMA FLOPs are 3x that"),
-                         "achieved_vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic_unit": "bytes/launch past L2 (rocprofv3 PMC, profiles/)",
-                         "avg_launch_ms": round(ms[dom] / cnt[dom], 4), "launches": int(cnt[dom]),
-                         "algorithmic_flops_per_launch": fl[dom] / cnt[dom],
-                         "note": "weight-gradient launches (side stream) overlap data-gradient launches in the timed region; "
-                                 "`isolated_*` = same kernel timed alone in an extra untimed pass of %d steps" % iso_steps,
-                         "isolated_achieved": round(ifl[dom] / (ims[dom] * 1e-3) / 1e12, 2),
-                         "isolated_frac": round(ifl[dom] / (ims[dom] * 1e-3) / 1e12 / peak, 4)},
-            "step_flops": {"algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
-                           "whole_step_tflops": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
-                           "whole_step_frac_of_f32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                           "whole_step_frac_of_f16x3_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)},
-            "step_bytes": {"algorithmic_mb_per_step": round(by_steps / 1e6, 1),
-                           "whole_step_gbs": round(by_steps / (ms_per_step * 1e-3) / 1e9, 1),
-                           "whole_step_frac_of_hbm_peak": round(by_steps / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                           "note": "compulsory bytes under perfect fusion (5 S + 2 X + 5 P); the step is MFMA-bound, this fraction "
-                                   "cannot exceed ~0.25 even at the f16x3 MFMA roof"},
-            "kernels": kernels,
-            "kernels_note": "per-kind figures come from an untimed %d-step probe pass with every GEMM launch bracketed by HIP events; "
-                            "the timed region brackets only the dominant kind (`roofline`), which keeps the events' queue time out of `value`" % probe_steps,
-            "loss": round(raw, 5),
+                       "chunks_per_gpu": chunks, "frames": t_lo if t_lo == t_hi else [t_lo, t_hi], "mean_frames": hs["mean_frames"],
+                       "feat_dim": D, "num_speakers": NSPK, "precision": args.precision, "parallelism": "dp%d" % world},
+            "roofline": hs["roofline"],
+            "step_flops": hs["step_flops"],
+            "step_bytes": dict(hs["step_bytes"], note="compulsory bytes under perfect fusion (5 S + 2 X + 5 P); the step is MFMA-bound, this "
+                                                      "fraction cannot exceed ~0.06 in fp32 / ~0.25 at the f16x3 MFMA roof"),
+            "kernels": hs["kernels"],
+            "kernels_note": "per-kind figures come from an untimed 3-step probe pass with every GEMM launch bracketed by HIP events; "
+                            "the timed region brackets only the dominant kind (`roofline`), which keeps the events' queue time out of `value`",
+            "loss": hs["loss"],
         }
+        if other is not None:
+            os_ = summarize(other, args, world, chunks)
+            out[other["precision"]] = {"dtype": DT[other["precision"]], "value": os_["value"], "unit": "chunks/s", "ms_per_step": os_["ms_per_step"],
+                                       "steps": args.steps, "warmup": args.warmup, "roofline": os_["roofline"], "step_flops": os_["step_flops"],
+                                       "kernels": os_["kernels"], "loss": os_["loss"],
+                                       "note": "same workload, same timed-region protocol, reported separately from the headline"}
+        if e2e is not None:
+            es = summarize(e2e, args, world, chunks)
+            out["e2e"] = {"value": es["value"], "unit": "chunks/s", "ms_per_step": es["ms_per_step"], "precision": args.precision,
+                          "h2d_bytes_per_step": int(chunks * es["mean_frames"] * D * 4 + chunks * 4),
+                          "note": "headline mode with the pinned-host -> device copy of every feature / label batch inside the timed region "
+                                  "(stream-ordered in front of its step, double-buffered); never `value`"}
+        if comm_all is not None:
+            out["comm"] = comm_all
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

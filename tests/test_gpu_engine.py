@@ -92,18 +92,18 @@ def test_variable_table_matches_reference_names():
 RELU_LAYERS = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5", "att_key0", "att_key1", "tdnn6", "tdnn7")
 
 
-def oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x, labels, lr, step, opt_state):
-    """Oracle train step whose ReLU on/off pattern is taken from the GPU forward.
-
-    ReLU makes the gradient a discontinuous function of the forward values: a pre-activation
-    that is -3e-6 in float64 and +4e-8 in fp32 flips one mask bit, and with only ~200 rows per
-    BatchNorm in these unit-test shapes one flipped bit moves a per-channel gradient by ~1 %.
-    That is rounding, not arithmetic, so the test (1) asserts that the GPU pattern differs from
-    the float64 pattern only where the float64 pre-activation is within 2e-5 of zero and in
-    fewer than 1e-4 of the positions, then (2) checks all gradients at 1e-4 against the oracle
-    evaluated on the GPU's pattern."""
+def oracle_forward(V, cfg_o, x):
+    """The float64 forward half of an oracle step: reusable for several GPU runs from the same variables and inputs
+    (the full-size tests compare both precisions against one oracle forward)."""
     bn_new = {}
     feats, ep, caches = O.tdnn_forward(V, x, cfg_o, True, bn_new)
+    return {"bn_new": bn_new, "feats": feats, "ep": ep, "caches": caches}
+
+
+def gpu_relu_pattern(eng, fwd, max_flip_fraction=1e-4):
+    """Endpoints of the oracle forward with every ReLU output replaced by the GPU's (see oracle_step_with_gpu_relu_pattern).
+    Asserts that the two on/off patterns differ only at rounding-level pre-activations."""
+    ep = fwd["ep"]
     ep_gpu = dict(ep)
     for prefix in RELU_LAYERS:
         key = prefix + "_relu"
@@ -111,18 +111,25 @@ def oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x, labels, lr, step, opt_st
             continue
         got = eng.endpoint(key).cpu().numpy().reshape(ep[key].shape)
         flips = (got > 0) != (ep[key] > 0)
-        assert flips.mean() < 1e-4, (key, flips.mean())
+        assert flips.mean() < max_flip_fraction, (key, flips.mean())
         pre = ep[prefix + "_bn"] if prefix + "_bn" in ep else ep[prefix + "_dense"]       # att_key1 with a plain ReLU (type 1)
         assert np.all(np.abs(pre[flips]) < 2e-5 * max(1.0, np.abs(pre).max())), key
         ep_gpu[key] = got.astype(np.float64)
-    raw_loss, logits, dfeat, Gl = O.loss_forward_backward(V, cfg_o, feats, labels, step)
+    return ep_gpu
+
+
+def oracle_backward_and_update(V, cfg_o, fwd, ep_for_backward, labels, lr, step, opt_state):
+    """Loss, every gradient (incl. the regulariser) and the optimiser step of the oracle, with the ReLU masks of
+    `ep_for_backward` (same code path as O.train_step)."""
+    ep, caches, bn_new = fwd["ep"], fwd["caches"], fwd["bn_new"]
+    raw_loss, logits, dfeat, Gl = O.loss_forward_backward(V, cfg_o, fwd["feats"], labels, step)
     reg, Gr = O.regularization(V, cfg_o)
-    G = O.tdnn_backward(V, cfg_o, ep_gpu, caches, dfeat)
+    G = O.tdnn_backward(V, cfg_o, ep_for_backward, caches, dfeat)
     G.update(Gl)
     for k, g in Gr.items():
         G[k] = G[k] + g
+    ep = dict(ep)
     ep["logits"] = logits
-    # optimiser on the oracle side (same code path as O.train_step)
     newV, new_state = {}, {}
     t = opt_state.get("__t__", 0) + 1
     for name, p in V.items():
@@ -142,6 +149,20 @@ def oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x, labels, lr, step, opt_st
     new_state["__t__"] = t
     info = {"raw_loss": raw_loss, "reg_loss": reg, "grads": G, "endpoints": ep}
     return newV, new_state, info
+
+
+def oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x, labels, lr, step, opt_state, fwd=None):
+    """Oracle train step whose ReLU on/off pattern is taken from the GPU forward.
+
+    ReLU makes the gradient a discontinuous function of the forward values: a pre-activation
+    that is -3e-6 in float64 and +4e-8 in fp32 flips one mask bit, and with only ~200 rows per
+    BatchNorm in these unit-test shapes one flipped bit moves a per-channel gradient by ~1 %.
+    That is rounding, not arithmetic, so the test (1) asserts that the GPU pattern differs from
+    the float64 pattern only where the float64 pre-activation is within 2e-5 of zero and in
+    fewer than 1e-4 of the positions, then (2) checks all gradients at 1e-4 against the oracle
+    evaluated on the GPU's pattern."""
+    fwd = fwd if fwd is not None else oracle_forward(V, cfg_o, x)
+    return oracle_backward_and_update(V, cfg_o, fwd, gpu_relu_pattern(eng, fwd), labels, lr, step, opt_state)
 
 
 @pytest.mark.parametrize("kw", CASES, ids=lambda d: "-".join(str(v).replace(" ", "") for v in d.values()))
@@ -231,8 +252,15 @@ def _check_train_step(kw, B, T, **dims):
     eng.loss(labels, step, True)
     eng.backward(-1)
     newV, _, info = oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x.astype(np.float64), labels, lr, step, {})
+    compare_step_with_oracle(eng, cfg_o, newV, info, lr)
+    eng.close()
+
+
+def compare_step_with_oracle(eng, cfg_o, newV, info, lr, endpoint_tol=5e-5, grad_tol=1e-4, var_tol=2e-5, report=None):
+    """Loss values, endpoints, every gradient and (after eng.apply) every variable of the engine against the oracle step
+    `info` / `newV`.  `report`: optional dict that receives the observed errors."""
     raw, reg = eng.losses()
-    assert abs(raw - info["raw_loss"]) <= 2e-5 * abs(info["raw_loss"]) + 1e-6
+    assert abs(raw - info["raw_loss"]) <= 2e-5 * abs(info["raw_loss"]) + 1e-6, (raw, info["raw_loss"])
     assert abs(reg - info["reg_loss"]) <= 2e-5 * abs(info["reg_loss"])
     names = ["tdnn1_conv", "tdnn1_relu", "tdnn2_conv", "tdnn3_conv", "tdnn3_relu", "tdnn4_dense", "tdnn5_dense",
              "tdnn5_bn", "tdnn5_relu", "pooling", "tdnn6_dense", "tdnn6_relu", "tdnn7_dense", "output", "logits"]
@@ -242,7 +270,10 @@ def _check_train_step(kw, B, T, **dims):
         ref = info["endpoints"][name]
         got = eng.endpoint(name).cpu().numpy()
         # north_star: embeddings within 1e-4 relative; measured ~1e-6..2e-5
-        assert rel_err(got, ref.reshape(got.shape)) <= 5e-5, (name, rel_err(got, ref.reshape(got.shape)))
+        err = rel_err(got, ref.reshape(got.shape))
+        if report is not None:
+            report["endpoint:" + name] = err
+        assert err <= endpoint_tol, (name, err)
     grads = eng.get_gradients()
     for name, g in grads.items():
         ref = info["grads"][name].reshape(g.shape)
@@ -250,14 +281,17 @@ def _check_train_step(kw, B, T, **dims):
             # no BN behind it: a real gradient for the tanh key, 0 + rounding noise for the affine key (the frame gradients
             # of a chunk sum to zero through the softmax) - absolute criterion on the scale of the layer's kernel gradient
             scale = max(np.abs(ref).max(), 1e-2 * np.abs(info["grads"][name.replace("/bias", "/kernel")]).max())
-            assert np.abs(g - ref).max() <= 1e-4 * scale, (name, np.abs(g - ref).max(), scale)
+            assert np.abs(g - ref).max() <= grad_tol * scale, (name, np.abs(g - ref).max(), scale)
             continue
         if name.endswith("_conv/bias") or (name.endswith("_dense/bias") and not (name.startswith("tdnn/tdnn7") and cfg_o.last_layer_no_bn)):
             # bias in front of a BatchNorm: the true gradient is exactly 0, both sides hold rounding noise
             assert np.abs(g).max() <= 1e-4 * max(1.0, np.abs(info["grads"][name.replace("/bias", "/kernel")]).max())
             continue
         assert np.all(np.isfinite(g)), name
-        assert rel_err(g, ref) <= 1e-4, (name, rel_err(g, ref))
+        err = rel_err(g, ref)
+        if report is not None:
+            report["grad:" + name] = err
+        assert err <= grad_tol, (name, err)
     # optimiser + BN moving averages
     eng.apply(lr, 1.0)
     after = eng.get_variables()
@@ -273,13 +307,14 @@ def _check_train_step(kw, B, T, **dims):
             # pinned on identical inputs in test_gpu_ops.py::test_optimizers_and_reductions.
             gref = np.abs(info["grads"][name].reshape(v.shape))
             diff = diff[gref >= 1e-3 * gref.max()]
-        # 2e-5 of the variable, plus - for SGD and the first momentum step - what the gradient tolerance above (1e-4 of its max) admits through lr*g
+        # var_tol of the variable, plus - for SGD and the first momentum step - what the gradient tolerance above admits through lr*g
         # (tiny batches have gradients that are large against the weights)
         slack = 0.0
         if cfg_o.optimizer in ("sgd", "momentum") and name in info["grads"]:      # first momentum step: lr*g, lr*(1+m)*g with nesterov
-            slack = lr * (1.0 + (cfg_o.momentum if cfg_o.optimizer == "momentum" else 0.0)) * 1e-4 * np.abs(info["grads"][name]).max()
-        assert diff.max() <= 2e-5 * denom + slack, (name, diff.max() / denom)
-    eng.close()
+            slack = lr * (1.0 + (cfg_o.momentum if cfg_o.optimizer == "momentum" else 0.0)) * grad_tol * np.abs(info["grads"][name]).max()
+        if report is not None:
+            report["var:" + name] = diff.max() / denom
+        assert diff.max() <= var_tol * denom + slack, (name, diff.max() / denom)
 
 
 def test_second_step_uses_updated_weights_and_staged_backward():
@@ -444,52 +479,39 @@ def test_out_of_range_label_poisons_the_loss_instead_of_faulting():
     eng.close()
 
 
-@pytest.mark.parametrize("scale", [1.0, 1e3, 1e-3], ids=["x1", "x1e3", "x1e-3"])
-def test_full_size_split_precision_agrees_with_fp32_mfma(scale, xv_precision):
-    """BASELINE shape S1 at full size, where the oracle's backward is too slow: the split-precision path against the fp32-input
-    MFMA path (itself pinned to the fp64 oracle at small sizes) from identical variables and inputs - reductions over 25 k rows,
-    7351 speakers and per-tensor power-of-two scales only show their worst case here.  Features scaled by 1e3 / 1e-3 move
-    every operand range of the first layers (BatchNorm brings the rest back).
-
-    Forward quantities must agree to rounding.  Gradients cannot be held to that at this size: the ReLU pattern is part of the
-    gradient, and rounding-level differences flip a handful of the 12 M frame-level and 65 k segment-level ReLU bits - one flipped
-    bit in the 128-row tdnn6 moves its weight gradient by ~1e-3 (Frobenius), near-constant tdnn5 channels enter the pooling
-    gradient with 1/std.  (Diagnosed on the box: the fp32 path against itself on features perturbed by 1e-7 relative noise
-    shows the same 1e-3 ... 2e-2 differences; where no bit flips the two precisions agree to 5e-6.)  So the gradient check is a
-    yardstick comparison - no worse than a few times what that perturbation does - plus a gross-error bound; the rounding-level
-    gradient parity lives in the oracle tests above, which evaluate the oracle on the GPU's own ReLU pattern.
-    """
+@pytest.mark.parametrize("scale", [1e3, 1e-3], ids=["x1e3", "x1e-3"])
+def test_full_size_split_precision_operand_ranges(scale, xv_precision):
+    """BASELINE shape S1 at full size with the features scaled by 1e3 / 1e-3 and a 40-sigma outlier: every operand range of the
+    first layers moves (BatchNorm brings the rest back), which is what the per-tensor power-of-two plane scales of the split
+    precision path have to follow.  Both precisions are held to the float64 oracle at this size and unit scale in
+    tests/test_gpu_full_size.py (loss, endpoints, every gradient, update); this test adds the two scaled inputs, for which
+    the fp32-input MFMA path is the reference: forward quantities to rounding, and the gradients behind the last ReLU (no
+    on/off pattern in them to flip between two roundings)."""
     if xv_precision == "f32":
         pytest.skip("compares the two precisions itself")
     from tf_kaldi_speaker_amd import engine as E
     rs = np.random.RandomState(3)
     x = (rs.randn(128, 200, 30) * scale).astype(np.float32)
     x[5, 17, 3] = 40.0 * scale                                  # an outlier sets the input plane scale
-    x_noise = (x * (1.0 + 1e-7 * rs.randn(*x.shape))).astype(np.float32)
     labels = rs.randint(0, 7351, 128).astype(np.int32)
 
-    def run(prec, xin):
+    def run(prec):
         eng = E.Engine(E.make_config(30, 7351, loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True,
                                      max_batch=128, max_frames=200, precision=prec))
         eng.init_variables(seed=1)
-        eng.forward(xin, True)
+        eng.forward(x, True)
         eng.loss(labels, 1000, True)
         eng.backward(-1)
         raw, reg = eng.losses()
         res = (raw, reg, eng.endpoint("tdnn6_dense").cpu().numpy(), eng.endpoint("tdnn5_bn").cpu().numpy()[:4096],
-               {k: v.copy() for k, v in eng.get_gradients().items()})
+               {k: v.copy() for k, v in eng.get_gradients().items() if k.startswith(("tdnn/tdnn7", "softmax"))})
         eng.close()
         return res
 
-    a, b, y = run("f32", x), run("f16x3", x), run("f32", x_noise)
+    a, b = run("f32"), run("f16x3")
     assert abs(a[0] - b[0]) <= 2e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 2e-6 * abs(a[1]), (a[0], b[0])
     assert rel_err(b[2], a[2]) <= 2e-5 and rel_err(b[3], a[3]) <= 2e-5, (rel_err(b[2], a[2]), rel_err(b[3], a[3]))
     for k in a[4]:
         if k.endswith("/bias") and not k.startswith("softmax"):
             continue
-        # Frobenius-relative: a flipped ReLU bit moves one row's outer product, the maximum over entries is all noise
-        fro = lambda g: np.linalg.norm((g - a[4][k]).astype(np.float64)) / np.linalg.norm(a[4][k].astype(np.float64))
-        err, yard = fro(b[4][k]), fro(y[4][k])
-        assert err <= 5.0 * yard + 5e-3, (k, err, yard)
-        if k.startswith(("tdnn/tdnn7", "softmax")):          # behind the last ReLU: no pattern to flip
-            assert rel_err(b[4][k], a[4][k]) <= 5e-5, (k, rel_err(b[4][k], a[4][k]))
+        assert rel_err(b[4][k], a[4][k]) <= 5e-5, (k, rel_err(b[4][k], a[4][k]))

@@ -19,13 +19,16 @@ except ImportError:      # drop-in layout: PYTHONPATH=$TF_KALDI_ROOT makes these
     from _lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, PRECISIONS, POOLINGS, XV_BWD_STAGES
 
 
-# How tdnn1-5's contractions are evaluated unless make_config(precision=...) / $XV_PRECISION says otherwise.
-#   "f16x3": every fp32 operand is carried as two fp16 planes (hi + lo, power-of-two scaled) and each product is three
-#            fp16 MFMA products accumulated in fp32 - fp32-class results (measured 5e-7..8e-7 of the output scale against
-#            float64, the fp32-input MFMA path measures 1.7e-7; both far inside the 1e-4 embedding tolerance) at
-#            ~2.2x the speed; passes the same parity tests at the same tolerances.
-#   "f32":   v_mfma_f32_32x32x2_f32 on fp32 operands.
-DEFAULT_PRECISION = "f16x3"
+# How tdnn1-5's contractions are evaluated unless make_config(precision=...) / the config key "precision" / $XV_PRECISION
+# says otherwise.
+#   "f32":   (default) fp32 operands on the fp32-input MFMA (v_mfma_f32_32x32x2_f32): the reference's dtype, exact fp32
+#            products, fp32 accumulation.
+#   "f16x3": opt-in.  Every fp32 operand is carried as two fp16 planes (hi + lo, power-of-two scaled: 22-bit significands)
+#            and each product is three fp16 MFMA products accumulated in fp32 - measured 5e-7..8e-7 of the output scale
+#            against float64 (the fp32 path measures 1.7e-7; both far inside the 1e-4 embedding tolerance) at ~2x the
+#            speed; passes the same parity tests at the same tolerances, but its operands are narrower than fp32, so it is
+#            never selected silently and bench.py reports it separately.
+DEFAULT_PRECISION = "f32"
 
 
 def _ptr(t):
@@ -317,6 +320,8 @@ class Engine(object):
                 self.backward_async(st)
                 b, e = self.stage_grad_range(st)
                 allreduce(self.grads[b:e], ready=lambda stream_ptr, st=st: self.stage_wait(st, stream_ptr))
+            if hasattr(allreduce, "mark_compute_done"):
+                allreduce.mark_compute_done()
             allreduce.wait()
             grad_scale = allreduce.grad_scale
         frozen = getattr(self, "_frozen_grads", None) or ()

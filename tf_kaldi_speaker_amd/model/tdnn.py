@@ -88,7 +88,7 @@ def engine_config(params, dim, num_speakers=0, loss_type="softmax", max_batch=12
               momentum=float(d.get("momentum", 0.0) or 0.0), use_nesterov=bool(d.get("use_nesterov", False)),
               clip_gradient_norm=float(d["clip_gradient_norm"]) if d.get("clip_gradient", False) else 0.0,
               max_batch=max_batch, max_frames=max_frames,
-              precision=d.get("precision", None),      # engine extension: "f16x3" (default) | "f32"; absent from reference configs
+              precision=d.get("precision", None),      # engine extension: "f32" (default) | "f16x3" (opt-in fast mode); absent from reference configs
               pooling_type=d["pooling_type"])
     if num_speakers and d.get("aux_loss_func"):      # loss.py:985-1036; every loss function adds them (loss.py:40,161,249,347)
         kw.update(aux_loss_func=tuple(d["aux_loss_func"]))

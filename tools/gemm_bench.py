@@ -15,7 +15,8 @@ def timeit(fn, n=20, warm=3):
 
 B = 128
 rs = np.random.RandomState(0)
-def rnd(*s): return torch.from_numpy(rs.randn(*s).astype(np.float32)).cuda()
+ZERO = float(os.environ.get('XV_DATA_SCALE', '1'))      # 0: all-zero operands (DVFS check, MI355X_MICROARCH.md give-back item 1)
+def rnd(*s): return torch.from_numpy((rs.randn(*s) * ZERO).astype(np.float32)).cuda()
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 layers = [("tdnn2", T - 4, 512, 5, 512), ("tdnn3", T - 8, 512, 7, 512), ("tdnn4", T - 14, 512, 1, 512), ("tdnn5", T - 14, 512, 1, 1500)]
 for name, t_in, c, k, o in layers:

@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--shapes", default="S1,S2,S3,S4")
     args = ap.parse_args()
     out = {"unit": "chunks/s", "steps": args.steps, "warmup": args.warmup, "seeds": list(range(args.seeds)),
-           "precision": args.precision or "default (f16x3)", "device": torch.cuda.get_device_name(0), "shapes": {}}
+           "precision": args.precision or "default (f32)", "device": torch.cuda.get_device_name(0), "shapes": {}}
     for shape in SHAPES:
         if shape[0] not in args.shapes.split(","):
             continue

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Training-dynamics check of the split-precision mode: the same synthetic speaker-classification task trained for a few
-hundred steps with precision="f16x3" (default) and precision="f32" from identical initial variables and batches.
+hundred steps with precision="f16x3" (opt-in) and precision="f32" (default) from identical initial variables and batches.
 Per-step GEMM results agree to ~1e-6 relative (tests/), so the two loss curves must stay together until chaotic
 divergence of SGD itself - measured by a yardstick run (f32 against f32 started from variables perturbed by 1e-6
 relative noise); the script prints both curves, their largest relative gap and the final training accuracy
