@@ -247,6 +247,9 @@ int xv_att_pool_backward_weights(void* stream, const float* z, int b, int t, int
                                  const float* pool_out, const float* dpool, float* dweights);
 int xv_att_key_backward(void* stream, const float* zk, int rows, int n, int act, const float* query, float scale, const float* dscore,
                         float* dzk, float* dquery, float* dbias, void* ws, size_t ws_bytes);
+/* y[i] = act(z[i]), act as in xv_att_score (0 identity, 1 relu, 3 tanh): the "<name>_relu" / "<name>_tanh" endpoints of
+ * common.py:150-213 dense_relu / dense_tanh for callers of pooling.self_attention (pooling.py:84-96). */
+int xv_key_activation(void* stream, const float* z, size_t count, int act, float* y);
 /* y[i] += x[i]  (the two gradient paths into tdnn4_relu: through tdnn5 and through the attention key network) */
 int xv_add_inplace(void* stream, float* y, const float* x, size_t count);
 

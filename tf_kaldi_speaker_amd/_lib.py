@@ -124,6 +124,7 @@ SIGNATURES = {
     "xv_softmax_segments_backward": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
     "xv_att_pool_backward_weights": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP]),
     "xv_att_key_backward": (_I, [_VP, _VP, _I, _I, _I, _VP, _F, _VP, _VP, _VP, _VP, _VP, _SZ]),
+    "xv_key_activation": (_I, [_VP, _VP, _SZ, _I, _VP]),
     "xv_add_inplace": (_I, [_VP, _VP, _VP, _SZ]),
     "xv_l2_scaling_forward": (_I, [_VP, _VP, _I, _I, _F, _VP]),
     "xv_l2_scaling_backward": (_I, [_VP, _VP, _VP, _I, _I, _F, _VP]),

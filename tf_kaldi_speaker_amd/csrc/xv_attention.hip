@@ -205,6 +205,22 @@ extern "C" int xv_att_key_backward(void* stream, const float* zk, int rows, int 
     return rc;
 }
 
+// y = act(z) elementwise with the key-layer activation codes (0 identity, 1 relu, 3 tanh): the "<name>_relu" / "<name>_tanh"
+// endpoints of common.py's dense_relu / dense_tanh for callers of model.pooling.self_attention (the score kernels apply
+// the activation themselves and never need this tensor)
+__global__ __launch_bounds__(256) void key_activation_kernel(const float* __restrict__ z, size_t count, int act, float* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) y[i] = key_act(z[i], act);
+}
+
+extern "C" int xv_key_activation(void* stream, const float* z, size_t count, int act, float* y) {
+    XV_REQUIRE(z && y && (act == 0 || act == 1 || act == 3), "key_activation: act must be 0 (identity), 1 (relu) or 3 (tanh)");
+    if (count == 0) return 0;
+    int blocks = (int)std::min<size_t>((count + 255) / 256, 8192);
+    hipLaunchKernelGGL(key_activation_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, count, act, y);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int xv_add_inplace(void* stream, float* y, const float* x, size_t count) {
     XV_REQUIRE(y && x && count % 4 == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)x % 16) == 0, "add_inplace: count and pointers must be 16-byte multiples");
     if (count == 0) return 0;

@@ -484,6 +484,12 @@ extern "C" int xv_engine_create(const xv_config* cfg, xv_engine** out) {
                "engine_create: mhe_loss needs a loss with normalised speaker weights (asoftmax / additive margin losses)");
     xv_engine* e = new xv_engine();
     e->cfg = *cfg;
+    if (cfg->loss_kind == XV_LOSS_ASOFTMAX && cfg->margin_m == 1.f) {
+        // asoftmax with m = 1 returns its plain cross entropy before aux_loss_func is reached (loss.py:110-115): no ring / MHE
+        // term, and the variable softmax_ringloss/r is never created
+        e->cfg.aux_ring = 0;
+        e->cfg.aux_mhe = 0;
+    }
     e->f16 = cfg->precision == XV_PRECISION_F16X3;
     build_variables(e);
     int rc = alloc_buffers(e);

@@ -169,7 +169,7 @@ def get_checkpoint(model, checkpoint="-1"):
     log.info("The checkpoint is %d" % checkpoint)
     assert checkpoint in steps, "The checkpoint %d not in the model directory" % checkpoint
     path = os.path.join(model, os.path.basename(current.rsplit("-", 1)[0] + "-" + str(checkpoint)))
-    write_checkpoint_state(model, path, [os.path.join(model, os.path.basename(p)) for p in all_paths])
+    write_checkpoint_state(model, os.path.basename(path), [os.path.basename(p) for p in all_paths])      # basenames: relocatable
     return path
 
 
@@ -212,7 +212,7 @@ def get_pretrain_model(pretrain_model, target_model, checkpoint="-1"):
             continue
         shutil.copyfile(filename, os.path.join(target_model, stem + "-0" + ext))
     path = os.path.join(target_model, stem + "-0")
-    write_checkpoint_state(target_model, path, [path])
+    write_checkpoint_state(target_model, os.path.basename(path), [os.path.basename(path)])
 
 
 def compute_cos_pairwise_eer(embeddings, labels, max_num_embeddings=1000):

@@ -82,7 +82,10 @@ def _run(kind, features, labels, num_outputs, params, reuse_variables, name, m, 
     endpoints["logits"] = logits[:, :num_outputs]
     endpoints["labels"] = y
     total = loss[0]
-    for aux in params.dict.get("aux_loss_func") or []:      # loss.py:985-1036, added by every loss function (loss.py:40,161,249,347)
+    aux_funcs = params.dict.get("aux_loss_func") or []
+    if kind == 1 and m == 1.0:       # asoftmax, m = 1: the reference returns before the auxiliary losses (loss.py:110-115)
+        aux_funcs = []
+    for aux in aux_funcs:            # loss.py:985-1036, added by every other loss function (loss.py:40,161,249,347)
         if aux == "ring_loss":
             r = get_variable(name + "_ringloss/r", (), reuse_variables, init=float(params.ring_loss_init))
             total = total + ops.ring_loss(x, r, float(params.ring_loss_lambda))

@@ -203,10 +203,13 @@ class Trainer(object):
             self.engine.set_update_filter(getattr(self, "_frozen", None) or ())
 
     # ------------------------------------------------------------------ checkpoints
-    def save(self, step):
+    def save(self, step, sync_bn=True):
+        """sync_bn: average the BN moving statistics over the ranks first - a COLLECTIVE, so every rank must make this call
+        (the epoch loop does); sync_bn=False is for a caller that runs on one rank only (get_finetune_model on rank 0)."""
         dist = _dist()
         if dist is not None:
-            average_bn_statistics(dist, self.engine.variables, self.engine.n_train, dist.get_world_size())
+            if sync_bn:
+                average_bn_statistics(dist, self.engine.variables, self.engine.n_train, dist.get_world_size())
             if dist.get_rank() != 0:
                 return
         os.makedirs(self.model, exist_ok=True)
@@ -217,15 +220,17 @@ class Trainer(object):
         tmp = path + ".tmp.npz"
         np.savez(tmp, **arrays)
         os.replace(tmp, path + ".npz")
-        _, all_paths = read_checkpoint_state(self.model)
-        all_paths = [p for p in all_paths if p != path] + [path]
+        # the index keeps BASENAMES (TF's save_relative_paths form): the model directory can be moved or copied and pruning
+        # / loading still find the payloads; entries written with a directory part by older runs are read by basename
+        name = os.path.basename(path)
+        _, listed = read_checkpoint_state(self.model)
+        names = [n for n in (os.path.basename(q) for q in listed) if n != name] + [name]
         keep = int(self.params.dict.get("keep_checkpoint_max", 5))
-        while keep > 0 and len(all_paths) > keep:
-            old = all_paths.pop(0)
-            for suffix in (".npz",):
-                if os.path.exists(old + suffix):
-                    os.remove(old + suffix)
-        write_checkpoint_state(self.model, path, all_paths)
+        while keep > 0 and len(names) > keep:
+            old = os.path.join(self.model, names.pop(0))
+            if os.path.exists(old + ".npz"):
+                os.remove(old + ".npz")
+        write_checkpoint_state(self.model, name, names)
 
     def load(self):
         log.info("Reading checkpoints...")
@@ -293,6 +298,10 @@ class Trainer(object):
         first = curr_step % steps_per_epoch if num_steps is None else 0
         show = int(p.dict.get("show_training_progress", 100))
         save_every = int(p.dict.get("save_checkpoints_steps", 0) or 0)
+        # data parallelism: BN moving statistics follow each rank's own batches (local batch statistics);
+        # they are re-averaged every `bn_sync_steps` optimiser steps (one all-reduce of a few thousand floats) and before every
+        # checkpoint, so replicas never drift further apart than that many moving-average updates
+        bn_sync = int(p.dict.get("bn_sync_steps", 100) or 0) if dist is not None else 0
         for step in range(first, steps_per_epoch):
             try:
                 start_time = time.time()
@@ -311,6 +320,8 @@ class Trainer(object):
                          % (epoch, step, steps_per_epoch, time.time() - start_time, raw, raw + reg))
             if save_every > 0 and step % save_every == 0 and curr_step != 0:
                 self.save(curr_step)
+            elif bn_sync > 0 and (curr_step + 1) % bn_sync == 0:
+                average_bn_statistics(dist, self.engine.variables, self.engine.n_train, dist.get_world_size())
             curr_step += 1
         return curr_step
 
@@ -444,7 +455,7 @@ class Trainer(object):
         for filename in glob.glob(os.path.join(self.model, os.path.basename(current)) + "*"):
             if not filename.endswith(".bak"):
                 shutil.copyfile(filename, filename + ".bak")
-        self.save(0)
+        self.save(0, sync_bn=False)      # no collective: nnet/lib/train.py calls this on rank 0 only (replicas are identical here)
         self.is_loaded = True
 
     def train_tune_lr(self, data, spklist, tune_period=100, aux_data=None, tune_times=None):

@@ -34,8 +34,13 @@ def main():
     logging.basicConfig(level=logging.INFO, format="%(levelname)s:%(name)s:%(message)s")
     log = logging.getLogger("tf_kaldi_speaker_amd")
     args = parser.parse_args()
+    # -g is an enable flag in the reference ("an arbitrary number except -1"; run_extract_embeddings.sh passes the JOB
+    # number with --gpuid), device choice being left to CUDA_VISIBLE_DEVICES.  Here: among the devices HIP_VISIBLE_DEVICES
+    # leaves visible, job N takes device N modulo their count, so `nj` parallel jobs spread over the GPUs of the node and
+    # a node with one device serves every job; -1 (the default) = the first visible device.
     if args.gpu >= 0:
-        os.environ["LOCAL_RANK"] = str(args.gpu)
+        import torch
+        os.environ["LOCAL_RANK"] = str(args.gpu % max(torch.cuda.device_count(), 1))
     nnet_dir = os.path.join(args.model_dir, "nnet")
     config_json = os.path.join(args.model_dir, "nnet/config.json")
     if not os.path.isfile(config_json):

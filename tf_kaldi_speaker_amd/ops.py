@@ -174,6 +174,13 @@ def att_score(zk, act, query, scale):
     return score
 
 
+def key_activation(z, act):
+    """act(z) with the key-layer codes: 0 identity, 1 relu, 3 tanh."""
+    y = torch.empty_like(z)
+    _lib.call("xv_key_activation", _s(), _p(z), C.c_size_t(z.numel()), int(act), _p(y))
+    return y
+
+
 def softmax_segments(score, b, t):
     w = _f32((b, t), score)
     _lib.call("xv_softmax_segments", _s(), _p(score), b, t, _p(w))
