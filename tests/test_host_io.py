@@ -9,8 +9,8 @@ import numpy as np
 import pytest
 
 from tf_kaldi_speaker_amd.dataset import kaldi_io
-from tf_kaldi_speaker_amd.dataset.data_loader import (KaldiDataRandomQueue, KaldiDataSeqQueue, DataOutOfRange, get_speaker_info,
-                                                      sample_random_batch)
+from tf_kaldi_speaker_amd.dataset.data_loader import (KaldiDataRandomQueue, KaldiDataSeqQueue, PlannedRandomQueue, DataOutOfRange,
+                                                      get_speaker_info, KaldiIndex, PlanReader, plan_random_batch)
 from tf_kaldi_speaker_amd.misc import utils as U
 from tests.kaldi_fixture import make_data_dir
 
@@ -89,38 +89,72 @@ def test_feature_reader_and_speaker_info(tmp_path):
 
 
 def test_random_batch_sampling_rules(tmp_path):
-    import random
+    """plan_random_batch on the utterance index: N distinct speakers x M segments, one T per batch, only utterances with
+    more than T frames, start frames inside the utterance; the planned rows come back from the native codec bit-exact
+    with the Python reader's."""
     data, spklist, mats = make_data_dir(str(tmp_path / "train"), num_spk=8, utts_per_spk=2, min_frames=50, max_frames=90)
-    spk2features, _, spk2index = get_speaker_info(data, spklist)
+    index = KaldiIndex(data, spklist)
+    assert len(index) == 16 and index.dim == 30 and index.num_total_speakers == 8
+    rng = np.random.default_rng(3)
+    reader = PlanReader(index, threads=3)
     rd = kaldi_io.FeatureReader(data)
-    r = random.Random(3)
-    for _ in range(5):
-        feats, labels = sample_random_batch(r, rd, spk2features, list(spk2features), 4, 2, 40, 80, True)
-        assert feats.shape[0] == 8 and feats.dtype == np.float32 and labels.dtype == np.int32
-        assert 40 <= feats.shape[1] <= 80 and feats.shape[2] == 30
-        assert len(set(labels[::2])) == 4 and np.array_equal(labels[::2], labels[1::2])   # N speakers x M segments
+    for _ in range(8):
+        plan = plan_random_batch(index, rng, 4, 2, 40, 80, True)
+        assert 40 <= plan.length <= 80 and plan.labels.dtype == np.int32
+        assert len(set(plan.labels[::2])) == 4 and np.array_equal(plan.labels[::2], plan.labels[1::2])   # N speakers x M segments
+        assert np.all(index.frames[plan.utts] > plan.length)
+        assert np.all(plan.starts >= 0) and np.all(plan.starts + plan.length <= index.frames[plan.utts])
+        assert np.array_equal(index.speaker[plan.utts], plan.labels)
+        feats, labels = reader.read(plan)
+        assert feats.shape == (8, plan.length, 30) and feats.dtype == np.float32
+        for j in (0, 5):
+            ref, _ = rd.read_segment(index.feature_name(int(plan.utts[j])), plan.length, shuffle=False, start=int(plan.starts[j]))
+            assert np.array_equal(feats[j], ref)
+    # every speaker too short for T: the plan replaces speakers until none is left, then gives up loudly
+    with pytest.raises(DataOutOfRange):
+        plan_random_batch(index, rng, 8, 1, 95, 95, True)
+    # a T only some speakers can serve: the others are replaced from outside the batch's first pick
+    long_spk = {int(index.speaker[u]) for u in range(len(index)) if index.frames[u] > 80}
+    if 0 < len(long_spk) < 8:
+        plan = plan_random_batch(index, rng, min(2, len(long_spk)), 1, 80, 80, True)
+        assert set(plan.labels.tolist()) <= long_spk
+    reader.close()
     rd.close()
 
 
-def test_queues_end_to_end_with_spawned_workers(tmp_path):
+def test_queues_end_to_end(tmp_path):
     data, spklist, mats = make_data_dir(str(tmp_path / "train"), num_spk=5, utts_per_spk=4, min_frames=45, max_frames=70)
-    q = KaldiDataRandomQueue(data, spklist, num_parallel=2, max_qsize=4, num_speakers=3, num_segments=1, min_len=20, max_len=40)
-    assert q.num_total_speakers == 5
-    q.start()
-    for _ in range(3):
-        f, l = q.fetch()
-        assert f.shape[0] == 3 and 20 <= f.shape[1] <= 40 and len(set(l)) == 3
-    q.stop()
+    for cls in (KaldiDataRandomQueue, PlannedRandomQueue):
+        q = cls(data, spklist, num_parallel=2, max_qsize=4, num_speakers=3, num_segments=1, min_len=20, max_len=40)
+        assert q.num_total_speakers == 5
+        q.start()
+        for _ in range(3):
+            f, l = q.fetch()
+            assert f.shape[0] == 3 and 20 <= f.shape[1] <= 40 and len(set(l)) == 3 and f.dtype == np.float32
+        q.stop()
     s = KaldiDataSeqQueue(data, spklist, num_parallel=2, max_qsize=4, batch_size=4, min_len=20, max_len=40, shuffle=False)
     s.start()
-    seen = 0
+    seen, keys = 0, []
     with pytest.raises(DataOutOfRange):
         while True:
             f, l = s.fetch()
+            assert f.shape[0] == 4 and 20 <= f.shape[1] <= 40 and l.dtype == np.int32
             seen += f.shape[0]
-    # 20 utterances over 2 workers -> 10 each -> int(10 / 4) = 2 full batches per worker; the remainder is
+    # 20 utterances in 2 runs of 10 -> int(10 / 4) = 2 full batches per run; the remainder is
     # dropped exactly as in the reference (data_loader.py:443)
     assert seen == 16
+    # shuffle=False: frame 0 onwards, labels = the utterances' speakers, file order within a speaker
+    s = KaldiDataSeqQueue(data, spklist, num_parallel=1, max_qsize=2, batch_size=5, min_len=30, max_len=30, shuffle=False)
+    s.start()
+    f, l = s.fetch()
+    index = KaldiIndex(data, spklist)
+    first = np.concatenate([index.by_speaker[int(sp)] for sp in index.speakers])[:5]
+    assert np.array_equal(l, index.speaker[first])
+    rd = kaldi_io.FeatureReader(data)
+    ref, _ = rd.read_segment(index.feature_name(int(first[2])), 30, shuffle=False, start=0)
+    assert np.array_equal(f[2], ref)
+    rd.close()
+    s.stop()
 
 
 def test_params_accepts_comment_keys_and_roundtrips(tmp_path):

@@ -75,6 +75,62 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Epilogue of the NT kernels: acc += bias, C tile <- acc.  The bias is added in a pass of its own in front of the stores:
+// written as "v = acc + bias; if (in range) C = v" per element, hipcc put the bias load's s_waitcnt vmcnt(0) inside every
+// predicated store block - and stores count on vmcnt too, so each of the 64 stores of a lane waited for the previous one to
+// retire (a serialised ~30k-cycle tail per tile, with every workgroup of a one-round grid in it at the same time).  Interior
+// tiles store without predication.
+__device__ __forceinline__ void nt_store_tile(f32x16 (&acc)[2][2], float* __restrict__ C, long ldc, const float* __restrict__ bias,
+                                              int m0, int n0, int M, int N, int wr, int wc, int li, int lh) {
+    if (bias) {
+        float bias_v[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wc * 64 + b * 32 + li;
+            bias_v[b] = bias[min(n, N - 1)];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] += bias_v[b];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(acc[a][b]));      // keeps hipcc from sinking the adds back into the store blocks
+    }
+    float* c0 = C + (long)(m0 + wr * 64 + 4 * lh) * ldc + n0 + wc * 64 + li;
+    if (m0 + BM <= M && n0 + BN <= N) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c0[(long)(a * 32 + (r & 3) + 8 * (r >> 2)) * ldc + b * 32] = acc[a][b][r];
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int n = n0 + wc * 64 + b * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < M && n < N) c0[(long)(a * 32 + (r & 3) + 8 * (r >> 2)) * ldc + b * 32] = acc[a][b][r];
+                }
+            }
+    }
+}
+
+#ifndef XV_NT_ABLATE
+// diagnostics only (tools/variant_libs.sh; wrong results): 1 = no LDS fragment reads, 2 = no staging DMA, 3 = MFMA only.
+// [measured, round 2, tdnn2 forward at S1] full 112.6 TF | 1: 124.5 | 2: 128.2 | 3: 138.8 (= the fp32 MFMA rate at the 2.13 GHz the
+// chip holds on this kernel).  What did NOT move the full kernel (all within +-2 %): 5 workgroups per CU, s_setprio around the
+// MFMA block, a different static priority per co-resident workgroup, a start-up stagger between them, fragments of the next
+// half K-step read before the current half's MFMAs, K-step 32; per-wave private staging without any barrier was 20 % slower.
+#define XV_NT_ABLATE 0
+#endif
 template <bool STATS>
 __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * NT_PITCH];
@@ -192,25 +248,31 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    if (nk > 0) NT_STAGE_FIRST();
-    __syncthreads();
-
     const int a_off = (wr * 64 + li) * NT_PITCH;
     const int b_off = (wc * 64 + li) * NT_PITCH;
     const int fsw = NT_SWZ(li);     // rows wr*64 + a*32 + li share f(li): the offsets are multiples of 16
+    if (nk > 0) NT_STAGE_FIRST();
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+#if !(XV_NT_ABLATE & 2)
         if (kt + 1 < nk) NT_STAGE_NEXT(kt, buf);
+#endif
         const float* sa = smem + buf * (2 * BM * NT_PITCH);
         const float* sb = sa + BM * NT_PITCH;
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 af[2], bf[2];
             const int pos = (((2 * q + lh) ^ fsw) << 2);
+#if XV_NT_ABLATE & 1
+            af[0] = af[1] = bf[0] = bf[1] = f32x4{(float)pos, 1.f, 2.f, (float)kt};
+            asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(bf[0]), "+v"(bf[1]));
+#else
             af[0] = *(const f32x4*)(sa + a_off + pos);
             af[1] = *(const f32x4*)(sa + a_off + 32 * NT_PITCH + pos);
             bf[0] = *(const f32x4*)(sb + b_off + pos);
             bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[0][e], acc[0][0], 0, 0, 0);
@@ -225,27 +287,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
 
     // ---- epilogue
     float* C = p.C + (long)blockIdx.z * p.c_split_stride;
-    float bias_v[2] = {0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            int n = n0 + wc * 64 + b * 32 + li;
-            bias_v[b] = n < p.N ? p.bias[n] : 0.f;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            int n = n0 + wc * 64 + b * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = acc[a][b][r] + bias_v[b];
-                acc[a][b][r] = v;
-                if (m < p.M && n < p.N) C[(long)m * p.ldc + n] = v;
-            }
-        }
+    nt_store_tile(acc, C, p.ldc, p.bias, m0, n0, p.M, p.N, wr, wc, li, lh);
 
     if (STATS) xv_tile_stats_epilogue(acc, smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part_sum);
 }

@@ -312,6 +312,9 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
         __syncthreads();
     }
     const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
+    // scale + bias in a pass of their own, THEN the stores: with both in one predicated block per element hipcc put the
+    // s_waitcnt vmcnt(0) of the amax / bias loads in front of every store, and stores count on vmcnt - each store waited for
+    // the previous one to retire
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int n = n0 + wc * 64 + b * 16 + lc;
@@ -319,11 +322,21 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[a][b][jj] = acc[a][b][jj] * out_scale + bias_v;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(acc[a][b]));      // keeps hipcc from sinking the pass back into the store blocks
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = n0 + wc * 64 + b * 16 + lc;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int m = m0 + wr * 64 + a * 16 + lg * 4 + jj;
-                const float v = acc[a][b][jj] * out_scale + bias_v;
-                acc[a][b][jj] = v;
-                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = v;
+                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = acc[a][b][jj];
             }
     }
     if (EPI == 1) xv_tile_stats_epilogue16(acc, (float*)smem, tid, wr, wc, lane, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
@@ -389,6 +402,16 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
         bias_v[b] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
 #pragma unroll
+    for (int a = 0; a < 2; ++a)      // scale + bias first, stores afterwards (see the 16x16 form above)
+#pragma unroll
+        for (int b = 0; b < NB16; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = acc[a][b][r] * out_scale + bias_v[b];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB16; ++b) asm volatile("" : "+v"(acc[a][b]));      // keeps hipcc from sinking the pass back into the store blocks
+#pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < NB16; ++b) {
@@ -396,9 +419,7 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = acc[a][b][r] * out_scale + bias_v[b];
-                acc[a][b][r] = v;
-                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = v;
+                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = acc[a][b][r];
             }
         }
     if (EPI == 1) xv_tile_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
@@ -571,6 +592,9 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
         }
     }
     const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
+    // scale + bias in a pass of their own, THEN the stores: with both in one predicated block per element hipcc put the
+    // s_waitcnt vmcnt(0) of the amax / bias loads in front of every store, and stores count on vmcnt - each store waited for
+    // the previous one to retire
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int n = n0 + wc * 64 + b * 16 + lc;
@@ -578,11 +602,21 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[a][b][jj] = acc[a][b][jj] * out_scale + bias_v;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(acc[a][b]));      // keeps hipcc from sinking the pass back into the store blocks
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = n0 + wc * 64 + b * 16 + lc;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int m = m0 + wr * 64 + a * 16 + lg * 4 + jj;
-                const float v = acc[a][b][jj] * out_scale + bias_v;
-                acc[a][b][jj] = v;
-                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = v;
+                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = acc[a][b][jj];
             }
     }
     {
@@ -654,6 +688,16 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
         bias_v[b] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
 #pragma unroll
+    for (int a = 0; a < 2; ++a)      // scale + bias first, stores afterwards
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = acc[a][b][r] * out_scale + bias_v[b];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(acc[a][b]));
+#pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -661,9 +705,7 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = acc[a][b][r] * out_scale + bias_v[b];
-                acc[a][b][r] = v;
-                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = v;
+                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = acc[a][b][r];
             }
         }
     // the statistics epilogues work on 128-row tiles: each group of 4 waves is one (own scratch, same barriers)

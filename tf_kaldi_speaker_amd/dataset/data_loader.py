@@ -1,237 +1,332 @@
-"""Minibatch loaders over a Kaldi data directory - the host side that feeds Trainer.train / .valid.
+"""Minibatch queues over a Kaldi data directory with the reference's names (dataset/data_loader.py:
+get_speaker_info :14, KaldiDataRandomQueue :310, KaldiDataSeqQueue :467, DataOutOfRange) and batch contract
+(features [B,T,D] float32 + labels [B] int32, one length T per batch) - built differently:
 
-Mirrors the reference's dataset/data_loader.py API (KaldiDataRandomQueue :310, KaldiDataSeqQueue
-:467, DataOutOfRange, get_speaker_info :14) and its sampling rules (batch_random :229-307,
-batch_sequence :417-464):
-  random queue : sample `num_speakers` speakers -> ONE random length T in [min_len, max_len] for the
-                 whole batch -> per speaker keep the utterances with num_frames > T (resample the
-                 speaker if none) -> `num_segments` utterances -> random start frame.
-  seq queue    : every utterance once, batches of `batch_size`, T = min(random T, shortest utt).
-Workers are daemon processes started with the *spawn* method (the parent owns a HIP context;
-forking it is not safe) feeding a bounded multiprocessing.Queue.  NumPy only - no torch import here.
+  * the directory is parsed ONCE into a flat utterance table (`KaldiIndex`: NumPy columns for ark, byte offset, frame
+    count and speaker id, plus one index array per speaker) instead of dictionaries of "utt path:offset" strings;
+  * a batch is first *planned* - which utterance, which start frame, which T (`plan_random_batch`,
+    `plan_sequence_batches`: the reference's sampling rules, data_loader.py:271-298 and :417-464, on the index
+    arrays) - and then *filled* by the native codec (`libxvector_io.so::xvio_read_rows`, which decodes only the planned
+    rows of a 'CM ' matrix) on a pool of threads that write straight into the batch array; ctypes releases the GIL, so
+    there are no worker processes, no pickling and no multiprocessing.Queue;
+  * the training stream `KaldiDataRandomQueue` IS the C++ loader (`NativeRandomQueue`: planning and decoding both in
+    native threads, pinned staging, asynchronous H2D); `PlannedRandomQueue` is the same stream planned in Python, kept
+    for tests of the sampling rules and as `XV_LOADER=python`.
 """
-import multiprocessing as mp
+import concurrent.futures
 import os
-import random
-import time
+import queue as _queue
+import threading
 
 import numpy as np
 
-from .kaldi_io import FeatureReader
+from . import native_loader
+from .native_loader import NativeRandomQueue
 
 
 class DataOutOfRange(Exception):
     pass
 
 
+class KaldiIndex(object):
+    """Flat table of the utterances of a Kaldi data directory whose speaker is listed in `spklist`.
+
+    Columns (one entry per feats.scp line, in file order): key, ark (index into .arks), offset, frames, speaker.
+    .by_speaker[s] = utterance rows of speaker id s; .speakers = ids that own at least one utterance."""
+
+    def __init__(self, data, spklist):
+        assert os.path.isdir(data) and os.path.isfile(spklist)
+        self.data = data
+        self.spk2index = {}
+        with open(spklist) as f:
+            for line in f:
+                name, idx = line.split()
+                self.spk2index[name] = int(idx)
+        owner = {}
+        with open(os.path.join(data, "spk2utt")) as f:
+            for line in f:
+                fields = line.split()
+                sid = self.spk2index[fields[0]]          # a speaker missing from spklist is an error, as in the reference
+                for utt in fields[1:]:
+                    owner[utt] = sid
+        nframes = {}
+        path = os.path.join(data, "utt2num_frames")
+        assert os.path.exists(path), "[Error] Expect utt2num_frames exists in %s " % data
+        with open(path) as f:
+            for line in f:
+                utt, n = line.split()
+                nframes[utt] = int(n)
+        keys, ark, offset, frames, speaker = [], [], [], [], []
+        self.arks, ark_id = [], {}
+        with open(os.path.join(data, "feats.scp")) as f:
+            for line in f:
+                key, rx = line.strip().split(" ", 1)
+                fname, off = rx.rsplit(":", 1)
+                if fname not in ark_id:
+                    ark_id[fname] = len(self.arks)
+                    self.arks.append(fname)
+                keys.append(key)
+                ark.append(ark_id[fname])
+                offset.append(int(off))
+                frames.append(nframes[key])
+                speaker.append(owner[key])
+        self.keys = keys
+        self.ark = np.asarray(ark, np.int32)
+        self.offset = np.asarray(offset, np.int64)
+        self.frames = np.asarray(frames, np.int32)
+        self.speaker = np.asarray(speaker, np.int32)
+        order = np.argsort(self.speaker, kind="stable")
+        ids, first = np.unique(self.speaker[order], return_index=True)
+        bounds = list(first) + [len(order)]
+        self.by_speaker = {int(s): order[bounds[i]:bounds[i + 1]] for i, s in enumerate(ids)}
+        self.speakers = np.asarray(sorted(self.by_speaker), np.int32)
+        self.num_total_speakers = len(self.spk2index)
+        self._dim = None
+
+    def __len__(self):
+        return len(self.keys)
+
+    @property
+    def dim(self):
+        if self._dim is None:
+            self._dim = native_loader.read_rows(self.arks[self.ark[0]], int(self.offset[0]), 0, 1, max_elems=1 << 16).shape[1]
+        return self._dim
+
+    def feature_name(self, u):
+        """The reference's "utt path:offset" string of utterance row u."""
+        return "%s %s:%d" % (self.keys[u], self.arks[self.ark[u]], self.offset[u])
+
+
 def get_speaker_info(data, spklist):
-    """(spk2features, features2spk, spk2index); a feature is the string "utt path:offset"."""
-    assert os.path.isdir(data) and os.path.isfile(spklist)
-    spk2index = {}
-    with open(spklist, "r") as f:
-        for line in f:
-            spk, index = line.strip().split(" ")
-            spk2index[spk] = int(index)
-    utt2spk = {}
-    with open(os.path.join(data, "spk2utt"), "r") as f:
-        for line in f:
-            spk, utts = line.strip().split(" ", 1)
-            for utt in utts.split(" "):
-                utt2spk[utt] = spk2index[spk]
+    """(spk2features, features2spk, spk2index) in the reference's shape (data_loader.py:14-60): speaker id -> list of
+    "utt path:offset" strings and back.  A view of KaldiIndex for callers of the reference API; the queues below work on
+    the index arrays."""
+    index = KaldiIndex(data, spklist)
     spk2features, features2spk = {}, {}
-    with open(os.path.join(data, "feats.scp"), "r") as f:
-        for line in f:
-            key, rxfile = line.strip().split(" ", 1)
-            spk = utt2spk[key]
-            feat = key + " " + rxfile
-            spk2features.setdefault(spk, []).append(feat)
-            features2spk[feat] = spk
-    return spk2features, features2spk, spk2index
+    for u in range(len(index)):
+        name, s = index.feature_name(u), int(index.speaker[u])
+        spk2features.setdefault(s, []).append(name)
+        features2spk[name] = s
+    return spk2features, features2spk, index.spk2index
 
 
-def sample_random_batch(rd, reader, spk2features, speakers, num_speakers, num_segments, min_len, max_len, shuffle):
-    """One batch of the random queue (reference batch_random loop body, data_loader.py:271-298)."""
-    batch_speakers = rd.sample(speakers, num_speakers)
-    batch_length = rd.randint(min_len, max_len)
-    features = np.zeros((num_speakers * num_segments, batch_length, reader.dim), dtype=np.float32)
-    labels = np.zeros((num_speakers * num_segments), dtype=np.int32)
-    for i, speaker in enumerate(batch_speakers):
-        spk = speaker
-        feature_list = []
-        while len(feature_list) == 0:
-            feature_list = [f for f in spk2features[spk] if reader.utt2num_frames[f.split(" ")[0]] > batch_length]
-            if len(feature_list) == 0:
-                spk = rd.choice(list(set(speakers) - set(batch_speakers)))
-                batch_speakers[i] = spk
-        labels[i * num_segments:(i + 1) * num_segments] = spk
-        if len(feature_list) < num_segments:
-            feature_list = feature_list * (int(num_segments / len(feature_list)) + 1)
-        for j, feat in enumerate(rd.sample(feature_list, num_segments)):
-            features[i * num_segments + j], _ = reader.read_segment(feat, batch_length, shuffle=shuffle)
-    return features, labels
+class BatchPlan(object):
+    __slots__ = ("utts", "starts", "length", "labels")
+
+    def __init__(self, utts, starts, length, labels):
+        self.utts, self.starts, self.length, self.labels = utts, starts, int(length), labels
 
 
-def batch_random(stop_event, queue, data, spk2features, num_total_speakers, num_speakers=10, num_segments=10,
-                 min_len=200, max_len=400, shuffle=True, seed=0):
-    rd = random.Random(int.from_bytes(os.urandom(4), "little") + 7919 * seed)
-    random.seed(int.from_bytes(os.urandom(4), "little") + 104729 * seed)   # FeatureReader draws start frames here
-    reader = FeatureReader(data)
-    speakers = list(spk2features.keys())
-    if num_total_speakers < num_speakers:
-        print("[Warning] The number of available speakers are less than the required speaker. Some speakers will be duplicated.")
-        speakers = speakers * (int(num_speakers / num_total_speakers) + 1)
-    while not stop_event.is_set():
-        batch = sample_random_batch(rd, reader, spk2features, speakers, num_speakers, num_segments, min_len, max_len, shuffle)
-        while not stop_event.is_set():
-            try:
-                queue.put(batch, timeout=0.5)
+def _starts(index, rng, utts, length, shuffle):
+    if not shuffle:
+        return np.zeros(len(utts), np.int64)
+    room = index.frames[utts].astype(np.int64) - length          # a start frame uniform in [0, frames - T]
+    return (rng.random(len(utts)) * (room + 1)).astype(np.int64).clip(0, np.maximum(room, 0))
+
+
+def plan_random_batch(index, rng, num_speakers, num_segments, min_len, max_len, shuffle=True):
+    """The random queue's rules (reference data_loader.py:271-298): `num_speakers` distinct speakers; ONE length T in
+    [min_len, max_len] for the whole batch; per speaker only utterances with MORE than T frames qualify - a speaker with
+    none is replaced by one drawn from outside the batch's original pick; `num_segments` different utterances of the
+    speaker (repeating the list first when it is shorter); a random start frame each.  rng: numpy Generator."""
+    pool = index.speakers
+    if len(pool) < num_speakers:       # fewer speakers than asked for: some are duplicated (reference :263-266)
+        pool = np.tile(pool, num_speakers // len(pool) + 1)
+    picked = rng.choice(pool, size=num_speakers, replace=False)
+    length = int(rng.integers(min_len, max_len + 1))
+    spare = np.setdiff1d(pool, picked)
+    utts = np.empty(num_speakers * num_segments, np.int64)
+    labels = np.empty(num_speakers * num_segments, np.int32)
+    for i in range(num_speakers):
+        s = int(picked[i])
+        while True:
+            mine = index.by_speaker[s]
+            ok = mine[index.frames[mine] > length]
+            if len(ok):
                 break
-            except Exception:
-                continue
-    reader.close()
+            if len(spare) == 0:
+                raise DataOutOfRange("no utterance longer than %d frames outside the sampled speakers" % length)
+            s = int(rng.choice(spare))
+            spare = spare[spare != s]      # in the batch now (or found too short): not a candidate for a later replacement
+        if len(ok) < num_segments:
+            ok = np.tile(ok, num_segments // len(ok) + 1)
+        utts[i * num_segments:(i + 1) * num_segments] = rng.choice(ok, size=num_segments, replace=False)
+        labels[i * num_segments:(i + 1) * num_segments] = s
+    return BatchPlan(utts, _starts(index, rng, utts, length, shuffle), length, labels)
 
 
-def batch_sequence(stop_event, queue, data, feature_list, features2spk, batch_size=128, min_len=200, max_len=400,
-                   shuffle=True, seed=0):
-    rd = random.Random(int.from_bytes(os.urandom(4), "little") + 7919 * seed)
-    random.seed(int.from_bytes(os.urandom(4), "little") + 104729 * seed)
-    reader = FeatureReader(data)
-    num_batches = int(len(feature_list) / batch_size)
-    for i in range(num_batches):
-        chunk = feature_list[i * batch_size:(i + 1) * batch_size]
-        batch_length = rd.randint(min_len, max_len)
-        for feat in chunk:
-            n = reader.utt2num_frames[feat.split(" ")[0]]
-            if n < batch_length:
-                batch_length = n
-        features = np.zeros((batch_size, batch_length, reader.dim), dtype=np.float32)
-        labels = np.zeros((batch_size), dtype=np.int32)
-        for j, feat in enumerate(chunk):
-            features[j], _ = reader.read_segment(feat, batch_length, shuffle=shuffle)
-            labels[j] = features2spk[feat]
-        queue.put((features, labels))
-    stop_event.set()
-    reader.close()
+def plan_sequence_batches(index, utt_order, batch_size, rng, min_len, max_len, shuffle=True):
+    """Every utterance of `utt_order` once, in batches of `batch_size` (an incomplete last batch is dropped, reference
+    data_loader.py:443); T = a random length in [min_len, max_len], shortened to the shortest utterance of the batch."""
+    for b in range(len(utt_order) // batch_size):
+        utts = np.asarray(utt_order[b * batch_size:(b + 1) * batch_size], np.int64)
+        length = min(int(rng.integers(min_len, max_len + 1)), int(index.frames[utts].min()))
+        yield BatchPlan(utts, _starts(index, rng, utts, length, shuffle), length, index.speaker[utts].astype(np.int32))
 
 
-def _ctx():
-    return mp.get_context("spawn")
+class PlanReader(object):
+    """Fills planned batches with the native codec on a thread pool (one task per utterance segment, written in place)."""
+
+    def __init__(self, index, threads=4):
+        self.index = index
+        self.lib = native_loader.load()
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, int(threads)))
+        self._arks = [a.encode() for a in index.arks]
+
+    def _segment(self, out_row, u, start, length):
+        import ctypes as C
+        rows, cols = C.c_int32(), C.c_int32()
+        rc = self.lib.xvio_read_rows(self._arks[self.index.ark[u]], int(self.index.offset[u]), int(start), int(length),
+                                     out_row.ctypes.data, out_row.size, C.byref(rows), C.byref(cols))
+        if rc != 0 or rows.value != length:
+            raise IOError("Cannot read features from %s (%s)" % (self.index.feature_name(u),
+                                                                 self.lib.xvio_last_error().decode(errors="replace")))
+
+    def read(self, plan):
+        feats = np.empty((len(plan.utts), plan.length, self.index.dim), np.float32)
+        jobs = [self.pool.submit(self._segment, feats[j], int(plan.utts[j]), int(plan.starts[j]), plan.length)
+                for j in range(len(plan.utts))]
+        for j in jobs:
+            j.result()
+        return feats, plan.labels
+
+    def close(self):
+        self.pool.shutdown(wait=True)
 
 
-class KaldiDataRandomQueue(object):
-    """Endless stream of random (features [B,T,D] f32, labels [B] i32) batches."""
+class _Prefetcher(threading.Thread):
+    """Runs a (plan iterator -> batches) pipeline ahead of the consumer through a bounded queue."""
 
-    def __init__(self, data_dir, spklist, num_parallel=1, max_qsize=10, num_speakers=None, num_segments=None,
-                 min_len=None, max_len=None, shuffle=True):
+    def __init__(self, plans, reader, depth):
+        threading.Thread.__init__(self, daemon=True)
+        self.plans, self.reader = plans, reader
+        self.out = _queue.Queue(max(1, int(depth)))
+        self.halt = threading.Event()
+
+    def run(self):
+        try:
+            for plan in self.plans:
+                if self.halt.is_set():
+                    return
+                item = self.reader.read(plan)
+                while not self.halt.is_set():
+                    try:
+                        self.out.put(item, timeout=0.2)
+                        break
+                    except _queue.Full:
+                        continue
+            self.out.put(None)
+        except Exception as exc:      # surfaces in fetch()
+            self.out.put(exc)
+
+    def get(self):
+        item = self.out.get()
+        if isinstance(item, Exception):
+            raise item
+        return item
+
+
+class _QueueBase(object):
+    def _setup(self, data_dir, spklist, num_parallel, max_qsize, min_len, max_len, shuffle):
         self.data = data_dir
-        self.num_speakers = num_speakers
-        self.num_segments = num_segments
-        self.min_len = min_len
-        self.max_len = max_len
+        self.index = KaldiIndex(data_dir, spklist)
+        self.num_total_speakers = self.index.num_total_speakers
         self.num_parallel_datasets = num_parallel
-        self.shuffle = shuffle
-        self.spk2features, self.features2spk, spk2index = get_speaker_info(data_dir, spklist)
-        self.num_total_speakers = len(list(spk2index.keys()))
-        self._mp = _ctx()
-        self.queue = self._mp.Queue(max_qsize)
-        self.stop_event = self._mp.Event()
-        self.processes = []
-
-    def set_batch(self, num_speakers, num_segments):
-        self.num_speakers = num_speakers
-        self.num_segments = num_segments
+        self.max_qsize = max_qsize
+        self.min_len, self.max_len, self.shuffle = min_len, max_len, shuffle
+        self._reader = self._thread = None
 
     def set_length(self, min_len, max_len):
-        self.min_len = min_len
-        self.max_len = max_len
+        self.min_len, self.max_len = min_len, max_len
 
-    def start(self):
-        self.processes = [self._mp.Process(target=batch_random,
-                                           args=(self.stop_event, self.queue, self.data, self.spk2features,
-                                                 self.num_total_speakers, self.num_speakers, self.num_segments,
-                                                 self.min_len, self.max_len, self.shuffle, i))
-                          for i in range(self.num_parallel_datasets)]
-        for p in self.processes:
-            p.daemon = True
-            p.start()
-
-    def fetch(self):
-        return self.queue.get()
+    def _launch(self, plans):
+        self._reader = PlanReader(self.index, threads=max(2, 2 * int(self.num_parallel_datasets)))
+        self._thread = _Prefetcher(plans, self._reader, self.max_qsize)
+        self._thread.start()
 
     def stop(self):
-        self.stop_event.set()
-        deadline = time.time() + 5.0
-        while time.time() < deadline and any(p.is_alive() for p in self.processes):
-            try:
-                self.queue.get(timeout=0.1)
-            except Exception:
-                pass
-        for p in self.processes:
-            if p.is_alive():
-                p.terminate()
-            p.join(1.0)
-        self.processes = []
+        if self._thread is not None:
+            self._thread.halt.set()
+            while self._thread.is_alive():          # unblock a producer waiting on a full queue
+                try:
+                    self._thread.out.get(timeout=0.05)
+                except _queue.Empty:
+                    pass
+            self._thread = None
+        if self._reader is not None:
+            self._reader.close()
+            self._reader = None
 
 
-class KaldiDataSeqQueue(object):
-    """Every utterance once per pass (validation); raises DataOutOfRange when exhausted."""
+class PlannedRandomQueue(_QueueBase):
+    """The random training stream planned in Python (plan_random_batch) and decoded by the native codec: the readable
+    twin of NativeRandomQueue, selected with XV_LOADER=python."""
+
+    def __init__(self, data_dir, spklist, num_parallel=1, max_qsize=10, num_speakers=None, num_segments=None,
+                 min_len=None, max_len=None, shuffle=True, seed=None):
+        self._setup(data_dir, spklist, num_parallel, max_qsize, min_len, max_len, shuffle)
+        self.num_speakers, self.num_segments = num_speakers, num_segments
+        self.seed = seed
+
+    def set_batch(self, num_speakers, num_segments):
+        self.num_speakers, self.num_segments = num_speakers, num_segments
+
+    def start(self):
+        rng = np.random.default_rng(self.seed)
+
+        def plans():
+            while True:
+                yield plan_random_batch(self.index, rng, self.num_speakers, self.num_segments, self.min_len, self.max_len,
+                                        self.shuffle)
+        self._launch(plans())
+
+    def fetch(self):
+        return self._thread.get()
+
+
+class KaldiDataRandomQueue(NativeRandomQueue):
+    """Endless stream of random (features [B,T,D] f32, labels [B] i32) batches: the C++ loader under the reference's
+    class name.  `num_total_speakers` is available before start() (train.py:74 reads it from a bare instance)."""
+
+    def __init__(self, data_dir, spklist, num_parallel=1, max_qsize=10, num_speakers=None, num_segments=None,
+                 min_len=None, max_len=None, shuffle=True, seed=None):
+        NativeRandomQueue.__init__(self, data_dir, spklist, num_parallel=num_parallel, max_qsize=max_qsize,
+                                   num_speakers=num_speakers, num_segments=num_segments, min_len=min_len, max_len=max_len,
+                                   shuffle=shuffle, seed=seed)
+        with open(spklist) as f:
+            self.num_total_speakers = sum(1 for line in f if line.strip())
+
+
+class KaldiDataSeqQueue(_QueueBase):
+    """Every utterance once per pass (validation); fetch() raises DataOutOfRange when the pass is over.  The utterance
+    list is cut into `num_parallel` runs, each batched on its own (so up to batch_size - 1 utterances per run are dropped,
+    as the reference's per-worker batching does, data_loader.py:443,530-537)."""
 
     def __init__(self, data_dir, spklist, num_parallel=1, max_qsize=10, batch_size=128, min_len=None, max_len=None,
-                 shuffle=True):
-        self.data = data_dir
+                 shuffle=True, seed=None):
+        self._setup(data_dir, spklist, num_parallel, max_qsize, min_len, max_len, shuffle)
         self.batch_size = batch_size
-        self.min_len = min_len
-        self.max_len = max_len
-        self.num_parallel_datasets = num_parallel
-        self.shuffle = shuffle
-        self.spk2features, self.features2spk, spk2index = get_speaker_info(data_dir, spklist)
-        self.num_total_speakers = len(list(spk2index.keys()))
-        self.feature_list = []
-        for spk in self.spk2features:
-            self.feature_list += self.spk2features[spk]
+        self._rng = np.random.default_rng(seed)
+        order = np.concatenate([self.index.by_speaker[int(s)] for s in self.index.speakers]) if len(self.index) else np.empty(0, np.int64)
         if shuffle:
-            random.shuffle(self.feature_list)
-        n_sub = len(self.feature_list) // num_parallel
-        self.sub_feature_list = []
-        for i in range(num_parallel):
-            if i == num_parallel - 1:
-                self.sub_feature_list.append(self.feature_list[i * n_sub:])
-            else:
-                self.sub_feature_list.append(self.feature_list[i * n_sub:(i + 1) * n_sub])
-        self._mp = _ctx()
-        self.queue = self._mp.Queue(max_qsize)
-        self.stop_event = [self._mp.Event() for _ in range(num_parallel)]
-        self.processes = []
+            order = self._rng.permutation(order)
+        n_sub = len(order) // num_parallel
+        self.runs = [order[i * n_sub:(i + 1) * n_sub] if i < num_parallel - 1 else order[i * n_sub:] for i in range(num_parallel)]
 
     def set_batch(self, batch_size):
         self.batch_size = batch_size
 
-    def set_length(self, min_len, max_len):
-        self.min_len = min_len
-        self.max_len = max_len
-
     def start(self):
-        self.processes = [self._mp.Process(target=batch_sequence,
-                                           args=(self.stop_event[i], self.queue, self.data, self.sub_feature_list[i],
-                                                 self.features2spk, self.batch_size, self.min_len, self.max_len,
-                                                 self.shuffle, i))
-                          for i in range(self.num_parallel_datasets)]
-        for p in self.processes:
-            p.daemon = True
-            p.start()
+        def plans():
+            for run in self.runs:
+                for plan in plan_sequence_batches(self.index, run, self.batch_size, self._rng, self.min_len, self.max_len,
+                                                  self.shuffle):
+                    yield plan
+        self._launch(plans())
 
     def fetch(self):
-        while True:
-            try:
-                return self.queue.get(timeout=0.2)
-            except Exception:
-                if all(e.is_set() for e in self.stop_event) and self.queue.empty():
-                    self.stop()
-                    raise DataOutOfRange
-
-    def stop(self):
-        for p in self.processes:
-            if p.is_alive():
-                p.terminate()
-            p.join(1.0)
-        self.processes = []
+        item = self._thread.get() if self._thread is not None else None
+        if item is None:
+            self.stop()
+            raise DataOutOfRange
+        return item
