@@ -99,8 +99,8 @@ def test_random_batch_sampling_rules(tmp_path):
     reader = PlanReader(index, threads=3)
     rd = kaldi_io.FeatureReader(data)
     for _ in range(8):
-        plan = plan_random_batch(index, rng, 4, 2, 40, 80, True)
-        assert 40 <= plan.length <= 80 and plan.labels.dtype == np.int32
+        plan = plan_random_batch(index, rng, 4, 2, 30, 49, True)      # every utterance has >= 50 frames: no speaker needs replacing
+        assert 30 <= plan.length <= 49 and plan.labels.dtype == np.int32
         assert len(set(plan.labels[::2])) == 4 and np.array_equal(plan.labels[::2], plan.labels[1::2])   # N speakers x M segments
         assert np.all(index.frames[plan.utts] > plan.length)
         assert np.all(plan.starts >= 0) and np.all(plan.starts + plan.length <= index.frames[plan.utts])

@@ -27,8 +27,7 @@ try:
     from .. import engine as E
     from .. import _lib
     from ..parallel import GradAllReduce, average_bn_statistics, broadcast_variables
-    from ..dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, DataOutOfRange
-    from ..dataset.native_loader import NativeRandomQueue
+    from ..dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, PlannedRandomQueue, DataOutOfRange
     from ..misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state
     from .tdnn import tdnn, engine_config, collect_endpoints, check_params
     from . import loss as _loss
@@ -36,8 +35,7 @@ except (ImportError, ValueError):      # drop-in layout: PYTHONPATH=$TF_KALDI_RO
     import engine as E
     import _lib
     from parallel import GradAllReduce, average_bn_statistics, broadcast_variables
-    from dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, DataOutOfRange
-    from dataset.native_loader import NativeRandomQueue
+    from dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, PlannedRandomQueue, DataOutOfRange
     from misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state
     from model.tdnn import tdnn, engine_config, collect_endpoints, check_params
     from model import loss as _loss
@@ -268,9 +266,9 @@ class Trainer(object):
         if dist is not None:
             broadcast_variables(dist, self.engine.variables, 0)
             self.engine.lib.xv_engine_invalidate_weights(self.engine.h)
-        # C++ decoder threads by default (libxvector_io.so); XV_LOADER=python selects the multiprocessing mirror of the
-        # reference's queue (dataset/data_loader.py) - same sampling rules, same batch contract
-        queue_cls = KaldiDataRandomQueue if os.environ.get("XV_LOADER", "native") == "python" else NativeRandomQueue
+        # KaldiDataRandomQueue = the C++ loader (libxvector_io.so: planning + decoding in native threads); XV_LOADER=python
+        # plans the batches in Python and only decodes natively (dataset/data_loader.py) - same rules, same batch contract
+        queue_cls = PlannedRandomQueue if os.environ.get("XV_LOADER", "native") == "python" else KaldiDataRandomQueue
         loader = queue_cls(data, spklist, num_parallel=p.num_parallel_datasets, max_qsize=p.max_queue_size,
                            num_speakers=p.num_speakers_per_batch, num_segments=p.num_segments_per_speaker,
                            min_len=p.min_segment_len, max_len=p.max_segment_len, shuffle=True)
@@ -468,7 +466,7 @@ class Trainer(object):
         self.engine.init_variables(seed=int(p.dict.get("seed", 0)))
         if os.path.isfile(os.path.join(self.model, "checkpoint")):
             self.load()
-        queue_cls = KaldiDataRandomQueue if os.environ.get("XV_LOADER", "native") == "python" else NativeRandomQueue
+        queue_cls = PlannedRandomQueue if os.environ.get("XV_LOADER", "native") == "python" else KaldiDataRandomQueue
         loader = queue_cls(data, spklist, num_parallel=p.num_parallel_datasets, max_qsize=p.max_queue_size,
                            num_speakers=p.num_speakers_per_batch, num_segments=p.num_segments_per_speaker,
                            min_len=p.min_segment_len, max_len=p.max_segment_len, shuffle=True)
