@@ -202,6 +202,50 @@ def test_learning_rate_schedule_table():
     assert U.should_stop(10, 1e-3, best, 1e-6, 10)        # early stop
 
 
+def test_epoch_ledger_side_car_files_resume_and_fixed_schedule(tmp_path):
+    """EpochLedger = the bookkeeping of nnet/lib/train.py: same LR / stop decisions as the table above, the side-car files in
+    the reference's formats (train.py:121-131), a continued run picks up rates and the best epoch from them, and a schedule
+    file fixes the rates in advance (train.py:52-58)."""
+    model = tmp_path / "nnet"
+    model.mkdir()
+    cfg = {"learning_rate": 0.01, "num_epochs": 12, "reduce_lr_epochs": 2, "num_steps_per_epoch": 100}
+    (tmp_path / "c.json").write_text(json.dumps(cfg))
+    params = U.Params(str(tmp_path / "c.json"))
+    led = U.EpochLedger(str(model), params, 0)
+    assert params.early_stop_epochs == 10 and params.min_learning_rate == 1e-5       # defaults inserted like train.py:101-104
+    led.write_feature_dim(30)
+    assert (model / "feature_dim").read_text() == "30\n"
+    losses = [3.0, 2.5, 2.6, 2.7, 2.8]
+    for epoch, loss in enumerate(losses):
+        assert led.rate(epoch) == [0.01, 0.01, 0.01, 0.01, 0.005][epoch]
+        assert not led.close_epoch(epoch, loss, 0.1)
+    assert (model / "learning_rate").read_text().splitlines() == ["0 0.01000000", "1 0.01000000", "2 0.01000000", "3 0.01000000",
+                                                                  "4 0.00500000", "5 0.00500000"]
+    assert (model / "valid_loss").read_text().splitlines()[1] == "1 2.500000 0.100000"
+    # continue after epoch 4 (first_epoch = 5): rates and best epoch come back from the files
+    led2 = U.EpochLedger(str(model), params, 5)
+    assert led2.rate(5) == 0.005 and led2.best.min_loss == 2.5 and led2.best.min_loss_epoch == 1
+    with pytest.raises(AssertionError):
+        U.EpochLedger(str(model), params, 3)             # learning_rate file does not match the resume point
+    # stop once the rate would fall below min_learning_rate
+    params.dict["min_learning_rate"] = 0.004
+    assert led2.close_epoch(5, 2.9, 0.1) and led2.rate(6) == 0.0025
+    # a rank that did not evaluate adopts the decision
+    led3 = U.EpochLedger(str(tmp_path / "other"), params, 0) if (tmp_path / "other").mkdir() is None else None
+    led3.adopt(0, 0.02)
+    assert led3.rate(1) == 0.02
+    # fixed schedule file: no tuning, never stops early
+    sched = tmp_path / "lr.txt"
+    sched.write_text("\n".join(str(0.1 / (i + 1)) for i in range(13)) + "\n")
+    params.dict["learning_rate"] = str(sched)
+    led4 = U.EpochLedger(str(tmp_path / "other"), params, 0)
+    assert led4.fixed_schedule and led4.rate(3) == 0.1 / 4
+    assert not led4.close_epoch(0, 9.9, 0.5) and led4.rate(1) == 0.05
+    # the step the checkpoint index points at
+    U.write_checkpoint_state(str(model), "model-700", ["model-600", "model-700"])
+    assert U.checkpoint_step(str(model)) == 700 and U.checkpoint_step(str(tmp_path / "other")) is None
+
+
 def test_chunk_split_and_weighted_average():
     """extract.py:69-93 on synthetic lengths: T=25001, chunk=10000 -> 5 chunks."""
     chunks = U.split_into_chunks(25001, 10000)

@@ -282,6 +282,78 @@ def should_stop(epoch, next_lr, min_valid_loss, min_learning_rate, early_stop_ep
     return next_lr < (min_learning_rate - 1e-12) or epoch - min_valid_loss.min_loss_epoch >= early_stop_epochs
 
 
+class EpochLedger(object):
+    """The epoch-level bookkeeping of a training run and its side-car files under <model>/nnet (what the reference keeps in
+    loose variables across egs/voxceleb/v1/nnet/lib/train.py:44-139):
+
+        feature_dim     one line, the feature dimension                       (read by extract.py)
+        learning_rate   "<epoch> <lr>" per line, epoch e = the rate epoch e ran / will run with
+        valid_loss      "<epoch> <loss> <eer>" per line                      (get_checkpoint picks the best epoch from it)
+
+    The learning rate of an epoch comes from one of three sources: a schedule file named by params.learning_rate (one rate
+    per line, fixed in advance), the learning_rate file of a run being continued, or params.learning_rate itself; in the
+    last two cases the next rate is decided after each epoch by tune_learning_rate / should_stop."""
+
+    def __init__(self, model_dir, params, first_epoch, default_early_stop=10):
+        self.dir = model_dir
+        self.params = params
+        self.first_epoch = int(first_epoch)
+        p = params.dict
+        p.setdefault("early_stop_epochs", default_early_stop)
+        p.setdefault("min_learning_rate", 1e-5)
+        spec = params.learning_rate
+        self.fixed_schedule = os.path.isfile(str(spec))
+        own = os.path.join(model_dir, "learning_rate")
+        if self.fixed_schedule:
+            with open(str(spec)) as f:
+                self.rates = [float(line) for line in f if line.strip()]
+            assert len(self.rates) > params.num_epochs, "The learning rate file is shorter than the num of epochs."
+            log.info("Using specified learning rate decay strategy.")
+        elif os.path.isfile(own):
+            self.rates = load_lr(own)
+            assert len(self.rates) == self.first_epoch + 1, "Not enough learning rates in the learning_rate file."
+        else:
+            self.rates = [float(spec)] * (self.first_epoch + 1)
+        best = os.path.join(model_dir, "valid_loss")
+        self.best = load_valid_loss(best) if os.path.isfile(best) else ValidLoss()
+
+    def write_feature_dim(self, dim):
+        with open(os.path.join(self.dir, "feature_dim"), "w") as f:
+            f.write("%d\n" % dim)
+
+    def rate(self, epoch):
+        return self.rates[epoch]
+
+    def close_epoch(self, epoch, valid_loss, eer):
+        """Record the epoch's validation result, derive the next learning rate, append the side-car lines; returns True when
+        training should stop (rate below min_learning_rate, or no improvement for early_stop_epochs)."""
+        p = self.params
+        if not self.fixed_schedule:
+            self.rates.append(tune_learning_rate(epoch, self.rates[epoch], valid_loss, self.best, p.reduce_lr_epochs))
+        with open(os.path.join(self.dir, "learning_rate"), "a") as f:
+            if epoch == 0:
+                f.write("0 %.8f\n" % self.rates[0])
+            f.write("%d %.8f\n" % (epoch + 1, self.rates[epoch + 1]))
+        with open(os.path.join(self.dir, "valid_loss"), "a") as f:
+            f.write("%d %f %f\n" % (epoch, valid_loss, eer))
+        if self.fixed_schedule:
+            return False
+        return should_stop(epoch, self.rates[epoch + 1], self.best, p.min_learning_rate, p.early_stop_epochs)
+
+    def adopt(self, epoch, next_rate):
+        """A rank that did not evaluate takes over rank 0's decision for the next epoch."""
+        if len(self.rates) <= epoch + 1:
+            self.rates.append(float(next_rate))
+
+
+def checkpoint_step(model_dir):
+    """Global step of the checkpoint the index file points at (the digits that end its name), or None."""
+    current, _ = read_checkpoint_state(model_dir)
+    if not current:
+        return None
+    return int(re.search(r"(\d+)(?!.*\d)", os.path.basename(current)).group(1))
+
+
 def split_into_chunks(num_frames, chunk_size):
     """[(start, length)] of the half-overlapping chunks extract.py:69-79 cuts a long utterance into.
     (`chunk_size / 2` is Python-2 integer division in the reference.)"""
