@@ -328,7 +328,15 @@ typedef struct xv_config {
     float ring_loss_lambda;
     int32_t aux_mhe;                  /* "mhe_loss" in aux_loss_func (loss.py:1018-1033); margin losses only (normalised weights) */
     float mhe_lambda;
+    /* Frame-layer table.  0 = the reference's five layers (tdnn.py:35-127: contexts 5/5/7/1/1, widths 512 x 4 + num_nodes_pooling_layer).
+     * Otherwise 3..XV_MAX_FRAME_LAYERS layers of (context k >= 1 contiguous frames, output channels); context 1 = dense.  Variables
+     * are named tdnn<i>_conv / tdnn<i>_dense / tdnn<i>_bn as in the reference; the two segment-level layers follow as tdnn<F+1>,
+     * tdnn<F+2>.  Extended tables have NO reference counterpart (BASELINE configs[4]). */
+    int32_t num_frame_layers;
+    int32_t frame_context[12];
+    int32_t frame_width[12];
 } xv_config;
+#define XV_MAX_FRAME_LAYERS 12
 #define XV_POOL_STATISTICS 0
 /* self_attention in the shipped single-head form (nnet_conf/..._tdnn4_att.json): key network on tdnn4_relu, value = tdnn5_relu,
  * one head, key not split, no value network, no penalty term, no post non-linearity */

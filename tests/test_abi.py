@@ -53,8 +53,16 @@ def test_config_struct_layout_matches_header():
         if m:
             for nm in m.group(2).split(","):
                 fields.append((m.group(1), nm.strip()))
-    mirror = [("int32_t" if t is ctypes.c_int32 else "float", n) for n, t in _lib.XvConfig._fields_]
+    def mirror_field(n, t):
+        if t is ctypes.c_int32:
+            return ("int32_t", n)
+        if t is ctypes.c_float:
+            return ("float", n)
+        assert issubclass(t, ctypes.Array) and t._type_ is ctypes.c_int32, (n, t)      # int32_t name[len]
+        return ("int32_t", "%s[%d]" % (n, t._length_))
+    mirror = [mirror_field(n, t) for n, t in _lib.XvConfig._fields_]
     assert fields == mirror
+    assert _lib.XV_MAX_FRAME_LAYERS == 12 and "#define XV_MAX_FRAME_LAYERS 12" in src
 
 
 def test_engine_refuses_to_run_without_gpu():

@@ -89,7 +89,7 @@ def test_variable_table_matches_reference_names():
     eng.close()
 
 
-RELU_LAYERS = ("tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5", "att_key0", "att_key1", "tdnn6", "tdnn7")
+RELU_LAYERS = tuple("tdnn%d" % i for i in range(1, 15)) + ("att_key0", "att_key1")
 
 
 def oracle_forward(V, cfg_o, x):
@@ -188,6 +188,35 @@ def test_train_step_matches_oracle_odd_dimensions(c):
     _check_train_step(c["kw"], c["B"], c["T"], N=c["N"], P=c["P"], D=c["D"], L=c["L"])
 
 
+# Extended frame-layer tables (BASELINE configs[4] "Deep TDNN, extended context, 10 layers"; no reference counterpart - model/tdnn.py
+# hard-codes its five layers): the oracle and the engine build the stack from the same (context, width) table
+EXTENDED = [
+    dict(B=4, T=40, kw=dict(loss_func="asoftmax", margin_m=4, lambda_min=10, lambda_gamma=1e-5, last_layer_linear=True,
+                            frame_layers=((5, 512), (1, 512), (3, 512), (1, 512), (3, 512), (1, 512), (3, 512), (1, 512), (1, 512), (1, 1500)))),
+    dict(B=5, T=24, kw=dict(loss_func="softmax", frame_layers=((3, 64), (2, 128), (1, 1500)))),
+    dict(B=4, T=36, kw=dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, pooling_type="self_attention",
+                            att_key_num_nodes=(96, 64), frame_layers=((5, 256), (3, 512), (1, 384), (7, 512), (1, 128), (1, 1500)))),
+    dict(B=3, T=60, kw=dict(loss_func="softmax", optimizer="momentum", momentum=0.9,
+                            frame_layers=((5, 512), (5, 512), (7, 512), (1, 512), (1, 512), (3, 256), (1, 256), (3, 512), (1, 512), (1, 512), (1, 512),
+                                          (1, 1500)))),
+]
+
+
+@pytest.mark.parametrize("c", EXTENDED, ids=lambda c: "%dlayers" % len(c["kw"]["frame_layers"]))
+def test_train_step_matches_oracle_extended_frame_layers(c):
+    _check_train_step(c["kw"], c["B"], c["T"])
+
+
+def test_extended_table_is_validated():
+    from tf_kaldi_speaker_amd import engine as E
+    with pytest.raises(ValueError):
+        E.make_config(30, 10, frame_layers=((5, 512), (1, 512)))                         # fewer than 3 layers
+    with pytest.raises(ValueError):
+        E.make_config(30, 10, frame_layers=((5, 512), (1, 512), (1, 512)))               # last width != num_nodes_pooling_layer
+    with pytest.raises(Exception):
+        E.Engine(E.make_config(30, 10, max_batch=2, max_frames=10, frame_layers=((5, 512), (5, 512), (5, 512), (1, 1500))))   # receptive field 13 > 10
+
+
 def _shipped_combinations():
     import json
     import os
@@ -262,8 +291,10 @@ def compare_step_with_oracle(eng, cfg_o, newV, info, lr, endpoint_tol=5e-5, grad
     raw, reg = eng.losses()
     assert abs(raw - info["raw_loss"]) <= 2e-5 * abs(info["raw_loss"]) + 1e-6, (raw, info["raw_loss"])
     assert abs(reg - info["reg_loss"]) <= 2e-5 * abs(info["reg_loss"])
-    names = ["tdnn1_conv", "tdnn1_relu", "tdnn2_conv", "tdnn3_conv", "tdnn3_relu", "tdnn4_dense", "tdnn5_dense",
-             "tdnn5_bn", "tdnn5_relu", "pooling", "tdnn6_dense", "tdnn6_relu", "tdnn7_dense", "output", "logits"]
+    fl = O.frame_layers(cfg_o)
+    nf = len(fl)
+    names = ["%s_%s" % (p, kind) for p, kind, _, _ in fl] + ["tdnn1_relu", "tdnn3_relu", "tdnn%d_bn" % nf, "tdnn%d_relu" % nf, "pooling",
+                                                            "tdnn%d_dense" % (nf + 1), "tdnn%d_relu" % (nf + 1), "tdnn%d_dense" % (nf + 2), "output", "logits"]
     if cfg_o.pooling_type == "self_attention":
         names += ["att_key0_dense", "att_key0_relu", "att_key1_dense", "attention_weights"]
     for name in names:
@@ -283,7 +314,8 @@ def compare_step_with_oracle(eng, cfg_o, newV, info, lr, endpoint_tol=5e-5, grad
             scale = max(np.abs(ref).max(), 1e-2 * np.abs(info["grads"][name.replace("/bias", "/kernel")]).max())
             assert np.abs(g - ref).max() <= grad_tol * scale, (name, np.abs(g - ref).max(), scale)
             continue
-        if name.endswith("_conv/bias") or (name.endswith("_dense/bias") and not (name.startswith("tdnn/tdnn7") and cfg_o.last_layer_no_bn)):
+        last = "tdnn/tdnn%d_" % (len(O.frame_layers(cfg_o)) + 2)
+        if name.endswith("_conv/bias") or (name.endswith("_dense/bias") and not (name.startswith(last) and cfg_o.last_layer_no_bn)):
             # bias in front of a BatchNorm: the true gradient is exactly 0, both sides hold rounding noise
             assert np.abs(g).max() <= 1e-4 * max(1.0, np.abs(info["grads"][name.replace("/bias", "/kernel")]).max())
             continue

@@ -41,7 +41,12 @@ def torch_forward(V, x, cfg, labels, step, training=True):
             y = F.batch_norm(z2, mm, mv, g, b, False, 0.0, eps)
         return y.reshape(z.shape)
 
-    for prefix, kind in O._FRAME_LAYERS:
+    # the torch side builds the stack from the table itself (reference: 5/5/7/1/1; extended: cfg.frame_layers), not from the oracle's helper
+    table = cfg.frame_layers if cfg.frame_layers else ((5, 512), (5, 512), (7, 512), (1, 512), (1, cfg.num_nodes_pooling_layer))
+    nf = len(table)
+    s0, s1 = "tdnn%d" % (nf + 1), "tdnn%d" % (nf + 2)
+    for li, (ctx, _) in enumerate(table):
+        prefix, kind = "tdnn%d" % (li + 1), ("conv" if ctx > 1 else "dense")
         name = "%s_%s" % (prefix, kind)
         K, b = tv["tdnn/%s/kernel" % name], tv["tdnn/%s/bias" % name]
         if kind == "conv":
@@ -54,7 +59,7 @@ def torch_forward(V, x, cfg, labels, step, training=True):
         ep[prefix + "_relu"] = h
     if cfg.pooling_type == "self_attention":
         a0, a1 = "tdnn/attention/att_key0/att_key0_dense/", "tdnn/attention/att_key1/att_key1_dense/"
-        k = act("att_key0", bn("att_key0", F.linear(ep["tdnn4_relu"], tv[a0 + "kernel"].t(), tv[a0 + "bias"]), "attention/att_key0/"),
+        k = act("att_key0", bn("att_key0", F.linear(ep["tdnn%d_relu" % (nf - 1)], tv[a0 + "kernel"].t(), tv[a0 + "bias"]), "attention/att_key0/"),
                 "attention/att_key0/")
         k = F.linear(k, tv[a1 + "kernel"].t(), tv[a1 + "bias"])
         ep["att_key1_dense"] = k
@@ -78,16 +83,16 @@ def torch_forward(V, x, cfg, labels, step, training=True):
     var = (1 - mask) * var + mask * 1e-12
     h = torch.cat([mean, var.sqrt()], dim=1)
     ep["pooling"] = h
-    z = F.linear(h, tv["tdnn/tdnn6_dense/kernel"].t(), tv["tdnn/tdnn6_dense/bias"])
-    ep["tdnn6_dense"] = z
-    h = act("tdnn6", bn("tdnn6", z))
-    z = F.linear(h, tv["tdnn/tdnn7_dense/kernel"].t(), tv["tdnn/tdnn7_dense/bias"])
-    ep["tdnn7_dense"] = z
+    z = F.linear(h, tv["tdnn/%s_dense/kernel" % s0].t(), tv["tdnn/%s_dense/bias" % s0])
+    ep[s0 + "_dense"] = z
+    h = act(s0, bn(s0, z))
+    z = F.linear(h, tv["tdnn/%s_dense/kernel" % s1].t(), tv["tdnn/%s_dense/bias" % s1])
+    ep[s1 + "_dense"] = z
     h = z
     if not cfg.last_layer_no_bn:
-        h = bn("tdnn7", h)
+        h = bn(s1, h)
     if not cfg.last_layer_linear:
-        h = act("tdnn7", h)
+        h = act(s1, h)
     if cfg.feature_norm:
         ss = (h * h).sum(dim=-1, keepdim=True)
         h = h * torch.rsqrt(torch.clamp(ss, min=1e-12)) * cfg.feature_scaling_factor
@@ -171,10 +176,17 @@ CASES = [
     dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, network_relu_type="prelu",
          pooling_type="self_attention", att_key_num_nodes=(16, 12), att_key_network_type=1),
     dict(loss_func="softmax", network_relu_type="lrelu", pooling_type="self_attention", att_key_num_nodes=(16, 12), att_key_network_type=2),
+    # extended frame-layer tables (no reference counterpart, BASELINE configs[4]): 10 layers of mixed contexts, a 3-layer stack,
+    # and a 6-layer one under the attention head (key input = the last-but-one frame layer)
+    dict(loss_func="asoftmax", margin_m=4, lambda_min=10, lambda_gamma=1e-5, last_layer_linear=True,
+         frame_layers=((5, 16), (1, 16), (3, 24), (1, 16), (3, 16), (1, 16), (3, 16), (1, 16), (1, 16), (1, 20))),
+    dict(loss_func="softmax", frame_layers=((3, 8), (2, 12), (1, 20))),
+    dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, pooling_type="self_attention", att_key_num_nodes=(16, 12),
+         frame_layers=((5, 16), (3, 16), (1, 24), (3, 16), (1, 12), (1, 20))),
 ]
 
 
-@pytest.mark.parametrize("kw", CASES, ids=lambda d: d["loss_func"] + "_" + str(d.get("margin_m", "")) + ("_att%d" % d["att_key_network_type"] if "att_key_network_type" in d else "_att" if "pooling_type" in d else "") + ("_aux" if "aux_loss_func" in d else "") + ("_" + d["network_relu_type"] if "network_relu_type" in d else ""))
+@pytest.mark.parametrize("kw", CASES, ids=lambda d: d["loss_func"] + "_" + str(d.get("margin_m", "")) + ("_%dlayers" % len(d["frame_layers"]) if "frame_layers" in d else "") + ("_att%d" % d["att_key_network_type"] if "att_key_network_type" in d else "_att" if "pooling_type" in d else "") + ("_aux" if "aux_loss_func" in d else "") + ("_" + d["network_relu_type"] if "network_relu_type" in d else ""))
 def test_full_step_forward_backward(kw):
     cfg = O.Config(feat_dim=6, num_speakers=11, num_nodes_pooling_layer=20, num_nodes_last_layer=16, **kw)
     # the layer widths 512 are fixed by tdnn.py; keep B,T small instead
@@ -194,7 +206,8 @@ def test_full_step_forward_backward(kw):
 
     assert abs(float(loss.detach()) - float(info["raw_loss"])) < 1e-10 * max(1, abs(float(loss.detach())))
     assert abs(float((loss + reg).detach()) - float(info["total_loss"])) < 1e-10 * max(1, abs(float((loss + reg).detach())))
-    names = ["tdnn1_conv", "tdnn3_conv", "tdnn5_dense", "pooling", "tdnn6_dense", "tdnn7_dense", "output"]
+    nf = len(cfg.frame_layers) if cfg.frame_layers else 5
+    names = ["tdnn1_conv", "tdnn3_conv" if not cfg.frame_layers else "tdnn1_relu", "pooling", "tdnn%d_dense" % (nf + 1), "tdnn%d_dense" % (nf + 2), "output"]
     if cfg.pooling_type == "self_attention":
         names += ["att_key1_dense", "attention_weights"]
     for name in names:

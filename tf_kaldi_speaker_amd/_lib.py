@@ -57,6 +57,9 @@ class XvConfig(C.Structure):
         ("ring_loss_lambda", C.c_float),
         ("aux_mhe", C.c_int32),
         ("mhe_lambda", C.c_float),
+        ("num_frame_layers", C.c_int32),
+        ("frame_context", C.c_int32 * 12),
+        ("frame_width", C.c_int32 * 12),
     ]
 
 
@@ -160,6 +163,7 @@ SIGNATURES = {
 }
 
 XV_BWD_STAGES = 4
+XV_MAX_FRAME_LAYERS = 12
 _lib = None
 
 

@@ -60,12 +60,21 @@ struct xv_engine {
     std::vector<Var> vars;
     size_t n_train = 0, n_all = 0, n_opt = 0;
     float *V = nullptr, *G = nullptr, *S = nullptr;   // bound buffers
-    Affine L[9];                          // tdnn1..7, then the attention key layers att_key0, att_key1 (self-attention pooling)
+    // frame-level layers tdnn1..tdnnF (F = 5 in the reference, tdnn.py:35-127; any table of (context, width) in the extended
+    // form), then the two segment-level layers tdnn(F+1), tdnn(F+2), then the attention key layers att_key0, att_key1
+    std::vector<Affine> L;
+    int F = 5;                            // frame-level layers
     int NL = 7;                           // layers in use
+    int S0() const { return F; }          // index of the first segment-level layer (tdnn6 in the reference)
+    int S1() const { return F + 1; }
+    int K0() const { return F + 2; }      // attention key layers
+    int K1() const { return F + 3; }
+    int amax_a = 1, amax_wt = 0, amax_dz = 0;   // slot ranges inside `amax`, see amax layout below
     bool att = false;
     int v_query = -1;
     float *att_score = nullptr, *att_w = nullptr, *att_dw = nullptr, *att_ds = nullptr;   // [B*T5]
-    float* bufA = nullptr;                // d tdnn4_relu through the key network, [B*T5][512]
+    float* bufA = nullptr;                // d (key input) through the key network, [B*T_pool][width of tdnn(F-1)]
+    int min_frames = 15;                  // receptive field of the frame layers
     float* bwd_part = nullptr;            // BN-backward reduction partials written by a data-gradient GEMM epilogue
     int bwd_part_layer = -1, bwd_part_chunks = 0;   // ... for this layer's BN backward (-1: none pending)
     int v_loss_kernel = -1, v_loss_bias = -1, v_ring = -1;
@@ -107,7 +116,7 @@ struct xv_engine {
     bool reg_valid = false;
     // state of the most recent forward
     int B = 0, T = 0, training = 0;
-    int Tl[6] = {0, 0, 0, 0, 0, 0};   // frames after each frame layer (index 0 = input)
+    int Tl[XV_MAX_FRAME_LAYERS + 1] = {};   // frames after each frame layer (index 0 = input)
     float lambda = 0.f;
     int with_margin = 1;
     hipStream_t last_stream = nullptr;
@@ -116,12 +125,16 @@ struct xv_engine {
 
 namespace {
 
-// amax slots: 0 input x | 1..5 BN+ReLU outputs of tdnn1..4, att_key0 | 8..14 weights of tdnn1..5, att_key0/1 (both layouts) |
-// 24..30 dz of tdnn1..5, att_key0/1 (one slot per layer: zeroed once per backward pass, not once per layer)
-enum { AMAX_X = 0, AMAX_A = 1, AMAX_WT = 8, AMAX_DZ = 24, AMAX_SLOTS = 32 };
+// amax layout (F = frame layers): 0 input x | amax_a + [0, F): BN+ReLU outputs of tdnn1..F-1 and att_key0 (slot F-1) |
+// amax_wt + [0, F+2): weights of tdnn1..F, att_key0/1 (both layouts share a slot) | amax_dz + [0, F+2): dz of the same layers
+// (one slot per layer: zeroed once per backward pass, not once per layer)
+enum { AMAX_X = 0, AMAX_SLOTS = 64 };
+#define AMAX_A (e->amax_a)
+#define AMAX_WT (e->amax_wt)
+#define AMAX_DZ (e->amax_dz)
 
-// frame-level layers (rows = chunks x frames): tdnn1-5 and the attention key layers; tdnn6/7 are segment level
-inline bool is_frame(int i) { return i < 5 || i >= 7; }
+// frame-level layers (rows = chunks x frames): tdnn1..F and the attention key layers; the two layers after pooling are segment level
+inline bool is_frame(const xv_engine* e, int i) { return i < e->F || i >= e->F + 2; }
 
 float* carve(xv_engine* e, size_t floats) {
     size_t bytes = xv_align(floats * sizeof(float), 256);
@@ -155,37 +168,46 @@ void build_variables(xv_engine* e) {
     e->Lout = c.num_nodes_last_layer;
     e->N = c.num_speakers;
     e->att = c.pooling == XV_POOL_SELF_ATTENTION;
-    e->NL = e->att ? 9 : 7;
-    struct Spec { const char* prefix; const char* kind; const char* scope; int k, cin, cout; bool bn, relu, fused; int in_layer, act; };
-    const Spec specs[9] = {
-        {"tdnn1", "conv", "", 5, D, 512, true, true, true, -1, 0},
-        {"tdnn2", "conv", "", 5, 512, 512, true, true, true, 0, 0},
-        {"tdnn3", "conv", "", 7, 512, 512, true, true, true, 1, 0},
-        {"tdnn4", "dense", "", 1, 512, 512, true, true, false, 2, 0},
-        {"tdnn5", "dense", "", 1, 512, e->P, true, true, false, 3, 0},
-        {"tdnn6", "dense", "", 1, 2 * e->P, 512, true, true, false, -1, 0},
-        {"tdnn7", "dense", "", 1, 512, e->Lout, !c.last_layer_no_bn, !c.last_layer_linear, false, 5, 0},
-        // self-attention key network (pooling.py:78-96): dense+bn+relu on tdnn4_relu, then dense (+tanh)
-        {"att_key0", "dense", "attention/att_key0/", 1, 512, c.att_key0_nodes, true, true, false, 3, 0},
-        // last key layer (att_key_network_type): 0 affine, 1 + relu, 3 + tanh as an activation inside the score kernels; 2 = + bn + relu
-        {"att_key1", "dense", "attention/att_key1/", 1, c.att_key0_nodes, c.att_key1_nodes, c.att_key_type == 2, c.att_key_type == 2, false, 7,
-         c.att_key_type == 2 ? 0 : c.att_key_type},
-    };
-    // graph-construction order of the reference: tdnn1-5, the pooling layer's variables, tdnn6-7
-    const int order[9] = {0, 1, 2, 3, 4, 7, 8, 5, 6};
-    for (int oi = 0; oi < 9; ++oi) {
-        const int i = order[oi];
+    const int F = e->F;
+    e->NL = e->att ? F + 4 : F + 2;
+    e->L.assign(F + 4, Affine());
+    e->amax_a = 1; e->amax_wt = 1 + F; e->amax_dz = e->amax_wt + F + 2;
+    struct Spec { std::string prefix; const char* kind; const char* scope; int k, cin, cout; bool bn, relu, fused; int in_layer, act; };
+    std::vector<Spec> specs;
+    {
+        int cin = D;
+        for (int i = 0; i < F; ++i) {
+            const int k = c.num_frame_layers > 0 ? c.frame_context[i] : (i == 0 || i == 1 ? 5 : (i == 2 ? 7 : 1));
+            const int w = c.num_frame_layers > 0 ? c.frame_width[i] : (i == F - 1 ? e->P : 512);
+            // [TF] rank-4 inputs (the conv layers, tdnn.py:39-93) take the fused BN kernel: SURVEY N4
+            specs.push_back({"tdnn" + std::to_string(i + 1), k > 1 ? "conv" : "dense", "", k, cin, w, true, true, k > 1, i - 1, 0});
+            cin = w;
+        }
+    }
+    const int Ckey = specs[F - 2].cout;      // the attention key network reads the last-but-one frame layer (tdnn4_relu in the shipped configs)
+    specs.push_back({"tdnn" + std::to_string(F + 1), "dense", "", 1, 2 * e->P, 512, true, true, false, -1, 0});
+    specs.push_back({"tdnn" + std::to_string(F + 2), "dense", "", 1, 512, e->Lout, !c.last_layer_no_bn, !c.last_layer_linear, false, F, 0});
+    // self-attention key network (pooling.py:78-96): dense+bn+relu on the key input, then dense (+tanh)
+    specs.push_back({"att_key0", "dense", "attention/att_key0/", 1, Ckey, c.att_key0_nodes, true, true, false, F - 2, 0});
+    // last key layer (att_key_network_type): 0 affine, 1 + relu, 3 + tanh as an activation inside the score kernels; 2 = + bn + relu
+    specs.push_back({"att_key1", "dense", "attention/att_key1/", 1, c.att_key0_nodes, c.att_key1_nodes, c.att_key_type == 2, c.att_key_type == 2, false,
+                     F + 2, c.att_key_type == 2 ? 0 : c.att_key_type});
+    // graph-construction order of the reference: the frame layers, the pooling layer's variables, the segment layers
+    std::vector<int> order;
+    for (int i = 0; i < F; ++i) order.push_back(i);
+    order.push_back(F + 2); order.push_back(F + 3); order.push_back(F); order.push_back(F + 1);
+    for (int i : order) {
         if (i >= e->NL) continue;
         Affine& a = e->L[i];
         const Spec& s = specs[i];
         a.prefix = s.prefix; a.kind = s.kind; a.scope = s.scope; a.in_layer = s.in_layer; a.act = s.act;
         a.k = s.k; a.c_in = s.cin; a.c_out = s.cout;
         // operand pitch: 16-byte chunks of fp16 planes need multiples of 8 (feature layer 30 -> 32, att_key1 1500 -> 1504)
-        a.c_pad = (int)xv_align(s.cin, (i == 0 || (e->f16 && is_frame(i))) ? 8 : 4);
+        a.c_pad = (int)xv_align(s.cin, (i == 0 || (e->f16 && is_frame(e, i))) ? 8 : 4);
         a.o_ld = (int)xv_align(s.cout, 8);
         a.has_bn = s.bn; a.has_relu = s.relu; a.fused_bn = s.fused;
-        a.wslot = i < 5 ? i : i - 2;          // amax slots of the weights: tdnn1-5 -> 0..4, att_key0/1 -> 5, 6
-        a.aslot = i < 5 ? i : 4;              // BN+ReLU output planes: tdnn1-4 -> 0..3, att_key0 -> 4
+        a.wslot = i < F ? i : i - 2;          // amax slots of the weights: tdnn1..F -> 0..F-1, att_key0/1 -> F, F+1
+        a.aslot = i < F ? i : F - 1;          // BN+ReLU output planes: tdnn1..F-1 -> 0..F-2, att_key0 -> F-1
         std::string base = std::string("tdnn/") + s.scope + s.prefix + "_" + s.kind;
         if (s.k > 1) a.v_kernel = add_var(e, base + "/kernel", {1, s.k, s.cin, s.cout}, true);
         else a.v_kernel = add_var(e, base + "/kernel", {s.cin, s.cout}, true);
@@ -198,7 +220,7 @@ void build_variables(xv_engine* e) {
             a.v_mmean = add_var(e, bn + "/moving_mean", {s.cout}, false);
             a.v_mvar = add_var(e, bn + "/moving_variance", {s.cout}, false);
         }
-        if (i == 8) e->v_query = add_var(e, "tdnn/attention/query", {1, s.cout}, true);   // [heads, key dim], pooling.py:131
+        if (i == F + 3) e->v_query = add_var(e, "tdnn/attention/query", {1, s.cout}, true);   // [heads, key dim], pooling.py:131
     }
     e->c_pad0 = e->L[0].c_pad;
     if (e->N > 0) {
@@ -216,24 +238,37 @@ void build_variables(xv_engine* e) {
 
     // backward stages -> contiguous gradient ranges (stage 0 finishes the tail of the buffer)
     auto first_off = [&](int layer) { return e->vars[e->L[layer].v_kernel].offset; };
-    e->stage_begin[0] = first_off(5); e->stage_end[0] = e->n_train;   // tdnn6, tdnn7, loss
-    e->stage_begin[1] = first_off(3); e->stage_end[1] = first_off(5); // tdnn4, tdnn5
-    e->stage_begin[2] = first_off(2); e->stage_end[2] = first_off(3); // tdnn3
-    e->stage_begin[3] = 0;            e->stage_end[3] = first_off(2); // tdnn1, tdnn2
+    // stage 0: segment layers + loss | 1: the last two frame layers (+ attention keys, created between them and the segment
+    // layers) | 2: the middle frame layers | 3: the first two (reference F = 5: tdnn4-5 | tdnn3 | tdnn1-2)
+    const int lo = F >= 4 ? 2 : 1;                                     // first layer of stage 2
+    e->stage_begin[0] = first_off(F);     e->stage_end[0] = e->n_train;
+    e->stage_begin[1] = first_off(F - 2); e->stage_end[1] = first_off(F);
+    e->stage_begin[2] = first_off(lo);    e->stage_end[2] = first_off(F - 2);
+    e->stage_begin[3] = 0;                e->stage_end[3] = first_off(lo);
 }
 
 int alloc_buffers(xv_engine* e) {
     const xv_config& c = e->cfg;
     const size_t B = c.max_batch, T = c.max_frames;
-    XV_REQUIRE(B >= 1 && T >= 15, "engine: max_batch >= 1 and max_frames >= 15 required (receptive field of tdnn1-3)");
-    size_t rows[6];
-    rows[0] = B * T; rows[1] = B * (T - 4); rows[2] = B * (T - 8); rows[3] = rows[4] = rows[5] = B * (T - 14);
+    const int F = e->F;
+    int field = 1;
+    for (int i = 0; i < F; ++i) field += e->L[i].k - 1;
+    e->min_frames = field;
+    XV_REQUIRE(B >= 1 && (int)T >= field, "engine: max_batch >= 1 and max_frames >= %d required (receptive field of the frame layers)", field);
+    std::vector<size_t> rows(F + 1);      // rows[i] = chunks x frames entering frame layer i; rows[F] = frames that are pooled
+    {
+        size_t t_cur = T;
+        rows[0] = B * T;
+        for (int i = 0; i < F; ++i) { t_cur -= (size_t)(e->L[i].k - 1); rows[i + 1] = B * t_cur; }
+    }
+    const size_t rows_pool = rows[F];
+    const int c_key_in = e->L[F - 2].c_out;
     e->ldl = e->N > 0 ? (int)xv_align(e->N, 4) : 0;
     // --- size pass
     size_t need = 0;
     auto want = [&](size_t floats) { need += xv_align(floats * sizeof(float), 256); };
     want(rows[0] * e->c_pad0);
-    auto lrows = [&](int i) -> size_t { return i < 5 ? rows[i + 1] : (i >= 7 ? rows[5] : B); };
+    auto lrows = [&](int i) -> size_t { return i < F ? rows[i + 1] : (i >= F + 2 ? rows_pool : B); };
     for (int i = 0; i < e->NL; ++i) {
         Affine& a = e->L[i];
         size_t r = lrows(i);
@@ -246,33 +281,40 @@ int alloc_buffers(xv_engine* e) {
     if (e->f16) {
         want(rows[0] * e->c_pad0);                                              // xh: 2 planes of halfs == 1 float per element
         for (int i = 0; i < e->NL; ++i) {
-            if (!is_frame(i)) continue;
+            if (!is_frame(e, i)) continue;
             Affine& a = e->L[i];
             want((size_t)a.c_out * a.k * a.c_pad);                              // wth
             if (i > 0) want((size_t)a.c_in * a.k * a.o_ld);                     // wfh
-            if (i < 4 || i == 7) want(lrows(i) * a.o_ld);                       // ah
+            if (i < F - 1 || i == F + 2) want(lrows(i) * a.o_ld);               // ah
             want(a.c_out); want(a.c_out);                                       // zmin, zmax
         }
         want(AMAX_SLOTS);
     }
-    if (e->att) { for (int j = 0; j < 4; ++j) want(rows[5]); want(rows[5] * 512); }
+    if (e->att) { for (int j = 0; j < 4; ++j) want(rows_pool); want(rows_pool * c_key_in); }
     want(B * 2 * e->P); want(B * e->Lout); want(B * e->Lout);
     if (e->N > 0 && c.aux_mhe) { want(1 + 2 * (size_t)e->Lout); want(e->N); }
     if (e->N > 0) {
         want(B * e->ldl); want(B * e->ldl); want(B); want(B);
         want(e->N); want((size_t)e->Lout * e->ldl); want((size_t)e->N * e->Lout); want((size_t)e->Lout * e->ldl);
     }
-    size_t maxc = e->P > 512 ? e->P : 512;
-    if (e->att) { maxc = std::max<size_t>(maxc, (size_t)c.att_key0_nodes); maxc = std::max<size_t>(maxc, (size_t)c.att_key1_nodes); }
-    size_t bufd = rows[1] * 512;
-    if (rows[5] * maxc > bufd) bufd = rows[5] * maxc;
-    size_t bufz = B * (T - 8 + 8) * 512;                        // tdnn2: (T2 + 2*4) frames
-    if (B * (T - 14 + 12) * 512 > bufz) bufz = B * (T - 14 + 12) * 512;
-    if (rows[5] * maxc > bufz) bufz = rows[5] * maxc;
-    if (rows[1] * 512 > bufz) bufz = rows[1] * 512;
+    // widest frame-level tensor (channels) and the ping-pong buffers of the backward pass: bufD holds d(layer output) /
+    // d(layer input) ([rows][c]), bufZ a dz with k-1 zero frames around every chunk
+    size_t maxc = 512;
+    size_t bufd = 0, bufz = 0, max_pad_rows = 0;
+    for (int i = 0; i < e->NL; ++i) {
+        if (!is_frame(e, i)) continue;
+        const Affine& a = e->L[i];
+        maxc = std::max<size_t>(maxc, (size_t)a.c_out);
+        maxc = std::max<size_t>(maxc, (size_t)a.c_in);
+        const size_t r_out = lrows(i), r_in = i < F ? rows[i] : rows_pool;
+        bufd = std::max(bufd, std::max(r_out * a.c_out, r_in * (size_t)a.c_in));
+        const size_t padded = r_out + B * 2 * (size_t)(a.k - 1);
+        bufz = std::max(bufz, padded * a.c_out);
+        max_pad_rows = std::max(max_pad_rows, padded);
+    }
     want(bufd); want(bufz); want(bufz);
     if (e->f16) want((size_t)xv_cdiv(rows[1], XV_TILE_M) * 3 * maxc);
-    const size_t dzh_halfs = xv_align(B * (T + 12) * (size_t)xv_align(maxc, 8), 8);
+    const size_t dzh_halfs = xv_align(max_pad_rows * (size_t)xv_align(maxc, 8), 8);
     if (e->f16) { want(dzh_halfs); want(dzh_halfs); }
     want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512)); want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512));
     want(16);
@@ -284,7 +326,7 @@ int alloc_buffers(xv_engine* e) {
         int M = a.k * a.c_pad, Nn = a.c_out;
         size_t s = (size_t)xv_tn_splits(M, Nn, (int)r) * M * Nn * sizeof(float);
         if (s > ws) ws = s;
-        if (e->f16 && is_frame(i)) {
+        if (e->f16 && is_frame(e, i)) {
             s = (size_t)xv_tn16_splits(M, a.o_ld, (int)r) * M * a.o_ld * sizeof(float);
             if (s > ws) ws = s;
         }
@@ -298,7 +340,7 @@ int alloc_buffers(xv_engine* e) {
     size_t opws = xv_op_workspace_bytes((int)rows[1], 2 * e->P, 2 * e->P);
     if (opws > ws) ws = opws;
     if (e->att) {       // xv_att_key_backward: per-chunk partials + the column-sum workspace
-        size_t s = 2 * ((size_t)xv_cdiv(rows[5], 64) * 2 * c.att_key1_nodes * sizeof(float) + xv_op_workspace_bytes((int)rows[5], c.att_key1_nodes, c.att_key1_nodes)) + 4096;
+        size_t s = 2 * ((size_t)xv_cdiv(rows_pool, 64) * 2 * c.att_key1_nodes * sizeof(float) + xv_op_workspace_bytes((int)rows_pool, c.att_key1_nodes, c.att_key1_nodes)) + 4096;
         if (s > ws) ws = s;
     }
     ws = xv_align(ws, 256);
@@ -324,7 +366,7 @@ int alloc_buffers(xv_engine* e) {
     if (e->f16) {
         e->xh = (unsigned short*)carve(e, rows[0] * e->c_pad0);
         for (int i = 0; i < e->NL; ++i) {
-            if (!is_frame(i)) continue;
+            if (!is_frame(e, i)) continue;
             Affine& a = e->L[i];
             a.wth_stride = (size_t)a.c_out * a.k * a.c_pad;
             a.wth = (unsigned short*)carve(e, a.wth_stride);
@@ -332,15 +374,15 @@ int alloc_buffers(xv_engine* e) {
                 a.wfh_stride = (size_t)a.c_in * a.k * a.o_ld;
                 a.wfh = (unsigned short*)carve(e, a.wfh_stride);
             }
-            if (i < 4 || i == 7) a.ah = (unsigned short*)carve(e, lrows(i) * a.o_ld);
+            if (i < F - 1 || i == F + 2) a.ah = (unsigned short*)carve(e, lrows(i) * a.o_ld);
             a.zmin = carve(e, a.c_out);
             a.zmax = carve(e, a.c_out);
         }
         e->amax = (uint32_t*)carve(e, AMAX_SLOTS);
     }
     if (e->att) {
-        e->att_score = carve(e, rows[5]); e->att_w = carve(e, rows[5]); e->att_dw = carve(e, rows[5]); e->att_ds = carve(e, rows[5]);
-        e->bufA = carve(e, rows[5] * 512);
+        e->att_score = carve(e, rows_pool); e->att_w = carve(e, rows_pool); e->att_dw = carve(e, rows_pool); e->att_ds = carve(e, rows_pool);
+        e->bufA = carve(e, rows_pool * c_key_in);
     }
     e->pool = carve(e, B * 2 * e->P);
     e->h7_buf = carve(e, B * e->Lout);
@@ -398,7 +440,7 @@ int ensure_weights(xv_engine* e, hipStream_t s) {
     for (int i = 0; i < e->NL; ++i) {
         Affine& a = e->L[i];
         const float* w = vptr(e, a.v_kernel);
-        if (e->f16 && is_frame(i)) {
+        if (e->f16 && is_frame(e, i)) {
             // fp16 planes scaled by the tensor's own max |w|; the forward and dgrad layouts hold the same values, so one
             // max per layer, taken on the variable itself
             const unsigned* am = e->amax + AMAX_WT + a.wslot;
@@ -419,7 +461,7 @@ int ensure_weights(xv_engine* e, hipStream_t s) {
         }
     }
     if (A.n) {
-        XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_WT, 0, 16 * sizeof(uint32_t), s));
+        XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_WT, 0, (e->F + 2) * sizeof(uint32_t), s));
         int rc = xv_launch_amax_multi(s, A);
         if (rc) return rc;
     }
@@ -482,8 +524,20 @@ extern "C" int xv_engine_create(const xv_config* cfg, xv_engine** out) {
     }
     XV_REQUIRE(!cfg->aux_mhe || cfg->num_speakers == 0 || cfg->loss_kind != XV_LOSS_SOFTMAX,
                "engine_create: mhe_loss needs a loss with normalised speaker weights (asoftmax / additive margin losses)");
+    if (cfg->num_frame_layers != 0) {       // extended frame-layer table (no reference counterpart: tdnn.py hard-codes 5 layers)
+        XV_REQUIRE(cfg->num_frame_layers >= 3 && cfg->num_frame_layers <= XV_MAX_FRAME_LAYERS,
+                   "engine_create: num_frame_layers must be 0 (the reference's 5) or 3..%d (got %d)", XV_MAX_FRAME_LAYERS, cfg->num_frame_layers);
+        for (int i = 0; i < cfg->num_frame_layers; ++i) {
+            XV_REQUIRE(cfg->frame_context[i] >= 1 && cfg->frame_context[i] <= 15, "engine_create: frame_context[%d] = %d is outside 1..15", i, cfg->frame_context[i]);
+            XV_REQUIRE(cfg->frame_width[i] > 0 && cfg->frame_width[i] % 4 == 0, "engine_create: frame_width[%d] = %d must be a positive multiple of 4", i,
+                       cfg->frame_width[i]);
+        }
+        XV_REQUIRE(cfg->frame_width[cfg->num_frame_layers - 1] == cfg->num_nodes_pooling_layer,
+                   "engine_create: the last frame layer is the pooling layer: frame_width[%d] must equal num_nodes_pooling_layer", cfg->num_frame_layers - 1);
+    }
     xv_engine* e = new xv_engine();
     e->cfg = *cfg;
+    e->F = cfg->num_frame_layers > 0 ? cfg->num_frame_layers : 5;
     if (cfg->loss_kind == XV_LOSS_ASOFTMAX && cfg->margin_m == 1.f) {
         // asoftmax with m = 1 returns its plain cross entropy before aux_loss_func is reached (loss.py:110-115): no ring / MHE
         // term, and the variable softmax_ringloss/r is never created
@@ -553,7 +607,7 @@ extern "C" int xv_engine_invalidate_weights(xv_engine* e) {
 extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* features, int b, int t, int training) {
     XV_REQUIRE(e && e->V, "engine_forward: engine not bound");
     XV_REQUIRE(b >= 1 && b <= e->cfg.max_batch, "engine_forward: batch %d exceeds capacity %d", b, e->cfg.max_batch);
-    XV_REQUIRE(t >= 15 && t <= e->cfg.max_frames, "engine_forward: %d frames outside [15, %d]", t, e->cfg.max_frames);
+    XV_REQUIRE(t >= e->min_frames && t <= e->cfg.max_frames, "engine_forward: %d frames outside [%d, %d]", t, e->min_frames, e->cfg.max_frames);
     hipStream_t s = (hipStream_t)stream;
     e->last_stream = s;
     e->B = b; e->T = t; e->training = training;
@@ -561,9 +615,10 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
     if (rc) return rc;
     int cur_t = t;
     e->Tl[0] = t;
+    const int F = e->F;
     if (e->f16) {
         // split precision: every frame-level operand travels as two fp16 planes + a device-side max |x|
-        XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_X, 0, 8 * sizeof(uint32_t), s));
+        XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_X, 0, (1 + F) * sizeof(uint32_t), s));      // x and every BN+ReLU output slot
         rc = xv_amax(s, features, (size_t)b * t * e->cfg.feat_dim, e->amax + AMAX_X);
         if (rc) return rc;
         rc = xv_split_planes(s, features, b * t, e->cfg.feat_dim, e->cfg.feat_dim, e->xh, e->c_pad0, (size_t)b * t * e->c_pad0,
@@ -572,7 +627,7 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
         const unsigned short* curh = e->xh;
         size_t cur_stride = (size_t)b * t * e->c_pad0;
         const uint32_t* cur_amax = e->amax + AMAX_X;
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < F; ++i) {
             Affine& a = e->L[i];
             int t_out = cur_t - a.k + 1;
             int rows = b * t_out;
@@ -580,7 +635,7 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             rc = xv_affine_forward_f16x3(s, curh, cur_stride, cur_amax, b, cur_t, a.c_pad, a.k, a.wth, a.wth_stride,
                                          e->amax + AMAX_WT + a.wslot, vptr(e, a.v_bias), a.z, a.c_out, a.c_out, a.bn_part);
             if (rc) return rc;
-            uint32_t* out_amax = i < 4 ? e->amax + AMAX_A + a.aslot : nullptr;
+            uint32_t* out_amax = i < F - 1 ? e->amax + AMAX_A + a.aslot : nullptr;
             const xv_config& c = e->cfg;
             if (training) {
                 rc = xv_bn_finalize(s, a.bn_part, rows, a.c_out, vptr(e, a.v_gamma), vptr(e, a.v_beta), c.bn_epsilon, c.batchnorm_momentum,
@@ -593,7 +648,7 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
                 if (out_amax) rc = xv_bn_output_range(s, a.bn_part, rows, a.c_out, a.scale, a.shift, 1, a.zmin, a.zmax, out_amax);
             }
             if (rc) return rc;
-            if (i < 4) {
+            if (i < F - 1) {
                 rc = xv_bn_apply_split(s, a.z, rows, a.c_out, a.c_out, a.scale, a.shift, 1, out_amax, a.ah, a.o_ld, (size_t)rows * a.o_ld);
                 if (rc) return rc;
                 curh = a.ah; cur_stride = (size_t)rows * a.o_ld; cur_amax = out_amax;
@@ -603,9 +658,10 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             e->Tl[i + 1] = t_out;
         }
         if (e->att) {
-            // key network on tdnn4_relu (its planes are still there): att_key0 = dense+bn+relu -> planes, att_key1 = dense
+            // key network on the last-but-one frame layer's output (tdnn4_relu; its planes are still there):
+            // att_key0 = dense+bn+relu -> planes, att_key1 = dense
             const xv_config& c = e->cfg;
-            Affine &k0 = e->L[7], &k1 = e->L[8], &in = e->L[3];
+            Affine &k0 = e->L[e->K0()], &k1 = e->L[e->K1()], &in = e->L[F - 2];
             const int rows = b * cur_t;
             uint32_t* k0_amax = e->amax + AMAX_A + k0.aslot;
             rc = xv_affine_forward_f16x3(s, in.ah, (size_t)rows * in.o_ld, e->amax + AMAX_A + in.aslot, rows, 1, k0.c_pad, 1, k0.wth,
@@ -647,23 +703,23 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
         rc = xv_pad_channels(s, features, b * t, e->cfg.feat_dim, e->xpad, e->c_pad0);
         if (rc) return rc;
         const float* cur = e->xpad;
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < F; ++i) {
             Affine& a = e->L[i];
             int t_out = cur_t - a.k + 1;
             int rows = b * t_out;
             rc = xv_affine_forward(s, cur, b, cur_t, a.c_pad, a.k, a.wt, vptr(e, a.v_bias), a.z, a.c_out, a.c_out,
                                    training ? a.bn_part : nullptr, e->ws, e->ws_bytes);
             if (rc) return rc;
-            rc = bn_forward(e, s, a, rows, true, i < 4 ? a.a : nullptr);
+            rc = bn_forward(e, s, a, rows, true, i < F - 1 ? a.a : nullptr);
             if (rc) return rc;
             a.rows = rows;
             cur = a.a; cur_t = t_out;
             e->Tl[i + 1] = t_out;
         }
         if (e->att) {
-            Affine &k0 = e->L[7], &k1 = e->L[8];
+            Affine &k0 = e->L[e->K0()], &k1 = e->L[e->K1()];
             const int rows = b * cur_t;
-            rc = xv_affine_forward(s, e->L[3].a, rows, 1, k0.c_pad, 1, k0.wt, vptr(e, k0.v_bias), k0.z, k0.c_out, k0.c_out,
+            rc = xv_affine_forward(s, e->L[F - 2].a, rows, 1, k0.c_pad, 1, k0.wt, vptr(e, k0.v_bias), k0.z, k0.c_out, k0.c_out,
                                    training ? k0.bn_part : nullptr, e->ws, e->ws_bytes);
             if (rc) return rc;
             rc = bn_forward(e, s, k0, rows, true, k0.a);
@@ -681,7 +737,7 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
     const float* frame_w = nullptr;
     if (e->att) {
         // scores = key.query (/ sqrt(dk)), weights = softmax over the frames of each chunk (pooling.py:134-148)
-        Affine& k1 = e->L[8];
+        Affine& k1 = e->L[e->K1()];
         const float scale = e->cfg.att_use_scale ? 1.0f / sqrtf((float)k1.c_out) : 1.0f;
         rc = xv_att_score(s, k1.has_bn ? k1.a : k1.z, b * cur_t, k1.c_out, k1.c_out, k1.act, vptr(e, e->v_query), scale, e->att_score);
         if (rc) return rc;
@@ -689,17 +745,17 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
         if (rc) return rc;
         frame_w = e->att_w;
     }
-    // tdnn5's BN + ReLU is applied inside the pooling reduction: its [b*t][1500] activation is never written
-    rc = xv_stat_pool_forward_bn(s, e->L[4].z, b, cur_t, e->P, e->L[4].scale, e->L[4].shift, 1, frame_w, e->pool);
+    // the last frame layer's BN + ReLU is applied inside the pooling reduction: its [b*t][1500] activation is never written
+    rc = xv_stat_pool_forward_bn(s, e->L[F - 1].z, b, cur_t, e->P, e->L[F - 1].scale, e->L[F - 1].shift, 1, frame_w, e->pool);
     if (rc) return rc;
     // segment-level layers
-    Affine& l6 = e->L[5];
+    Affine& l6 = e->L[e->S0()];
     rc = xv_affine_forward(s, e->pool, b, 1, l6.c_pad, 1, l6.wt, vptr(e, l6.v_bias), l6.z, l6.c_out, l6.c_out, nullptr, e->ws, e->ws_bytes);
     if (rc) return rc;
     rc = bn_forward(e, s, l6, b, false, l6.a);
     if (rc) return rc;
     l6.rows = b;
-    Affine& l7 = e->L[6];
+    Affine& l7 = e->L[e->S1()];
     rc = xv_affine_forward(s, l6.a, b, 1, l7.c_pad, 1, l7.wt, vptr(e, l7.v_bias), l7.z, l7.c_out, l7.c_out, nullptr, e->ws, e->ws_bytes);
     if (rc) return rc;
     l7.rows = b;
@@ -825,7 +881,7 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     const int pad = (dx && a.k > 1) ? a.k - 1 : 0;
     int rc;
     const int lidx = (int)(&a - &e->L[0]);
-    if (e->f16 && is_frame(lidx)) return layer_backward_f16(e, s, lidx, da, segs, t_in, dx);
+    if (e->f16 && is_frame(e, lidx)) return layer_backward_f16(e, s, lidx, da, segs, t_in, dx);
     const float* dz = nullptr;
     xv_engine::ZRing& zr = e->zr[e->f16 ? 1 : 0];
     const int zi = zr.cur;
@@ -835,12 +891,12 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
         zr.pending[zi] = false;
     }
     if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
-        XV_REQUIRE(&a == &e->L[4] && a.has_bn, "engine_backward: only tdnn5 takes its gradient from the pooling layer");
-        rc = xv_bn_relu_backward_pooled(s, e->pool, e->d_small0, e->att ? e->att_w : nullptr, e->B, e->Tl[5], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale,
+        XV_REQUIRE(lidx == e->F - 1 && a.has_bn, "engine_backward: only the last frame layer takes its gradient from the pooling layer");
+        rc = xv_bn_relu_backward_pooled(s, e->pool, e->d_small0, e->att ? e->att_w : nullptr, e->B, e->Tl[e->F], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale,
                                         a.shift, 1, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
         if (rc) return rc;
         dz = Z;
-    } else if (a.has_bn && pad == 0 && segs * t_out <= XV_BN_SMALL_MAX_ROWS && !is_frame(lidx)) {      // segment-level layers: one launch
+    } else if (a.has_bn && pad == 0 && segs * t_out <= XV_BN_SMALL_MAX_ROWS && !is_frame(e, lidx)) {      // segment-level layers: one launch
         rc = xv_bn_small_backward(s, da, a.z, segs * t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift,
                                   a.has_relu ? 1 : 0, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias));
         if (rc) return rc;
@@ -917,13 +973,13 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
         x.da = da;
         x.zero_amax = false;           // the dz slots were zeroed at the start of this backward pass
         if (!da) {       // tdnn5: the upstream gradient is the (attention-weighted) pooling backward of (pool, d pool)
-            XV_REQUIRE(li == 4, "engine_backward: only tdnn5 takes its gradient from the pooling layer");
-            x.pool_out = e->pool; x.dpool = e->d_small0; x.pool_t = e->Tl[5]; x.weights = e->att ? e->att_w : nullptr;
+            XV_REQUIRE(li == e->F - 1, "engine_backward: only the last frame layer takes its gradient from the pooling layer");
+            x.pool_out = e->pool; x.dpool = e->d_small0; x.pool_t = e->Tl[e->F]; x.weights = e->att ? e->att_w : nullptr;
         } else if (e->bwd_part_layer == li && e->bwd_part_chunks == xv_cdiv(segs * t_out, XV_TILE_M)) {
             // the GEMM that produced `da` already reduced it against this layer's z (xv_affine_dgrad_bnstats_f16x3)
             x.ext_part = e->bwd_part; x.ext_chunks = e->bwd_part_chunks;
         }
-        rc = xv_bn_relu_backward_split_ex(s, x, a.z, da ? segs : e->B * e->Tl[5], da ? t_out : 1, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd,
+        rc = xv_bn_relu_backward_split_ex(s, x, a.z, da ? segs : e->B * e->Tl[e->F], da ? t_out : 1, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd,
                                           a.scale, a.shift, a.zmin, a.zmax, 1, pad, Z, a.o_ld, zstride, zamax, gptr(e, a.v_gamma),
                                           gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
     }
@@ -958,7 +1014,7 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
         // [measured] off by default: the epilogue's extra z-tile reads cost each data-gradient GEMM 50-60 us at S1, the
         // reduce kernels they replace 37 us each (3.17 vs 3.03 ms/step); XV_FUSE_BWD_STATS=1 turns it on for experiments
         static const bool fuse_env = getenv("XV_FUSE_BWD_STATS") && getenv("XV_FUSE_BWD_STATS")[0] == '1';
-        const bool fuse = fuse_env && in >= 0 && is_frame(in) && e->L[in].has_bn && e->L[in].has_relu && !(e->att && in == 3) && e->bwd_part;
+        const bool fuse = fuse_env && in >= 0 && is_frame(e, in) && e->L[in].has_bn && e->L[in].has_relu && !(e->att && in == e->F - 2) && e->bwd_part;
         if (fuse) {
             Affine& p = e->L[in];
             rc = xv_affine_dgrad_bnstats_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WT + a.wslot, dx,
@@ -1020,7 +1076,7 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
     const int b = e->B;
     int rc;
     if (stage == -1 || stage == 0) {
-        if (e->f16) XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_DZ, 0, 8 * sizeof(uint32_t), s));   // every layer's dz scale slot
+        if (e->f16) XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_DZ, 0, (e->F + 2) * sizeof(uint32_t), s));   // every layer's dz scale slot
         // d out = dlogits . wn^T   (pad column of both is zero, so K = ldl is exact)
         XvGemmNT g = {};
         g.A = e->dlogits; g.lda = e->ldl; g.a_rps = 1; g.a_pitch = 1;
@@ -1082,22 +1138,33 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
         }
         // tdnn7 -> d a6 (into bufD), tdnn6 -> d pool (into d_small0); the pooling backward itself is evaluated
         // inside tdnn5's BN backward (stage 1) from (pool, d pool): d a5 is never written
-        rc = layer_backward(e, s, e->L[6], d, e->L[5].a, b, 1, e->bufD, e->h7);
+        rc = layer_backward(e, s, e->L[e->S1()], d, e->L[e->S0()].a, b, 1, e->bufD, e->h7);
         if (rc) return rc;
-        rc = layer_backward(e, s, e->L[5], e->bufD, e->pool, b, 1, e->d_small0, nullptr);
+        rc = layer_backward(e, s, e->L[e->S0()], e->bufD, e->pool, b, 1, e->d_small0, nullptr);
         if (rc) return rc;
         if (stage == 0) { rc = end_stage(e, s, 0, defer); if (rc) return rc; }
     }
+    const int F = e->F;
+    const int Tp = e->Tl[F];          // pooled frames
+    // backward of frame layer i: a context layer sees chunks of Tl[i] frames, a dense layer one "chunk" per frame
+    auto frame_backward = [&](int i, const float* da) -> int {
+        Affine& a = e->L[i];
+        const float* x = i > 0 ? e->L[i - 1].a : e->xpad;
+        float* dx = i > 0 ? e->bufD : nullptr;
+        if (a.k > 1) return layer_backward(e, s, a, da, x, b, e->Tl[i], dx, nullptr);
+        return layer_backward(e, s, a, da, x, b * e->Tl[i + 1], 1, dx, nullptr);
+    };
+    const int lo = F >= 4 ? 2 : 1;    // first layer of stage 2 (build_variables: stage ranges)
     if (stage == -1 || stage == 1) {
         if (e->att) {
             // through the attention weights into the key network (pooling.py:134-155): d weights from the pooled statistics,
-            // softmax backward, then att_key1 (dense [+ tanh]) and att_key0 (dense + bn + relu) down to tdnn4_relu (bufA)
-            Affine &k0 = e->L[7], &k1 = e->L[8];
-            const int rows = b * e->Tl[5];
+            // softmax backward, then att_key1 (dense [+ tanh]) and att_key0 (dense + bn + relu) down to the key input (bufA)
+            Affine &k0 = e->L[e->K0()], &k1 = e->L[e->K1()];
+            const int rows = b * Tp;
             const float scale = c.att_use_scale ? 1.0f / sqrtf((float)k1.c_out) : 1.0f;
-            rc = xv_att_pool_backward_weights(s, e->L[4].z, b, e->Tl[5], e->P, e->L[4].scale, e->L[4].shift, 1, e->pool, e->d_small0, e->att_dw);
+            rc = xv_att_pool_backward_weights(s, e->L[F - 1].z, b, Tp, e->P, e->L[F - 1].scale, e->L[F - 1].shift, 1, e->pool, e->d_small0, e->att_dw);
             if (rc) return rc;
-            rc = xv_softmax_segments_backward(s, e->att_w, e->att_dw, b, e->Tl[5], e->att_ds);
+            rc = xv_softmax_segments_backward(s, e->att_w, e->att_dw, b, Tp, e->att_ds);
             if (rc) return rc;
             // dzk (fp32) takes the current slot of the fp32 dz ring: a segment-level weight gradient (side stream) may still be
             // reading it.  In split precision its consumer (key1's plane split) runs on `s`, so the slot is not flipped; in
@@ -1114,27 +1181,29 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             if (rc) return rc;
             rc = layer_backward(e, s, k1, dzk, k0.a, rows, 1, e->bufD, nullptr);      // -> d att_key0_relu (bufD)
             if (rc) return rc;
-            rc = layer_backward(e, s, k0, e->bufD, e->L[3].a, rows, 1, e->bufA, nullptr);  // -> d tdnn4_relu through the keys (bufA)
+            rc = layer_backward(e, s, k0, e->bufD, e->L[F - 2].a, rows, 1, e->bufA, nullptr);  // -> d (key input) through the keys (bufA)
             if (rc) return rc;
         }
-        rc = layer_backward(e, s, e->L[4], nullptr, e->L[3].a, b * e->Tl[5], 1, e->bufD, nullptr);   // tdnn5 (da = pooling backward) -> d a4
+        rc = frame_backward(F - 1, nullptr);                                           // last frame layer (da = pooling backward)
         if (rc) return rc;
-        if (e->att) rc = xv_add_inplace(s, e->bufD, e->bufA, (size_t)b * e->Tl[5] * 512);                // the two paths into tdnn4_relu
+        if (e->att) rc = xv_add_inplace(s, e->bufD, e->bufA, (size_t)b * Tp * e->L[F - 2].c_out);   // the two paths into the key input
         if (rc) return rc;
-        rc = layer_backward(e, s, e->L[3], e->bufD, e->L[2].a, b * e->Tl[4], 1, e->bufD, nullptr);   // tdnn4
+        rc = frame_backward(F - 2, e->bufD);
         if (rc) return rc;
         if (stage == 1) { rc = end_stage(e, s, 1, defer); if (rc) return rc; }
     }
     if (stage == -1 || stage == 2) {
-        rc = layer_backward(e, s, e->L[2], e->bufD, e->L[1].a, b, e->Tl[2], e->bufD, nullptr);        // tdnn3 -> d a2
-        if (rc) return rc;
+        for (int i = F - 3; i >= lo; --i) {
+            rc = frame_backward(i, e->bufD);
+            if (rc) return rc;
+        }
         if (stage == 2) { rc = end_stage(e, s, 2, defer); if (rc) return rc; }
     }
     if (stage == -1 || stage == 3) {
-        rc = layer_backward(e, s, e->L[1], e->bufD, e->L[0].a, b, e->Tl[1], e->bufD, nullptr);        // tdnn2 -> d a1
-        if (rc) return rc;
-        rc = layer_backward(e, s, e->L[0], e->bufD, e->xpad, b, e->Tl[0], nullptr, nullptr);           // tdnn1
-        if (rc) return rc;
+        for (int i = lo - 1; i >= 0; --i) {
+            rc = frame_backward(i, e->bufD);
+            if (rc) return rc;
+        }
         rc = end_stage(e, s, XV_BWD_STAGES - 1, defer);       // end of the backward pass: every gradient is visible to `stream`
         if (rc) return rc;
     }
@@ -1199,14 +1268,14 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
         Affine& a = e->L[i];
         if (n == a.prefix + "_" + a.kind) return set(a.z, a.rows, a.c_out, a.c_out);
         if (n == a.prefix + "_relu" && a.has_relu) {
-            if ((e->f16 && (i < 4 || i == 7)) || i == 4) {     // not materialised on the hot path (fp16 planes / fused into pooling): rebuild on demand
+            if ((e->f16 && (i < e->F - 1 || i == e->K0())) || i == e->F - 1) {     // not materialised on the hot path (fp16 planes / fused into pooling): rebuild on demand
                 int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 1, a.a, a.c_out);
                 if (rc) return rc;
             }
-            return set(i == 6 ? e->h7 : a.a, a.rows, a.c_out, a.c_out);
+            return set(i == e->S1() ? e->h7 : a.a, a.rows, a.c_out, a.c_out);
         }
         if (n == a.prefix + "_bn" && a.has_bn) {
-            if (!a.has_relu) return set(i == 6 ? e->h7 : a.a, a.rows, a.c_out, a.c_out);
+            if (!a.has_relu) return set(i == e->S1() ? e->h7 : a.a, a.rows, a.c_out, a.c_out);
             // BN output is never materialised on the hot path (fused with ReLU): rebuild on demand
             int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 0, e->bufZ[0], a.c_out);
             if (rc) return rc;
@@ -1215,17 +1284,17 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
     }
     // debug views of the backward scratch (valid right after backward stage 0)
     if (n == "debug:da5") {     // evaluated on demand with the standalone pooling backward (valid after backward stage 0, before stage 1)
-        Affine& a5 = e->L[4];
+        Affine& a5 = e->L[e->F - 1];
         int rc = xv_bn_apply(e->last_stream, a5.z, a5.rows, a5.c_out, a5.c_out, a5.scale, a5.shift, 1, a5.a, a5.c_out);
         if (rc) return rc;
-        rc = xv_stat_pool_backward(e->last_stream, a5.a, e->pool, e->d_small0, e->B, e->Tl[5], e->P, e->bufD);
+        rc = xv_stat_pool_backward(e->last_stream, a5.a, e->pool, e->d_small0, e->B, e->Tl[e->F], e->P, e->bufD);
         if (rc) return rc;
-        return set(e->bufD, e->B * e->Tl[5], e->P, e->P);
+        return set(e->bufD, e->B * e->Tl[e->F], e->P, e->P);
     }
     if (n == "debug:dpool") return set(e->d_small0, e->B, 2 * e->P, 2 * e->P);
-    if (n == "attention_weights" && e->att) return set(e->att_w, e->B, e->Tl[5], e->Tl[5]);     // [b, heads = 1, frames]
-    if (n == "att_key1_relu" && e->att && e->L[8].act == 1) {      // relu key (type 1) lives inside the score kernels: rebuild on demand
-        Affine& k1 = e->L[8];
+    if (n == "attention_weights" && e->att) return set(e->att_w, e->B, e->Tl[e->F], e->Tl[e->F]);     // [b, heads = 1, frames]
+    if (n == "att_key1_relu" && e->att && e->L[e->K1()].act == 1) {      // relu key (type 1) lives inside the score kernels: rebuild on demand
+        Affine& k1 = e->L[e->K1()];
         int rc = xv_relu_backward(e->last_stream, k1.z, k1.z, (size_t)k1.rows * k1.c_out, e->bufZ[0]);      // z > 0 ? z : 0
         if (rc) return rc;
         return set(e->bufZ[0], k1.rows, k1.c_out, k1.c_out);

@@ -46,7 +46,7 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
                 bn_epsilon=1e-3, fused_bn_unbiased_moving_var=True, optimizer="sgd", momentum=0.9, use_nesterov=False,
                 clip_gradient_norm=0.0, max_batch=128, max_frames=400, precision=None, pooling_type="statistics_pooling",
                 att_key_num_nodes=(1500, 1500), att_key_network_type=3, att_use_scale=True, aux_loss_func=(), ring_loss_init=20.0,
-                ring_loss_lambda=0.01, mhe_lambda=0.01):
+                ring_loss_lambda=0.01, mhe_lambda=0.01, frame_layers=None):
     if pooling_type not in POOLINGS:
         raise NotImplementedError("Not implement %s pooling" % pooling_type)
     if loss_func not in LOSS_KINDS:
@@ -89,6 +89,17 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
     c.ring_loss_init, c.ring_loss_lambda = float(ring_loss_init), float(ring_loss_lambda)
     c.aux_mhe = int("mhe_loss" in (aux_loss_func or ()))
     c.mhe_lambda = float(mhe_lambda)
+    if frame_layers:
+        # extended frame-layer table ((context, width), ...): no reference counterpart (model/tdnn.py hard-codes its five layers;
+        # BASELINE configs[4] "extended context, 10 layers").  A width of None / 0 in the last entry = num_nodes_pooling_layer.
+        table = [(int(k), int(w) if w else int(num_nodes_pooling_layer)) for k, w in frame_layers]
+        if not 3 <= len(table) <= _lib.XV_MAX_FRAME_LAYERS:
+            raise ValueError("frame_layers: 3..%d layers (got %d)" % (_lib.XV_MAX_FRAME_LAYERS, len(table)))
+        if table[-1][1] != int(num_nodes_pooling_layer):
+            raise ValueError("frame_layers: the last frame layer is the pooling layer, its width must equal num_nodes_pooling_layer")
+        c.num_frame_layers = len(table)
+        for i, (k, w) in enumerate(table):
+            c.frame_context[i], c.frame_width[i] = k, w
     c.pooling = POOLINGS[pooling_type]
     if pooling_type == "self_attention":
         # the shipped single-head form (nnet_conf/*_tdnn4_att.json): two key layers on tdnn4_relu, value = tdnn5_relu

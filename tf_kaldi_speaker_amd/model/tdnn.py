@@ -19,13 +19,36 @@ except (ImportError, ValueError):
 
 _GRAPH = {"engine": None, "key": None}
 
-ENDPOINT_ORDER = ["tdnn1_conv", "tdnn1_bn", "tdnn1_relu", "tdnn2_conv", "tdnn2_bn", "tdnn2_relu",
-                  "tdnn3_conv", "tdnn3_bn", "tdnn3_relu", "tdnn4_dense", "tdnn4_bn", "tdnn4_relu",
-                  "tdnn5_dense", "tdnn5_bn", "tdnn5_relu",
-                  # self_attention only (pooling.py:78-149); absent names are skipped for statistics pooling
-                  "att_key0_dense", "att_key0_bn", "att_key0_relu", "att_key1_dense", "att_key1_bn", "att_key1_relu", "attention_weights",
-                  "pooling", "tdnn6_dense", "tdnn6_bn", "tdnn6_relu",
-                  "tdnn7_dense", "tdnn7_bn", "tdnn7_relu"]
+# network_type "extended_tdnn": the layer recipe of tdnn() on a caller-supplied table of (context, width) frame layers
+# (params.tdnn_layers).  It has NO counterpart in the reference (model/tdnn.py:39-189 hard-codes 5 + 2 layers; BASELINE configs[4]
+# "extended context, 10 layers"); the default is the 10-layer shape of the extended x-vector recipe with contiguous contexts.
+DEFAULT_EXTENDED_LAYERS = ((5, 512), (1, 512), (3, 512), (1, 512), (3, 512), (1, 512), (3, 512), (1, 512), (1, 512), (1, None))
+
+
+def frame_layer_table(params):
+    """None for the reference network, else [(context, width)] with the pooling width filled in."""
+    if params.dict.get("network_type", "tdnn") != "extended_tdnn":
+        return None
+    table = params.dict.get("tdnn_layers") or DEFAULT_EXTENDED_LAYERS
+    pool = int(params.dict.get("num_nodes_pooling_layer", 1500))
+    return tuple((int(k), int(w) if w else pool) for k, w in table)
+
+
+def endpoint_order(table=None):
+    """Endpoint names in the reference's insertion order (tdnn.py:45-189) for a frame-layer table (None = the reference's)."""
+    table = table or ((5, 512), (5, 512), (7, 512), (1, 512), (1, 1500))
+    names = []
+    for i, (k, _) in enumerate(table):
+        names += ["tdnn%d_%s" % (i + 1, "conv" if k > 1 else "dense"), "tdnn%d_bn" % (i + 1), "tdnn%d_relu" % (i + 1)]
+    # self_attention only (pooling.py:78-149); absent names are skipped for statistics pooling
+    names += ["att_key0_dense", "att_key0_bn", "att_key0_relu", "att_key1_dense", "att_key1_bn", "att_key1_relu", "attention_weights", "pooling"]
+    n = len(table)
+    names += ["tdnn%d_dense" % (n + 1), "tdnn%d_bn" % (n + 1), "tdnn%d_relu" % (n + 1), "tdnn%d_dense" % (n + 2), "tdnn%d_bn" % (n + 2),
+              "tdnn%d_relu" % (n + 2)]
+    return names
+
+
+ENDPOINT_ORDER = endpoint_order()
 
 
 def reset_default_graph():
@@ -45,10 +68,11 @@ def check_params(params):
         # (value network, several heads, split keys, penalty term, post non-linearity) is refused by name
         d = params.dict
         unsupported = []
-        if d.get("att_key_input") != "tdnn4_relu":
-            unsupported.append("att_key_input=%r (tdnn4_relu)" % d.get("att_key_input"))
-        if d.get("att_value_input") != "tdnn5_relu":
-            unsupported.append("att_value_input=%r (tdnn5_relu)" % d.get("att_value_input"))
+        nf = len(frame_layer_table(params) or ()) or 5       # key = the last-but-one frame layer, value = the last (tdnn4_relu / tdnn5_relu)
+        if d.get("att_key_input") != "tdnn%d_relu" % (nf - 1):
+            unsupported.append("att_key_input=%r (tdnn%d_relu)" % (d.get("att_key_input"), nf - 1))
+        if d.get("att_value_input") != "tdnn%d_relu" % nf:
+            unsupported.append("att_value_input=%r (tdnn%d_relu)" % (d.get("att_value_input"), nf))
         if len(d.get("att_value_num_nodes", [])) != 0:
             unsupported.append("att_value_num_nodes (no value network)")
         if len(d.get("att_key_num_nodes", [])) != 2:
@@ -88,6 +112,7 @@ def engine_config(params, dim, num_speakers=0, loss_type="softmax", max_batch=12
               momentum=float(d.get("momentum", 0.0) or 0.0), use_nesterov=bool(d.get("use_nesterov", False)),
               clip_gradient_norm=float(d["clip_gradient_norm"]) if d.get("clip_gradient", False) else 0.0,
               max_batch=max_batch, max_frames=max_frames,
+              frame_layers=frame_layer_table(params),
               precision=d.get("precision", None),      # engine extension: "f32" (default) | "f16x3" (opt-in fast mode); absent from reference configs
               pooling_type=d["pooling_type"])
     if num_speakers and d.get("aux_loss_func"):      # loss.py:985-1036; every loss function adds them (loss.py:40,161,249,347)
@@ -112,7 +137,10 @@ def engine_config(params, dim, num_speakers=0, loss_type="softmax", max_batch=12
 def collect_endpoints(eng, b, names=None):
     """OrderedDict of device tensors in the reference's insertion order; frame-level ones are [B,T_l,C]."""
     out = OrderedDict()
-    for name in (names or ENDPOINT_ORDER):
+    if names is None:
+        nf = int(eng.config.num_frame_layers)
+        names = endpoint_order([(int(eng.config.frame_context[i]), int(eng.config.frame_width[i])) for i in range(nf)] if nf else None)
+    for name in names:
         try:
             t = eng.endpoint(name)
         except Exception:
@@ -129,7 +157,7 @@ def tdnn(features, params, is_training=None, reuse_variables=None, aux_features=
     b, t, dim = x.shape
     check_params(params)
     key = (dim, params.dict["num_nodes_pooling_layer"], params.dict["num_nodes_last_layer"],
-           bool(params.last_layer_no_bn), bool(params.last_layer_linear))
+           bool(params.last_layer_no_bn), bool(params.last_layer_linear), frame_layer_table(params))
     eng = _GRAPH["engine"]
     if eng is None:
         if reuse_variables is True:
@@ -150,5 +178,13 @@ def tdnn(features, params, is_training=None, reuse_variables=None, aux_features=
             _GRAPH["engine"] = eng
     eng.forward(x, bool(is_training))
     endpoints = collect_endpoints(eng, b)
-    last = [k for k in endpoints if k.startswith("tdnn7")][-1]
+    nf = len(frame_layer_table(params) or ()) or 5
+    last = [k for k in endpoints if k.startswith("tdnn%d_" % (nf + 2))][-1]
     return endpoints[last], endpoints
+
+
+def extended_tdnn(features, params, is_training=None, reuse_variables=None, aux_features=None):
+    """tdnn() on params.tdnn_layers (network_type "extended_tdnn"); same signature, same endpoint naming scheme."""
+    if params.dict.get("network_type") != "extended_tdnn":
+        params.dict["network_type"] = "extended_tdnn"
+    return tdnn(features, params, is_training, reuse_variables, aux_features)

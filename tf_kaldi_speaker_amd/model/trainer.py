@@ -29,7 +29,7 @@ try:
     from ..parallel import GradAllReduce, average_bn_statistics, broadcast_variables
     from ..dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, PlannedRandomQueue, DataOutOfRange
     from ..misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state
-    from .tdnn import tdnn, engine_config, collect_endpoints, check_params
+    from .tdnn import tdnn, extended_tdnn, engine_config, collect_endpoints, check_params
     from . import loss as _loss
 except (ImportError, ValueError):      # drop-in layout: PYTHONPATH=$TF_KALDI_ROOT
     import engine as E
@@ -37,7 +37,7 @@ except (ImportError, ValueError):      # drop-in layout: PYTHONPATH=$TF_KALDI_RO
     from parallel import GradAllReduce, average_bn_statistics, broadcast_variables
     from dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, PlannedRandomQueue, DataOutOfRange
     from misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state
-    from model.tdnn import tdnn, engine_config, collect_endpoints, check_params
+    from model.tdnn import tdnn, extended_tdnn, engine_config, collect_endpoints, check_params
     from model import loss as _loss
 
 log = logging.getLogger("tf_kaldi_speaker_amd")
@@ -71,6 +71,8 @@ class Trainer(object):
         self.network_type = params.network_type
         if params.network_type == "tdnn":
             self.network = tdnn
+        elif params.network_type == "extended_tdnn":      # tdnn's layer recipe on params.tdnn_layers (no reference counterpart)
+            self.network = extended_tdnn
         else:
             raise NotImplementedError("Not implement %s network" % params.network_type)
         self.loss_type = None
