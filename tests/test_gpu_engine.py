@@ -191,12 +191,12 @@ def test_train_step_matches_oracle_odd_dimensions(c):
 # Extended frame-layer tables (BASELINE configs[4] "Deep TDNN, extended context, 10 layers"; no reference counterpart - model/tdnn.py
 # hard-codes its five layers): the oracle and the engine build the stack from the same (context, width) table
 EXTENDED = [
-    dict(B=4, T=40, kw=dict(loss_func="asoftmax", margin_m=4, lambda_min=10, lambda_gamma=1e-5, last_layer_linear=True,
+    dict(B=6, T=40, kw=dict(loss_func="asoftmax", margin_m=4, lambda_min=10, lambda_gamma=1e-5, last_layer_linear=True,
                             frame_layers=((5, 512), (1, 512), (3, 512), (1, 512), (3, 512), (1, 512), (3, 512), (1, 512), (1, 512), (1, 1500)))),
     dict(B=5, T=24, kw=dict(loss_func="softmax", frame_layers=((3, 64), (2, 128), (1, 1500)))),
-    dict(B=4, T=36, kw=dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, pooling_type="self_attention",
+    dict(B=6, T=36, kw=dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, pooling_type="self_attention",
                             att_key_num_nodes=(96, 64), frame_layers=((5, 256), (3, 512), (1, 384), (7, 512), (1, 128), (1, 1500)))),
-    dict(B=3, T=60, kw=dict(loss_func="softmax", optimizer="momentum", momentum=0.9,
+    dict(B=6, T=60, kw=dict(loss_func="softmax", optimizer="momentum", momentum=0.9,
                             frame_layers=((5, 512), (5, 512), (7, 512), (1, 512), (1, 512), (3, 256), (1, 256), (3, 512), (1, 512), (1, 512), (1, 512),
                                           (1, 1500)))),
 ]

@@ -123,8 +123,10 @@ struct XvPrepJob {
     long plane;                      // plane stride in elements (16-bit types)
     const unsigned* amax;
 };
-struct XvPrepJobs { int n, total_tiles; XvPrepJob j[16]; };
-struct XvAmaxJobs { int n; const float* x[8]; size_t count[8]; unsigned* out[8]; };
+#define XV_PREP_MAX_JOBS 32      // two layouts x (XV_MAX_FRAME_LAYERS + 2 segment + 2 attention-key layers)
+struct XvPrepJobs { int n, total_tiles; XvPrepJob j[XV_PREP_MAX_JOBS]; };
+#define XV_AMAX_MAX_JOBS 16
+struct XvAmaxJobs { int n; const float* x[XV_AMAX_MAX_JOBS]; size_t count[XV_AMAX_MAX_JOBS]; unsigned* out[XV_AMAX_MAX_JOBS]; };
 int xv_prep_add(XvPrepJobs& J, int type, const float* w, int k, int C, int O, int c_pad, int o_ld, void* dst, long plane, const unsigned* amax);
 int xv_launch_weight_prep(hipStream_t s, const XvPrepJobs& J);
 int xv_launch_amax_multi(hipStream_t s, const XvAmaxJobs& J);

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(XvPrepJobs J) {
 
 int xv_prep_add(XvPrepJobs& J, int type, const float* w, int k, int C, int O, int c_pad, int o_ld, void* dst, long plane,
                 const unsigned* amax) {
-    XV_REQUIRE(J.n < 16, "weight_prep: too many jobs");
+    XV_REQUIRE(J.n < XV_PREP_MAX_JOBS, "weight_prep: too many jobs");
     XvPrepJob& q = J.j[J.n++];
     q.type = type; q.k = k; q.C = C; q.O = O; q.c_pad = c_pad; q.o_ld = o_ld; q.w = w; q.dst = dst; q.plane = plane; q.amax = amax;
     int tiles_y;

@@ -444,6 +444,7 @@ int ensure_weights(xv_engine* e, hipStream_t s) {
             // fp16 planes scaled by the tensor's own max |w|; the forward and dgrad layouts hold the same values, so one
             // max per layer, taken on the variable itself
             const unsigned* am = e->amax + AMAX_WT + a.wslot;
+            XV_REQUIRE(A.n < XV_AMAX_MAX_JOBS, "ensure_weights: too many weight tensors for one amax launch");
             A.x[A.n] = w; A.count[A.n] = (size_t)a.k * a.c_in * a.c_out; A.out[A.n] = e->amax + AMAX_WT + a.wslot; A.n++;
             int rc = xv_prep_add(J, XV_PREP_T16, w, a.k, a.c_in, a.c_out, a.c_pad, a.o_ld, a.wth, (long)a.wth_stride, am);
             if (rc) return rc;
