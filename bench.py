@@ -71,25 +71,37 @@ def pmc_traffic(kind):
     return None
 
 
-def step_flops(b, t, d, n, attention=False):
+REFERENCE_LAYERS = ((5, 512), (5, 512), (7, 512), (1, 512), (1, 1500))          # tdnn.py:35-127
+# BASELINE configs[4] "Deep TDNN (extended context, 10 layers)": no reference counterpart; the 10-layer shape of the
+# extended x-vector recipe with contiguous contexts (tf_kaldi_speaker_amd/model/tdnn.py DEFAULT_EXTENDED_LAYERS)
+EXTENDED_LAYERS = ((5, 512), (1, 512), (3, 512), (1, 512), (3, 512), (1, 512), (3, 512), (1, 512), (1, 512), (1, 1500))
+
+
+def step_flops(b, t, d, n, attention=False, layers=REFERENCE_LAYERS):
     """2*M*K*N per contraction, backward = 2x forward (attention = shape S4: the key network
-    512 -> 1500 -> 1500 of nnet_conf/*_tdnn4_att.json on the T-14 frames)."""
-    t1, t2, t3 = t - 4, t - 8, t - 14
-    fwd = 2.0 * b * (t1 * 5 * d * 512 + t2 * 2560 * 512 + t3 * 3584 * 512 + t3 * 512 * 512 + t3 * 512 * 1500)
-    fwd += 2.0 * b * (3000 * 512 + 512 * 512 + 512 * n)
+    512 -> 1500 -> 1500 of nnet_conf/*_tdnn4_att.json on the pooled frames)."""
+    fwd, cin, tt = 0.0, d, t
+    for k, w in layers:
+        tt -= k - 1
+        fwd += 2.0 * b * tt * k * cin * w
+        cin = w
+    fwd += 2.0 * b * (2 * cin * 512 + 512 * 512 + 512 * n)
     if attention:
-        fwd += 2.0 * b * t3 * (512 * 1500 + 1500 * 1500)
+        fwd += 2.0 * b * tt * (layers[-2][1] * 1500 + 1500 * 1500)
     return fwd, 3.0 * fwd
 
 
-def step_bytes(b, t, d, n):
+def step_bytes(b, t, d, n, layers=REFERENCE_LAYERS):
     """Compulsory HBM traffic of one step under perfect fusion: every frame-level activation
     written once + read once forward, read once more backward, its gradient written + read (5 S); input read twice;
     parameters read fwd + bwd, gradient written + read, parameter written (5 P).  fp32 bytes."""
-    t1, t2, t3 = t - 4, t - 8, t - 14
-    S = 4.0 * b * (t1 * 512 + t2 * 512 + t3 * 512 + t3 * 512 + t3 * 1500)
-    P = 4.0 * (5 * d * 512 + 5 * 512 * 512 + 7 * 512 * 512 + 512 * 512 + 512 * 1500 + 3000 * 512 + 512 * 512 + 512 * n
-               + 6 * 512 * 5 + 1500 * 5)
+    S, P, cin, tt = 0.0, 0.0, d, t
+    for k, w in layers:
+        tt -= k - 1
+        S += 4.0 * b * tt * w
+        P += 4.0 * (k * cin * w + 5 * w)
+        cin = w
+    P += 4.0 * (2 * cin * 512 + 512 * 512 + 512 * n + 2 * 512 * 5)
     return 5.0 * S + 2.0 * 4.0 * b * t * d + 5.0 * P
 
 
@@ -146,10 +158,12 @@ def run_mode(precision, args, dev, rank, world, dist, chunks, t_lo, t_hi, h2d=Fa
     from tf_kaldi_speaker_amd import _lib, engine as E
     from tf_kaldi_speaker_amd.parallel import GradAllReduce
     lib = _lib.load()
-    cfg = E.make_config(D, NSPK, loss_func="additive_margin_softmax", margin_m=0.2, lambda_min=0.0, lambda_base=1000.0,
-                        lambda_gamma=1e-4, lambda_power=5.0, last_layer_linear=True, weight_l2_regularizer=1e-2,
+    loss_kw = (dict(loss_func="asoftmax", margin_m=4, lambda_min=10.0, lambda_base=1000.0, lambda_gamma=1e-5, lambda_power=5.0) if args.extended else
+               dict(loss_func="additive_margin_softmax", margin_m=0.2, lambda_min=0.0, lambda_base=1000.0, lambda_gamma=1e-4, lambda_power=5.0))
+    cfg = E.make_config(D, NSPK, last_layer_linear=True, weight_l2_regularizer=1e-2,
                         batchnorm_momentum=0.99, optimizer="sgd", max_batch=chunks, max_frames=t_hi, precision=precision,
-                        pooling_type="self_attention" if args.attention else "statistics_pooling")
+                        pooling_type="self_attention" if args.attention else "statistics_pooling",
+                        frame_layers=EXTENDED_LAYERS if args.extended else None, **loss_kw)
     eng = E.Engine(cfg, device=str(dev))
     eng.init_variables(seed=0)       # identical replicas on every rank
     rs = np.random.RandomState(1000 + rank)
@@ -246,9 +260,10 @@ def summarize(res, args, world, chunks):
     ts, nb = res["ts"], res["nb"]
     steps_t = [ts[(args.warmup + i) % nb] for i in range(args.steps)]
     ms_per_step = res["elapsed"] / args.steps * 1e3
-    fl_steps = [step_flops(chunks, t, D, NSPK, args.attention) for t in steps_t]
+    layers = EXTENDED_LAYERS if args.extended else REFERENCE_LAYERS
+    fl_steps = [step_flops(chunks, t, D, NSPK, args.attention, layers) for t in steps_t]
     total_flops = float(np.mean([f[1] for f in fl_steps]))
-    by_steps = float(np.mean([step_bytes(chunks, t, D, NSPK) for t in steps_t]))
+    by_steps = float(np.mean([step_bytes(chunks, t, D, NSPK, layers) for t in steps_t]))
     out = {"value": round(world * chunks * args.steps / res["elapsed"], 1), "ms_per_step": round(ms_per_step, 4),
            "mean_frames": float(np.mean(steps_t)), "loss": round(res["loss"], 5)}
     if "dom" in res:
@@ -301,6 +316,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=B, help="chunks per GPU per step (default %d)" % B)
     ap.add_argument("--attention", action="store_true", help="self-attention pooling of nnet_conf/*_tdnn4_att.json instead of "
                     "statistics pooling (SURVEY 8d shape S4, BASELINE configs[3])")
+    ap.add_argument("--extended", action="store_true", help="BASELINE configs[4]: 10-layer extended-context TDNN + A-Softmax (m = 4) instead of the "
+                    "reference's 5-layer TDNN + AM-Softmax; use with --frames 400 (no reference counterpart, SURVEY.md D4)")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
                     help="arithmetic of the headline (default f32 = the engine's default); at one GPU the other mode is timed as well "
                          "and reported separately unless --single-mode")
@@ -372,9 +389,11 @@ def main():
             "vs_baseline": None,
             "dtype": DT[args.precision],
             "data": "synthetic",
-            "config": {"workload": "TDNN x-vector (tdnn.py 5 frame + 2 segment layers, %s) + AM-Softmax m=0.2, "
+            "config": {"workload": "%s, "
                                    "full optimiser step (fwd+bwd+L2+SGD%s), %d chunks/GPU x %s frames x %d-dim, %d speakers"
-                                   % ("self-attention pooling 512-1500-1500 keys" if args.attention else "stat pooling",
+                                   % (("extended TDNN x-vector (10 frame layers, contexts 5/1/3/1/3/1/3/1/1/1, + 2 segment layers, %s) + A-Softmax m=4"
+                                       if args.extended else "TDNN x-vector (tdnn.py 5 frame + 2 segment layers, %s) + AM-Softmax m=0.2")
+                                      % ("self-attention pooling 512-1500-1500 keys" if args.attention else "stat pooling"),
                                       "+RCCL all-reduce" if world > 1 else "", chunks, args.frames, D, NSPK),
                        "chunks_per_gpu": chunks, "frames": t_lo if t_lo == t_hi else [t_lo, t_hi], "mean_frames": hs["mean_frames"],
                        "feat_dim": D, "num_speakers": NSPK, "precision": args.precision, "parallelism": "dp%d" % world},

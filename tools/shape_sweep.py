@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""SURVEY.md section 8(d) sweep: shapes S1-S4 x seeds 0..4, >= 20 warm-up + >= 100 timed optimiser steps each,
+"""SURVEY.md section 8(d) sweep: shapes S1-S4 (+ S5 = the 10-layer extended TDNN of BASELINE configs[4]) x seeds 0..4, >= 20 warm-up + >= 100 timed optimiser steps each,
 per-step durations from HIP events recorded at the step boundaries on the launching stream -> median / p10 / p90.
 
   python tools/shape_sweep.py [--seeds 5] [--steps 100] [--warmup 20] [--precision f16x3|f32] > profiles/rNN_shapes.json
@@ -18,18 +18,21 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from bench import D, NSPK, step_flops
+from bench import D, NSPK, step_flops, EXTENDED_LAYERS, REFERENCE_LAYERS
 
-SHAPES = [("S1", 128, 200, 200, False), ("S2", 128, 400, 400, False), ("S3", 64, 200, 400, False), ("S4", 128, 200, 200, True)]
+# S5 = BASELINE configs[4]: the 10-layer extended-context TDNN + A-Softmax at 400-frame chunks (no reference counterpart)
+SHAPES = [("S1", 128, 200, 200, False, False), ("S2", 128, 400, 400, False, False), ("S3", 64, 200, 400, False, False),
+          ("S4", 128, 200, 200, True, False), ("S5", 128, 400, 400, False, True)]
 
 
 def run(shape, seed, steps, warmup, precision):
     from tf_kaldi_speaker_amd import engine as E
-    name, chunks, t_lo, t_hi, att = shape
-    cfg = E.make_config(D, NSPK, loss_func="additive_margin_softmax", margin_m=0.2, lambda_min=0.0, lambda_base=1000.0,
-                        lambda_gamma=1e-4, lambda_power=5.0, last_layer_linear=True, weight_l2_regularizer=1e-2,
+    name, chunks, t_lo, t_hi, att, ext = shape
+    loss_kw = (dict(loss_func="asoftmax", margin_m=4, lambda_min=10.0, lambda_base=1000.0, lambda_gamma=1e-5, lambda_power=5.0) if ext else
+               dict(loss_func="additive_margin_softmax", margin_m=0.2, lambda_min=0.0, lambda_base=1000.0, lambda_gamma=1e-4, lambda_power=5.0))
+    cfg = E.make_config(D, NSPK, last_layer_linear=True, weight_l2_regularizer=1e-2,
                         batchnorm_momentum=0.99, optimizer="sgd", max_batch=chunks, max_frames=t_hi, precision=precision,
-                        pooling_type="self_attention" if att else "statistics_pooling")
+                        pooling_type="self_attention" if att else "statistics_pooling", frame_layers=EXTENDED_LAYERS if ext else None, **loss_kw)
     eng = E.Engine(cfg, device="cuda:0")
     eng.init_variables(seed=seed)
     rs = np.random.RandomState(seed)
@@ -50,7 +53,7 @@ def run(shape, seed, steps, warmup, precision):
     tt = np.array([ts[(warmup + i) % nb] for i in range(steps)], dtype=np.float64)
     raw, _ = eng.losses()
     assert np.isfinite(raw), "loss is not finite"
-    fl = np.array([step_flops(chunks, int(t), D, NSPK, att)[1] for t in tt])
+    fl = np.array([step_flops(chunks, int(t), D, NSPK, att, EXTENDED_LAYERS if ext else REFERENCE_LAYERS)[1] for t in tt])
     del eng
     return ms, tt, fl, chunks
 
@@ -61,7 +64,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default=None)
-    ap.add_argument("--shapes", default="S1,S2,S3,S4")
+    ap.add_argument("--shapes", default="S1,S2,S3,S4,S5")
     args = ap.parse_args()
     out = {"unit": "chunks/s", "steps": args.steps, "warmup": args.warmup, "seeds": list(range(args.seeds)),
            "precision": args.precision or "default (f32)", "device": torch.cuda.get_device_name(0), "shapes": {}}
@@ -82,6 +85,7 @@ def main():
         total_s = float(msall.sum() * 1e-3)
         out["shapes"][shape[0]] = {
             "chunks_per_step": shape[1], "frames": shape[2] if shape[2] == shape[3] else [shape[2], shape[3]], "attention": shape[4],
+            "extended_10_layer_tdnn": shape[5],
             "chunks_per_s": {"median": round(float(np.median(rate)), 1), "p10": round(float(np.percentile(rate, 10)), 1),
                              "p90": round(float(np.percentile(rate, 90)), 1), "mean_over_time": round(shape[1] * len(msall) / total_s, 1)},
             "ms_per_step": {"median": round(float(np.median(msall)), 4), "p10": round(float(np.percentile(msall, 10)), 4),
