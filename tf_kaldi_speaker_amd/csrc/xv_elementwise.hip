@@ -643,33 +643,54 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
 }
 
-// Backward pass 2: dz = gamma*invstd*(dy - c1 - xhat*c2) into the segment-padded layout.
+// Backward pass 2: dz = gamma*invstd*(dy - c1 - xhat*c2) into the segment-padded layout (fp32).
+// Thread = one channel quad (16 B) x a strip of rows, block = 64 quads x 4 row lanes over BAF_ROWS padded rows: the seven
+// per-channel parameter vectors are loaded once per thread and the pooled statistics once per chunk (the element-per-thread
+// form reloaded both - and divided - for every 16 bytes of z: 115 us for tdnn5's 143 MB at S1).
+#define BAF_ROWS 32
 template <bool POOLED>
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ da, PoolGrad pg, const float* __restrict__ z, int segs, int t, int nq,
-                                    const float* __restrict__ gamma, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const float* __restrict__ scale,
-                                    const float* __restrict__ shift, const float* __restrict__ coef, int relu, int pad,
-                                    float* __restrict__ dz) {
-    const int tp = t + 2 * pad, n = nq * 4;
-    const unsigned total = (unsigned)segs * tp * nq;      // < 2^31 (checked by the wrapper): 32-bit index arithmetic
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const unsigned dr = i / nq;
-        int col = (int)(i - dr * nq) * 4;
-        int seg = (int)(dr / tp), u = (int)(dr - (unsigned)seg * tp) - pad;
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ da, PoolGrad pg, const float* __restrict__ z, int segs,
+                                                           int t, int n, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ coef, int relu, int pad,
+                                                           float* __restrict__ dz) {
+    const int tp = t + 2 * pad;
+    const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int rl = threadIdx.x >> 6;
+    if (col >= n) return;
+    const int total_rows = segs * tp;
+    const int r0 = blockIdx.y * BAF_ROWS, r1 = min(total_rows, r0 + BAF_ROWS);
+    const f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
+    const f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
+    const f32x4 c1 = *(const f32x4*)(coef + col), c2 = *(const f32x4*)(coef + n + col);
+    const f32x4 g_is = *(const f32x4*)(gamma + col) * is;
+    int seg = r0 / tp, u = r0 - seg * tp;          // padded row r0 -> (segment, frame + pad)
+    u += rl;
+    while (u >= tp) { u -= tp; ++seg; }
+    PoolCoef pc = {};
+    int b_end = 0;                                 // first row beyond the chunk whose statistics are in pc
+    float invT = 0.f;
+    for (int dr = r0 + rl; dr < r1; dr += 4) {
         f32x4 out = {0, 0, 0, 0};
-        if (u >= 0 && u < t) {
-            long r = (long)seg * t + u;
-            f32x4 zz = *(const f32x4*)(z + r * n + col);
-            f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
-            PoolCoef pc = {};
-            float invT = 0.f;
-            if (POOLED) { pc = pool_coef(pg, (int)((unsigned)r / (unsigned)pg.t), n, col); invT = pool_frame_weight(pg, r); }
-            f32x4 dd = upstream_grad<POOLED>(da, pc, invT, r, n, col, zz, *(const f32x4*)(scale + col), *(const f32x4*)(shift + col), relu);
-            f32x4 xh = (zz - mu) * is;
-            f32x4 c1 = *(const f32x4*)(coef + col), c2 = *(const f32x4*)(coef + n + col);
-            out = (*(const f32x4*)(gamma + col) * is) * (dd - c1 - xh * c2);
+        const int f = u - pad;
+        if (f >= 0 && f < t) {
+            const long r = (long)seg * t + f;
+            if (POOLED) {
+                if (r >= b_end) {
+                    const int pb = (int)r / pg.t;
+                    b_end = (pb + 1) * pg.t;
+                    pc = pool_coef(pg, pb, n, col);
+                }
+                invT = pool_frame_weight(pg, r);
+            }
+            const f32x4 zz = *(const f32x4*)(z + r * n + col);
+            const f32x4 dd = upstream_grad<POOLED>(da, pc, invT, r, n, col, zz, sc, sh, relu);
+            const f32x4 xh = (zz - mu) * is;
+            out = g_is * (dd - c1 - xh * c2);
         }
         *(f32x4*)(dz + (long)dr * n + col) = out;
+        u += 4;
+        while (u >= tp) { u -= tp; ++seg; }
     }
 }
 
@@ -772,9 +793,9 @@ static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, co
                        dgamma, dbeta, coef, gamma, invstd, dbias, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (unsigned*)nullptr);
     XV_LAUNCH_CHECK();
-    long total = (long)segs * (t + 2 * pad) * (n / 4);
-    hipLaunchKernelGGL(pooled ? bn_bwd_apply_kernel<true> : bn_bwd_apply_kernel<false>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, da,
-                       pg, z, segs, t, n / 4, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad, dz_pad);
+    dim3 agrid(xv_cdiv(n / 4, 64), xv_cdiv(segs * (t + 2 * pad), BAF_ROWS));
+    hipLaunchKernelGGL(pooled ? bn_bwd_apply_kernel<true> : bn_bwd_apply_kernel<false>, agrid, dim3(256), 0, s, da,
+                       pg, z, segs, t, n, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad, dz_pad);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -1048,17 +1069,19 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
         f32x4 v3 = act(*(const f32x4*)(xp + (long)(t + 24) * C));
         const float w0 = wp ? wp[t] : 1.f, w1 = wp ? wp[t + 8] : 1.f, w2 = wp ? wp[t + 16] : 1.f, w3 = wp ? wp[t + 24] : 1.f;
         f32x4 d;
-        n += w0; d = v0 - mean; if (n > 0.f) mean += d * (w0 / n); m2 += d * (v0 - mean) * w0;
-        n += w1; d = v1 - mean; if (n > 0.f) mean += d * (w1 / n); m2 += d * (v1 - mean) * w1;
-        n += w2; d = v2 - mean; if (n > 0.f) mean += d * (w2 / n); m2 += d * (v2 - mean) * w2;
-        n += w3; d = v3 - mean; if (n > 0.f) mean += d * (w3 / n); m2 += d * (v3 - mean) * w3;
+        // w / n through v_rcp_f32 (1 ulp): the IEEE division sequence (div_scale, rcp, 4 fma, div_fmas, div_fixup) sat on the
+        // serial mean -> M2 dependency chain of every frame and made this HBM-bound pass VALU-latency-bound (38 us for 143 MB)
+        n += w0; d = v0 - mean; if (n > 0.f) mean += d * (w0 * __builtin_amdgcn_rcpf(n)); m2 += d * (v0 - mean) * w0;
+        n += w1; d = v1 - mean; if (n > 0.f) mean += d * (w1 * __builtin_amdgcn_rcpf(n)); m2 += d * (v1 - mean) * w1;
+        n += w2; d = v2 - mean; if (n > 0.f) mean += d * (w2 * __builtin_amdgcn_rcpf(n)); m2 += d * (v2 - mean) * w2;
+        n += w3; d = v3 - mean; if (n > 0.f) mean += d * (w3 * __builtin_amdgcn_rcpf(n)); m2 += d * (v3 - mean) * w3;
     }
     for (; t < T; t += 8) {
         f32x4 v = act(*(const f32x4*)(xp + (long)t * C));
         const float w = wp ? wp[t] : 1.f;
         n += w;
         f32x4 d = v - mean;
-        if (n > 0.f) mean += d * (w / n);
+        if (n > 0.f) mean += d * (w * __builtin_amdgcn_rcpf(n));
         m2 += d * (v - mean) * w;
     }
     // merge the two frame lanes of this wave

@@ -59,11 +59,14 @@ struct NTArgs {
 // The page is ordinary hipMalloc'd global memory handed in through the kernel arguments (a
 // __device__ constant made the selected pointer generic -> flat_load, which also counts on
 // lgkmcnt and so serialised the LDS fragment reads behind the global loads).
+// The page is XV_ZERO_PAGE_FLOATS long: an out-of-range ROW is redirected to it ONCE (its base pointer), after which "base + k"
+// stays inside the page for every k < K <= XV_ZERO_PAGE_FLOATS - so full K-steps stage with no per-step select at all.
+#define XV_ZERO_PAGE_FLOATS 16384
 static float* g_zero_page = nullptr;
 static int ensure_zero_page() {
     if (g_zero_page) return 0;
-    XV_CHECK_HIP(hipMalloc((void**)&g_zero_page, 256));
-    XV_CHECK_HIP(hipMemset(g_zero_page, 0, 256));
+    XV_CHECK_HIP(hipMalloc((void**)&g_zero_page, XV_ZERO_PAGE_FLOATS * sizeof(float)));
+    XV_CHECK_HIP(hipMemset(g_zero_page, 0, XV_ZERO_PAGE_FLOATS * sizeof(float)));
     return 0;
 }
 
@@ -157,38 +160,41 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
     constexpr int NT_RPI = 64 / NT_KQ;          // tile rows per wave-instruction (16 at BK=16)
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int lrow = lane / NT_KQ, lpos = lane % NT_KQ;
+    // per-lane source pointers, the swizzled chunk offset folded in; out-of-range rows point into the zero page for good
+    const float* __restrict__ zp = p.zero;
     const float* ap[NT_RPT];
     const float* bp[NT_RPT];
-    bool av[NT_RPT], bv[NT_RPT];
     int ksrc[NT_RPT];
 #pragma unroll
     for (int i = 0; i < NT_RPT; ++i) {
         int row = NT_RPI * (NT_RPT * wave + i) + lrow;
         ksrc[i] = ((lpos ^ NT_SWZ(row)) << 2);
         int m = m0 + row;
-        av[i] = m < p.M;
-        int mm = av[i] ? m : 0;
+        int mm = m < p.M ? m : 0;
         int seg = mm / p.a_rps, tt = mm - seg * p.a_rps;
-        ap[i] = p.A + ((long)seg * p.a_pitch + tt) * p.lda;
+        ap[i] = (m < p.M ? p.A + ((long)seg * p.a_pitch + tt) * p.lda : zp) + ksrc[i];
         int n = n0 + row;
-        bv[i] = n < p.N;
-        bp[i] = p.Bt + (long)(bv[i] ? n : 0) * p.ldb;
+        bp[i] = (n < p.N ? p.Bt + (long)n * p.ldb : zp) + ksrc[i];
     }
-    const float* __restrict__ zp = p.zero;
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     auto gstage = [&](int kt, int buf) {
         float* sa = smem + buf * (2 * BM * NT_PITCH) + NT_RPI * NT_RPT * uwave * NT_PITCH;
         float* sb = sa + BM * NT_PITCH;
         const int k0 = k_begin + kt * BK;
+        if (k0 + BK <= k_end) {        // full K-step (uniform): the address is base + k0, nothing else per step
 #pragma unroll
-        for (int i = 0; i < NT_RPT; ++i) {
-            const int k = k0 + ksrc[i];
-            const bool kv = k < k_end;
-            const float* pa = (kv && av[i]) ? ap[i] + k : zp;
-            const float* pb = (kv && bv[i]) ? bp[i] + k : zp;
-            __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+            for (int i = 0; i < NT_RPT; ++i) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(ap[i] + k0), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(bp[i] + k0), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+            }
+        } else {                       // ragged last step: chunks at or beyond k_end come from the zero page
+#pragma unroll
+            for (int i = 0; i < NT_RPT; ++i) {
+                const bool kv = k0 + ksrc[i] < k_end;
+                __builtin_amdgcn_global_load_lds((gptr_t)(kv ? ap[i] + k0 : zp), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(kv ? bp[i] + k0 : zp), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+            }
         }
     };
 #define NT_STAGE_FIRST() gstage(0, 0)
@@ -360,6 +366,7 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     XV_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm_nt: K/lda/ldb must be multiples of 4 (K=%d lda=%ld ldb=%ld)", g.K, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0, "gemm_nt: operands must be 16-byte aligned");
     XV_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.a_rps > 0, "gemm_nt: empty problem");
+    XV_REQUIRE(g.K <= XV_ZERO_PAGE_FLOATS, "gemm_nt: K = %d exceeds the zero page (%d)", g.K, XV_ZERO_PAGE_FLOATS);
     if (ensure_zero_page()) return 1;
     NTArgs p;
     p.zero = g_zero_page;
