@@ -139,6 +139,9 @@ int xv_bn_relu_backward(void* stream, const float* da, const float* z, int segs,
                         const float* gamma, const float* mean, const float* invstd,
                         const float* scale, const float* shift, int relu, int pad,
                         float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes);
+/* prelu, common.py:27-42: y[r][c] = relu(x) + alpha[c] * (x - |x|) / 2 = x > 0 ? x : alpha[c] * x  (tf.nn.leaky_relu: alpha = 0.2 everywhere).
+ * Inside the engine the same non-linearity follows every BatchNorm when xv_config.relu_type says so. */
+int xv_prelu_forward(void* stream, const float* x, int rows, int n, const float* alpha, float* y);
 /* Backward of a bare ReLU (no BN in front): dz = da * (a > 0). */
 int xv_relu_backward(void* stream, const float* da, const float* a, size_t count, float* dz);
 
@@ -335,8 +338,14 @@ typedef struct xv_config {
     int32_t num_frame_layers;
     int32_t frame_context[12];
     int32_t frame_width[12];
+    int32_t relu_type;                /* XV_RELU_*: network_relu_type, tdnn.py:24-30 (no shipped config sets it) */
 } xv_config;
 #define XV_MAX_FRAME_LAYERS 12
+/* the non-linearity behind every BatchNorm: relu | prelu = relu(x) + alpha (x - |x|) / 2 with a trainable per-channel alpha
+ * "<prefix>_relu/alpha" initialised to 0.01 (common.py:27-42) | tf.nn.leaky_relu (alpha 0.2) */
+#define XV_RELU_RELU 0
+#define XV_RELU_PRELU 1
+#define XV_RELU_LRELU 2
 #define XV_POOL_STATISTICS 0
 /* self_attention in the shipped single-head form (nnet_conf/..._tdnn4_att.json): key network on tdnn4_relu, value = tdnn5_relu,
  * one head, key not split, no value network, no penalty term, no post non-linearity */

@@ -64,6 +64,8 @@ def _make(kw, B, T, N=37, P=1500, seed=0, max_batch=None, max_frames=None, D=30,
     for k in V:   # move BN parameters / biases / moving stats off their trivial init
         if k.endswith(("gamma", "beta", "bias")):
             V[k] = V[k] + 0.1 * rs.randn(*V[k].shape)
+        if k.endswith("alpha"):
+            V[k] = V[k] + 0.3 * rs.rand(*V[k].shape)
         if k.endswith("moving_mean"):
             V[k] = 0.2 * rs.randn(*V[k].shape)
         if k.endswith("moving_variance"):
@@ -100,11 +102,14 @@ def oracle_forward(V, cfg_o, x):
     return {"bn_new": bn_new, "feats": feats, "ep": ep, "caches": caches}
 
 
-def gpu_relu_pattern(eng, fwd, max_flip_fraction=1e-4):
+def gpu_relu_pattern(eng, fwd, max_flip_fraction=1e-4, cfg_o=None):
     """Endpoints of the oracle forward with every ReLU output replaced by the GPU's (see oracle_step_with_gpu_relu_pattern).
-    Asserts that the two on/off patterns differ only at rounding-level pre-activations."""
+    Asserts that the two on/off patterns differ only at rounding-level pre-activations.
+    prelu / lrelu (cfg_o.network_relu_type): the oracle differentiates those on the SIGN OF THE ACTIVATION'S INPUT, so the rounding-level
+    entries whose sign the GPU sees differently get the GPU's sign in fwd["caches"] (patched in place; positive slopes assumed)."""
     ep = fwd["ep"]
     ep_gpu = dict(ep)
+    leaky = cfg_o is not None and cfg_o.network_relu_type != "relu"
     for prefix in RELU_LAYERS:
         key = prefix + "_relu"
         if key not in ep:
@@ -115,6 +120,10 @@ def gpu_relu_pattern(eng, fwd, max_flip_fraction=1e-4):
         pre = ep[prefix + "_bn"] if prefix + "_bn" in ep else ep[prefix + "_dense"]       # att_key1 with a plain ReLU (type 1)
         assert np.all(np.abs(pre[flips]) < 2e-5 * max(1.0, np.abs(pre).max())), key
         ep_gpu[key] = got.astype(np.float64)
+        if leaky and flips.any():
+            x = fwd["caches"][prefix + "_act_in"].copy()
+            x[flips] = np.where(got[flips] > 0, 1.0, -1.0) * np.abs(x[flips])
+            fwd["caches"][prefix + "_act_in"] = x
     return ep_gpu
 
 
@@ -162,7 +171,7 @@ def oracle_step_with_gpu_relu_pattern(eng, V, cfg_o, x, labels, lr, step, opt_st
     fewer than 1e-4 of the positions, then (2) checks all gradients at 1e-4 against the oracle
     evaluated on the GPU's pattern."""
     fwd = fwd if fwd is not None else oracle_forward(V, cfg_o, x)
-    return oracle_backward_and_update(V, cfg_o, fwd, gpu_relu_pattern(eng, fwd), labels, lr, step, opt_state)
+    return oracle_backward_and_update(V, cfg_o, fwd, gpu_relu_pattern(eng, fwd, cfg_o=cfg_o), labels, lr, step, opt_state)
 
 
 @pytest.mark.parametrize("kw", CASES, ids=lambda d: "-".join(str(v).replace(" ", "") for v in d.values()))
@@ -215,6 +224,33 @@ def test_extended_table_is_validated():
         E.make_config(30, 10, frame_layers=((5, 512), (1, 512), (1, 512)))               # last width != num_nodes_pooling_layer
     with pytest.raises(Exception):
         E.Engine(E.make_config(30, 10, max_batch=2, max_frames=10, frame_layers=((5, 512), (5, 512), (5, 512), (1, 1500))))   # receptive field 13 > 10
+
+
+# network_relu_type (tdnn.py:24-30, common.py:27-42; SURVEY.md N3 - no shipped config sets it): prelu with its trainable per-channel
+# alpha variables, tf.nn.leaky_relu; statistics and attention pooling, a ReLU'd last layer with and without BatchNorm, an extended table
+RELU_VARIANTS = [
+    dict(loss_func="softmax", network_relu_type="lrelu"),
+    dict(loss_func="softmax", network_relu_type="prelu"),
+    dict(loss_func="softmax", network_relu_type="prelu", last_layer_no_bn=True),
+    dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, network_relu_type="prelu", pooling_type="self_attention",
+         att_key_num_nodes=(64, 48), att_key_network_type=3),
+    dict(loss_func="softmax", network_relu_type="lrelu", pooling_type="self_attention", att_key_num_nodes=(64, 48), att_key_network_type=2),
+    dict(loss_func="asoftmax", margin_m=2, lambda_min=5, lambda_gamma=1e-3, last_layer_linear=True, network_relu_type="prelu",
+         frame_layers=((5, 128), (1, 256), (3, 128), (1, 1500))),
+]
+
+
+@pytest.mark.parametrize("kw", RELU_VARIANTS, ids=lambda d: d["network_relu_type"] + ("_att%d" % d["att_key_network_type"] if "pooling_type" in d else "")
+                         + ("_nobn" if d.get("last_layer_no_bn") else "") + ("_ext" if "frame_layers" in d else ""))
+def test_train_step_matches_oracle_prelu_lrelu(kw):
+    _check_train_step(kw, 6, 40)
+
+
+def test_prelu_with_fused_relu_key_layer_is_refused():
+    from tf_kaldi_speaker_amd import engine as E
+    with pytest.raises(Exception):
+        E.Engine(E.make_config(30, 10, network_relu_type="prelu", pooling_type="self_attention", att_key_num_nodes=(64, 48), att_key_network_type=1,
+                               max_batch=2, max_frames=30))
 
 
 def _shipped_combinations():

@@ -60,6 +60,7 @@ class XvConfig(C.Structure):
         ("num_frame_layers", C.c_int32),
         ("frame_context", C.c_int32 * 12),
         ("frame_width", C.c_int32 * 12),
+        ("relu_type", C.c_int32),
     ]
 
 
@@ -72,6 +73,7 @@ LOSS_KINDS = {
 OPTIMIZERS = {"sgd": 0, "momentum": 1, "adam": 2}
 PRECISIONS = {"f32": 0, "f16x3": 1}
 POOLINGS = {"statistics_pooling": 0, "self_attention": 1}
+RELU_TYPES = {"relu": 0, "prelu": 1, "lrelu": 2}
 
 _VP = C.c_void_p
 _SZ = C.c_size_t
@@ -101,6 +103,7 @@ SIGNATURES = {
     "xv_bn_inference_scale": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _F, _VP, _VP]),
     "xv_bn_apply": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP, _I]),
     "xv_bn_relu_backward": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _SZ]),
+    "xv_prelu_forward": (_I, [_VP, _VP, _I, _I, _VP, _VP]),
     "xv_relu_backward": (_I, [_VP, _VP, _VP, _SZ, _VP]),
     "xv_amax": (_I, [_VP, _VP, _SZ, _VP]),
     "xv_split_planes": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _SZ, _VP]),

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void softmax_segments_bwd_kernel(const float* 
 __global__ __launch_bounds__(256) void att_pool_dw_kernel(const float* __restrict__ z, int rows, int t, int n,
                                                           const float* __restrict__ scale, const float* __restrict__ shift, int relu,
                                                           const float* __restrict__ pool, const float* __restrict__ dpool,
-                                                          float* __restrict__ dw) {
+                                                          float* __restrict__ dw, const float* __restrict__ slope) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const int b = row / t;
@@ -90,7 +90,11 @@ __global__ __launch_bounds__(256) void att_pool_dw_kernel(const float* __restric
         f32x4 zz = *(const f32x4*)(zr + c);
         f32x4 a = zz;
         if (scale) a = zz * *(const f32x4*)(scale + c) + *(const f32x4*)(shift + c);
-        if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+        if (relu && slope) {      // prelu / leaky ReLU value tensor (act context, xv_common.h)
+            const f32x4 sl = *(const f32x4*)(slope + c);
+            a.x = a.x > 0.f ? a.x : a.x * sl.x; a.y = a.y > 0.f ? a.y : a.y * sl.y;
+            a.z = a.z > 0.f ? a.z : a.z * sl.z; a.w = a.w > 0.f ? a.w : a.w * sl.w;
+        } else if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
         f32x4 mean = *(const f32x4*)(o + c), sd = *(const f32x4*)(o + n + c);
         f32x4 dm = *(const f32x4*)(g + c), dsd = *(const f32x4*)(g + n + c);
         f32x4 dv;
@@ -180,7 +184,7 @@ extern "C" int xv_att_pool_backward_weights(void* stream, const float* z, int b,
                                             int relu, const float* pool_out, const float* dpool, float* dweights) {
     XV_REQUIRE(z && pool_out && dpool && dweights && b > 0 && t > 0 && c > 0 && c % 4 == 0, "att_pool_backward_weights: bad arguments");
     hipLaunchKernelGGL(att_pool_dw_kernel, dim3(xv_cdiv(b * t, 4)), dim3(256), 0, (hipStream_t)stream, z, b * t, t, c, scale, shift, relu,
-                       pool_out, dpool, dweights);
+                       pool_out, dpool, dweights, relu ? xv_act_context().slope : nullptr);
     XV_LAUNCH_CHECK();
     return 0;
 }

@@ -152,6 +152,16 @@ int xv_bn_relu_backward_split_ex(hipStream_t s, const XvBnBwdSplit& x, const flo
                                  const float* zmax, int relu, int pad, void* dz_planes, int ldp, size_t plane_stride, uint32_t* dz_amax,
                                  float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes);
 
+// Activation behind a BatchNorm in the layer being processed (network_relu_type, tdnn.py:24-30): y > 0 ? y : slope[c] * y.
+// slope == nullptr: ReLU.  Set by the engine around a layer's calls (prelu: the layer's alpha variable, with dalpha = its gradient;
+// lrelu: a constant 0.2 vector); every entry point that takes a `relu` flag reads it (xv_elementwise.hip).
+struct XvActContext { const float* slope; float* dalpha; };
+void xv_set_act_context(const float* slope, float* dalpha);
+XvActContext xv_act_context();
+// a = act(z) (da == nullptr) or dz = da * act'(z) + d alpha (segment-level tensors, rows <= XV_BN_SMALL_MAX_ROWS): a layer with the
+// activation but no BatchNorm in front (tdnn7 with last_layer_no_bn)
+int xv_act_small(hipStream_t s, const float* da, const float* z, int rows, int n, float* out);
+
 // Live launch timing (xv_profile_begin/end): brackets one GEMM launch with hipEvents on its stream.
 struct XvProfScope {
     hipStream_t s; int idx;

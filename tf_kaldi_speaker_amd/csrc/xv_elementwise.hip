@@ -334,6 +334,33 @@ extern "C" int xv_col_stats(void* stream, const float* z, int rows, int n, int l
 }
 
 // ------------------------------------------------------------------------------------
+// Activation context (network_relu_type, tdnn.py:24-30 / common.py:27-42): the non-linearity behind a BatchNorm is
+//   act(y) = y > 0 ? y : slope[c] * y     slope = NULL: ReLU | a constant 0.2 vector: tf.nn.leaky_relu | the layer's alpha: prelu
+// (prelu(x) = relu(x) + alpha (x - |x|) / 2 is exactly that).  The engine sets the context around a layer's calls; every entry
+// point with a `relu` flag reads it, so the C signatures stay as they are.  dalpha: where the backward entry points write
+// d alpha[c] = sum_rows d act * min(y, 0) (prelu only).
+// ------------------------------------------------------------------------------------
+static thread_local XvActContext g_act = {nullptr, nullptr};
+void xv_set_act_context(const float* slope, float* dalpha) { g_act.slope = slope; g_act.dalpha = dalpha; }
+XvActContext xv_act_context() { return g_act; }
+
+__device__ __forceinline__ float act1(float y, float sl) { return y > 0.f ? y : y * sl; }
+__device__ __forceinline__ f32x4 act4(f32x4 y, f32x4 sl) {
+    f32x4 r;
+    r.x = act1(y.x, sl.x); r.y = act1(y.y, sl.y); r.z = act1(y.z, sl.z); r.w = act1(y.w, sl.w);
+    return r;
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    return v;
+}
+__device__ __forceinline__ f32x4 neg4(f32x4 y) {      // min(y, 0)
+    f32x4 r;
+    r.x = fminf(y.x, 0.f); r.y = fminf(y.y, 0.f); r.z = fminf(y.z, 0.f); r.w = fminf(y.w, 0.f);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------
 // BatchNorm
 // ------------------------------------------------------------------------------------
 // block = 256 threads = 8 channels x 32 tile lanes (n/8 workgroups: the partials are few, the latency of a
@@ -347,7 +374,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ mvar, float* __restrict__ mean_o,
                                                           float* __restrict__ invstd_o, float* __restrict__ scale_o,
                                                           float* __restrict__ shift_o, float* __restrict__ zmin_o,
-                                                          float* __restrict__ zmax_o, unsigned* __restrict__ amax_o, int relu) {
+                                                          float* __restrict__ zmax_o, unsigned* __restrict__ amax_o, int relu,
+                                                          const float* __restrict__ slope) {
     __shared__ double s_cnt[FIN_LANES][FIN_CH], s_mean[FIN_LANES][FIN_CH], s_m2[FIN_LANES][FIN_CH];
     __shared__ float s_mn[FIN_LANES][FIN_CH], s_mx[FIN_LANES][FIN_CH];
     const int cx = threadIdx.x & (FIN_CH - 1), tl = threadIdx.x / FIN_CH;
@@ -395,6 +423,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         // exact range of y = z*sc + sh over the batch (affine => extremes at the ends), same fma as bn_apply
         float y0 = zmn * sc + sh, y1 = zmx * sc + sh;
         float am = relu ? fmaxf(0.f, fmaxf(y0, y1)) : fmaxf(fabsf(y0), fabsf(y1));
+        if (relu && slope) am = fmaxf(fabsf(act1(y0, slope[c])), fabsf(act1(y1, slope[c])));      // piecewise linear through 0: extremes at the ends
         atomicMax(amax_o, __float_as_uint(am));          // max of non-negative floats == max of their bit patterns
     }
     if (mmean) {
@@ -411,7 +440,8 @@ extern "C" int xv_bn_finalize(void* stream, const float* bn_part, int rows, int 
     XV_REQUIRE(rows > 0 && n > 0, "bn_finalize: bad shape");
     int tiles = xv_cdiv(rows, XV_TILE_M);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, (hipStream_t)stream, bn_part, rows, n, tiles,
-                       gamma, beta, eps, momentum, unbiased_moving, moving_mean, moving_var, mean, invstd, scale, shift, zmin, zmax, amax, relu);
+                       gamma, beta, eps, momentum, unbiased_moving, moving_mean, moving_var, mean, invstd, scale, shift, zmin, zmax, amax, relu,
+                       g_act.slope);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -420,7 +450,7 @@ extern "C" int xv_bn_finalize(void* stream, const float* bn_part, int rows, int 
 // relu?(z*scale+shift) for given (e.g. inference) scale/shift: *amax |= its float bits.
 __global__ void bn_output_range_kernel(const float* __restrict__ part, int rows, int n, int tiles, const float* __restrict__ scale,
                                        const float* __restrict__ shift, int relu, float* __restrict__ zmin_o,
-                                       float* __restrict__ zmax_o, unsigned* __restrict__ amax_o) {
+                                       float* __restrict__ zmax_o, unsigned* __restrict__ amax_o, const float* __restrict__ slope) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     float mn = INFINITY, mx = -INFINITY;
@@ -431,6 +461,7 @@ __global__ void bn_output_range_kernel(const float* __restrict__ part, int rows,
     if (zmin_o) { zmin_o[c] = mn; zmax_o[c] = mx; }
     float y0 = mn * scale[c] + shift[c], y1 = mx * scale[c] + shift[c];
     float am = relu ? fmaxf(0.f, fmaxf(y0, y1)) : fmaxf(fabsf(y0), fabsf(y1));
+    if (relu && slope) am = fmaxf(fabsf(act1(y0, slope[c])), fabsf(act1(y1, slope[c])));
     atomicMax(amax_o, __float_as_uint(am));
 }
 
@@ -439,7 +470,7 @@ extern "C" int xv_bn_output_range(void* stream, const float* bn_part, int rows, 
     XV_REQUIRE(bn_part && rows > 0 && n > 0 && scale && shift && amax, "bn_output_range: bad arguments");
     int tiles = xv_cdiv(rows, XV_TILE_M);
     hipLaunchKernelGGL(bn_output_range_kernel, dim3(xv_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, bn_part, rows, n, tiles, scale, shift,
-                       relu, zmin, zmax, (unsigned*)amax);
+                       relu, zmin, zmax, (unsigned*)amax, g_act.slope);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -465,7 +496,7 @@ extern "C" int xv_bn_inference_scale(void* stream, int n, const float* gamma, co
 
 // a = relu?(z*scale+shift), 16 B per lane along channels
 __global__ void bn_apply_kernel(const float* __restrict__ z, long rows, int nq, long ldz, const float* __restrict__ scale,
-                                const float* __restrict__ shift, int relu, float* __restrict__ a, long lda) {
+                                const float* __restrict__ shift, int relu, float* __restrict__ a, long lda, const float* __restrict__ slope) {
     const unsigned total = (unsigned)(rows * nq);      // < 2^31 (checked by the wrapper)
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const long r = i / (unsigned)nq;
@@ -474,9 +505,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ z, long rows, int nq, 
         f32x4 sc = *(const f32x4*)(scale + 4 * q);
         f32x4 sh = *(const f32x4*)(shift + 4 * q);
         v = v * sc + sh;
-        if (relu) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
+        if (relu) v = slope ? act4(v, *(const f32x4*)(slope + 4 * q)) : relu4(v);
         *(f32x4*)(a + r * lda + 4 * q) = v;
     }
 }
@@ -487,7 +516,7 @@ extern "C" int xv_bn_apply(void* stream, const float* z, int rows, int n, int ld
     long total = (long)rows * (n / 4);
     XV_REQUIRE(total < (1L << 31), "bn_apply: tensor too large for 32-bit indexing");
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, z, (long)rows, n / 4,
-                       (long)ldz, scale, shift, relu, a, (long)lda);
+                       (long)ldz, scale, shift, relu, a, (long)lda, g_act.slope);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -520,21 +549,30 @@ __device__ __forceinline__ f32x4 pool_grad(const PoolCoef& pc, float invT, f32x4
 __device__ __forceinline__ float pool_frame_weight(const PoolGrad& pg, long row) { return pg.w ? pg.w[row] : 1.f / (float)pg.t; }
 
 // masked upstream gradient of one channel quad: POOLED ? pooling backward on the fly : da, zeroed where the ReLU was off
+// sl / hs: the activation's negative-side slope of this channel quad and whether there is one (act context); dneg, if given,
+// receives d act * min(y, 0) - the summand of d alpha (prelu).
 template <bool POOLED>
 __device__ __forceinline__ f32x4 upstream_grad(const float* __restrict__ da, const PoolCoef& pc, float invT, long r, int n, int col,
-                                               f32x4 zz, f32x4 sc, f32x4 sh, int relu) {
+                                               f32x4 zz, f32x4 sc, f32x4 sh, int relu, f32x4 sl = f32x4{0, 0, 0, 0}, bool hs = false,
+                                               f32x4* dneg = nullptr) {
     f32x4 y = zz * sc + sh;
     f32x4 dd;
     if (POOLED) {
         f32x4 a = y;
-        if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+        if (relu) a = hs ? act4(a, sl) : relu4(a);
         dd = pool_grad(pc, invT, a);
     } else {
         dd = *(const f32x4*)(da + r * n + col);
     }
     if (relu) {
-        dd.x = y.x > 0.f ? dd.x : 0.f; dd.y = y.y > 0.f ? dd.y : 0.f;
-        dd.z = y.z > 0.f ? dd.z : 0.f; dd.w = y.w > 0.f ? dd.w : 0.f;
+        if (dneg) *dneg = dd * neg4(y);
+        if (hs) {
+            dd.x = y.x > 0.f ? dd.x : dd.x * sl.x; dd.y = y.y > 0.f ? dd.y : dd.y * sl.y;
+            dd.z = y.z > 0.f ? dd.z : dd.z * sl.z; dd.w = y.w > 0.f ? dd.w : dd.w * sl.w;
+        } else {
+            dd.x = y.x > 0.f ? dd.x : 0.f; dd.y = y.y > 0.f ? dd.y : 0.f;
+            dd.z = y.z > 0.f ? dd.z : 0.f; dd.w = y.w > 0.f ? dd.w : 0.f;
+        }
     }
     return dd;
 }
@@ -547,15 +585,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             int n, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu,
-                                                            float* __restrict__ part /* [chunks][3][n]: sum dy, sum dy*xhat, max |dy| */) {
-    __shared__ f32x4 red[3][4][64];
+                                                            float* __restrict__ part /* [chunks][nstat][n]: sum dy, sum dy*xhat, max |dy| (, sum d act*min(y,0)) */,
+                                                            const float* __restrict__ slope, int nstat) {
+    __shared__ f32x4 red[4][4][64];
     const int qx = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + qx) * 4;
     const int r0 = blockIdx.y * BB_ROWS, r1 = min(rows, r0 + BB_ROWS);
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0};
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0}, s4 = {0, 0, 0, 0};
+    const bool hs = slope != nullptr, want4 = nstat == 4;
     if (col < n) {
         f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
         f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
+        f32x4 sl = {0, 0, 0, 0};
+        if (hs) sl = *(const f32x4*)(slope + col);
         PoolCoef pc = {};
         int pb = -1, b_end = 0;           // chunk whose statistics are in pc; its first row beyond
         float invT = 0.f;
@@ -564,10 +606,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 if (r >= b_end) { pb = r / pg.t; b_end = (pb + 1) * pg.t; pc = pool_coef(pg, pb, n, col); }
                 invT = pool_frame_weight(pg, r);
             }
-            f32x4 dd = upstream_grad<POOLED>(da, pc, invT, (long)r, n, col, zz, sc, sh, relu);
+            f32x4 dn = {0, 0, 0, 0};
+            f32x4 dd = upstream_grad<POOLED>(da, pc, invT, (long)r, n, col, zz, sc, sh, relu, sl, hs, want4 ? &dn : nullptr);
             f32x4 xh = (zz - mu) * is;
             s1 += dd;
             s2 += dd * xh;
+            s4 += dn;
             s3.x = fmaxf(s3.x, fabsf(dd.x)); s3.y = fmaxf(s3.y, fabsf(dd.y));
             s3.z = fmaxf(s3.z, fabsf(dd.z)); s3.w = fmaxf(s3.w, fabsf(dd.w));
         };
@@ -590,6 +634,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     red[0][rl][qx] = s1;
     red[1][rl][qx] = s2;
     red[2][rl][qx] = s3;
+    red[3][rl][qx] = s4;
     __syncthreads();
     if (rl == 0 && col < n) {
         f32x4 t1 = (red[0][0][qx] + red[0][1][qx]) + (red[0][2][qx] + red[0][3][qx]);
@@ -599,9 +644,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         t3.y = fmaxf(fmaxf(red[2][0][qx].y, red[2][1][qx].y), fmaxf(red[2][2][qx].y, red[2][3][qx].y));
         t3.z = fmaxf(fmaxf(red[2][0][qx].z, red[2][1][qx].z), fmaxf(red[2][2][qx].z, red[2][3][qx].z));
         t3.w = fmaxf(fmaxf(red[2][0][qx].w, red[2][1][qx].w), fmaxf(red[2][2][qx].w, red[2][3][qx].w));
-        *(f32x4*)(part + ((long)blockIdx.y * 3 + 0) * n + col) = t1;
-        *(f32x4*)(part + ((long)blockIdx.y * 3 + 1) * n + col) = t2;
-        *(f32x4*)(part + ((long)blockIdx.y * 3 + 2) * n + col) = t3;
+        *(f32x4*)(part + ((long)blockIdx.y * nstat + 0) * n + col) = t1;
+        *(f32x4*)(part + ((long)blockIdx.y * nstat + 1) * n + col) = t2;
+        *(f32x4*)(part + ((long)blockIdx.y * nstat + 2) * n + col) = t3;
+        if (want4) *(f32x4*)(part + ((long)blockIdx.y * nstat + 3) * n + col) = (red[3][0][qx] + red[3][1][qx]) + (red[3][2][qx] + red[3][3][qx]);
     }
 }
 
@@ -612,25 +658,27 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               float* __restrict__ dbias, const float* __restrict__ mean,
                                                               const float* __restrict__ zmin, const float* __restrict__ zmax,
-                                                              unsigned* __restrict__ dz_amax) {
-    __shared__ float r1[FIN_LANES][FIN_CH], r2[FIN_LANES][FIN_CH], r3[FIN_LANES][FIN_CH];
+                                                              unsigned* __restrict__ dz_amax, int nstat, float* __restrict__ dalpha) {
+    __shared__ float r1[FIN_LANES][FIN_CH], r2[FIN_LANES][FIN_CH], r3[FIN_LANES][FIN_CH], r4[FIN_LANES][FIN_CH];
     const int cx = threadIdx.x & (FIN_CH - 1), cl = threadIdx.x / FIN_CH;
     const int c = blockIdx.x * FIN_CH + cx;
-    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
     if (c < n)
         for (int k = cl; k < chunks; k += FIN_LANES) {
-            s1 += part[((long)k * 3 + 0) * n + c];
-            s2 += part[((long)k * 3 + 1) * n + c];
-            s3 = fmaxf(s3, part[((long)k * 3 + 2) * n + c]);
+            s1 += part[((long)k * nstat + 0) * n + c];
+            s2 += part[((long)k * nstat + 1) * n + c];
+            s3 = fmaxf(s3, part[((long)k * nstat + 2) * n + c]);
+            if (nstat == 4) s4 += part[((long)k * nstat + 3) * n + c];
         }
-    r1[cl][cx] = s1; r2[cl][cx] = s2; r3[cl][cx] = s3;
+    r1[cl][cx] = s1; r2[cl][cx] = s2; r3[cl][cx] = s3; r4[cl][cx] = s4;
     __syncthreads();
     if (cl != 0 || c >= n) return;
-    s1 = 0.f; s2 = 0.f; s3 = 0.f;
+    s1 = 0.f; s2 = 0.f; s3 = 0.f; s4 = 0.f;
 #pragma unroll
-    for (int k = 0; k < FIN_LANES; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; s3 = fmaxf(s3, r3[k][cx]); }
+    for (int k = 0; k < FIN_LANES; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; s3 = fmaxf(s3, r3[k][cx]); s4 += r4[k][cx]; }
     dbeta[c] = s1;
     dgamma[c] = s2;
+    if (dalpha) dalpha[c] = s4;
     const float c1 = s1 / (float)rows;
     coef[c] = c1;
     coef[n + c] = s2 / (float)rows;
@@ -653,7 +701,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int t, int n, const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ coef, int relu, int pad,
-                                                           float* __restrict__ dz) {
+                                                           float* __restrict__ dz, const float* __restrict__ slope) {
     const int tp = t + 2 * pad;
     const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int rl = threadIdx.x >> 6;
@@ -664,6 +712,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
     const f32x4 c1 = *(const f32x4*)(coef + col), c2 = *(const f32x4*)(coef + n + col);
     const f32x4 g_is = *(const f32x4*)(gamma + col) * is;
+    const bool hs = slope != nullptr;
+    f32x4 sl = {0, 0, 0, 0};
+    if (hs) sl = *(const f32x4*)(slope + col);
     int seg = r0 / tp, u = r0 - seg * tp;          // padded row r0 -> (segment, frame + pad)
     u += rl;
     while (u >= tp) { u -= tp; ++seg; }
@@ -684,7 +735,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 invT = pool_frame_weight(pg, r);
             }
             const f32x4 zz = *(const f32x4*)(z + r * n + col);
-            const f32x4 dd = upstream_grad<POOLED>(da, pc, invT, r, n, col, zz, sc, sh, relu);
+            const f32x4 dd = upstream_grad<POOLED>(da, pc, invT, r, n, col, zz, sc, sh, relu, sl, hs);
             const f32x4 xh = (zz - mu) * is;
             out = g_is * (dd - c1 - xh * c2);
         }
@@ -707,7 +758,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split_kernel(const float* __
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  const float* __restrict__ coef, int relu, int pad,
                                                                  const unsigned* __restrict__ amax, unsigned short* __restrict__ dst,
-                                                                 long ldd, long plane_stride) {
+                                                                 long ldd, long plane_stride, const float* __restrict__ slope) {
     const float s = xv_pow2_scale(*amax);
     const int tp = t + 2 * pad;
     const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 8;
@@ -715,13 +766,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split_kernel(const float* __
     if (col >= ldd) return;
     const int total_rows = segs * tp;
     const int r0 = blockIdx.y * BAS_ROWS, r1 = min(total_rows, r0 + BAS_ROWS);
-    f32x4 g_is[2], mu[2], is[2], sc[2], sh[2], c1[2], c2[2];
+    f32x4 g_is[2], mu[2], is[2], sc[2], sh[2], c1[2], c2[2], sl[2];
     bool cv[2];
+    const bool hs = slope != nullptr;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = col + 4 * q;
         cv[q] = c < n;
         const int cc = cv[q] ? c : 0;
+        sl[q] = hs ? *(const f32x4*)(slope + cc) : f32x4{0, 0, 0, 0};
         mu[q] = *(const f32x4*)(mean + cc); is[q] = *(const f32x4*)(invstd + cc);
         sc[q] = *(const f32x4*)(scale + cc); sh[q] = *(const f32x4*)(shift + cc);
         c1[q] = *(const f32x4*)(coef + cc); c2[q] = *(const f32x4*)(coef + n + cc);
@@ -752,7 +805,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split_kernel(const float* __
                 if (!cv[q]) continue;
                 const int c = col + 4 * q;
                 f32x4 zz = *(const f32x4*)(z + r * n + c);
-                f32x4 dd = upstream_grad<POOLED>(da, pc[q], invT, r, n, c, zz, sc[q], sh[q], relu);
+                f32x4 dd = upstream_grad<POOLED>(da, pc[q], invT, r, n, c, zz, sc[q], sh[q], relu, sl[q], hs);
                 f32x4 xh = (zz - mu[q]) * is[q];
                 f32x4 o = g_is[q] * (dd - c1[q] - xh * c2[q]);
                 v[4 * q] = o.x; v[4 * q + 1] = o.y; v[4 * q + 2] = o.z; v[4 * q + 3] = o.w;
@@ -781,21 +834,23 @@ static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, co
     XV_REQUIRE((long)segs * (t + 2 * pad) * (n / 4) < (1L << 31), "bn_relu_backward: tensor too large for 32-bit indexing");
     const int rows = segs * t;
     const int chunks = xv_cdiv(rows, BB_ROWS);
-    size_t need = ((size_t)chunks * 3 * n + 2 * n) * sizeof(float);
+    const XvActContext act = g_act;
+    const int nstat = (relu && act.slope && act.dalpha) ? 4 : 3;      // prelu: one more reduction, sum d act * min(y, 0)
+    size_t need = ((size_t)chunks * nstat * n + 2 * n) * sizeof(float);
     XV_REQUIRE(need <= ws_bytes, "bn_relu_backward: workspace too small (%zu > %zu)", need, ws_bytes);
     float* part = (float*)ws;
-    float* coef = part + (size_t)chunks * 3 * n;
+    float* coef = part + (size_t)chunks * nstat * n;
     const bool pooled = pg.out != nullptr;
     hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
-                       da, pg, z, rows, n, mean, invstd, scale, shift, relu, part);
+                       da, pg, z, rows, n, mean, invstd, scale, shift, relu, part, relu ? act.slope : nullptr, nstat);
     XV_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
                        dgamma, dbeta, coef, gamma, invstd, dbias, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (unsigned*)nullptr);
+                       (unsigned*)nullptr, nstat, nstat == 4 ? act.dalpha : (float*)nullptr);
     XV_LAUNCH_CHECK();
     dim3 agrid(xv_cdiv(n / 4, 64), xv_cdiv(segs * (t + 2 * pad), BAF_ROWS));
     hipLaunchKernelGGL(pooled ? bn_bwd_apply_kernel<true> : bn_bwd_apply_kernel<false>, agrid, dim3(256), 0, s, da,
-                       pg, z, segs, t, n, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad, dz_pad);
+                       pg, z, segs, t, n, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad, dz_pad, relu ? act.slope : nullptr);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -812,24 +867,28 @@ static int bn_relu_backward_split_impl(hipStream_t s, const float* da, PoolGrad 
     // the reduction partials either come from the data-gradient GEMM's epilogue (ext_part, one chunk per 128-row tile) or
     // are computed here from (da, z)
     const int chunks = ext_part ? ext_chunks : xv_cdiv(rows, BB_ROWS);
-    size_t need = ((size_t)(ext_part ? 0 : chunks) * 3 * n + 2 * n) * sizeof(float);
+    const XvActContext act = g_act;
+    XV_REQUIRE(!(ext_part && relu && act.slope), "bn_relu_backward_split: GEMM-epilogue partials only exist for a plain ReLU");
+    const int nstat = (relu && act.slope && act.dalpha) ? 4 : 3;
+    size_t need = ((size_t)(ext_part ? 0 : chunks) * nstat * n + 2 * n) * sizeof(float);
     XV_REQUIRE(need <= ws_bytes, "bn_relu_backward_split: workspace too small (%zu > %zu)", need, ws_bytes);
     float* part = ext_part ? const_cast<float*>(ext_part) : (float*)ws;
-    float* coef = ext_part ? (float*)ws : part + (size_t)chunks * 3 * n;
+    float* coef = ext_part ? (float*)ws : part + (size_t)chunks * nstat * n;
     const bool pooled = pg.out != nullptr;
     if (zero_amax) XV_CHECK_HIP(hipMemsetAsync(dz_amax, 0, sizeof(uint32_t), s));
     if (!ext_part) {
         hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
-                           da, pg, z, rows, n, mean, invstd, scale, shift, relu, part);
+                           da, pg, z, rows, n, mean, invstd, scale, shift, relu, part, relu ? act.slope : nullptr, nstat);
         XV_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
-                       dgamma, dbeta, coef, gamma, invstd, dbias, mean, zmin, zmax, (unsigned*)dz_amax);
+                       dgamma, dbeta, coef, gamma, invstd, dbias, mean, zmin, zmax, (unsigned*)dz_amax, nstat,
+                       nstat == 4 ? act.dalpha : (float*)nullptr);
     XV_LAUNCH_CHECK();
     dim3 agrid(xv_cdiv(ldp / 8, 64), xv_cdiv(segs * (t + 2 * pad), BAS_ROWS));
     hipLaunchKernelGGL(pooled ? bn_bwd_apply_split_kernel<true> : bn_bwd_apply_split_kernel<false>, agrid,
                        dim3(256), 0, s, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad,
-                       (const unsigned*)dz_amax, (unsigned short*)dz_planes, (long)ldp, (long)plane_stride);
+                       (const unsigned*)dz_amax, (unsigned short*)dz_planes, (long)ldp, (long)plane_stride, relu ? act.slope : nullptr);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -917,7 +976,8 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
                                                            const float* __restrict__ beta, float eps, float momentum, int unbiased,
                                                            float* __restrict__ mmean, float* __restrict__ mvar, float* __restrict__ mean_o,
                                                            float* __restrict__ invstd_o, float* __restrict__ scale_o,
-                                                           float* __restrict__ shift_o, int relu, float* __restrict__ a) {
+                                                           float* __restrict__ shift_o, int relu, float* __restrict__ a,
+                                                           const float* __restrict__ slope) {
     __shared__ float red[16][16];
     const int cx = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
@@ -942,7 +1002,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
     if (a)
         for (int r = rl; r < rows; r += 16) {
             float y = z[(long)r * n + c] * sc + sh;
-            a[(long)r * n + c] = relu ? fmaxf(y, 0.f) : y;
+            a[(long)r * n + c] = relu ? (slope ? act1(y, slope[c]) : fmaxf(y, 0.f)) : y;
         }
 }
 
@@ -951,7 +1011,7 @@ int xv_bn_small_forward(hipStream_t s, const float* z, int rows, int n, const fl
                         int relu, float* a) {
     XV_REQUIRE(rows > 0 && rows <= XV_BN_SMALL_MAX_ROWS && n > 0, "bn_small_forward: bad shape (rows=%d)", rows);
     hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(xv_cdiv(n, 16)), dim3(256), 0, s, z, rows, n, gamma, beta, eps, momentum, unbiased_moving,
-                       moving_mean, moving_var, mean, invstd, scale, shift, relu, a);
+                       moving_mean, moving_var, mean, invstd, scale, shift, relu, a, relu ? g_act.slope : nullptr);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -961,33 +1021,37 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu, float* __restrict__ dz,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           float* __restrict__ dbias) {
+                                                           float* __restrict__ dbias, const float* __restrict__ slope,
+                                                           float* __restrict__ dalpha) {
     __shared__ float red[16][16];
     const int cx = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
     const bool cv = c < n;
-    float mu = 0.f, is = 0.f, sc = 0.f, sh = 0.f;
-    if (cv) { mu = mean[c]; is = invstd[c]; sc = scale[c]; sh = shift[c]; }
-    float s1 = 0.f, s2 = 0.f;
+    float mu = 0.f, is = 0.f, sc = 0.f, sh = 0.f, sl = 0.f;
+    if (cv) { mu = mean[c]; is = invstd[c]; sc = scale[c]; sh = shift[c]; sl = slope ? slope[c] : 0.f; }
+    float s1 = 0.f, s2 = 0.f, s4 = 0.f;
     if (cv)
         for (int r = rl; r < rows; r += 16) {
             float zz = z[(long)r * n + c], dd = da[(long)r * n + c];
-            if (relu && !(zz * sc + sh > 0.f)) dd = 0.f;
+            const float y = zz * sc + sh;
+            if (relu) { s4 += dd * fminf(y, 0.f); if (!(y > 0.f)) dd *= sl; }
             s1 += dd;
             s2 += dd * ((zz - mu) * is);
         }
     s1 = small_reduce16(s1, red, rl, cx);
     s2 = small_reduce16(s2, red, rl, cx);
+    if (dalpha) s4 = small_reduce16(s4, red, rl, cx);      // (uniform: every thread of the block takes the same path)
     if (!cv) return;
     const float c1 = s1 / (float)rows, c2 = s2 / (float)rows;
     const float g = gamma[c] * is;
     if (rl == 0) {
         dbeta[c] = s1; dgamma[c] = s2;
         if (dbias) dbias[c] = g * (s1 - c1 * (float)rows);
+        if (dalpha) dalpha[c] = s4;
     }
     for (int r = rl; r < rows; r += 16) {
         float zz = z[(long)r * n + c], dd = da[(long)r * n + c];
-        if (relu && !(zz * sc + sh > 0.f)) dd = 0.f;
+        if (relu && !(zz * sc + sh > 0.f)) dd *= sl;
         dz[(long)r * n + c] = g * (dd - c1 - ((zz - mu) * is) * c2);
     }
 }
@@ -997,7 +1061,7 @@ int xv_bn_small_backward(hipStream_t s, const float* da, const float* z, int row
                          float* dbias) {
     XV_REQUIRE(rows > 0 && rows <= XV_BN_SMALL_MAX_ROWS && n > 0, "bn_small_backward: bad shape (rows=%d)", rows);
     hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(xv_cdiv(n, 16)), dim3(256), 0, s, da, z, rows, n, gamma, mean, invstd, scale, shift, relu,
-                       dz, dgamma, dbeta, dbias);
+                       dz, dgamma, dbeta, dbias, relu ? g_act.slope : nullptr, (relu && g_act.slope) ? g_act.dalpha : nullptr);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -1006,6 +1070,51 @@ __global__ void relu_bwd_kernel(const float* __restrict__ da, const float* __res
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
         dz[i] = a[i] > 0.f ? da[i] : 0.f;
 }
+// The same with a slope (act context): forward a = act(z) and backward dz = da * act'(z), d alpha[c] = sum_r da * min(z, 0); rows <= XV_BN_SMALL_MAX_ROWS
+__global__ __launch_bounds__(256) void act_small_kernel(const float* __restrict__ da, const float* __restrict__ z, int rows, int n,
+                                                        const float* __restrict__ slope, float* __restrict__ out,
+                                                        float* __restrict__ dalpha) {
+    __shared__ float red[16][16];
+    const int cx = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    const bool cv = c < n;
+    const float sl = cv ? slope[c] : 0.f;
+    float s4 = 0.f;
+    if (cv)
+        for (int r = rl; r < rows; r += 16) {
+            const float zz = z[(long)r * n + c];
+            if (da) {
+                const float dd = da[(long)r * n + c];
+                s4 += dd * fminf(zz, 0.f);
+                out[(long)r * n + c] = zz > 0.f ? dd : dd * sl;
+            } else {
+                out[(long)r * n + c] = act1(zz, sl);
+            }
+        }
+    if (dalpha) {
+        s4 = small_reduce16(s4, red, rl, cx);
+        if (cv && rl == 0) dalpha[c] = s4;
+    }
+}
+int xv_act_small(hipStream_t s, const float* da, const float* z, int rows, int n, float* out) {
+    XV_REQUIRE(g_act.slope && rows > 0 && rows <= XV_BN_SMALL_MAX_ROWS && n > 0, "act_small: needs an activation slope and a segment-level tensor");
+    hipLaunchKernelGGL(act_small_kernel, dim3(xv_cdiv(n, 16)), dim3(256), 0, s, da, z, rows, n, g_act.slope, out, da ? g_act.dalpha : (float*)nullptr);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// y[r][c] = x > 0 ? x : alpha[c] * x  (common.py:27-42 prelu = relu(x) + alpha (x - |x|) / 2; a constant alpha = leaky ReLU)
+__global__ void prelu_fwd_kernel(const float* __restrict__ x, size_t count, int n, const float* __restrict__ alpha, float* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) y[i] = act1(x[i], alpha[i % n]);
+}
+extern "C" int xv_prelu_forward(void* stream, const float* x, int rows, int n, const float* alpha, float* y) {
+    XV_REQUIRE(x && alpha && y && rows > 0 && n > 0, "prelu_forward: bad arguments");
+    const size_t count = (size_t)rows * n;
+    hipLaunchKernelGGL(prelu_fwd_kernel, dim3(grid_for((long)count, 256)), dim3(256), 0, (hipStream_t)stream, x, count, n, alpha, y);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int xv_relu_backward(void* stream, const float* da, const float* a, size_t count, float* dz) {
     XV_REQUIRE(count > 0, "relu_backward: empty");
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for((long)count, 256)), dim3(256), 0, (hipStream_t)stream, da, a, count, dz);
@@ -1036,7 +1145,7 @@ __device__ __forceinline__ void wf_merge(f32x4& mean, f32x4& m2, float& n, const
 template <bool BN>
 __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restrict__ x, int T, int C, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu, const float* __restrict__ wts,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, const float* __restrict__ slope) {
     __shared__ f32x4 s_mean[4][32], s_m2[4][32];
     __shared__ float s_n[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1048,11 +1157,13 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
     const float* xp = x + (long)b * T * C + (cv ? col : 0);
     f32x4 mean = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
     f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
-    if (BN && cv) { sc = *(const f32x4*)(scale + col); sh = *(const f32x4*)(shift + col); }
+    f32x4 sl = {0, 0, 0, 0};
+    const bool hs = BN && slope != nullptr;
+    if (BN && cv) { sc = *(const f32x4*)(scale + col); sh = *(const f32x4*)(shift + col); if (hs) sl = *(const f32x4*)(slope + col); }
     auto act = [&](f32x4 v) {
         if (BN) {
             v = v * sc + sh;
-            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (relu) v = hs ? act4(v, sl) : relu4(v);
         }
         return v;
     };
@@ -1069,21 +1180,20 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
         f32x4 v3 = act(*(const f32x4*)(xp + (long)(t + 24) * C));
         const float w0 = wp ? wp[t] : 1.f, w1 = wp ? wp[t + 8] : 1.f, w2 = wp ? wp[t + 16] : 1.f, w3 = wp ? wp[t + 24] : 1.f;
         f32x4 d;
-        // w / n through v_rcp_f32 (1 ulp): the IEEE division sequence (div_scale, rcp, 4 fma, div_fmas, div_fixup) sat on the
-        // serial mean -> M2 dependency chain of every frame and made this HBM-bound pass VALU-latency-bound (38 us for 143 MB)
-        n += w0; d = v0 - mean; if (n > 0.f) mean += d * (w0 * __builtin_amdgcn_rcpf(n)); m2 += d * (v0 - mean) * w0;
-        n += w1; d = v1 - mean; if (n > 0.f) mean += d * (w1 * __builtin_amdgcn_rcpf(n)); m2 += d * (v1 - mean) * w1;
-        n += w2; d = v2 - mean; if (n > 0.f) mean += d * (w2 * __builtin_amdgcn_rcpf(n)); m2 += d * (v2 - mean) * w2;
-        n += w3; d = v3 - mean; if (n > 0.f) mean += d * (w3 * __builtin_amdgcn_rcpf(n)); m2 += d * (v3 - mean) * w3;
+        // unit weights (statistics pooling): 1 / n through v_rcp_f32 (1 ulp, exact for n = 1): the IEEE division sequence (div_scale,
+        // rcp, 4 fma, div_fmas, div_fixup) sat on the serial mean -> M2 dependency chain of every frame and made this HBM-bound pass
+        // VALU-latency-bound (38 us for 143 MB).  Attention weights keep the exact quotient: there w / n must be exactly 1 on a
+        // lane's first frame, or a constant chunk no longer has a zero variance (reference test_utils.py / pooling.py:160-162 clamp).
+#define XV_POOL_STEP(v, w) { n += (w); d = (v) - mean; if (n > 0.f) mean += d * (wp ? (w) / n : __builtin_amdgcn_rcpf(n)); m2 += d * ((v) - mean) * (w); }
+        XV_POOL_STEP(v0, w0) XV_POOL_STEP(v1, w1) XV_POOL_STEP(v2, w2) XV_POOL_STEP(v3, w3)
     }
     for (; t < T; t += 8) {
         f32x4 v = act(*(const f32x4*)(xp + (long)t * C));
         const float w = wp ? wp[t] : 1.f;
-        n += w;
-        f32x4 d = v - mean;
-        if (n > 0.f) mean += d * (w * __builtin_amdgcn_rcpf(n));
-        m2 += d * (v - mean) * w;
+        f32x4 d;
+        XV_POOL_STEP(v, w)
     }
+#undef XV_POOL_STEP
     // merge the two frame lanes of this wave
     f32x4 mean_b, m2_b;
     mean_b.x = __shfl_xor(mean.x, 32); mean_b.y = __shfl_xor(mean.y, 32);
@@ -1114,7 +1224,7 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
 extern "C" int xv_stat_pool_forward(void* stream, const float* x, int b, int t, int c, float* out) {
     XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0, "stat_pool_forward: bad shape (c=%d must be a multiple of 4)", c);
     hipLaunchKernelGGL(stat_pool_fwd_kernel<false>, dim3(xv_cdiv(c / 4, 32), b), dim3(256), 0, (hipStream_t)stream, x, t, c,
-                       (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, out);
+                       (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, out, (const float*)nullptr);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -1123,7 +1233,7 @@ extern "C" int xv_stat_pool_forward_bn(void* stream, const float* z, int b, int 
                                        const float* weights, float* out) {
     XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0 && scale && shift, "stat_pool_forward_bn: bad shape (c=%d must be a multiple of 4)", c);
     hipLaunchKernelGGL(stat_pool_fwd_kernel<true>, dim3(xv_cdiv(c / 4, 32), b), dim3(256), 0, (hipStream_t)stream, z, t, c, scale, shift,
-                       relu, weights, out);
+                       relu, weights, out, relu ? g_act.slope : nullptr);
     XV_LAUNCH_CHECK();
     return 0;
 }

@@ -51,6 +51,7 @@ struct Affine {   // one conv/dense layer (+ optional BN, ReLU)
     int in_layer = -1;                    // index of the layer whose output this one reads (-1: the features / the pooled vector)
     int act = 0;                          // 3: tanh on the affine output (att_key_network_type 3), no BN
     int wslot = 0, aslot = 0;             // amax slots of the weights / of the BN+ReLU output planes
+    int v_alpha = -1;                     // prelu: the layer's "<prefix>_relu/alpha" variable (network_relu_type, common.py:35-39)
 };
 
 }  // namespace
@@ -93,6 +94,8 @@ struct xv_engine {
     // second stream: weight gradients run beside the data-gradient chain (they only share dz)
     hipStream_t side = nullptr;
     hipEvent_t ev_dz = nullptr, ev_lw = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_lossprep = nullptr;     // side-stream halves of ensure_weights
+    bool prep_pending = false, lossprep_pending = false;
     hipEvent_t ev_stage[XV_BWD_STAGES][2] = {};   // [stage][0 main, 1 side]: that stage's gradients are complete (backward_async)
     bool stage_side[XV_BWD_STAGES] = {};          // the side-stream event of the stage was recorded
     // dz ping-pong state.  ring 0: the frame-level layers' dz (fp16 planes `dzh` in split precision) and, in fp32, every
@@ -103,6 +106,7 @@ struct xv_engine {
     bool concurrent = true;
     void* ws_side = nullptr;
     float *scalars = nullptr;   // [0] raw loss, [1] reg loss, [2] grad sumsq
+    float* lrelu_slope = nullptr;   // network_relu_type lrelu: a constant 0.2 vector as wide as the widest layer
     // split precision state
     bool f16 = false;
     unsigned short* xh = nullptr;             // planes of the (channel-padded) input features
@@ -160,6 +164,17 @@ int add_var(xv_engine* e, const std::string& name, std::initializer_list<int> sh
 
 float* vptr(xv_engine* e, int idx) { return e->V + e->vars[idx].offset; }
 float* gptr(xv_engine* e, int idx) { return e->G + e->vars[idx].offset; }
+
+// network_relu_type (tdnn.py:24-30): while in scope, the entry points that take a `relu` flag apply y > 0 ? y : slope[c] * y for this
+// layer - prelu: slope = the layer's alpha variable (d alpha goes to its gradient slot), lrelu: the constant 0.2 vector (xv_common.h)
+struct ActScope {
+    ActScope(xv_engine* e, const Affine& a) {
+        if (!a.has_relu || e->cfg.relu_type == XV_RELU_RELU) return;
+        if (e->cfg.relu_type == XV_RELU_PRELU) xv_set_act_context(vptr(e, a.v_alpha), e->G ? gptr(e, a.v_alpha) : nullptr);
+        else xv_set_act_context(e->lrelu_slope, nullptr);
+    }
+    ~ActScope() { xv_set_act_context(nullptr, nullptr); }
+};
 
 void build_variables(xv_engine* e) {
     const xv_config& c = e->cfg;
@@ -220,6 +235,8 @@ void build_variables(xv_engine* e) {
             a.v_mmean = add_var(e, bn + "/moving_mean", {s.cout}, false);
             a.v_mvar = add_var(e, bn + "/moving_variance", {s.cout}, false);
         }
+        if (c.relu_type == XV_RELU_PRELU && s.relu)      // prelu(x, name): variable_scope("<prefix>_relu") / "alpha" [C], common.py:35-39
+            a.v_alpha = add_var(e, std::string("tdnn/") + s.scope + s.prefix + "_relu/alpha", {s.cout}, true);
         if (i == F + 3) e->v_query = add_var(e, "tdnn/attention/query", {1, s.cout}, true);   // [heads, key dim], pooling.py:131
     }
     e->c_pad0 = e->L[0].c_pad;
@@ -318,6 +335,7 @@ int alloc_buffers(xv_engine* e) {
     if (e->f16) { want(dzh_halfs); want(dzh_halfs); }
     want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512)); want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512));
     want(16);
+    want(xv_align(maxc, 4) + 4);      // lrelu_slope
     // GEMM split slabs: weight-gradient partials dominate
     size_t ws = 0;
     for (int i = 0; i < e->NL; ++i) {
@@ -412,6 +430,11 @@ int alloc_buffers(xv_engine* e) {
     e->d_small0 = carve(e, small);
     e->d_small1 = carve(e, small);
     e->scalars = carve(e, 16);
+    e->lrelu_slope = carve(e, xv_align(maxc, 4) + 4);
+    if (c.relu_type == XV_RELU_LRELU) {
+        std::vector<float> h(xv_align(maxc, 4) + 4, 0.2f);      // tf.nn.leaky_relu default alpha
+        XV_CHECK_HIP(hipMemcpy(e->lrelu_slope, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     e->ws = carve(e, ws / sizeof(float));
     e->ws_side = carve(e, ws / sizeof(float));
     e->ws_bytes = ws;
@@ -426,18 +449,32 @@ int alloc_buffers(xv_engine* e) {
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < 2; ++i) XV_CHECK_HIP(hipEventCreateWithFlags(&e->zr[r].ev[i], hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lw, hipEventDisableTiming));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_prep, hipEventDisableTiming));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lossprep, hipEventDisableTiming));
     for (int k = 0; k < XV_BWD_STAGES; ++k)
         for (int j = 0; j < 2; ++j) XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_stage[k][j], hipEventDisableTiming));
     return 0;
 }
 
-// Kernel-layout (and, in split precision, fp16-plane) copies of the weights, rebuilt after every update: one
-// memset + one multi-tensor amax + one multi-job layout kernel (+ the loss head's two) instead of ~28 launches.
-int ensure_weights(xv_engine* e, hipStream_t s) {
-    if (!e->weights_dirty) return 0;
+// Kernel-layout (and, in split precision, fp16-plane) copies of the weights, rebuilt after every update: one memset + one
+// multi-tensor amax + one multi-job layout kernel (+ the loss head's two) instead of ~28 launches.
+// With `overlap` (the training forward pass) only the FIRST layer's copies are made on `s`; the other layers' and the loss
+// head's go to the side stream behind an event on `s` and are waited for where they are first used (wait_prep before the
+// second layer, wait_lossprep before the logits) - they then run under the feature split / first GEMM instead of in front
+// of them (58 us of a 5.8 ms fp32 step, 112 us of a 2.7 ms f16x3 step were spent there with the chip otherwise idle).
+int wait_prep(xv_engine* e, hipStream_t s) {
+    if (e->prep_pending) { XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_prep, 0)); e->prep_pending = false; }
+    return 0;
+}
+int wait_lossprep(xv_engine* e, hipStream_t s) {
+    if (e->lossprep_pending) { XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_lossprep, 0)); e->lossprep_pending = false; }
+    return 0;
+}
+
+int prep_layers(xv_engine* e, hipStream_t s, int first, int last) {
     XvPrepJobs J = {};
     XvAmaxJobs A = {};
-    for (int i = 0; i < e->NL; ++i) {
+    for (int i = first; i < last; ++i) {
         Affine& a = e->L[i];
         const float* w = vptr(e, a.v_kernel);
         if (e->f16 && is_frame(e, i)) {
@@ -462,24 +499,54 @@ int ensure_weights(xv_engine* e, hipStream_t s) {
         }
     }
     if (A.n) {
-        XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_WT, 0, (e->F + 2) * sizeof(uint32_t), s));
+        // one memset over the slot range of these layers (tdnn first..F-1 -> slots first..F-1, key layers -> F, F+1: contiguous)
+        unsigned *lo = A.out[0], *hi = A.out[0];
+        for (int j = 1; j < A.n; ++j) { lo = std::min(lo, A.out[j]); hi = std::max(hi, A.out[j]); }
+        XV_CHECK_HIP(hipMemsetAsync(lo, 0, (size_t)(hi - lo + 1) * sizeof(uint32_t), s));
         int rc = xv_launch_amax_multi(s, A);
         if (rc) return rc;
     }
-    int rc = xv_launch_weight_prep(s, J);
-    if (rc) return rc;
-    if (e->N > 0) {
-        rc = xv_loss_prep_weight(s, vptr(e, e->v_loss_kernel), e->Lout, e->N, e->cfg.loss_kind != XV_LOSS_SOFTMAX, e->inv_norm,
-                                 e->wn, e->ldl, e->wnt);
+    return xv_launch_weight_prep(s, J);
+}
+
+int prep_loss_head(xv_engine* e, hipStream_t s) {
+    if (e->N <= 0) return 0;
+    return xv_loss_prep_weight(s, vptr(e, e->v_loss_kernel), e->Lout, e->N, e->cfg.loss_kind != XV_LOSS_SOFTMAX, e->inv_norm, e->wn, e->ldl,
+                               e->wnt);
+}
+
+int ensure_weights(xv_engine* e, hipStream_t s, bool overlap = false) {
+    if (!e->weights_dirty) return 0;
+    int rc;
+    if (overlap && e->concurrent && e->side) {
+        rc = prep_layers(e, s, 0, 1);
+        if (rc) return rc;
+        XV_CHECK_HIP(hipEventRecord(e->ev_dz, s));              // the update that made the copies stale is ahead of this point on `s`
+        XV_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_dz, 0));
+        rc = prep_layers(e, e->side, 1, e->NL);
+        if (rc) return rc;
+        XV_CHECK_HIP(hipEventRecord(e->ev_prep, e->side));
+        e->prep_pending = true;
+        rc = prep_loss_head(e, e->side);
+        if (rc) return rc;
+        XV_CHECK_HIP(hipEventRecord(e->ev_lossprep, e->side));
+        e->lossprep_pending = true;
+    } else {
+        rc = prep_layers(e, s, 0, e->NL);
+        if (rc) return rc;
+        rc = prep_loss_head(e, s);
         if (rc) return rc;
     }
     e->weights_dirty = false;
     return 0;
 }
 
+inline int c_relu_type(const xv_engine* e) { return e->cfg.relu_type; }
+
 // BN (+ReLU) forward of one layer given z
 int bn_forward(xv_engine* e, hipStream_t s, Affine& a, int rows, bool stats_from_gemm, float* dst_a) {
     const xv_config& c = e->cfg;
+    ActScope act(e, a);
     int rc;
     if (e->training && !stats_from_gemm && rows <= XV_BN_SMALL_MAX_ROWS)      // segment-level layers: one launch
         return xv_bn_small_forward(s, a.z, rows, a.c_out, vptr(e, a.v_gamma), vptr(e, a.v_beta), c.bn_epsilon, c.batchnorm_momentum,
@@ -536,6 +603,9 @@ extern "C" int xv_engine_create(const xv_config* cfg, xv_engine** out) {
         XV_REQUIRE(cfg->frame_width[cfg->num_frame_layers - 1] == cfg->num_nodes_pooling_layer,
                    "engine_create: the last frame layer is the pooling layer: frame_width[%d] must equal num_nodes_pooling_layer", cfg->num_frame_layers - 1);
     }
+    XV_REQUIRE(cfg->relu_type >= XV_RELU_RELU && cfg->relu_type <= XV_RELU_LRELU, "engine_create: unknown network_relu_type code %d", cfg->relu_type);
+    XV_REQUIRE(!(cfg->relu_type != XV_RELU_RELU && cfg->pooling == XV_POOL_SELF_ATTENTION && cfg->att_key_type == 1),
+               "engine_create: att_key_network_type 1 (affine + relu inside the score kernel) is built for a plain ReLU; use type 0, 2 or 3 with prelu / lrelu");
     xv_engine* e = new xv_engine();
     e->cfg = *cfg;
     e->F = cfg->num_frame_layers > 0 ? cfg->num_frame_layers : 5;
@@ -560,6 +630,8 @@ extern "C" void xv_engine_destroy(xv_engine* e) {
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < 2; ++i) if (e->zr[r].ev[i]) (void)hipEventDestroy(e->zr[r].ev[i]);
     if (e->ev_lw) (void)hipEventDestroy(e->ev_lw);
+    if (e->ev_prep) (void)hipEventDestroy(e->ev_prep);
+    if (e->ev_lossprep) (void)hipEventDestroy(e->ev_lossprep);
     for (int k = 0; k < XV_BWD_STAGES; ++k)
         for (int j = 0; j < 2; ++j) if (e->ev_stage[k][j]) (void)hipEventDestroy(e->ev_stage[k][j]);
 
@@ -612,7 +684,8 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
     hipStream_t s = (hipStream_t)stream;
     e->last_stream = s;
     e->B = b; e->T = t; e->training = training;
-    int rc = ensure_weights(e, s);
+    // training steps only: there xv_engine_loss_forward always follows and picks up the loss head's event
+    int rc = ensure_weights(e, s, training != 0 && e->N > 0);
     if (rc) return rc;
     int cur_t = t;
     e->Tl[0] = t;
@@ -632,6 +705,8 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             Affine& a = e->L[i];
             int t_out = cur_t - a.k + 1;
             int rows = b * t_out;
+            if (i == 1) { rc = wait_prep(e, s); if (rc) return rc; }
+            ActScope act(e, a);
             // the epilogue's column min/max are needed in inference too (they fix the next operand's scale)
             rc = xv_affine_forward_f16x3(s, curh, cur_stride, cur_amax, b, cur_t, a.c_pad, a.k, a.wth, a.wth_stride,
                                          e->amax + AMAX_WT + a.wslot, vptr(e, a.v_bias), a.z, a.c_out, a.c_out, a.bn_part);
@@ -668,6 +743,7 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             rc = xv_affine_forward_f16x3(s, in.ah, (size_t)rows * in.o_ld, e->amax + AMAX_A + in.aslot, rows, 1, k0.c_pad, 1, k0.wth,
                                          k0.wth_stride, e->amax + AMAX_WT + k0.wslot, vptr(e, k0.v_bias), k0.z, k0.c_out, k0.c_out, k0.bn_part);
             if (rc) return rc;
+            ActScope act0(e, k0);
             if (training) {
                 rc = xv_bn_finalize(s, k0.bn_part, rows, k0.c_out, vptr(e, k0.v_gamma), vptr(e, k0.v_beta), c.bn_epsilon, c.batchnorm_momentum,
                                     0, vptr(e, k0.v_mmean), vptr(e, k0.v_mvar), k0.mean, k0.invstd, k0.scale, k0.shift, k0.zmin, k0.zmax,
@@ -686,6 +762,7 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
                                          k1.has_bn ? k1.bn_part : nullptr);
             if (rc) return rc;
             if (k1.has_bn) {      // att_key_network_type 2: the key is relu(bn(.)), kept in fp32 for the score (no GEMM consumes it)
+                ActScope act1(e, k1);
                 if (training) {
                     rc = xv_bn_finalize(s, k1.bn_part, rows, k1.c_out, vptr(e, k1.v_gamma), vptr(e, k1.v_beta), c.bn_epsilon,
                                         c.batchnorm_momentum, 0, vptr(e, k1.v_mmean), vptr(e, k1.v_mvar), k1.mean, k1.invstd, k1.scale,
@@ -708,6 +785,7 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
             Affine& a = e->L[i];
             int t_out = cur_t - a.k + 1;
             int rows = b * t_out;
+            if (i == 1) { rc = wait_prep(e, s); if (rc) return rc; }
             rc = xv_affine_forward(s, cur, b, cur_t, a.c_pad, a.k, a.wt, vptr(e, a.v_bias), a.z, a.c_out, a.c_out,
                                    training ? a.bn_part : nullptr, e->ws, e->ws_bytes);
             if (rc) return rc;
@@ -747,7 +825,10 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
         frame_w = e->att_w;
     }
     // the last frame layer's BN + ReLU is applied inside the pooling reduction: its [b*t][1500] activation is never written
-    rc = xv_stat_pool_forward_bn(s, e->L[F - 1].z, b, cur_t, e->P, e->L[F - 1].scale, e->L[F - 1].shift, 1, frame_w, e->pool);
+    {
+        ActScope act(e, e->L[F - 1]);
+        rc = xv_stat_pool_forward_bn(s, e->L[F - 1].z, b, cur_t, e->P, e->L[F - 1].scale, e->L[F - 1].shift, 1, frame_w, e->pool);
+    }
     if (rc) return rc;
     // segment-level layers
     Affine& l6 = e->L[e->S0()];
@@ -762,6 +843,11 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
     l7.rows = b;
     if (l7.has_bn) {
         rc = bn_forward(e, s, l7, b, false, e->h7_buf);
+        if (rc) return rc;
+        e->h7 = e->h7_buf;
+    } else if (l7.has_relu && c_relu_type(e) != XV_RELU_RELU) {
+        ActScope act(e, l7);
+        rc = xv_act_small(s, nullptr, l7.z, b, l7.c_out, e->h7_buf);
         if (rc) return rc;
         e->h7 = e->h7_buf;
     } else if (l7.has_relu) {
@@ -790,6 +876,10 @@ extern "C" int xv_engine_loss_forward(xv_engine* e, void* stream, const int32_t*
     e->labels_dev = (int32_t*)labels;
     e->with_margin = with_margin;
     int rc = ensure_weights(e, s);
+    if (rc) return rc;
+    rc = wait_prep(e, s);
+    if (rc) return rc;
+    rc = wait_lossprep(e, s);
     if (rc) return rc;
     XvGemmNT g = {};
     g.A = e->out; g.lda = e->Lout; g.a_rps = 1; g.a_pitch = 1;
@@ -883,6 +973,7 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     int rc;
     const int lidx = (int)(&a - &e->L[0]);
     if (e->f16 && is_frame(e, lidx)) return layer_backward_f16(e, s, lidx, da, segs, t_in, dx);
+    ActScope act(e, a);
     const float* dz = nullptr;
     xv_engine::ZRing& zr = e->zr[e->f16 ? 1 : 0];
     const int zi = zr.cur;
@@ -905,6 +996,10 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     } else if (a.has_bn) {
         rc = xv_bn_relu_backward(s, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift,
                                  a.has_relu ? 1 : 0, pad, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
+        if (rc) return rc;
+        dz = Z;
+    } else if (a.has_relu && c.relu_type != XV_RELU_RELU) {       // activation without a BN in front (tdnn7, last_layer_no_bn): needs the pre-activation
+        rc = xv_act_small(s, da, a.z, segs * t_out, a.c_out, Z);
         if (rc) return rc;
         dz = Z;
     } else if (a.has_relu) {
@@ -948,6 +1043,7 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
 int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int segs, int t_in, float* dx) {
     Affine& a = e->L[li];
     const xv_config& c = e->cfg;
+    ActScope act(e, a);
     const int t_out = t_in - a.k + 1;
     const int pad = (dx && a.k > 1) ? a.k - 1 : 0;
     xv_engine::ZRing& zr = e->zr[0];
@@ -1015,7 +1111,7 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
         // [measured] off by default: the epilogue's extra z-tile reads cost each data-gradient GEMM 50-60 us at S1, the
         // reduce kernels they replace 37 us each (3.17 vs 3.03 ms/step); XV_FUSE_BWD_STATS=1 turns it on for experiments
         static const bool fuse_env = getenv("XV_FUSE_BWD_STATS") && getenv("XV_FUSE_BWD_STATS")[0] == '1';
-        const bool fuse = fuse_env && in >= 0 && is_frame(e, in) && e->L[in].has_bn && e->L[in].has_relu && !(e->att && in == e->F - 2) && e->bwd_part;
+        const bool fuse = fuse_env && c.relu_type == XV_RELU_RELU && in >= 0 && is_frame(e, in) && e->L[in].has_bn && e->L[in].has_relu && !(e->att && in == e->F - 2) && e->bwd_part;
         if (fuse) {
             Affine& p = e->L[in];
             rc = xv_affine_dgrad_bnstats_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WT + a.wslot, dx,
@@ -1094,6 +1190,20 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             if (!e->with_margin) XV_CHECK_HIP(hipMemsetAsync(gptr(e, e->v_ring), 0, sizeof(float), s));
             if (rc) return rc;
         }
+        const float* d = e->d_small0;
+        if (c.feature_norm) {
+            rc = xv_l2_scaling_backward(s, e->h7, d, b, e->Lout, c.feature_scaling_factor, e->d_small1);
+            if (rc) return rc;
+            d = e->d_small1;
+        }
+        // tdnn7 -> d a6 (into bufD), tdnn6 -> d pool (into d_small0); the pooling backward itself is evaluated
+        // inside tdnn5's BN backward (stage 1) from (pool, d pool): d a5 is never written
+        rc = layer_backward(e, s, e->L[e->S1()], d, e->L[e->S0()].a, b, 1, e->bufD, e->h7);
+        if (rc) return rc;
+        rc = layer_backward(e, s, e->L[e->S0()], e->bufD, e->pool, b, 1, e->d_small0, nullptr);
+        if (rc) return rc;
+        // (enqueued AFTER the segment layers' weight gradients: the side stream runs in order, and the last frame layer's BN backward
+        // waits for the dz-ring slot tdnn7's weight gradient reads - behind this 5-kernel chain it waited 77 us per step in fp32 mode)
         // d wn = out^T . dlogits and the gradient through l2_normalize: on the side stream (only reads
         // dlogits / out / wn, which the main chain never rewrites during backward)
         {
@@ -1131,18 +1241,6 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
                 e->lw_pending = true;
             }
         }
-        const float* d = e->d_small0;
-        if (c.feature_norm) {
-            rc = xv_l2_scaling_backward(s, e->h7, d, b, e->Lout, c.feature_scaling_factor, e->d_small1);
-            if (rc) return rc;
-            d = e->d_small1;
-        }
-        // tdnn7 -> d a6 (into bufD), tdnn6 -> d pool (into d_small0); the pooling backward itself is evaluated
-        // inside tdnn5's BN backward (stage 1) from (pool, d pool): d a5 is never written
-        rc = layer_backward(e, s, e->L[e->S1()], d, e->L[e->S0()].a, b, 1, e->bufD, e->h7);
-        if (rc) return rc;
-        rc = layer_backward(e, s, e->L[e->S0()], e->bufD, e->pool, b, 1, e->d_small0, nullptr);
-        if (rc) return rc;
         if (stage == 0) { rc = end_stage(e, s, 0, defer); if (rc) return rc; }
     }
     const int F = e->F;
@@ -1163,7 +1261,10 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             Affine &k0 = e->L[e->K0()], &k1 = e->L[e->K1()];
             const int rows = b * Tp;
             const float scale = c.att_use_scale ? 1.0f / sqrtf((float)k1.c_out) : 1.0f;
-            rc = xv_att_pool_backward_weights(s, e->L[F - 1].z, b, Tp, e->P, e->L[F - 1].scale, e->L[F - 1].shift, 1, e->pool, e->d_small0, e->att_dw);
+            {
+                ActScope actv(e, e->L[F - 1]);
+                rc = xv_att_pool_backward_weights(s, e->L[F - 1].z, b, Tp, e->P, e->L[F - 1].scale, e->L[F - 1].shift, 1, e->pool, e->d_small0, e->att_dw);
+            }
             if (rc) return rc;
             rc = xv_softmax_segments_backward(s, e->att_w, e->att_dw, b, Tp, e->att_ds);
             if (rc) return rc;
@@ -1231,6 +1332,12 @@ extern "C" int xv_engine_apply(xv_engine* e, void* stream, float lr, float grad_
     XV_REQUIRE(e->cfg.optimizer == 0 || e->S, "engine_apply: optimiser state buffer not bound");
     hipStream_t s = (hipStream_t)stream;
     const xv_config& c = e->cfg;
+    {   // the update rewrites the variables the side-stream halves of ensure_weights read (no-ops after a full step)
+        int rcw = wait_prep(e, s);
+        if (rcw) return rcw;
+        rcw = wait_lossprep(e, s);
+        if (rcw) return rcw;
+    }
     if (c.clip_gradient_norm > 0.f) {
         XV_CHECK_HIP(hipMemsetAsync(e->scalars + 2, 0, sizeof(float), s));
         int rc = xv_sumsq(s, e->G, e->n_train, e->scalars + 2);
@@ -1270,6 +1377,7 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
         if (n == a.prefix + "_" + a.kind) return set(a.z, a.rows, a.c_out, a.c_out);
         if (n == a.prefix + "_relu" && a.has_relu) {
             if ((e->f16 && (i < e->F - 1 || i == e->K0())) || i == e->F - 1) {     // not materialised on the hot path (fp16 planes / fused into pooling): rebuild on demand
+                ActScope act(e, a);
                 int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 1, a.a, a.c_out);
                 if (rc) return rc;
             }
@@ -1286,6 +1394,7 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
     // debug views of the backward scratch (valid right after backward stage 0)
     if (n == "debug:da5") {     // evaluated on demand with the standalone pooling backward (valid after backward stage 0, before stage 1)
         Affine& a5 = e->L[e->F - 1];
+        ActScope act(e, a5);
         int rc = xv_bn_apply(e->last_stream, a5.z, a5.rows, a5.c_out, a5.c_out, a5.scale, a5.shift, 1, a5.a, a5.c_out);
         if (rc) return rc;
         rc = xv_stat_pool_backward(e->last_stream, a5.a, e->pool, e->d_small0, e->B, e->Tl[e->F], e->P, e->bufD);

@@ -137,7 +137,7 @@ extern "C" int xv_split_planes(void* stream, const float* src, int rows, int c, 
 // n and ldz are multiples of 4 (checked by the wrapper): two float4 loads of z per thread.
 __global__ void bn_apply_split_kernel(const float* __restrict__ z, long rows, int n, long ldz, const float* __restrict__ scale,
                                       const float* __restrict__ shift, int relu, const unsigned* __restrict__ amax,
-                                      u16* __restrict__ dst, long ldd, long plane_stride) {
+                                      u16* __restrict__ dst, long ldd, long plane_stride, const float* __restrict__ slope) {
     const float s = xv_pow2_scale(*amax);
     const unsigned cq = (unsigned)(ldd / 8), total = (unsigned)rows * cq;      // < 2^31 (checked by the wrapper)
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -151,7 +151,11 @@ __global__ void bn_apply_split_kernel(const float* __restrict__ z, long rows, in
             if (c < n) {
                 float4 zz = *(const float4*)(z + r * ldz + c), sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
                 y.x = zz.x * sc.x + sh.x; y.y = zz.y * sc.y + sh.y; y.z = zz.z * sc.z + sh.z; y.w = zz.w * sc.w + sh.w;
-                if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+                if (relu && slope) {       // prelu / leaky ReLU (act context, xv_common.h)
+                    const float4 sl = *(const float4*)(slope + c);
+                    y.x = y.x > 0.f ? y.x : y.x * sl.x; y.y = y.y > 0.f ? y.y : y.y * sl.y;
+                    y.z = y.z > 0.f ? y.z : y.z * sl.z; y.w = y.w > 0.f ? y.w : y.w * sl.w;
+                } else if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
             }
             v[4 * q] = y.x; v[4 * q + 1] = y.y; v[4 * q + 2] = y.z; v[4 * q + 3] = y.w;
         }
@@ -168,7 +172,7 @@ extern "C" int xv_bn_apply_split(void* stream, const float* z, int rows, int n, 
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(bn_apply_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, (long)rows, n, (long)ldz, scale, shift,
-                       relu, (const unsigned*)amax, (u16*)planes, (long)ldp, (long)plane_stride);
+                       relu, (const unsigned*)amax, (u16*)planes, (long)ldp, (long)plane_stride, relu ? xv_act_context().slope : nullptr);
     XV_LAUNCH_CHECK();
     return 0;
 }

@@ -13,10 +13,10 @@ import torch
 
 try:
     from . import _lib
-    from ._lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, PRECISIONS, POOLINGS, XV_BWD_STAGES
+    from ._lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, PRECISIONS, POOLINGS, RELU_TYPES, XV_BWD_STAGES
 except ImportError:      # drop-in layout: PYTHONPATH=$TF_KALDI_ROOT makes these top-level modules
     import _lib
-    from _lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, PRECISIONS, POOLINGS, XV_BWD_STAGES
+    from _lib import XvConfig, XvError, LOSS_KINDS, OPTIMIZERS, PRECISIONS, POOLINGS, RELU_TYPES, XV_BWD_STAGES
 
 
 # How tdnn1-5's contractions are evaluated unless make_config(precision=...) / the config key "precision" / $XV_PRECISION
@@ -46,7 +46,7 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
                 bn_epsilon=1e-3, fused_bn_unbiased_moving_var=True, optimizer="sgd", momentum=0.9, use_nesterov=False,
                 clip_gradient_norm=0.0, max_batch=128, max_frames=400, precision=None, pooling_type="statistics_pooling",
                 att_key_num_nodes=(1500, 1500), att_key_network_type=3, att_use_scale=True, aux_loss_func=(), ring_loss_init=20.0,
-                ring_loss_lambda=0.01, mhe_lambda=0.01, frame_layers=None):
+                ring_loss_lambda=0.01, mhe_lambda=0.01, frame_layers=None, network_relu_type="relu"):
     if pooling_type not in POOLINGS:
         raise NotImplementedError("Not implement %s pooling" % pooling_type)
     if loss_func not in LOSS_KINDS:
@@ -89,6 +89,9 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
     c.ring_loss_init, c.ring_loss_lambda = float(ring_loss_init), float(ring_loss_lambda)
     c.aux_mhe = int("mhe_loss" in (aux_loss_func or ()))
     c.mhe_lambda = float(mhe_lambda)
+    if network_relu_type not in RELU_TYPES:
+        raise NotImplementedError("network_relu_type %r (relu, prelu or lrelu: tdnn.py:24-30)" % network_relu_type)
+    c.relu_type = RELU_TYPES[network_relu_type]
     if frame_layers:
         # extended frame-layer table ((context, width), ...): no reference counterpart (model/tdnn.py hard-codes its five layers;
         # BASELINE configs[4] "extended context, 10 layers").  A width of None / 0 in the last entry = num_nodes_pooling_layer.
@@ -209,6 +212,8 @@ class Engine(object):
                 vals[name] = np.clip(rs.randn(*shape) * 0.1, -0.2, 0.2).astype(np.float32)
             elif leaf in ("gamma", "moving_variance"):
                 vals[name] = np.ones(shape, np.float32)
+            elif leaf == "alpha":      # tf.constant_initializer(0.01), common.py:37
+                vals[name] = np.full(shape, 0.01, np.float32)
             else:
                 vals[name] = np.zeros(shape, np.float32)
         self.set_variables(vals)

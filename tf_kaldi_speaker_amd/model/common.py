@@ -30,5 +30,18 @@ def l2_scaling(x, scaling_factor, epsilon=1e-12, name="l2_norm"):
     return ops.l2_scaling_forward(flat, scaling_factor).reshape(x.shape)
 
 
+_ALPHAS = {}      # "<name>/alpha" -> device tensor (the tf.variable_scope(name) of common.py:35-39)
+
+
 def prelu(x, name="prelu", shared=False):
-    raise NotImplementedError("network_relu_type 'prelu' is not implemented (no shipped config uses it, SURVEY.md N3)")
+    """relu(x) + alpha * (x - |x|) / 2 with a trainable alpha per channel (last axis), initialised to 0.01; one scalar alpha when
+    `shared` (reference common.py:27-42).  The variable lives in a module-level store keyed by "<name>/alpha"."""
+    x = to_device(x)
+    c = x.shape[-1]
+    key = name + "/alpha"
+    if key not in _ALPHAS:
+        _ALPHAS[key] = torch.full((1 if shared else c,), 0.01, dtype=torch.float32, device=x.device)
+    alpha = _ALPHAS[key]
+    if alpha.numel() == 1 and c > 1:
+        alpha = alpha.expand(c).contiguous()
+    return ops.prelu_forward(x.reshape(-1, c), alpha).reshape(x.shape)

@@ -59,8 +59,8 @@ def reset_default_graph():
 
 def check_params(params):
     """The static checks of model/tdnn.py:24-30,111-113,133-142,162-184 (defaults are inserted into params)."""
-    if "network_relu_type" in params.dict and params.network_relu_type in ("prelu", "lrelu"):
-        raise NotImplementedError("network_relu_type %s is not implemented (no shipped config uses it)" % params.network_relu_type)
+    if params.dict.get("network_relu_type", "relu") not in ("relu", "prelu", "lrelu"):
+        raise NotImplementedError("network_relu_type %s (relu, prelu or lrelu: tdnn.py:24-30)" % params.network_relu_type)
     if "num_nodes_pooling_layer" not in params.dict:
         params.dict["num_nodes_pooling_layer"] = 1500
     if params.pooling_type == "self_attention":
@@ -79,6 +79,8 @@ def check_params(params):
             unsupported.append("att_key_num_nodes (two key layers)")
         if int(d.get("att_key_network_type", -1)) not in (0, 1, 2, 3):
             unsupported.append("att_key_network_type=%r (0..3)" % d.get("att_key_network_type"))
+        if int(d.get("att_key_network_type", -1)) == 1 and d.get("network_relu_type", "relu") != "relu":
+            unsupported.append("att_key_network_type 1 with network_relu_type %s (the score kernel's fused ReLU is a plain one)" % d["network_relu_type"])
         if int(d.get("att_num_heads", 1)) != 1 or d.get("att_split_key", False):
             unsupported.append("att_num_heads / att_split_key (one head)")
         if float(d.get("att_penalty_term", 0) or 0) != 0.0:
@@ -112,7 +114,7 @@ def engine_config(params, dim, num_speakers=0, loss_type="softmax", max_batch=12
               momentum=float(d.get("momentum", 0.0) or 0.0), use_nesterov=bool(d.get("use_nesterov", False)),
               clip_gradient_norm=float(d["clip_gradient_norm"]) if d.get("clip_gradient", False) else 0.0,
               max_batch=max_batch, max_frames=max_frames,
-              frame_layers=frame_layer_table(params),
+              frame_layers=frame_layer_table(params), network_relu_type=d.get("network_relu_type", "relu"),
               precision=d.get("precision", None),      # engine extension: "f32" (default) | "f16x3" (opt-in fast mode); absent from reference configs
               pooling_type=d["pooling_type"])
     if num_speakers and d.get("aux_loss_func"):      # loss.py:985-1036; every loss function adds them (loss.py:40,161,249,347)

@@ -146,6 +146,13 @@ def bn_relu_backward(da, z, segs, t, gamma, mean, invstd, scale, shift, relu, pa
     return (dz, dgamma, dbeta, dbias) if with_dbias else (dz, dgamma, dbeta)
 
 
+def prelu_forward(x2d, alpha):
+    """x > 0 ? x : alpha[c] * x over the last axis."""
+    y = torch.empty_like(x2d)
+    _lib.call("xv_prelu_forward", _s(), _p(x2d), x2d.shape[0], x2d.shape[1], _p(alpha), _p(y))
+    return y
+
+
 def relu_backward(da, a):
     dz = torch.empty_like(da)
     _lib.call("xv_relu_backward", _s(), _p(da), _p(a), C.c_size_t(da.numel()), _p(dz))
