@@ -129,7 +129,7 @@ struct xv_engine {
 
 namespace {
 
-// amax layout (F = frame layers): 0 input x | amax_a + [0, F): BN+ReLU outputs of tdnn1..F-1 and att_key0 (slot F-1) |
+// amax layout (F = frame layers; groups on 16-byte boundaries): 0 input x | amax_a + [0, F): BN+ReLU outputs of tdnn1..F-1 and att_key0 (slot F-1) |
 // amax_wt + [0, F+2): weights of tdnn1..F, att_key0/1 (both layouts share a slot) | amax_dz + [0, F+2): dz of the same layers
 // (one slot per layer: zeroed once per backward pass, not once per layer)
 enum { AMAX_X = 0, AMAX_SLOTS = 64 };
@@ -186,7 +186,9 @@ void build_variables(xv_engine* e) {
     const int F = e->F;
     e->NL = e->att ? F + 4 : F + 2;
     e->L.assign(F + 4, Affine());
-    e->amax_a = 1; e->amax_wt = 1 + F; e->amax_dz = e->amax_wt + F + 2;
+    // slot groups start on 16-byte boundaries and are zeroed in multiples of 16 bytes: an unaligned / odd-sized hipMemsetAsync is split
+    // into two fill kernels (~5 us each on the stream)
+    e->amax_a = 4; e->amax_wt = 4 + (int)xv_align(F, 4); e->amax_dz = e->amax_wt + (int)xv_align(F + 2, 4);
     struct Spec { std::string prefix; const char* kind; const char* scope; int k, cin, cout; bool bn, relu, fused; int in_layer, act; };
     std::vector<Spec> specs;
     {
@@ -502,7 +504,11 @@ int prep_layers(xv_engine* e, hipStream_t s, int first, int last) {
         // one memset over the slot range of these layers (tdnn first..F-1 -> slots first..F-1, key layers -> F, F+1: contiguous)
         unsigned *lo = A.out[0], *hi = A.out[0];
         for (int j = 1; j < A.n; ++j) { lo = std::min(lo, A.out[j]); hi = std::max(hi, A.out[j]); }
-        XV_CHECK_HIP(hipMemsetAsync(lo, 0, (size_t)(hi - lo + 1) * sizeof(uint32_t), s));
+        if (first == 0 && last == 1) {
+            XV_CHECK_HIP(hipMemsetAsync(lo, 0, sizeof(uint32_t), s));                    // layer 0 alone (its neighbours belong to the side-stream half)
+        } else {
+            XV_CHECK_HIP(hipMemsetAsync(lo, 0, (size_t)(hi - lo + 1) * sizeof(uint32_t), s));
+        }
         int rc = xv_launch_amax_multi(s, A);
         if (rc) return rc;
     }
@@ -692,7 +698,7 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
     const int F = e->F;
     if (e->f16) {
         // split precision: every frame-level operand travels as two fp16 planes + a device-side max |x|
-        XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_X, 0, (1 + F) * sizeof(uint32_t), s));      // x and every BN+ReLU output slot
+        XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_X, 0, (4 + xv_align(F, 4)) * sizeof(uint32_t), s));      // x and every BN+ReLU output slot
         rc = xv_amax(s, features, (size_t)b * t * e->cfg.feat_dim, e->amax + AMAX_X);
         if (rc) return rc;
         rc = xv_split_planes(s, features, b * t, e->cfg.feat_dim, e->cfg.feat_dim, e->xh, e->c_pad0, (size_t)b * t * e->c_pad0,
@@ -1173,7 +1179,7 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
     const int b = e->B;
     int rc;
     if (stage == -1 || stage == 0) {
-        if (e->f16) XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_DZ, 0, (e->F + 2) * sizeof(uint32_t), s));   // every layer's dz scale slot
+        if (e->f16) XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_DZ, 0, xv_align(e->F + 2, 4) * sizeof(uint32_t), s));   // every layer's dz scale slot
         // d out = dlogits . wn^T   (pad column of both is zero, so K = ldl is exact)
         XvGemmNT g = {};
         g.A = e->dlogits; g.lda = e->ldl; g.a_rps = 1; g.a_pitch = 1;
