@@ -255,7 +255,12 @@ def run_mode(precision, args, dev, rank, world, dist, chunks, t_lo, t_hi, h2d=Fa
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     res["elapsed"] = elapsed
-    res["comm"] = allreduce.timing_report() if allreduce is not None else None
+    res["comm"] = None
+    if allreduce is not None:
+        try:
+            res["comm"] = allreduce.timing_report()
+        except Exception as exc:       # the report must never cost the bench line
+            res["comm"] = {"error": repr(exc)}
     if not light:
         # Untimed extra pass with the side stream off: the weight-gradient launches of the timed region run
         # concurrently with data-gradient launches, so their in-region durations include time shared with

@@ -153,3 +153,13 @@ def test_bench_two_ranks_sharing_the_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 100 and line["scaling"] == "weak" and line["config"]["parallelism"] == "dp2"
     assert "cpu_baseline" not in line and np.isfinite(line["loss"])
+    # the per-rank communication report the scaling runs are read with: backend / world size as the process group reports them, one
+    # all-reduce time per gradient slice (events on the communication stream), how much of it the backward pass did not cover
+    comm = line["comm"]
+    assert [c["rank"] for c in sorted(comm, key=lambda c: c["rank"])] == [0, 1]
+    for c in comm:
+        assert c["world_size"] == 2 and c["backend"] == "gloo", c
+        rep = c["report"]
+        assert "error" not in rep and rep["steps"] == 3 and len(rep["slices"]) == 4, rep
+        assert abs(sum(sl["mbytes"] for sl in rep["slices"]) - 39.3) < 0.3               # the whole 9.83 M-float gradient buffer
+        assert rep["allreduce_ms_per_step"] > 0 and 0.0 <= rep["overlap_frac"] <= 1.0
