@@ -100,7 +100,10 @@ struct xv_engine {
     bool stage_side[XV_BWD_STAGES] = {};          // the side-stream event of the stage was recorded
     // dz ping-pong state.  ring 0: the frame-level layers' dz (fp16 planes `dzh` in split precision) and, in fp32, every
     // layer's dz (`bufZ`); ring 1 (split precision only): the fp32 dz of the segment-level layers and the attention key
-    // gradient in `bufZ` - its own ring, so a frame layer never waits for a segment layer's weight gradient
+    // gradient in `bufZ` - its own ring, so a frame layer never waits for a segment layer's weight gradient.
+    // [measured, same box] giving fp32 mode that second ring as well (it removes a 77 us wait of the last frame layer's BN backward
+    // for the slot tdnn7's weight gradient reads) makes the step 0.07 ms SLOWER: the BN backward then runs beside the loss head's
+    // side-stream chain and both crawl
     struct ZRing { int cur = 0; bool pending[2] = {false, false}; hipEvent_t ev[2] = {nullptr, nullptr}; } zr[2];
     bool lw_pending = false;      // the loss head's weight gradient (side stream) - it reads no dz buffer, so it has its own event
     bool concurrent = true;
@@ -1196,22 +1199,11 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             if (!e->with_margin) XV_CHECK_HIP(hipMemsetAsync(gptr(e, e->v_ring), 0, sizeof(float), s));
             if (rc) return rc;
         }
-        const float* d = e->d_small0;
-        if (c.feature_norm) {
-            rc = xv_l2_scaling_backward(s, e->h7, d, b, e->Lout, c.feature_scaling_factor, e->d_small1);
-            if (rc) return rc;
-            d = e->d_small1;
-        }
-        // tdnn7 -> d a6 (into bufD), tdnn6 -> d pool (into d_small0); the pooling backward itself is evaluated
-        // inside tdnn5's BN backward (stage 1) from (pool, d pool): d a5 is never written
-        rc = layer_backward(e, s, e->L[e->S1()], d, e->L[e->S0()].a, b, 1, e->bufD, e->h7);
-        if (rc) return rc;
-        rc = layer_backward(e, s, e->L[e->S0()], e->bufD, e->pool, b, 1, e->d_small0, nullptr);
-        if (rc) return rc;
-        // (enqueued AFTER the segment layers' weight gradients: the side stream runs in order, and the last frame layer's BN backward
-        // waits for the dz-ring slot tdnn7's weight gradient reads - behind this 5-kernel chain it waited 77 us per step in fp32 mode)
         // d wn = out^T . dlogits and the gradient through l2_normalize: on the side stream (only reads
-        // dlogits / out / wn, which the main chain never rewrites during backward)
+        // dlogits / out / wn, which the main chain never rewrites during backward).  [measured, same box] enqueueing this chain BEHIND
+        // the segment layers' weight gradients (so that the last frame layer's BN backward does not wait 77 us for its dz-ring slot)
+        // costs fp32 mode 0.2 ms/step: the chain then runs beside the big data-gradient GEMMs, 10x slower, with the weight-gradient
+        // GEMMs queued behind it
         {
             hipStream_t ss = e->concurrent ? e->side : s;
             if (e->concurrent) {
@@ -1247,6 +1239,18 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
                 e->lw_pending = true;
             }
         }
+        const float* d = e->d_small0;
+        if (c.feature_norm) {
+            rc = xv_l2_scaling_backward(s, e->h7, d, b, e->Lout, c.feature_scaling_factor, e->d_small1);
+            if (rc) return rc;
+            d = e->d_small1;
+        }
+        // tdnn7 -> d a6 (into bufD), tdnn6 -> d pool (into d_small0); the pooling backward itself is evaluated
+        // inside tdnn5's BN backward (stage 1) from (pool, d pool): d a5 is never written
+        rc = layer_backward(e, s, e->L[e->S1()], d, e->L[e->S0()].a, b, 1, e->bufD, e->h7);
+        if (rc) return rc;
+        rc = layer_backward(e, s, e->L[e->S0()], e->bufD, e->pool, b, 1, e->d_small0, nullptr);
+        if (rc) return rc;
         if (stage == 0) { rc = end_stage(e, s, 0, defer); if (rc) return rc; }
     }
     const int F = e->F;
