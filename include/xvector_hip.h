@@ -262,6 +262,31 @@ int xv_l2_scaling_backward(void* stream, const float* x, const float* dy, int ro
 
 /* Loss family, loss.py:9-355. */
 enum { XV_LOSS_SOFTMAX = 0, XV_LOSS_ASOFTMAX = 1, XV_LOSS_AMSOFTMAX = 2, XV_LOSS_ARCSOFTMAX = 3 };
+/* ---- segment-level layers in one launch (rows <= XV_SEGMENT_MAX_ROWS chunks of a batch) ------------------------------
+ * tf.layers.dense at tdnn.py:147,166 and the logits / gradient products of loss.py with M = chunks rows: the GEMM, its split-K sum
+ * and the consumer's per-column work run in one launch.  ws: slabs (xv_op_workspace_bytes); tickets: one ZEROED uint32 per 32
+ * output columns, left zeroed.  Optional row term (the ||x|| gradient of loss.py:122,147, what xv_add_norm_grad adds):
+ * acc[m][:] += (row_norm[m] > 0 ? row_coef[m] / row_norm[m] : 0) * xrow[m][:]. */
+#define XV_SEGMENT_MAX_ROWS 128
+/* c[m][n] = sum_k a[m][k] * bt[n][k] + bias[n] (+ row term) */
+int xv_segment_gemm(void* stream, const float* a, long lda, const float* bt, long ldb, int m, int n, int k, const float* bias,
+                    const float* row_coef, const float* row_norm, const float* xrow, long ldx, float* c, long ldc,
+                    void* ws, size_t ws_bytes, uint32_t* tickets);
+/* dense + training-mode tf.layers.batch_normalization (+ activation) of tdnn.py:147-189: z = x . wt^T + bias, batch statistics over
+ * the m rows (biased two-pass variance), moving averages, scale/shift, a = act(z*scale + shift) (a may be NULL).  Same arithmetic
+ * as xv_affine_forward + xv_bn_finalize + xv_bn_apply (relu != 0: ReLU). */
+int xv_segment_affine_bn_forward(void* stream, const float* x, long ldx, const float* wt, long ldw, int m, int n, int k,
+                                 const float* bias, const float* gamma, const float* beta, float eps, float momentum,
+                                 int unbiased_moving, float* moving_mean, float* moving_var, float* z, float* mean, float* invstd,
+                                 float* scale, float* shift, int relu, float* a, void* ws, size_t ws_bytes, uint32_t* tickets);
+/* d a = dy . wt^T (+ row term), then the backward of the BatchNorm (+ activation) layer whose pre-BN tensor is z [m][n]:
+ * dz, dgamma, dbeta, dbias (xv_bn_relu_backward's arithmetic on m rows). */
+int xv_segment_dgrad_bn_backward(void* stream, const float* dy, long lddy, const float* wt, long ldw, int m, int n, int k,
+                                 const float* row_coef, const float* row_norm, const float* xrow, long ldx, const float* z,
+                                 const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                 int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                                 uint32_t* tickets);
+
 /* tf.nn.l2_normalize(w, dim=0), loss.py:104: inv_norm[n], wn[c][ldn] = w*inv, wnt[n][c] = wn^T.
  * normalize == 0 copies unnormalised (plain softmax, loss.py:30). */
 int xv_loss_prep_weight(void* stream, const float* w, int c, int n, int normalize,

@@ -179,6 +179,24 @@ def test_train_step_matches_oracle(kw):
     _check_train_step(kw, 6, 40)
 
 
+# The segment-level layers run fused (GEMM + split-K sum + BatchNorm in one launch, xv_skinny.hip) for batches of <= 128 chunks - every
+# other test of this module - and as separate launches beyond that or with XV_SEGMENT_FUSED=0: both forms against the oracle, for the
+# configurations that take different branches there (BN / no BN / linear last layer, l2_scaling in between, prelu)
+SEGMENT_PATH_CASES = [CASES[0], dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, feature_norm=True),
+                      dict(loss_func="asoftmax", margin_m=2, lambda_min=5, lambda_gamma=1e-3, last_layer_no_bn=True),
+                      dict(loss_func="softmax", network_relu_type="prelu")]
+
+
+@pytest.mark.parametrize("kw", SEGMENT_PATH_CASES, ids=lambda d: "-".join(str(v).replace(" ", "") for v in d.values()))
+@pytest.mark.parametrize("form", ["B130", "unfused"])
+def test_train_step_matches_oracle_unfused_segment_layers(kw, form, monkeypatch):
+    if form == "unfused":
+        monkeypatch.setenv("XV_SEGMENT_FUSED", "0")
+        _check_train_step(kw, 6, 40)
+    else:
+        _check_train_step(kw, 130, 21, N=53)
+
+
 # feature / layer widths of the other shipped recipes and ragged everything: 23-dim MFCCs (egs/sre, egs/fisher: not a multiple
 # of 4 - padded to 24 / 32 channels inside), 40-dim, pooling layers of 600 / 3000 nodes, a 256-node last layer, odd batch,
 # frame and speaker counts (but at least 4 rows per BatchNorm: with 2 the normalised values are +-1/sqrt(1 + eps/var) and a

@@ -421,3 +421,59 @@ def test_auxiliary_losses_against_reference_golden_vectors(ops):
     assert abs(float(total.cpu()) - ref) <= 2e-5 * abs(ref), (float(total.cpu()), ref)
     assert "ring_loss_r" in ep
     L._VARIABLES.clear()
+
+
+# (rows, n, k): the segment-level problems of the reference topology (tdnn6 K=3000, tdnn7, logits N=7351, d out K=7352, d pool N=3000)
+# plus ragged rows / columns / K tails (K % 8 == 4, N % 32 != 0, one row, a single split)
+SEGMENT_CASES = [(128, 512, 3000), (64, 512, 512), (128, 7351, 512), (128, 512, 7352), (128, 3000, 512),
+                 (1, 512, 3000), (37, 100, 68), (128, 33, 4), (2, 600, 1204)]
+
+
+@pytest.mark.parametrize("rows,n,k", SEGMENT_CASES)
+def test_segment_gemm_and_fused_batchnorm(ops, rows, n, k):
+    """xv_segment_gemm / _affine_bn_forward / _dgrad_bn_backward (GEMM + split-K sum + the consumer's BatchNorm in one launch)
+    against the oracle's dense / BatchNorm forward and backward; twice on the same tickets (they must come back zeroed)."""
+    rs = np.random.RandomState(rows * 7 + n)
+    x = rs.randn(rows, k).astype(np.float32)
+    wt = (rs.randn(n, k) / np.sqrt(k)).astype(np.float32)
+    bias = rs.randn(n).astype(np.float32)
+    x64, wt64 = x.astype(np.float64), wt.astype(np.float64)
+    ref = x64 @ wt64.T + bias
+    for _ in range(2):
+        assert_close(host(ops.segment_gemm(dev(x), dev(wt), dev(bias))), ref, name="segment_gemm")
+    # the row term (gradient through ||x||): + (coef / norm) * xrow, 0 where norm == 0
+    coef, xrow = rs.randn(rows).astype(np.float32), rs.randn(rows, n).astype(np.float32)
+    norm = np.abs(rs.randn(rows)).astype(np.float32) + 0.1
+    norm[0] = 0.0
+    kf = np.where(norm > 0, coef / np.maximum(norm, 1e-30), 0.0).astype(np.float64)
+    got = ops.segment_gemm(dev(x), dev(wt), None, row_term=(dev(coef), dev(norm), dev(xrow)))
+    assert_close(host(got), x64 @ wt64.T + kf[:, None] * xrow, name="segment_gemm(row term)")
+    if rows < 2:
+        return
+    gamma, beta = (rs.rand(n) + 0.5).astype(np.float32), (0.3 * rs.randn(n)).astype(np.float32)
+    for relu in (1, 0):
+        mm, mv = dev(np.zeros(n)), dev(np.ones(n))
+        z, a, mean, invstd, scale, shift = ops.segment_affine_bn_forward(dev(x), dev(wt), dev(bias), dev(gamma), dev(beta), 1e-3, 0.99,
+                                                                         True, mm, mv, relu)
+        yref, cache = O.batchnorm_train_fwd(ref, gamma.astype(np.float64), beta.astype(np.float64))
+        assert_close(host(z), ref, name="z")
+        assert_close(host(a), np.maximum(yref, 0) if relu else yref, 2e-5, 1e-4, "a")
+        assert_close(host(mean), ref.mean(0), 2e-5, 1e-4, "mean")
+        assert_close(host(invstd), 1 / np.sqrt(ref.var(0) + 1e-3), 2e-5, 1e-4, "invstd")
+        assert_close(host(mm), 0.01 * ref.mean(0), 2e-5, 1e-4, "moving mean")
+        assert_close(host(mv), 0.99 + 0.01 * ref.var(0) * rows / (rows - 1), 2e-5, 1e-4, "moving var")
+        # backward: dy [rows][k2] . w2^T [n][k2] = d a of this layer, then its BN (+ReLU) backward
+        k2 = 64
+        dy = rs.randn(rows, k2).astype(np.float32)
+        w2 = (rs.randn(n, k2) / 8).astype(np.float32)
+        da = dy.astype(np.float64) @ w2.astype(np.float64).T + kf[:, None] * xrow
+        dyy = da * (yref > 0) if relu else da
+        dz_ref, dg_ref, db_ref = O.batchnorm_train_bwd(dyy, cache, gamma.astype(np.float64))
+        dz, dg, db, dbias = ops.segment_dgrad_bn_backward(dev(dy), dev(w2), z, dev(gamma), mean, invstd, scale, shift, relu,
+                                                          row_term=(dev(coef), dev(norm), dev(xrow)))
+        assert_close(host(dz), dz_ref, 2e-5, 2e-4, "dz")
+        assert_close(host(dg), dg_ref, 2e-5, 1e-4, "dgamma")
+        assert_close(host(db), db_ref, 2e-5, 1e-4, "dbeta")
+        assert np.abs(host(dbias)).max() <= 1e-4 * max(np.abs(dz_ref).sum(axis=0).max(), 1e-30)
+    from tf_kaldi_speaker_amd import ops as m
+    assert int(m._TICKETS[str(z.device)].abs().sum().item()) == 0

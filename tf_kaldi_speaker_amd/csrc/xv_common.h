@@ -57,6 +57,11 @@ static inline size_t xv_align(size_t x, size_t a) { return (x + a - 1) / a * a; 
 #endif
 #define XV_RESIDENT_WGS (256 * XV_WGS_PER_CU)
 
+// A device page of XV_ZERO_PAGE_FLOATS zeros (xv_gemm.hip): out-of-range rows / k of a GEMM operand are redirected to it (the select
+// is on the address, loads stay unconditional); "base + k" stays inside the page for every k < K <= XV_ZERO_PAGE_FLOATS
+#define XV_ZERO_PAGE_FLOATS 16384
+const float* xv_zero_page();
+
 // Internal GEMM launchers (xv_gemm.hip).
 // C[m][n] (+)= sum_k A[rowmap(m)][k] * Bt[n][k]   ("NT", both operands k-contiguous)
 // rowmap(m) = (m / a_rps) * a_pitch + (m % a_rps) rows of lda floats.
@@ -151,6 +156,34 @@ int xv_bn_relu_backward_split_ex(hipStream_t s, const XvBnBwdSplit& x, const flo
                                  const float* mean, const float* invstd, const float* scale, const float* shift, const float* zmin,
                                  const float* zmax, int relu, int pad, void* dz_planes, int ldp, size_t plane_stride, uint32_t* dz_amax,
                                  float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes);
+
+// Segment-level GEMM C[M][N] = A[M][K] . Bt[N][K]^T, M <= 128 rows (the chunks of one batch), with the split-K sum and the consumer's
+// per-column work in the same launch (xv_skinny.hip).  `ws` holds the [splits][N/32][128][32] slabs, `tickets` one zeroed uint32 per
+// 32 columns (left zeroed).  Optional row term before the epilogue: acc[m][n] += (row_norm[m] > 0 ? row_coef[m] / row_norm[m] : 0) * X[m][n].
+enum { XV_SK_PLAIN = 0,      // C = acc + bias
+       XV_SK_BN_FWD = 1,     // C = z = acc + bias; training-mode BatchNorm over the M rows (+ activation) -> a_out; vectors and moving averages written
+       XV_SK_BN_BWD = 2 };   // acc = d a of a BatchNorm(+activation) layer with pre-BN tensor z: C = dz, dgamma / dbeta / dbias / dalpha written
+struct XvSkinny {
+    const float* A; long lda;
+    const float* Bt; long ldb;
+    int M, N, K;
+    float* C; long ldc;                      // also the leading dimension of z and a_out
+    const float* bias;
+    const float* row_coef; const float* row_norm; const float* X; long ldx;
+    int epi;
+    const float* gamma; const float* beta; float eps, momentum; int unbiased; float* mmean; float* mvar;
+    float* mean; float* invstd; float* scale; float* shift;      // written by BN_FWD, read by BN_BWD
+    int relu; const float* slope; float* a_out;
+    const float* z; float* dgamma; float* dbeta; float* dbias; float* dalpha;
+    void* ws; size_t ws_bytes; uint32_t* tickets;
+};
+int xv_launch_skinny(hipStream_t s, const XvSkinny& g);
+size_t xv_skinny_tickets(int max_n);
+
+// xv_margin_softmax_rows in one launch (mean folded in through a ticket) that also writes ||x[r]|| (xv_loss.hip)
+int xv_margin_softmax_rows_ex(hipStream_t s, int kind, const float* logits, int rows, int n, int ldl, const float* x, int c,
+                              const int32_t* labels, float m, float lambda, float* dlogits, float* dnorm, float* row_loss,
+                              float* loss_out, float* xnorm, uint32_t* ticket);
 
 // Activation behind a BatchNorm in the layer being processed (network_relu_type, tdnn.py:24-30): y > 0 ? y : slope[c] * y.
 // slope == nullptr: ReLU.  Set by the engine around a layer's calls (prelu: the layer's alpha variable, with dalpha = its gradient;

@@ -93,6 +93,11 @@ struct xv_engine {
     float *bufD = nullptr, *bufZ[2] = {nullptr, nullptr}, *d_small0 = nullptr, *d_small1 = nullptr;
     // second stream: weight gradients run beside the data-gradient chain (they only share dz)
     hipStream_t side = nullptr;
+    // third stream: the loss head's weight gradient (5 launches, ~0.1 ms alone) starts as soon as dlogits exist and never sits in
+    // front of the segment layers' weight gradients on `side` (whose dz slots the main chain is waiting for)
+    hipStream_t side2 = nullptr;
+    void* ws_side2 = nullptr;
+    bool stage_lw = false;        // deferred stage 0: its slice also needs ev_lw
     hipEvent_t ev_dz = nullptr, ev_lw = nullptr;
     hipEvent_t ev_prep = nullptr, ev_lossprep = nullptr;     // side-stream halves of ensure_weights
     bool prep_pending = false, lossprep_pending = false;
@@ -109,6 +114,11 @@ struct xv_engine {
     bool concurrent = true;
     void* ws_side = nullptr;
     float *scalars = nullptr;   // [0] raw loss, [1] reg loss, [2] grad sumsq
+    // segment-level layers in one launch each (xv_skinny.hip) when the batch has <= XV_SEGMENT_MAX_ROWS chunks
+    bool sk = true;                 // XV_SEGMENT_FUSED=0 keeps the GEMM / slab-sum / BatchNorm launches apart (A/B, and what B > 128 runs)
+    uint32_t* sk_tickets = nullptr; // one per 32 output columns + the loss mean's
+    size_t sk_ntickets = 0;
+    float* xnorm = nullptr;         // [B] ||out[r]||, written with the loss rows
     float* lrelu_slope = nullptr;   // network_relu_type lrelu: a constant 0.2 vector as wide as the widest layer
     // split precision state
     bool f16 = false;
@@ -341,6 +351,8 @@ int alloc_buffers(xv_engine* e) {
     want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512)); want(B * (size_t)(2 * e->P > 512 ? 2 * e->P : 512));
     want(16);
     want(xv_align(maxc, 4) + 4);      // lrelu_slope
+    const size_t ntick = xv_skinny_tickets((int)std::max<size_t>(std::max<size_t>(e->N, 2 * (size_t)e->P), std::max<size_t>(maxc, (size_t)e->Lout))) + 8;
+    want(ntick); want(B);             // sk_tickets, xnorm
     // GEMM split slabs: weight-gradient partials dominate
     size_t ws = 0;
     for (int i = 0; i < e->NL; ++i) {
@@ -367,7 +379,7 @@ int alloc_buffers(xv_engine* e) {
         if (s > ws) ws = s;
     }
     ws = xv_align(ws, 256);
-    need += 2 * ws + 8192;
+    need += 3 * ws + 8192;
     XV_CHECK_HIP(hipMalloc((void**)&e->arena, need));
     XV_CHECK_HIP(hipMemset(e->arena, 0, need));
     e->arena_bytes = need;
@@ -440,8 +452,16 @@ int alloc_buffers(xv_engine* e) {
         std::vector<float> h(xv_align(maxc, 4) + 4, 0.2f);      // tf.nn.leaky_relu default alpha
         XV_CHECK_HIP(hipMemcpy(e->lrelu_slope, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    e->sk_ntickets = ntick;
+    e->sk_tickets = (uint32_t*)carve(e, ntick);       // zero (arena memset); every launch leaves them zero
+    e->xnorm = carve(e, B);
+    {
+        const char* v = getenv("XV_SEGMENT_FUSED");
+        e->sk = !(v && v[0] == '0');
+    }
     e->ws = carve(e, ws / sizeof(float));
     e->ws_side = carve(e, ws / sizeof(float));
+    e->ws_side2 = carve(e, ws / sizeof(float));
     e->ws_bytes = ws;
     XV_REQUIRE(e->ws != nullptr && e->ws_side != nullptr && e->scalars != nullptr, "engine: internal arena accounting error");
     {   // lowest priority: the weight-gradient GEMMs are filler work; the small kernels of the critical
@@ -449,6 +469,7 @@ int alloc_buffers(xv_engine* e) {
         int least = 0, greatest = 0;
         XV_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         XV_CHECK_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
+        XV_CHECK_HIP(hipStreamCreateWithPriority(&e->side2, hipStreamNonBlocking, least));
     }
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_dz, hipEventDisableTiming));
     for (int r = 0; r < 2; ++r)
@@ -635,6 +656,7 @@ extern "C" int xv_engine_create(const xv_config* cfg, xv_engine** out) {
 extern "C" void xv_engine_destroy(xv_engine* e) {
     if (!e) return;
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+    if (e->side2) { (void)hipStreamSynchronize(e->side2); (void)hipStreamDestroy(e->side2); }
     if (e->ev_dz) (void)hipEventDestroy(e->ev_dz);
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < 2; ++i) if (e->zr[r].ev[i]) (void)hipEventDestroy(e->zr[r].ev[i]);
@@ -839,20 +861,43 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
         rc = xv_stat_pool_forward_bn(s, e->L[F - 1].z, b, cur_t, e->P, e->L[F - 1].scale, e->L[F - 1].shift, 1, frame_w, e->pool);
     }
     if (rc) return rc;
-    // segment-level layers
+    // segment-level layers: dense (+ BatchNorm + activation).  With <= XV_SEGMENT_MAX_ROWS chunks the GEMM, its split-K sum and the
+    // training-mode BatchNorm are one launch (xv_skinny.hip); otherwise GEMM + slab sum, then the BatchNorm kernels
+    const bool sk = e->sk && b <= XV_SEGMENT_MAX_ROWS;
+    auto seg_forward = [&](Affine& a, const float* x, float* dst_a) -> int {
+        if (sk) {
+            XvSkinny g = {};
+            g.A = x; g.lda = a.c_pad; g.Bt = a.wt; g.ldb = a.c_pad; g.M = b; g.N = a.c_out; g.K = a.c_pad;
+            g.bias = vptr(e, a.v_bias); g.C = a.z; g.ldc = a.c_out;
+            g.ws = e->ws; g.ws_bytes = e->ws_bytes; g.tickets = e->sk_tickets;
+            if (a.has_bn && training) {
+                const xv_config& c = e->cfg;
+                ActScope act(e, a);
+                g.epi = XV_SK_BN_FWD;
+                g.gamma = vptr(e, a.v_gamma); g.beta = vptr(e, a.v_beta); g.eps = c.bn_epsilon; g.momentum = c.batchnorm_momentum;
+                g.unbiased = a.fused_bn && c.fused_bn_unbiased_moving_var; g.mmean = vptr(e, a.v_mmean); g.mvar = vptr(e, a.v_mvar);
+                g.mean = a.mean; g.invstd = a.invstd; g.scale = a.scale; g.shift = a.shift;
+                g.relu = a.has_relu ? 1 : 0; g.slope = a.has_relu ? xv_act_context().slope : nullptr; g.a_out = dst_a;
+                return xv_launch_skinny(s, g);
+            }
+            g.epi = XV_SK_PLAIN;
+            int r = xv_launch_skinny(s, g);
+            if (r) return r;
+        } else {
+            int r = xv_affine_forward(s, x, b, 1, a.c_pad, 1, a.wt, vptr(e, a.v_bias), a.z, a.c_out, a.c_out, nullptr, e->ws, e->ws_bytes);
+            if (r) return r;
+        }
+        return a.has_bn ? bn_forward(e, s, a, b, false, dst_a) : 0;
+    };
     Affine& l6 = e->L[e->S0()];
-    rc = xv_affine_forward(s, e->pool, b, 1, l6.c_pad, 1, l6.wt, vptr(e, l6.v_bias), l6.z, l6.c_out, l6.c_out, nullptr, e->ws, e->ws_bytes);
-    if (rc) return rc;
-    rc = bn_forward(e, s, l6, b, false, l6.a);
+    rc = seg_forward(l6, e->pool, l6.a);
     if (rc) return rc;
     l6.rows = b;
     Affine& l7 = e->L[e->S1()];
-    rc = xv_affine_forward(s, l6.a, b, 1, l7.c_pad, 1, l7.wt, vptr(e, l7.v_bias), l7.z, l7.c_out, l7.c_out, nullptr, e->ws, e->ws_bytes);
+    rc = seg_forward(l7, l6.a, e->h7_buf);
     if (rc) return rc;
     l7.rows = b;
     if (l7.has_bn) {
-        rc = bn_forward(e, s, l7, b, false, e->h7_buf);
-        if (rc) return rc;
         e->h7 = e->h7_buf;
     } else if (l7.has_relu && c_relu_type(e) != XV_RELU_RELU) {
         ActScope act(e, l7);
@@ -890,14 +935,23 @@ extern "C" int xv_engine_loss_forward(xv_engine* e, void* stream, const int32_t*
     if (rc) return rc;
     rc = wait_lossprep(e, s);
     if (rc) return rc;
-    XvGemmNT g = {};
-    g.A = e->out; g.lda = e->Lout; g.a_rps = 1; g.a_pitch = 1;
-    g.Bt = e->wnt; g.ldb = e->Lout;
-    g.C = e->logits; g.ldc = e->ldl;
-    g.M = b; g.N = e->N; g.K = e->Lout;
-    g.bias = e->v_loss_bias >= 0 ? vptr(e, e->v_loss_bias) : nullptr;
-    g.ws = e->ws; g.ws_bytes = e->ws_bytes;
-    rc = xv_launch_gemm_nt(s, g);
+    if (e->sk && b <= XV_SEGMENT_MAX_ROWS) {
+        XvSkinny g = {};
+        g.A = e->out; g.lda = e->Lout; g.Bt = e->wnt; g.ldb = e->Lout; g.M = b; g.N = e->N; g.K = e->Lout;
+        g.bias = e->v_loss_bias >= 0 ? vptr(e, e->v_loss_bias) : nullptr;
+        g.C = e->logits; g.ldc = e->ldl; g.epi = XV_SK_PLAIN;
+        g.ws = e->ws; g.ws_bytes = e->ws_bytes; g.tickets = e->sk_tickets;
+        rc = xv_launch_skinny(s, g);
+    } else {
+        XvGemmNT g = {};
+        g.A = e->out; g.lda = e->Lout; g.a_rps = 1; g.a_pitch = 1;
+        g.Bt = e->wnt; g.ldb = e->Lout;
+        g.C = e->logits; g.ldc = e->ldl;
+        g.M = b; g.N = e->N; g.K = e->Lout;
+        g.bias = e->v_loss_bias >= 0 ? vptr(e, e->v_loss_bias) : nullptr;
+        g.ws = e->ws; g.ws_bytes = e->ws_bytes;
+        rc = xv_launch_gemm_nt(s, g);
+    }
     if (rc) return rc;
     // lambda schedule, loss.py:144-145 (host side: global_step is a fed placeholder, trainer.py:507)
     double lam = (double)c.lambda_base * pow(1.0 + (double)c.lambda_gamma * (double)global_step, -(double)c.lambda_power);
@@ -906,8 +960,9 @@ extern "C" int xv_engine_loss_forward(xv_engine* e, void* stream, const int32_t*
     int kind = c.loss_kind;
     float m = c.margin_m;
     if (!with_margin && kind != XV_LOSS_SOFTMAX) { kind = XV_LOSS_ASOFTMAX; m = 1.0f; }   // trainer.py:261-271
-    rc = xv_margin_softmax_rows(s, kind, e->logits, b, e->N, e->ldl, e->out, e->Lout, labels, m, e->lambda, e->dlogits, e->dnorm,
-                                e->row_loss, e->scalars + 0);
+    // one launch: the rows, ||out[r]|| (divides the ||x|| gradient in backward) and the mean (last ticket of sk_tickets)
+    rc = xv_margin_softmax_rows_ex(s, kind, e->logits, b, e->N, e->ldl, e->out, e->Lout, labels, m, e->lambda, e->dlogits, e->dnorm,
+                                   e->row_loss, e->scalars + 0, e->xnorm, e->sk_tickets + (e->sk_ntickets - 1));
     if (rc) return rc;
     // auxiliary losses are part of the training loss only (trainer.py:279-289 clears aux_loss_func for validation)
     if (with_margin && c.aux_ring) {
@@ -974,54 +1029,65 @@ int join_side(xv_engine* e, hipStream_t s) {
 // only after the weight gradient that read it has finished (ZRing).
 int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int segs, int t_in, float* dx);
 
-int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, const float* x, int segs, int t_in, float* dx,
-                   const float* act_out) {
-    const xv_config& c = e->cfg;
-    const int t_out = t_in - a.k + 1;
-    const int pad = (dx && a.k > 1) ? a.k - 1 : 0;
-    int rc;
-    const int lidx = (int)(&a - &e->L[0]);
-    if (e->f16 && is_frame(e, lidx)) return layer_backward_f16(e, s, lidx, da, segs, t_in, dx);
-    ActScope act(e, a);
-    const float* dz = nullptr;
+// The current slot of the fp32 dz ring, once the weight gradient that last read it (two layers up, side stream) has finished.
+float* ring_take(xv_engine* e, hipStream_t s) {
     xv_engine::ZRing& zr = e->zr[e->f16 ? 1 : 0];
     const int zi = zr.cur;
-    float* Z = e->bufZ[zi];
-    if (zr.pending[zi]) {                       // WAR: the weight gradient two layers up read this buffer
-        XV_CHECK_HIP(hipStreamWaitEvent(s, zr.ev[zi], 0));
+    if (zr.pending[zi]) {                       // WAR
+        if (hipStreamWaitEvent(s, zr.ev[zi], 0) != hipSuccess) return nullptr;
         zr.pending[zi] = false;
     }
+    return e->bufZ[zi];
+}
+
+// dz of layer `a` (fp32 path) from the gradient w.r.t. its output: BN (+activation) backward, the activation alone, or da itself.
+// *ring: dz was written into the ring's current slot (ring_take) - the caller's weight gradient then owns the slot.
+int layer_dz(xv_engine* e, hipStream_t s, Affine& a, const float* da, int segs, int t_out, int pad, const float* act_out,
+             const float** dz_out, bool* ring) {
+    const xv_config& c = e->cfg;
+    const int lidx = (int)(&a - &e->L[0]);
+    ActScope act(e, a);
+    int rc;
+    *ring = true;
+    float* Z = ring_take(e, s);
+    XV_REQUIRE(Z, "engine_backward: waiting for a dz slot failed");
     if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
         XV_REQUIRE(lidx == e->F - 1 && a.has_bn, "engine_backward: only the last frame layer takes its gradient from the pooling layer");
         rc = xv_bn_relu_backward_pooled(s, e->pool, e->d_small0, e->att ? e->att_w : nullptr, e->B, e->Tl[e->F], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale,
                                         a.shift, 1, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
-        if (rc) return rc;
-        dz = Z;
     } else if (a.has_bn && pad == 0 && segs * t_out <= XV_BN_SMALL_MAX_ROWS && !is_frame(e, lidx)) {      // segment-level layers: one launch
         rc = xv_bn_small_backward(s, da, a.z, segs * t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift,
                                   a.has_relu ? 1 : 0, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias));
-        if (rc) return rc;
-        dz = Z;
     } else if (a.has_bn) {
         rc = xv_bn_relu_backward(s, da, a.z, segs, t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift,
                                  a.has_relu ? 1 : 0, pad, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
-        if (rc) return rc;
-        dz = Z;
     } else if (a.has_relu && c.relu_type != XV_RELU_RELU) {       // activation without a BN in front (tdnn7, last_layer_no_bn): needs the pre-activation
         rc = xv_act_small(s, da, a.z, segs * t_out, a.c_out, Z);
-        if (rc) return rc;
-        dz = Z;
     } else if (a.has_relu) {
         rc = xv_relu_backward(s, da, act_out, (size_t)segs * t_out * a.c_out, Z);
-        if (rc) return rc;
-        dz = Z;
     } else {
-        dz = da;
+        *dz_out = da;
+        *ring = (da == Z);       // the caller wrote d(output) into the ring's slot itself (attention key gradient)
+        return 0;
     }
+    *dz_out = Z;
+    return rc;
+}
+
+// Weight (and, without a BN, bias) gradient of layer `a` from (x, dz).  It only shares dz with the data-gradient chain, so it is
+// enqueued on the side stream: its workgroups fill the CUs that the tail of the data-gradient GEMM (and the small BN kernels of
+// the next layer) leave idle.  ring: dz is the ring's current slot - it is handed to the side stream and the ring moves on; a slot
+// is rewritten only after the weight gradient that read it has finished (ZRing).
+int layer_wgrad(xv_engine* e, hipStream_t s, Affine& a, const float* x, const float* dz, int segs, int t_in, int pad, bool ring) {
+    const xv_config& c = e->cfg;
+    const int t_out = t_in - a.k + 1;
     const int seg_pitch = t_out + 2 * pad;
-    const bool concurrent = e->concurrent && (dz == Z);   // dz aliasing the caller's buffer: keep everything in order
+    xv_engine::ZRing& zr = e->zr[e->f16 ? 1 : 0];
+    const int zi = zr.cur;
+    const bool concurrent = e->concurrent && ring;   // dz aliasing the caller's buffer: keep everything in order
     hipStream_t ws_stream = concurrent ? e->side : s;
     void* wws = concurrent ? e->ws_side : e->ws;
+    int rc;
     if (concurrent) {
         rc = chain(s, e->side, e->ev_dz);
         if (rc) return rc;
@@ -1037,7 +1103,22 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
         XV_CHECK_HIP(hipEventRecord(zr.ev[zi], e->side));
         zr.pending[zi] = true;
     }
-    if (dz == Z) zr.cur ^= 1;
+    if (ring) zr.cur ^= 1;
+    return 0;
+}
+
+int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, const float* x, int segs, int t_in, float* dx,
+                   const float* act_out) {
+    const int t_out = t_in - a.k + 1;
+    const int pad = (dx && a.k > 1) ? a.k - 1 : 0;
+    const int lidx = (int)(&a - &e->L[0]);
+    if (e->f16 && is_frame(e, lidx)) return layer_backward_f16(e, s, lidx, da, segs, t_in, dx);
+    const float* dz = nullptr;
+    bool ring = false;
+    int rc = layer_dz(e, s, a, da, segs, t_out, pad, act_out, &dz, &ring);
+    if (rc) return rc;
+    rc = layer_wgrad(e, s, a, x, dz, segs, t_in, pad, ring);
+    if (rc) return rc;
     if (dx) {
         const float* wf = a.k > 1 ? a.wf : vptr(e, a.v_kernel);
         rc = xv_affine_dgrad(s, dz, segs, t_out, a.c_out, a.k, wf, dx, a.c_in, e->ws, e->ws_bytes);
@@ -1150,6 +1231,7 @@ int end_stage(xv_engine* e, hipStream_t s, int stage, bool defer) {
         if (rc) return rc;
     }
     XV_CHECK_HIP(hipEventRecord(e->ev_stage[stage][0], s));
+    if (stage == 0) e->stage_lw = e->lw_pending;      // the loss head's weight gradient (third stream) belongs to this slice
     e->stage_side[stage] = !last && e->concurrent && e->side;
     if (e->stage_side[stage]) XV_CHECK_HIP(hipEventRecord(e->ev_stage[stage][1], e->side));
     return 0;
@@ -1169,6 +1251,7 @@ extern "C" int xv_engine_stage_wait(xv_engine* e, void* waiter_stream, int stage
     hipStream_t w = (hipStream_t)waiter_stream;
     XV_CHECK_HIP(hipStreamWaitEvent(w, e->ev_stage[stage][0], 0));
     if (e->stage_side[stage]) XV_CHECK_HIP(hipStreamWaitEvent(w, e->ev_stage[stage][1], 0));
+    if (stage == 0 && e->stage_lw) XV_CHECK_HIP(hipStreamWaitEvent(w, e->ev_lw, 0));
     return 0;
 }
 
@@ -1183,29 +1266,14 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
     int rc;
     if (stage == -1 || stage == 0) {
         if (e->f16) XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_DZ, 0, xv_align(e->F + 2, 4) * sizeof(uint32_t), s));   // every layer's dz scale slot
-        // d out = dlogits . wn^T   (pad column of both is zero, so K = ldl is exact)
-        XvGemmNT g = {};
-        g.A = e->dlogits; g.lda = e->ldl; g.a_rps = 1; g.a_pitch = 1;
-        g.Bt = e->wn; g.ldb = e->ldl;
-        g.C = e->d_small0; g.ldc = e->Lout;
-        g.M = b; g.N = e->Lout; g.K = e->ldl;
-        g.ws = e->ws; g.ws_bytes = e->ws_bytes;
-        rc = xv_launch_gemm_nt(s, g);
-        if (rc) return rc;
-        rc = xv_add_norm_grad(s, e->out, e->dnorm, b, e->Lout, e->d_small0);
-        if (rc) return rc;
-        if (e->v_ring >= 0) {      // d r of the ring loss was evaluated with the loss (0 when the auxiliary loss was off)
-            rc = e->with_margin ? xv_copy_2d(s, gptr(e, e->v_ring), 1, e->scalars + 3, 1, 1, 1) : 0;
-            if (!e->with_margin) XV_CHECK_HIP(hipMemsetAsync(gptr(e, e->v_ring), 0, sizeof(float), s));
-            if (rc) return rc;
-        }
-        // d wn = out^T . dlogits and the gradient through l2_normalize: on the side stream (only reads
-        // dlogits / out / wn, which the main chain never rewrites during backward).  [measured, same box] enqueueing this chain BEHIND
-        // the segment layers' weight gradients (so that the last frame layer's BN backward does not wait 77 us for its dz-ring slot)
-        // costs fp32 mode 0.2 ms/step: the chain then runs beside the big data-gradient GEMMs, 10x slower, with the weight-gradient
-        // GEMMs queued behind it
+        // d wn = out^T . dlogits and the gradient through l2_normalize: on a stream of its own (it only reads dlogits / out / wn, which
+        // the main chain never rewrites during backward), started before anything else of the backward pass.  [measured, same box]
+        // on the weight-gradient stream, BEHIND the segment layers' weight gradients, it cost fp32 mode 0.2 ms/step (it then ran beside
+        // the big data-gradient GEMMs, 10x slower, with the frame layers' weight gradients queued behind it); IN FRONT of them the
+        // last frame layer's BN backward waited ~80 us for the dz slot tdnn7's weight gradient still had to read
         {
-            hipStream_t ss = e->concurrent ? e->side : s;
+            hipStream_t ss = e->concurrent ? e->side2 : s;
+            void* lws = e->concurrent ? e->ws_side2 : e->ws_side;
             if (e->concurrent) {
                 rc = chain(s, ss, e->ev_dz);
                 if (rc) return rc;
@@ -1216,7 +1284,7 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             w.M = e->Lout; w.N = e->ldl; w.R = b;
             w.splits = xv_tn_splits(w.M, w.N, w.R);
             XV_REQUIRE((size_t)w.splits * w.M * w.N * sizeof(float) <= e->ws_bytes, "engine_backward: workspace too small for the loss weight gradient");
-            w.P = (float*)e->ws_side;
+            w.P = (float*)lws;
             rc = xv_launch_gemm_tn(ss, w);
             if (rc) return rc;
             rc = xv_launch_wgrad_reduce(ss, w.P, w.splits, 1, e->Lout, e->Lout, e->ldl, e->ldl, nullptr, 0, 0.f, e->dwn, e->ldl);
@@ -1227,30 +1295,118 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             }
             float ol2 = c.output_weight_l2_regularizer >= 0.f ? c.output_weight_l2_regularizer : c.weight_l2_regularizer;
             rc = xv_loss_weight_backward(ss, e->dwn, e->ldl, e->wn, e->ldl, e->inv_norm, vptr(e, e->v_loss_kernel), e->Lout, e->N,
-                                         c.loss_kind != XV_LOSS_SOFTMAX, ol2, gptr(e, e->v_loss_kernel), e->ws_side, e->ws_bytes);
+                                         c.loss_kind != XV_LOSS_SOFTMAX, ol2, gptr(e, e->v_loss_kernel), lws, e->ws_bytes);
             if (rc) return rc;
             if (e->v_loss_bias >= 0) {
-                rc = xv_colsum(ss, e->dlogits, b, e->N, e->ldl, gptr(e, e->v_loss_bias), e->ws_side, e->ws_bytes);
+                rc = xv_colsum(ss, e->dlogits, b, e->N, e->ldl, gptr(e, e->v_loss_bias), lws, e->ws_bytes);
                 if (rc) return rc;
             }
-            // its own event: tying it to a dz buffer's slot made the next-but-one layer wait ~50 us for it for nothing
             if (e->concurrent) {
                 XV_CHECK_HIP(hipEventRecord(e->ev_lw, ss));
                 e->lw_pending = true;
             }
         }
-        const float* d = e->d_small0;
-        if (c.feature_norm) {
-            rc = xv_l2_scaling_backward(s, e->h7, d, b, e->Lout, c.feature_scaling_factor, e->d_small1);
+        // d out = dlogits . wn^T   (pad column of both is zero, so K = ldl is exact), + the gradient through ||out|| (loss.py:122,147).
+        // Fused form (xv_skinny.hip): one launch, and with a BatchNorm in tdnn7 and no l2_scaling in between, tdnn7's BN backward too
+        Affine &l6 = e->L[e->S0()], &l7 = e->L[e->S1()];
+        const bool sk = e->sk && b <= XV_SEGMENT_MAX_ROWS;
+        const bool fuse7 = sk && l7.has_bn && !c.feature_norm;
+        float* dz7_fused = nullptr;
+        if (sk) {
+            XvSkinny g = {};
+            g.A = e->dlogits; g.lda = e->ldl; g.Bt = e->wn; g.ldb = e->ldl; g.M = b; g.N = e->Lout; g.K = e->ldl;
+            g.row_coef = e->dnorm; g.row_norm = e->xnorm; g.X = e->out; g.ldx = e->Lout;
+            g.ws = e->ws; g.ws_bytes = e->ws_bytes; g.tickets = e->sk_tickets;
+            if (fuse7) {
+                dz7_fused = ring_take(e, s);
+                XV_REQUIRE(dz7_fused, "engine_backward: waiting for a dz slot failed");
+                ActScope act(e, l7);
+                const XvActContext ac = xv_act_context();
+                g.epi = XV_SK_BN_BWD; g.C = dz7_fused; g.ldc = l7.c_out;
+                g.z = l7.z; g.gamma = vptr(e, l7.v_gamma); g.mean = l7.mean; g.invstd = l7.invstd; g.scale = l7.scale; g.shift = l7.shift;
+                g.relu = l7.has_relu ? 1 : 0; g.slope = l7.has_relu ? ac.slope : nullptr; g.dalpha = (l7.has_relu && ac.slope) ? ac.dalpha : nullptr;
+                g.dgamma = gptr(e, l7.v_gamma); g.dbeta = gptr(e, l7.v_beta); g.dbias = gptr(e, l7.v_bias);
+            } else {
+                g.epi = XV_SK_PLAIN; g.C = e->d_small0; g.ldc = e->Lout;
+            }
+            rc = xv_launch_skinny(s, g);
             if (rc) return rc;
-            d = e->d_small1;
+        } else {
+            XvGemmNT g = {};
+            g.A = e->dlogits; g.lda = e->ldl; g.a_rps = 1; g.a_pitch = 1;
+            g.Bt = e->wn; g.ldb = e->ldl;
+            g.C = e->d_small0; g.ldc = e->Lout;
+            g.M = b; g.N = e->Lout; g.K = e->ldl;
+            g.ws = e->ws; g.ws_bytes = e->ws_bytes;
+            rc = xv_launch_gemm_nt(s, g);
+            if (rc) return rc;
+            rc = xv_add_norm_grad(s, e->out, e->dnorm, b, e->Lout, e->d_small0);
+            if (rc) return rc;
         }
-        // tdnn7 -> d a6 (into bufD), tdnn6 -> d pool (into d_small0); the pooling backward itself is evaluated
-        // inside tdnn5's BN backward (stage 1) from (pool, d pool): d a5 is never written
-        rc = layer_backward(e, s, e->L[e->S1()], d, e->L[e->S0()].a, b, 1, e->bufD, e->h7);
-        if (rc) return rc;
-        rc = layer_backward(e, s, e->L[e->S0()], e->bufD, e->pool, b, 1, e->d_small0, nullptr);
-        if (rc) return rc;
+        if (e->v_ring >= 0) {      // d r of the ring loss was evaluated with the loss (0 when the auxiliary loss was off)
+            rc = e->with_margin ? xv_copy_2d(s, gptr(e, e->v_ring), 1, e->scalars + 3, 1, 1, 1) : 0;
+            if (!e->with_margin) XV_CHECK_HIP(hipMemsetAsync(gptr(e, e->v_ring), 0, sizeof(float), s));
+            if (rc) return rc;
+        }
+        if (!sk) {
+            const float* d = e->d_small0;
+            if (c.feature_norm) {
+                rc = xv_l2_scaling_backward(s, e->h7, d, b, e->Lout, c.feature_scaling_factor, e->d_small1);
+                if (rc) return rc;
+                d = e->d_small1;
+            }
+            // tdnn7 -> d a6 (into bufD), tdnn6 -> d pool (into d_small0); the pooling backward itself is evaluated
+            // inside tdnn5's BN backward (stage 1) from (pool, d pool): d a5 is never written
+            rc = layer_backward(e, s, l7, d, l6.a, b, 1, e->bufD, e->h7);
+            if (rc) return rc;
+            rc = layer_backward(e, s, l6, e->bufD, e->pool, b, 1, e->d_small0, nullptr);
+            if (rc) return rc;
+        } else {
+            // tdnn7's dz (already there when its BN backward rode on the d-out launch), its weight gradient on the side stream
+            const float* dz7 = dz7_fused;
+            bool ring7 = true;
+            if (!fuse7) {
+                const float* d = e->d_small0;
+                if (c.feature_norm) {
+                    rc = xv_l2_scaling_backward(s, e->h7, d, b, e->Lout, c.feature_scaling_factor, e->d_small1);
+                    if (rc) return rc;
+                    d = e->d_small1;
+                }
+                rc = layer_dz(e, s, l7, d, b, 1, 0, e->h7, &dz7, &ring7);
+                if (rc) return rc;
+            }
+            rc = layer_wgrad(e, s, l7, l6.a, dz7, b, 1, 0, ring7);
+            if (rc) return rc;
+            // d a6 = dz7 . W7^T and tdnn6's BatchNorm (+ activation) backward in one launch -> dz6
+            float* dz6 = ring_take(e, s);
+            XV_REQUIRE(dz6, "engine_backward: waiting for a dz slot failed");
+            XV_REQUIRE(l6.has_bn, "engine_backward: the first segment-level layer has a BatchNorm (tdnn.py:147-163)");
+            {
+                ActScope act(e, l6);
+                const XvActContext ac = xv_act_context();
+                XvSkinny g = {};
+                g.A = dz7; g.lda = l7.c_out; g.Bt = vptr(e, l7.v_kernel); g.ldb = l7.c_out; g.M = b; g.N = l7.c_in; g.K = l7.c_out;
+                g.epi = XV_SK_BN_BWD; g.C = dz6; g.ldc = l6.c_out;
+                g.z = l6.z; g.gamma = vptr(e, l6.v_gamma); g.mean = l6.mean; g.invstd = l6.invstd; g.scale = l6.scale; g.shift = l6.shift;
+                g.relu = l6.has_relu ? 1 : 0; g.slope = l6.has_relu ? ac.slope : nullptr; g.dalpha = (l6.has_relu && ac.slope) ? ac.dalpha : nullptr;
+                g.dgamma = gptr(e, l6.v_gamma); g.dbeta = gptr(e, l6.v_beta); g.dbias = gptr(e, l6.v_bias);
+                g.ws = e->ws; g.ws_bytes = e->ws_bytes; g.tickets = e->sk_tickets;
+                rc = xv_launch_skinny(s, g);
+                if (rc) return rc;
+            }
+            rc = layer_wgrad(e, s, l6, e->pool, dz6, b, 1, 0, true);
+            if (rc) return rc;
+            // d pool = dz6 . W6^T (into d_small0); the pooling backward itself is evaluated inside the last frame layer's BN backward
+            // (stage 1) from (pool, d pool): its d a is never written
+            {
+                XvSkinny g = {};
+                g.A = dz6; g.lda = l6.c_out; g.Bt = vptr(e, l6.v_kernel); g.ldb = l6.c_out; g.M = b; g.N = l6.c_in; g.K = l6.c_out;
+                g.epi = XV_SK_PLAIN; g.C = e->d_small0; g.ldc = l6.c_in;
+                g.ws = e->ws; g.ws_bytes = e->ws_bytes; g.tickets = e->sk_tickets;
+                rc = xv_launch_skinny(s, g);
+                if (rc) return rc;
+            }
+        }
         if (stage == 0) { rc = end_stage(e, s, 0, defer); if (rc) return rc; }
     }
     const int F = e->F;

@@ -61,7 +61,6 @@ struct NTArgs {
 // lgkmcnt and so serialised the LDS fragment reads behind the global loads).
 // The page is XV_ZERO_PAGE_FLOATS long: an out-of-range ROW is redirected to it ONCE (its base pointer), after which "base + k"
 // stays inside the page for every k < K <= XV_ZERO_PAGE_FLOATS - so full K-steps stage with no per-step select at all.
-#define XV_ZERO_PAGE_FLOATS 16384
 static float* g_zero_page = nullptr;
 static int ensure_zero_page() {
     if (g_zero_page) return 0;
@@ -69,6 +68,7 @@ static int ensure_zero_page() {
     XV_CHECK_HIP(hipMemset(g_zero_page, 0, XV_ZERO_PAGE_FLOATS * sizeof(float)));
     return 0;
 }
+const float* xv_zero_page() { return ensure_zero_page() ? nullptr : g_zero_page; }
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     // blocks b and b+8 share an XCD (round-robin dispatch): hand each XCD a contiguous run of

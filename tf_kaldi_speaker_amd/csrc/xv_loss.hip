@@ -88,9 +88,11 @@ __global__ __launch_bounds__(256) void margin_softmax_rows_kernel(int kind, cons
                                                                   long ldl, const float* __restrict__ x, int C,
                                                                   const int* __restrict__ labels, float m, float lambda,
                                                                   float* __restrict__ dlogits, float* __restrict__ dnorm,
-                                                                  float* __restrict__ row_loss) {
+                                                                  float* __restrict__ row_loss, float* __restrict__ xnorm,
+                                                                  unsigned* __restrict__ ticket, float* __restrict__ loss_out) {
     __shared__ float red[4];
     __shared__ float s_upd, s_dsel, s_dn;
+    __shared__ int s_last;
     const int r = blockIdx.x, tid = threadIdx.x;
     const float* lr = logits + (long)r * ldl;
     float* gr = dlogits + (long)r * ldl;
@@ -101,9 +103,12 @@ __global__ __launch_bounds__(256) void margin_softmax_rows_kernel(int kind, cons
     const bool margin = (kind != XV_LOSS_SOFTMAX) && !(kind == XV_LOSS_ASOFTMAX && m == 1.0f);
     float fa = 0.f, fs = 1.f;
     float ss = 0.f;
-    if (margin) {
+    if (margin || xnorm) {
         for (int c = tid; c < C; c += 256) { float v = x[(long)r * C + c]; ss += v * v; }
         ss = block_sum(ss, red);
+        if (xnorm && tid == 0) xnorm[r] = sqrtf(ss);       // ||x[r]||: what the ||x|| gradient is divided by (xv_add_norm_grad / the segment GEMM's row term)
+    }
+    if (margin) {
         fa = 1.0f / (1.0f + lambda);
         fs = 1.0f - fa;
         if (tid == 0) {
@@ -183,10 +188,27 @@ __global__ __launch_bounds__(256) void margin_softmax_rows_kernel(int kind, cons
         gr[j] = g;
     }
     if (tid == 0) {
-        row_loss[r] = bad_label ? NAN : lse - uy;
+        const float rl = bad_label ? NAN : lse - uy;
+        row_loss[r] = rl;
         float py = expf(uy - lse);
         dnorm[r] = margin ? s_dn * (py - 1.f) * inv_rows : 0.f;
+        if (ticket) {
+            // the mean over the rows in the same launch: the last workgroup to finish sums row_loss in index order (mean_kernel's
+            // arithmetic).  Hand-over by agent-scope atomics, not __threadfence() (a whole-L2 write-back per workgroup on gfx950)
+            __hip_atomic_store(row_loss + r, rl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (t == (unsigned)(rows - 1));
+            if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    if (!ticket) return;
+    __syncthreads();
+    if (!s_last) return;
+    float sum = 0.f;
+    for (int i = tid; i < rows; i += 256) sum += __hip_atomic_load(row_loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sum = block_sum(sum, red);
+    if (tid == 0) *loss_out = sum / (float)rows;
 }
 
 __global__ void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
@@ -206,9 +228,23 @@ extern "C" int xv_margin_softmax_rows(void* stream, int kind, const float* logit
         XV_REQUIRE(m == 1.0f || m == 2.0f || m == 4.0f, "[ERROR] m=%d is not unsupported.", (int)m);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(margin_softmax_rows_kernel, dim3(rows), dim3(256), 0, s, kind, logits, rows, n, (long)ldl, x, c,
-                       (const int*)labels, m, lambda, dlogits, dnorm, row_loss);
+                       (const int*)labels, m, lambda, dlogits, dnorm, row_loss, (float*)nullptr, (unsigned*)nullptr, (float*)nullptr);
     XV_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, (const float*)row_loss, rows, loss_out);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+// Engine form: also writes ||x[r]|| and folds the mean into the same launch (ticket: one zeroed uint32, left zeroed)
+int xv_margin_softmax_rows_ex(hipStream_t s, int kind, const float* logits, int rows, int n, int ldl, const float* x, int c,
+                              const int32_t* labels, float m, float lambda, float* dlogits, float* dnorm, float* row_loss,
+                              float* loss_out, float* xnorm, uint32_t* ticket) {
+    XV_REQUIRE(rows > 0 && n > 0 && ldl >= n && c > 0 && ticket, "margin_softmax_rows: bad shape");
+    XV_REQUIRE(kind >= XV_LOSS_SOFTMAX && kind <= XV_LOSS_ARCSOFTMAX, "Not implement loss kind %d", kind);
+    if (kind == XV_LOSS_ASOFTMAX)
+        XV_REQUIRE(m == 1.0f || m == 2.0f || m == 4.0f, "[ERROR] m=%d is not unsupported.", (int)m);
+    hipLaunchKernelGGL(margin_softmax_rows_kernel, dim3(rows), dim3(256), 0, s, kind, logits, rows, n, (long)ldl, x, c,
+                       (const int*)labels, m, lambda, dlogits, dnorm, row_loss, xnorm, (unsigned*)ticket, loss_out);
     XV_LAUNCH_CHECK();
     return 0;
 }

@@ -271,6 +271,65 @@ def add_norm_grad(x, dnorm, dx):
     return dx
 
 
+_TICKETS = {}
+
+
+def _tickets(like, n):
+    """Zeroed uint32 tickets for the segment-level launches (one per 32 output columns; every launch leaves them zero)."""
+    key = str(like.device)
+    need = (n + 31) // 32 + 8
+    if key not in _TICKETS or _TICKETS[key].numel() < need:
+        _TICKETS[key] = torch.zeros(max(need, 1024), dtype=torch.int32, device=like.device)
+    return _TICKETS[key]
+
+
+def _row_term(row_term):
+    if row_term is None:
+        return _p(None), _p(None), _p(None), 0
+    coef, norm, xrow = row_term
+    return _p(coef), _p(norm), _p(xrow), xrow.shape[1]
+
+
+def segment_gemm(a, bt, bias=None, row_term=None):
+    """c[m][n] = sum_k a[m][k] bt[n][k] + bias[n] (+ (coef[m]/norm[m]) xrow[m][n]); m <= 128 rows, one launch."""
+    m, k = a.shape
+    n = bt.shape[0]
+    c = _f32((m, n), a)
+    wp, wb = _ws(a)
+    rc, rn, rx, ldx = _row_term(row_term)
+    _lib.call("xv_segment_gemm", _s(), _p(a), a.stride(0), _p(bt), bt.stride(0), m, n, k, _p(bias), rc, rn, rx, ldx, _p(c), n,
+              wp, wb, _p(_tickets(a, n)))
+    return c
+
+
+def segment_affine_bn_forward(x, wt, bias, gamma, beta, eps, momentum, unbiased, moving_mean, moving_var, relu, want_a=True):
+    """dense + training-mode BatchNorm (+ ReLU) on m <= 128 rows in one launch.  Returns z, a, mean, invstd, scale, shift."""
+    m, k = x.shape
+    n = wt.shape[0]
+    z = _f32((m, n), x)
+    a = _f32((m, n), x) if want_a else None
+    mean, invstd, scale, shift = (_f32((n,), x) for _ in range(4))
+    wp, wb = _ws(x)
+    _lib.call("xv_segment_affine_bn_forward", _s(), _p(x), x.stride(0), _p(wt), wt.stride(0), m, n, k, _p(bias), _p(gamma), _p(beta),
+              float(eps), float(momentum), int(unbiased), _p(moving_mean), _p(moving_var), _p(z), _p(mean), _p(invstd), _p(scale),
+              _p(shift), int(relu), _p(a), wp, wb, _p(_tickets(x, n)))
+    return z, a, mean, invstd, scale, shift
+
+
+def segment_dgrad_bn_backward(dy, wt, z, gamma, mean, invstd, scale, shift, relu, row_term=None):
+    """d a = dy . wt^T (+ row term), then the BatchNorm (+ ReLU) backward of the layer with pre-BN tensor z.  Returns dz, dgamma, dbeta, dbias."""
+    m, k = dy.shape
+    n = wt.shape[0]
+    dz = _f32((m, n), dy)
+    dgamma, dbeta, dbias = (_f32((n,), dy) for _ in range(3))
+    wp, wb = _ws(dy)
+    rc, rn, rx, ldx = _row_term(row_term)
+    _lib.call("xv_segment_dgrad_bn_backward", _s(), _p(dy), dy.stride(0), _p(wt), wt.stride(0), m, n, k, rc, rn, rx, ldx, _p(z),
+              _p(gamma), _p(mean), _p(invstd), _p(scale), _p(shift), int(relu), _p(dz), _p(dgamma), _p(dbeta), _p(dbias), wp, wb,
+              _p(_tickets(dy, n)))
+    return dz, dgamma, dbeta, dbias
+
+
 def loss_weight_backward(dwn, wn, inv, w, normalize, l2_scale):
     c, n = w.shape
     dw = torch.empty_like(w)
