@@ -1,4 +1,4 @@
-"""Oracle parity at the BASELINE shapes, full size, on a real MI355X (S1-S4).
+"""Oracle parity at the BASELINE shapes, full size, on a real MI355X (S1-S4, and configs[4] as S5).
 
 Every other engine test compares with the float64 oracle at a few chunks x a few dozen frames; the reductions over
 ~25 000 (chunk, frame) rows per BatchNorm / weight gradient, the 7 351-column loss head and the per-tensor fp16 plane
@@ -9,6 +9,7 @@ optimiser step at
   S2  128 x 400, A-Softmax m = 4                                                      (chunk length / loss of configs[4])
   S3  64 chunks x one length drawn from U{200..400} (the shipped sampler), ArcFace    (configs[2])
   S4  S1 + the self-attention head of nnet_conf/*_tdnn4_att.json (1500/1500 keys)     (configs[3])
+  S5  128 x 400, the extended 10-layer frame stack, A-Softmax m = 4                   (configs[4]; no reference counterpart)
 
 with 7 351 speakers, in both precisions, and is compared with the oracle's float64 step from the same fp32 variables,
 features and labels: loss, regulariser, 15-19 endpoints incl. the `tdnn6_dense` embedding and the logits, every gradient
@@ -38,13 +39,18 @@ SHAPES = {
     "S4": dict(B=128, T=200, step=0,
                kw=dict(loss_func="softmax", pooling_type="self_attention", att_key_num_nodes=(1500, 1500),
                        att_key_network_type=3, att_use_scale=True)),
+    # BASELINE configs[4] "Deep TDNN, extended context, 10 layers, A-Softmax, 400-frame chunks" (no reference counterpart):
+    # the table `bench.py --extended` times
+    "S5": dict(B=128, T=400, step=20000,
+               kw=dict(loss_func="asoftmax", margin_m=4, lambda_min=10, lambda_gamma=1e-5, last_layer_linear=True,
+                       frame_layers=((5, 512), (1, 512), (3, 512), (1, 512), (3, 512), (1, 512), (3, 512), (1, 512), (1, 512), (1, 1500)))),
 }
 _ORACLE = {"shape": None}      # one shape's float64 forward at a time (S2's caches are ~5 GB)
 
 
 def _inputs(name):
     c = SHAPES[name]
-    rs = np.random.RandomState({"S1": 11, "S2": 12, "S3": 13, "S4": 14}[name])
+    rs = np.random.RandomState({"S1": 11, "S2": 12, "S3": 13, "S4": 14, "S5": 15}[name])
     T = c["T"] if c["T"] else int(rs.randint(200, 401))
     x = rs.randn(c["B"], T, 30).astype(np.float32)
     labels = rs.randint(0, NSPK, c["B"]).astype(np.int32)

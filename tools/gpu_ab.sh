@@ -1,3 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for q in 4 8 2; do echo "GPU_MAX_HW_QUEUES=$q"; GPU_MAX_HW_QUEUES=$q python3 tools/e2e_ab.py --rounds 2 2>&1 | grep -v amdgpu.ids; done
+O=$GRAFT_REPO_ROOT/gpurun_out/ab; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_full_size.py -x -q -m gpu -s -k "S5" > $O/fs.log 2>&1; echo "rc=$?"; grep "S5\|passed\|failed\|Error" $O/fs.log | tail; free -g | head -2
