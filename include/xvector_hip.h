@@ -181,6 +181,15 @@ int xv_bn_relu_backward_pooled(void* stream, const float* pool_out, const float*
                                const float* z, int n,
                                const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
                                int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes);
+/* The same pair with the pooling forward's by-product wpos [b][c] (the share of each chunk's frame weights on frames whose ReLU is
+ * on; amax [b][c], optional: each chunk's largest activation): given wpos, the BatchNorm backward gets sum(dy) and sum(dy*xhat) in
+ * closed form from the pooled statistics - no reduction pass over z (plain ReLU or no activation).  Same results up to rounding. */
+int xv_stat_pool_forward_bn_aux(void* stream, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
+                                const float* weights, float* out, float* wpos, float* amax);
+int xv_bn_relu_backward_pooled_aux(void* stream, const float* pool_out, const float* dpool, const float* weights, const float* wpos,
+                                   int b, int t, const float* z, int n, const float* gamma, const float* mean, const float* invstd,
+                                   const float* scale, const float* shift, int relu, float* dz, float* dgamma, float* dbeta,
+                                   float* dbias, void* ws, size_t ws_bytes);
 int xv_bn_relu_backward_pooled_split(void* stream, const float* pool_out, const float* dpool, const float* weights, int b, int t,
                                      const float* z, int n,
                                      const float* gamma, const float* mean, const float* invstd, const float* scale,

@@ -206,6 +206,44 @@ def test_pooling_fused_into_bn(ops, b, t, n):
     assert_close(host(db), db_ref, 2e-5, 1e-4, "pooled dbeta")
 
 
+@pytest.mark.parametrize("b,t,n", [(5, 37, 1500), (128, 186, 512), (7, 64, 96)])
+def test_pooled_bn_backward_closed_form(ops, b, t, n):
+    """The closed-form reductions (xv_bn_relu_backward_pooled_aux: sum dy and sum dy*xhat per channel from the pooled statistics and
+    the forward's by-product wpos, no pass over z) against the composed oracle and against the direct pass - also with chunks that
+    sit on the special branches: a constant chunk (variance clamp: no std gradient), a chunk 100x larger, a channel whose ReLU is
+    off for a whole chunk (wpos = 0) and one that is on everywhere (wpos = 1)."""
+    rs = np.random.RandomState(b * 100 + t)
+    z = (rs.randn(b, t, n) * 2 + 0.3).astype(np.float32)
+    z[0] = z[0, :1]                      # chunk 0: every frame the same
+    z[1] *= 100.0
+    z[2, :, 3] = -50.0                   # off for the whole chunk
+    z[2, :, 5] = 50.0 + rs.rand(t)       # on for the whole chunk
+    z = z.reshape(b * t, n)
+    gamma, beta = (rs.rand(n) + 0.5).astype(np.float32), (0.3 * rs.randn(n)).astype(np.float32)
+    gamma[7] = -gamma[7]                 # a negative scale
+    dout = rs.randn(b, 2 * n).astype(np.float32)
+    z64, g64, b64 = z.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64)
+    y, cache = O.batchnorm_train_fwd(z64, g64, b64)
+    a = np.maximum(y, 0).reshape(b, t, n)
+    pool_ref, pcache = O.statistics_pooling_fwd(a)
+    da = O.statistics_pooling_bwd(a, pcache, dout.astype(np.float64)).reshape(b * t, n)
+    dz_ref, dg_ref, db_ref = O.batchnorm_train_bwd(da * (y > 0), cache, g64)
+    part = ops.col_stats(dev(z))
+    mean, invstd, scale, shift = ops.bn_finalize(part, b * t, dev(gamma), dev(beta), 1e-3, 0.99, False, None, None)
+    pool, wpos, amax = ops.stat_pool_forward_bn_aux(dev(z), b, t, scale, shift, True)
+    assert_close(host(pool), pool_ref, 5e-6, 5e-5, "pool")
+    ygpu = host(dev(z)) * host(scale) + host(shift)      # the GPU's own on/off pattern (fp32 scale / shift)
+    on = (ygpu.astype(np.float32) > 0).reshape(b, t, n)
+    assert np.abs(host(wpos) - on.mean(axis=1)).max() <= 2.0 / t + 1e-6          # rounding-level pre-activations may flip a frame or two
+    assert_close(host(amax), a.max(axis=1), 2e-5, 2e-4, "amax")
+    dz, dg, db, dbias = ops.bn_relu_backward_pooled_aux(pool, dev(dout), wpos, b, t, dev(z), dev(gamma), mean, invstd, scale, shift, True)
+    dz2, dg2, db2, _ = ops.bn_relu_backward_pooled(pool, dev(dout), b, t, dev(z), dev(gamma), mean, invstd, scale, shift, True)
+    for name, got, direct, ref, tol in (("dz", dz, dz2, dz_ref, 2e-4), ("dgamma", dg, dg2, dg_ref, 1e-4), ("dbeta", db, db2, db_ref, 1e-4)):
+        assert_close(host(got), ref, 2e-5, tol, "closed-form " + name)
+        assert_close(host(got), host(direct), 2e-5, tol, "closed-form vs direct " + name)
+    assert np.abs(host(dbias)).max() <= 1e-4 * max(np.abs(dz_ref).sum(axis=0).max(), 1e-30)
+
+
 def test_l2_scaling(ops):
     rs = np.random.RandomState(3)
     x = rs.randn(100, 512).astype(np.float32)

@@ -121,6 +121,8 @@ SIGNATURES = {
     "xv_stat_pool_backward": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "xv_stat_pool_forward_bn": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP]),
     "xv_bn_relu_backward_pooled": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _SZ]),
+    "xv_stat_pool_forward_bn_aux": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "xv_bn_relu_backward_pooled_aux": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _SZ]),
     "xv_bn_relu_backward_pooled_split": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _SZ, _VP,
                                               _VP, _VP, _VP, _VP, _SZ]),
     "xv_ring_loss": (_I, [_VP, _VP, _I, _I, _I, _VP, _F, _VP, _VP, _VP]),

@@ -151,7 +151,7 @@ int xv_bn_small_backward(hipStream_t s, const float* da, const float* z, int row
 // (weighted) pooling backward of (pool_out, dpool) when pool_out != null; ext_part: reductions already done by a GEMM epilogue;
 // zero_amax = false: *dz_amax was zeroed by the caller (one memset per backward pass instead of one per layer).
 struct XvBnBwdSplit { const float* da; const float* pool_out; const float* dpool; const float* weights; int pool_t;
-                      const float* ext_part; int ext_chunks; bool zero_amax; };
+                      const float* ext_part; int ext_chunks; bool zero_amax; const float* wpos; const float* pamax; };
 int xv_bn_relu_backward_split_ex(hipStream_t s, const XvBnBwdSplit& x, const float* z, int segs, int t, int n, const float* gamma,
                                  const float* mean, const float* invstd, const float* scale, const float* shift, const float* zmin,
                                  const float* zmax, int relu, int pad, void* dz_planes, int ldp, size_t plane_stride, uint32_t* dz_amax,
@@ -179,6 +179,16 @@ struct XvSkinny {
 };
 int xv_launch_skinny(hipStream_t s, const XvSkinny& g);
 size_t xv_skinny_tickets(int max_n);
+
+// Statistics pooling fused with the last frame layer's BatchNorm, engine forms (xv_elementwise.hip): the forward also writes
+// wpos [b][c] = the share of each chunk's frame weights on frames with an active ReLU; given that, the BatchNorm backward gets its
+// two reductions in closed form from the pooled statistics instead of a pass over z (plain ReLU / no activation); amax [b][c] = each
+// chunk's largest activation, which bounds |d a| for the split-precision dz scale (XvBnBwdSplit.wpos / .pamax, unit frame weights)
+int xv_stat_pool_forward_bn_ex(hipStream_t s, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
+                               const float* weights, float* out, float* wpos, float* amax);
+int xv_bn_relu_backward_pooled_ex(hipStream_t s, const float* pool_out, const float* dpool, const float* weights, const float* wpos, int b, int t,
+                                  const float* z, int n, const float* gamma, const float* mean, const float* invstd, const float* scale,
+                                  const float* shift, int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes);
 
 // xv_margin_softmax_rows in one launch (mean folded in through a ticket) that also writes ||x[r]|| (xv_loss.hip)
 int xv_margin_softmax_rows_ex(hipStream_t s, int kind, const float* logits, int rows, int n, int ldl, const float* x, int c,

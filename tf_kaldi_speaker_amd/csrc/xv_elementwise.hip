@@ -541,7 +541,10 @@ extern "C" int xv_bn_apply(void* stream, const float* z, int rows, int n, int ld
 // Upstream gradient of a layer whose output feeds statistics pooling directly (tdnn5): instead of reading a
 // materialised d(activation), the BN backward evaluates the pooling backward (pooling.py:9-34) on the fly from the
 // pooled statistics [b][mean | std] and their gradient:  da = dmean/T + dstd/(T*std) * (a - mean),  a = relu?(z*scale+shift).
-struct PoolGrad { const float* out; const float* dout; int t; const float* w; };   // w: per-frame attention weights or null (1/t)
+struct PoolGrad { const float* out; const float* dout; int t; const float* w; const float* wpos; const float* amax; };   // w: per-frame attention weights or null (1/t)
+// wpos [b][n] (optional): the share of each chunk's frame weights that sits on frames with an active ReLU, written by the pooling forward -
+// with it the BatchNorm backward's two reductions have a closed form per (chunk, channel) and the pass over z is not needed (bn_bwd_pooled_stats_kernel).
+// amax [b][n] (optional): each chunk's largest activation - bounds |d a| for the split-precision dz scale
 
 // The pooled statistics of chunk b at one channel quad, in the form the per-element formula needs: they change only when
 // the row loop crosses into the next chunk, so the kernels reload them there instead of once per element (4 vector loads,
@@ -857,6 +860,80 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split_kernel(const float* __
     }
 }
 
+// BatchNorm backward reductions of a layer that feeds statistics pooling, WITHOUT a pass over z (plain ReLU or no activation).
+// With a = act(y), y = gamma*xhat + beta, frame weights omega (1/T or the attention weights, sum 1) and the pooled mean / variance
+// (mu, var) of chunk b, the upstream gradient on an active frame is  dd = omega*(dm + q*(a - mu)),  q = dstd/std, and xhat = (a - beta)/gamma
+// there; off frames contribute nothing.  Summed over the frames of the chunk, with W+ = the weight on active frames (pooling forward):
+//   sum dd        = dm*W+ + q*mu*(1 - W+)
+//   sum dd*xhat   = (dm*(mu - beta*W+) + q*(var - beta*mu*(1 - W+))) / gamma
+// (sum_on omega*a = mu and sum_on omega*a^2 = var + mu^2 because a = 0 off).  One workgroup = 16 channel quads x 16 chunk lanes, chunks
+// summed in a fixed order; also does bn_bwd_finalize_kernel's job.  gamma == 0 (xhat not recoverable from a) yields inf / nan - loudly.
+__global__ __launch_bounds__(256) void bn_bwd_pooled_stats_kernel(PoolGrad pg, int segs, int n, int rows, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ coef, float* __restrict__ dbias,
+                                                                  const float* __restrict__ zmin, const float* __restrict__ zmax,
+                                                                  unsigned* __restrict__ dz_amax) {
+    __shared__ f32x4 r1[16][16], r2[16][16], r3[16][16];
+    const int cq = threadIdx.x & 15, bl = threadIdx.x >> 4;
+    const int col = (blockIdx.x * 16 + cq) * 4;
+    const bool cv = col < n;
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0};
+    const float invT = 1.f / (float)pg.t;
+    if (cv) {
+        // beta = shift + mean*scale (shift = beta - mean*scale, bn_finalize)
+        const f32x4 bt = *(const f32x4*)(shift + col) + *(const f32x4*)(mean + col) * *(const f32x4*)(scale + col);
+        for (int b = bl; b < segs; b += 16) {
+            const PoolCoef pc = pool_coef(pg, b, n, col);
+            const f32x4 sd = *(const f32x4*)(pg.out + (long)b * 2 * n + n + col);
+            const f32x4 wp = *(const f32x4*)(pg.wpos + (long)b * n + col);
+            const f32x4 off = f32x4{1.f, 1.f, 1.f, 1.f} - wp;
+            s1 += pc.dm * wp + pc.q * pc.mean * off;
+            s2 += pc.dm * (pc.mean - bt * wp) + pc.q * (sd * sd - bt * pc.mean * off);
+            if (dz_amax) {
+                // |d a| over the chunk (unit frame weights): d a = (dm + q*(a - mu)) / T is linear in a, a in [0, amax] -> the ends
+                const f32x4 am = *(const f32x4*)(pg.amax + (long)b * n + col);
+                const f32x4 e0 = pc.dm - pc.q * pc.mean, e1 = pc.dm + pc.q * (am - pc.mean);
+                s3.x = fmaxf(s3.x, fmaxf(fabsf(e0.x), fabsf(e1.x)) * invT); s3.y = fmaxf(s3.y, fmaxf(fabsf(e0.y), fabsf(e1.y)) * invT);
+                s3.z = fmaxf(s3.z, fmaxf(fabsf(e0.z), fabsf(e1.z)) * invT); s3.w = fmaxf(s3.w, fmaxf(fabsf(e0.w), fabsf(e1.w)) * invT);
+            }
+        }
+    }
+    r1[bl][cq] = s1; r2[bl][cq] = s2; r3[bl][cq] = s3;
+    __syncthreads();
+    if (bl != 0 || !cv) return;
+    s1 = r1[0][cq]; s2 = r2[0][cq];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        s1 += r1[k][cq]; s2 += r2[k][cq];
+        s3.x = fmaxf(s3.x, r3[k][cq].x); s3.y = fmaxf(s3.y, r3[k][cq].y); s3.z = fmaxf(s3.z, r3[k][cq].z); s3.w = fmaxf(s3.w, r3[k][cq].w);
+    }
+    const f32x4 g = *(const f32x4*)(gamma + col), is = *(const f32x4*)(invstd + col);
+    s2.x /= g.x; s2.y /= g.y; s2.z /= g.z; s2.w /= g.w;
+    const float inv_rows = 1.0f / (float)rows;
+    const f32x4 c1 = s1 * inv_rows;
+    *(f32x4*)(dbeta + col) = s1;
+    *(f32x4*)(dgamma + col) = s2;
+    *(f32x4*)(coef + col) = c1;
+    *(f32x4*)(coef + n + col) = s2 * inv_rows;
+    if (dbias) *(f32x4*)(dbias + col) = g * is * (s1 - c1 * (float)rows);
+    if (dz_amax) {
+        // upper bound of |dz| = |gamma*invstd| * |d a - c1 - xhat*c2| over the batch (bn_bwd_finalize_kernel's, with the analytic |d a| bound)
+        const f32x4 mu = *(const f32x4*)(mean + col), zn = *(const f32x4*)(zmin + col), zx = *(const f32x4*)(zmax + col);
+        float bound = 0.f;
+        const float s3v[4] = {s3.x, s3.y, s3.z, s3.w}, s1v[4] = {c1.x, c1.y, c1.z, c1.w}, s2v[4] = {s2.x, s2.y, s2.z, s2.w};
+        const float gv[4] = {g.x, g.y, g.z, g.w}, iv[4] = {is.x, is.y, is.z, is.w}, muv[4] = {mu.x, mu.y, mu.z, mu.w};
+        const float znv[4] = {zn.x, zn.y, zn.z, zn.w}, zxv[4] = {zx.x, zx.y, zx.z, zx.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = fmaxf(fabsf(zxv[j] - muv[j]), fabsf(znv[j] - muv[j])) * iv[j];
+            bound = fmaxf(bound, fabsf(gv[j] * iv[j]) * (s3v[j] + fabsf(s1v[j]) + xh * fabsf(s2v[j] * inv_rows)) * 1.0001f);
+        }
+        atomicMax(dz_amax, __float_as_uint(bound));
+    }
+}
+
 static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, const float* z, int segs, int t, int n, const float* gamma,
                                  const float* mean, const float* invstd, const float* scale, const float* shift, int relu, int pad,
                                  float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
@@ -871,13 +948,20 @@ static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, co
     float* part = (float*)ws;
     float* coef = part + (size_t)chunks * nstat * n;
     const bool pooled = pg.out != nullptr;
-    hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
-                       da, pg, z, rows, n, mean, invstd, scale, shift, relu, part, relu ? act.slope : nullptr, nstat);
-    XV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
-                       dgamma, dbeta, coef, gamma, invstd, dbias, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (unsigned*)nullptr, nstat, nstat == 4 ? act.dalpha : (float*)nullptr);
-    XV_LAUNCH_CHECK();
+    if (pooled && pg.wpos && !(relu && act.slope)) {
+        // closed form from the pooled statistics: no pass over z, no finalize launch
+        hipLaunchKernelGGL(bn_bwd_pooled_stats_kernel, dim3(xv_cdiv(n / 4, 16)), dim3(256), 0, s, pg, rows / pg.t, n, rows, gamma, shift, mean,
+                           invstd, scale, dgamma, dbeta, coef, dbias, (const float*)nullptr, (const float*)nullptr, (unsigned*)nullptr);
+        XV_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
+                           da, pg, z, rows, n, mean, invstd, scale, shift, relu, part, relu ? act.slope : nullptr, nstat);
+        XV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
+                           dgamma, dbeta, coef, gamma, invstd, dbias, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                           (unsigned*)nullptr, nstat, nstat == 4 ? act.dalpha : (float*)nullptr);
+        XV_LAUNCH_CHECK();
+    }
     dim3 agrid(xv_cdiv(n / 4, 64), xv_cdiv(segs * (t + 2 * pad), BAF_ROWS));
     hipLaunchKernelGGL(pooled ? bn_bwd_apply_kernel<true> : bn_bwd_apply_kernel<false>, agrid, dim3(256), 0, s, da,
                        pg, z, segs, t, n, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad, dz_pad, relu ? act.slope : nullptr);
@@ -906,15 +990,22 @@ static int bn_relu_backward_split_impl(hipStream_t s, const float* da, PoolGrad 
     float* coef = ext_part ? (float*)ws : part + (size_t)chunks * nstat * n;
     const bool pooled = pg.out != nullptr;
     if (zero_amax) XV_CHECK_HIP(hipMemsetAsync(dz_amax, 0, sizeof(uint32_t), s));
-    if (!ext_part) {
-        hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
-                           da, pg, z, rows, n, mean, invstd, scale, shift, relu, part, relu ? act.slope : nullptr, nstat);
+    if (pooled && pg.wpos && pg.amax && !pg.w && !ext_part && !(relu && act.slope)) {
+        // statistics pooling, plain ReLU: reductions, finalize and the |dz| bound in closed form from the pooled statistics (no pass over z)
+        hipLaunchKernelGGL(bn_bwd_pooled_stats_kernel, dim3(xv_cdiv(n / 4, 16)), dim3(256), 0, s, pg, rows / pg.t, n, rows, gamma, shift, mean,
+                           invstd, scale, dgamma, dbeta, coef, dbias, zmin, zmax, (unsigned*)dz_amax);
+        XV_LAUNCH_CHECK();
+    } else {
+        if (!ext_part) {
+            hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
+                               da, pg, z, rows, n, mean, invstd, scale, shift, relu, part, relu ? act.slope : nullptr, nstat);
+            XV_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
+                           dgamma, dbeta, coef, gamma, invstd, dbias, mean, zmin, zmax, (unsigned*)dz_amax, nstat,
+                           nstat == 4 ? act.dalpha : (float*)nullptr);
         XV_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
-                       dgamma, dbeta, coef, gamma, invstd, dbias, mean, zmin, zmax, (unsigned*)dz_amax, nstat,
-                       nstat == 4 ? act.dalpha : (float*)nullptr);
-    XV_LAUNCH_CHECK();
     dim3 agrid(xv_cdiv(ldp / 8, 64), xv_cdiv(segs * (t + 2 * pad), BAS_ROWS));
     hipLaunchKernelGGL(pooled ? bn_bwd_apply_split_kernel<true> : bn_bwd_apply_split_kernel<false>, agrid,
                        dim3(256), 0, s, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad,
@@ -927,7 +1018,7 @@ extern "C" int xv_bn_relu_backward(void* stream, const float* da, const float* z
                                    const float* mean, const float* invstd, const float* scale, const float* shift, int relu,
                                    int pad, float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
     XV_REQUIRE(da, "bn_relu_backward: null upstream gradient");
-    PoolGrad pg = {nullptr, nullptr, 1, nullptr};
+    PoolGrad pg = {nullptr, nullptr, 1, nullptr, nullptr, nullptr};
     return bn_relu_backward_impl((hipStream_t)stream, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, relu, pad, dz_pad, dgamma,
                                  dbeta, dbias, ws, ws_bytes);
 }
@@ -938,7 +1029,7 @@ extern "C" int xv_bn_relu_backward_split(void* stream, const float* da, const fl
                                          size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta, float* dbias, void* ws,
                                          size_t ws_bytes) {
     XV_REQUIRE(da, "bn_relu_backward_split: null upstream gradient");
-    PoolGrad pg = {nullptr, nullptr, 1, nullptr};
+    PoolGrad pg = {nullptr, nullptr, 1, nullptr, nullptr, nullptr};
     return bn_relu_backward_split_impl((hipStream_t)stream, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, zmin, zmax, relu, pad,
                                        dz_planes, ldp, plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes);
 }
@@ -948,7 +1039,7 @@ int xv_bn_relu_backward_split_ex(hipStream_t s, const XvBnBwdSplit& x, const flo
                                  const float* mean, const float* invstd, const float* scale, const float* shift, const float* zmin,
                                  const float* zmax, int relu, int pad, void* dz_planes, int ldp, size_t plane_stride, uint32_t* dz_amax,
                                  float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
-    PoolGrad pg = {x.pool_out, x.dpool, x.pool_out ? x.pool_t : 1, x.weights};
+    PoolGrad pg = {x.pool_out, x.dpool, x.pool_out ? x.pool_t : 1, x.weights, x.pool_out ? x.wpos : nullptr, x.pool_out ? x.pamax : nullptr};
     return bn_relu_backward_split_impl(s, x.da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, zmin, zmax, relu, pad, dz_planes, ldp,
                                        plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes, x.ext_part, x.ext_chunks, x.zero_amax);
 }
@@ -961,7 +1052,7 @@ extern "C" int xv_bn_relu_backward_split_from_part(void* stream, const float* pa
                                                    void* dz_planes, int ldp, size_t plane_stride, uint32_t* dz_amax, float* dgamma,
                                                    float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
     XV_REQUIRE(da && part && chunks == xv_cdiv(segs * t, XV_TILE_M), "bn_relu_backward_split_from_part: one chunk per 128-row tile expected");
-    PoolGrad pg = {nullptr, nullptr, 1, nullptr};
+    PoolGrad pg = {nullptr, nullptr, 1, nullptr, nullptr, nullptr};
     return bn_relu_backward_split_impl((hipStream_t)stream, da, pg, z, segs, t, n, gamma, mean, invstd, scale, shift, zmin, zmax, 1, pad,
                                        dz_planes, ldp, plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes, part, chunks);
 }
@@ -972,9 +1063,27 @@ extern "C" int xv_bn_relu_backward_pooled(void* stream, const float* pool_out, c
                                           const float* shift, int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws,
                                           size_t ws_bytes) {
     XV_REQUIRE(pool_out && dpool && b > 0 && t > 0, "bn_relu_backward_pooled: bad arguments");
-    PoolGrad pg = {pool_out, dpool, t, weights};
+    PoolGrad pg = {pool_out, dpool, t, weights, nullptr, nullptr};
     return bn_relu_backward_impl((hipStream_t)stream, nullptr, pg, z, b * t, 1, n, gamma, mean, invstd, scale, shift, relu, 0, dz, dgamma,
                                  dbeta, dbias, ws, ws_bytes);
+}
+
+extern "C" int xv_bn_relu_backward_pooled_aux(void* stream, const float* pool_out, const float* dpool, const float* weights, const float* wpos,
+                                              int b, int t, const float* z, int n, const float* gamma, const float* mean, const float* invstd,
+                                              const float* scale, const float* shift, int relu, float* dz, float* dgamma, float* dbeta,
+                                              float* dbias, void* ws, size_t ws_bytes) {
+    XV_REQUIRE(wpos, "bn_relu_backward_pooled_aux: wpos is required");
+    return xv_bn_relu_backward_pooled_ex((hipStream_t)stream, pool_out, dpool, weights, wpos, b, t, z, n, gamma, mean, invstd, scale, shift, relu,
+                                         dz, dgamma, dbeta, dbias, ws, ws_bytes);
+}
+
+// Engine form: wpos from xv_stat_pool_forward_bn_ex (see PoolGrad) - the reductions then need no pass over z
+int xv_bn_relu_backward_pooled_ex(hipStream_t s, const float* pool_out, const float* dpool, const float* weights, const float* wpos, int b, int t,
+                                  const float* z, int n, const float* gamma, const float* mean, const float* invstd, const float* scale,
+                                  const float* shift, int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
+    XV_REQUIRE(pool_out && dpool && b > 0 && t > 0, "bn_relu_backward_pooled: bad arguments");
+    PoolGrad pg = {pool_out, dpool, t, weights, wpos, nullptr};
+    return bn_relu_backward_impl(s, nullptr, pg, z, b * t, 1, n, gamma, mean, invstd, scale, shift, relu, 0, dz, dgamma, dbeta, dbias, ws, ws_bytes);
 }
 
 extern "C" int xv_bn_relu_backward_pooled_split(void* stream, const float* pool_out, const float* dpool, const float* weights, int b, int t,
@@ -984,7 +1093,7 @@ extern "C" int xv_bn_relu_backward_pooled_split(void* stream, const float* pool_
                                                 int ldp, size_t plane_stride, uint32_t* dz_amax, float* dgamma, float* dbeta,
                                                 float* dbias, void* ws, size_t ws_bytes) {
     XV_REQUIRE(pool_out && dpool && b > 0 && t > 0, "bn_relu_backward_pooled_split: bad arguments");
-    PoolGrad pg = {pool_out, dpool, t, weights};
+    PoolGrad pg = {pool_out, dpool, t, weights, nullptr, nullptr};
     return bn_relu_backward_split_impl((hipStream_t)stream, nullptr, pg, z, b * t, 1, n, gamma, mean, invstd, scale, shift, zmin, zmax, relu,
                                        0, dz_planes, ldp, plane_stride, dz_amax, dgamma, dbeta, dbias, ws, ws_bytes);
 }
@@ -1154,9 +1263,8 @@ extern "C" int xv_relu_backward(void* stream, const float* da, const float* a, s
 
 // ------------------------------------------------------------------------------------
 // statistics pooling (pooling.py:9-34)
-// wave = 32 channel-quads x 2 frame lanes (lane ^ 32 partner), block = 4 waves = 8 frame lanes.
-// Each lane runs Welford over its frames for 4 channels; lanes are merged with Chan's formula:
-// across the two halves of a wave by __shfl_xor, across waves through LDS.
+// wave = 64 channel-quads of one frame, block = 4 waves = 4 frame lanes.  Each lane runs Welford over its frames for 4 channels (two
+// interleaved chains); chains and waves are merged with Chan's formula (through LDS across waves).
 // ------------------------------------------------------------------------------------
 struct Wf4 { f32x4 mean, m2; float n; };
 __device__ __forceinline__ void wf_merge(f32x4& mean, f32x4& m2, float& n, const f32x4& mean_b, const f32x4& m2_b, float n_b) {
@@ -1170,24 +1278,25 @@ __device__ __forceinline__ void wf_merge(f32x4& mean, f32x4& m2, float& n, const
     n = nn;
 }
 
-// BN: the pooled tensor is relu?(x*scale + shift) evaluated on the fly (x = the pre-BN output of tdnn5), so the
+// BN: the pooled tensor is relu?(x*scale + shift) evaluated on the fly (x = the pre-BN output of the last frame layer), so the
 // activation is never written to memory.
+// A wave reads ONE contiguous KiB per instruction (64 channel quads of one frame), the 4 waves are 4 frame lanes, every lane keeps 8
+// loads in flight and runs TWO Welford chains (alternate frames of its lane), merged at the end.  [measured, S1: 143 MB] 33 us warm
+// (Infinity Cache) / 54 us cold with event overhead - what a plain streaming read of the tensor takes (own amax kernel 32 / 53 us,
+// torch.sum 35 / 60 us); the first form (32 quads x 8 frame lanes, 4 loads, one chain) took 41 / 61 us.
 template <bool BN>
 __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restrict__ x, int T, int C, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu, const float* __restrict__ wts,
-                                                            float* __restrict__ out, const float* __restrict__ slope) {
-    __shared__ f32x4 s_mean[4][32], s_m2[4][32];
+                                                            float* __restrict__ out, const float* __restrict__ slope,
+                                                            float* __restrict__ wpos, float* __restrict__ amax_o) {
+    __shared__ f32x4 s_mean[4][64], s_m2[4][64], s_wp[4][64], s_mx[4][64];
     __shared__ float s_n[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int qx = lane & 31, half = lane >> 5;
-    const int col = (blockIdx.x * 32 + qx) * 4;
+    const int col = (blockIdx.x * 64 + lane) * 4;
     const int b = blockIdx.y;
-    const int fl = wave * 2 + half;          // frame lane 0..7
     const bool cv = col < C;
     const float* xp = x + (long)b * T * C + (cv ? col : 0);
-    f32x4 mean = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
-    f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
-    f32x4 sl = {0, 0, 0, 0};
+    f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0}, sl = {0, 0, 0, 0};
     const bool hs = BN && slope != nullptr;
     if (BN && cv) { sc = *(const f32x4*)(scale + col); sh = *(const f32x4*)(shift + col); if (hs) sl = *(const f32x4*)(slope + col); }
     auto act = [&](f32x4 v) {
@@ -1197,51 +1306,67 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
         }
         return v;
     };
-    float n = 0.f;
-    int t = fl;
-    // frame weights: 1 (statistics pooling; n counts frames) or the attention weights of this chunk (n sums them);
-    // weighted incremental mean / M2 (West), identical to Welford for unit weights
     const float* wp = wts ? wts + (long)b * T : nullptr;
-    // 4 loads in flight per lane
-    for (; t + 24 < T; t += 32) {
-        f32x4 v0 = act(*(const f32x4*)(xp + (long)t * C));
-        f32x4 v1 = act(*(const f32x4*)(xp + (long)(t + 8) * C));
-        f32x4 v2 = act(*(const f32x4*)(xp + (long)(t + 16) * C));
-        f32x4 v3 = act(*(const f32x4*)(xp + (long)(t + 24) * C));
-        const float w0 = wp ? wp[t] : 1.f, w1 = wp ? wp[t + 8] : 1.f, w2 = wp ? wp[t + 16] : 1.f, w3 = wp ? wp[t + 24] : 1.f;
-        f32x4 d;
-        // unit weights (statistics pooling): 1 / n through v_rcp_f32 (1 ulp, exact for n = 1): the IEEE division sequence (div_scale,
-        // rcp, 4 fma, div_fmas, div_fixup) sat on the serial mean -> M2 dependency chain of every frame and made this HBM-bound pass
-        // VALU-latency-bound (38 us for 143 MB).  Attention weights keep the exact quotient: there w / n must be exactly 1 on a
-        // lane's first frame, or a constant chunk no longer has a zero variance (reference test_utils.py / pooling.py:160-162 clamp).
-#define XV_POOL_STEP(v, w) { n += (w); d = (v) - mean; if (n > 0.f) mean += d * (wp ? (w) / n : __builtin_amdgcn_rcpf(n)); m2 += d * ((v) - mean) * (w); }
-        XV_POOL_STEP(v0, w0) XV_POOL_STEP(v1, w1) XV_POOL_STEP(v2, w2) XV_POOL_STEP(v3, w3)
+    f32x4 mean0 = {0, 0, 0, 0}, m20 = {0, 0, 0, 0}, mean1 = {0, 0, 0, 0}, m21 = {0, 0, 0, 0};
+    f32x4 wpp = {0, 0, 0, 0};       // sum of the frame weights where the activation is on (all frames without a ReLU)
+    const bool cnt_all = !(BN && relu);
+    f32x4 amx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    auto on = [&](f32x4 a, float w) {
+        wpp.x += (cnt_all || a.x > 0.f) ? w : 0.f; wpp.y += (cnt_all || a.y > 0.f) ? w : 0.f;
+        wpp.z += (cnt_all || a.z > 0.f) ? w : 0.f; wpp.w += (cnt_all || a.w > 0.f) ? w : 0.f;
+        amx.x = fmaxf(amx.x, a.x); amx.y = fmaxf(amx.y, a.y); amx.z = fmaxf(amx.z, a.z); amx.w = fmaxf(amx.w, a.w);
+    };
+    float n0 = 0.f, n1 = 0.f;
+    // frame weights: 1 (statistics pooling; n counts frames) or the attention weights of this chunk (n sums them); weighted incremental
+    // mean / M2 (West), identical to Welford for unit weights.  Unit weights: 1 / n through v_rcp_f32 (1 ulp, exact for n = 1) - the
+    // IEEE division sequence sat on the serial mean -> M2 chain of every frame and made this pass VALU-latency-bound.  Attention weights
+    // keep the exact quotient: there w / n must be exactly 1 on a lane's first frame, or a constant chunk no longer has a zero variance
+    // (reference test_utils.py / pooling.py:160-162 clamp).
+#define XV_POOL_STEP2(mean, m2, n, v, w) { n += (w); const f32x4 d_ = (v) - mean; if (n > 0.f) mean += d_ * (wp ? (w) / n : __builtin_amdgcn_rcpf(n)); m2 += d_ * ((v) - mean) * (w); }
+    int t = wave;
+    for (; t + 28 < T; t += 32) {
+        f32x4 v[8];
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(xp + (long)(t + 4 * u) * C);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = wp ? wp[t + 4 * u] : 1.f;
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            const f32x4 a0 = act(v[u]), a1 = act(v[u + 1]);
+            XV_POOL_STEP2(mean0, m20, n0, a0, w[u])
+            XV_POOL_STEP2(mean1, m21, n1, a1, w[u + 1])
+            if (wpos) { on(a0, w[u]); on(a1, w[u + 1]); }
+        }
     }
-    for (; t < T; t += 8) {
-        f32x4 v = act(*(const f32x4*)(xp + (long)t * C));
-        const float w = wp ? wp[t] : 1.f;
-        f32x4 d;
-        XV_POOL_STEP(v, w)
+    for (; t < T; t += 4) {
+        const f32x4 a0 = act(*(const f32x4*)(xp + (long)t * C));
+        const float w0 = wp ? wp[t] : 1.f;
+        XV_POOL_STEP2(mean0, m20, n0, a0, w0)
+        if (wpos) on(a0, w0);
     }
-#undef XV_POOL_STEP
-    // merge the two frame lanes of this wave
-    f32x4 mean_b, m2_b;
-    mean_b.x = __shfl_xor(mean.x, 32); mean_b.y = __shfl_xor(mean.y, 32);
-    mean_b.z = __shfl_xor(mean.z, 32); mean_b.w = __shfl_xor(mean.w, 32);
-    m2_b.x = __shfl_xor(m2.x, 32); m2_b.y = __shfl_xor(m2.y, 32);
-    m2_b.z = __shfl_xor(m2.z, 32); m2_b.w = __shfl_xor(m2.w, 32);
-    float n_b = __shfl_xor(n, 32);
-    if (half == 0) {
-        wf_merge(mean, m2, n, mean_b, m2_b, n_b);
-        s_mean[wave][qx] = mean;
-        s_m2[wave][qx] = m2;
-        if (qx == 0) s_n[wave] = n;
-    }
+#undef XV_POOL_STEP2
+    wf_merge(mean0, m20, n0, mean1, m21, n1);
+    s_mean[wave][lane] = mean0;
+    s_m2[wave][lane] = m20;
+    s_wp[wave][lane] = wpp;
+    s_mx[wave][lane] = amx;
+    if (lane == 0) s_n[wave] = n0;
     __syncthreads();
-    if (wave == 0 && half == 0 && cv) {
-        mean = s_mean[0][qx]; m2 = s_m2[0][qx]; n = s_n[0];
-        for (int w = 1; w < 4; ++w) wf_merge(mean, m2, n, s_mean[w][qx], s_m2[w][qx], s_n[w]);
-        f32x4 var = m2 * (1.f / n);      // n == T for unit weights, the sum of the attention weights (1) otherwise
+    if (wave == 0 && cv) {
+        f32x4 mean = s_mean[0][lane], m2 = s_m2[0][lane];
+        float n = s_n[0];
+        for (int w = 1; w < 4; ++w) wf_merge(mean, m2, n, s_mean[w][lane], s_m2[w][lane], s_n[w]);
+        if (wpos) *(f32x4*)(wpos + (long)b * C + col) = ((s_wp[0][lane] + s_wp[1][lane]) + (s_wp[2][lane] + s_wp[3][lane])) * (1.f / n);
+        if (amax_o) {
+            f32x4 mx = s_mx[0][lane];
+            for (int w = 1; w < 4; ++w) {
+                mx.x = fmaxf(mx.x, s_mx[w][lane].x); mx.y = fmaxf(mx.y, s_mx[w][lane].y);
+                mx.z = fmaxf(mx.z, s_mx[w][lane].z); mx.w = fmaxf(mx.w, s_mx[w][lane].w);
+            }
+            *(f32x4*)(amax_o + (long)b * C + col) = mx;
+        }
+        f32x4 var = m2 * (1.f / n);
         const float eps = 1e-12f;
         f32x4 sd;
         sd.x = sqrtf(var.x <= eps ? eps : var.x); sd.y = sqrtf(var.y <= eps ? eps : var.y);
@@ -1253,19 +1378,31 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
 
 extern "C" int xv_stat_pool_forward(void* stream, const float* x, int b, int t, int c, float* out) {
     XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0, "stat_pool_forward: bad shape (c=%d must be a multiple of 4)", c);
-    hipLaunchKernelGGL(stat_pool_fwd_kernel<false>, dim3(xv_cdiv(c / 4, 32), b), dim3(256), 0, (hipStream_t)stream, x, t, c,
-                       (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, out, (const float*)nullptr);
+    hipLaunchKernelGGL(stat_pool_fwd_kernel<false>, dim3(xv_cdiv(c / 4, 64), b), dim3(256), 0, (hipStream_t)stream, x, t, c,
+                       (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, out, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
     XV_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int xv_stat_pool_forward_bn(void* stream, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
-                                       const float* weights, float* out) {
+// wpos, amax (optional, [b][c]): see PoolGrad
+int xv_stat_pool_forward_bn_ex(hipStream_t s, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
+                               const float* weights, float* out, float* wpos, float* amax) {
     XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0 && scale && shift, "stat_pool_forward_bn: bad shape (c=%d must be a multiple of 4)", c);
-    hipLaunchKernelGGL(stat_pool_fwd_kernel<true>, dim3(xv_cdiv(c / 4, 32), b), dim3(256), 0, (hipStream_t)stream, z, t, c, scale, shift,
-                       relu, weights, out, relu ? g_act.slope : nullptr);
+    hipLaunchKernelGGL(stat_pool_fwd_kernel<true>, dim3(xv_cdiv(c / 4, 64), b), dim3(256), 0, s, z, t, c, scale, shift,
+                       relu, weights, out, relu ? g_act.slope : nullptr, wpos, wpos ? amax : nullptr);
     XV_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int xv_stat_pool_forward_bn_aux(void* stream, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
+                                           const float* weights, float* out, float* wpos, float* amax) {
+    XV_REQUIRE(wpos, "stat_pool_forward_bn_aux: wpos is required");
+    return xv_stat_pool_forward_bn_ex((hipStream_t)stream, z, b, t, c, scale, shift, relu, weights, out, wpos, amax);
+}
+
+extern "C" int xv_stat_pool_forward_bn(void* stream, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
+                                       const float* weights, float* out) {
+    return xv_stat_pool_forward_bn_ex((hipStream_t)stream, z, b, t, c, scale, shift, relu, weights, out, nullptr, nullptr);
 }
 
 __global__ void stat_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ out, const float* __restrict__ dout,

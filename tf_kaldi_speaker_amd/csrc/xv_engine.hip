@@ -119,6 +119,8 @@ struct xv_engine {
     uint32_t* sk_tickets = nullptr; // one per 32 output columns + the loss mean's
     size_t sk_ntickets = 0;
     float* xnorm = nullptr;         // [B] ||out[r]||, written with the loss rows
+    float* pool_wpos = nullptr;     // [B][P] share of each chunk's frame weights on ReLU-active frames (pooling forward -> BN backward)
+    float* pool_amax = nullptr;     // [B][P] each chunk's largest pooled activation
     float* lrelu_slope = nullptr;   // network_relu_type lrelu: a constant 0.2 vector as wide as the widest layer
     // split precision state
     bool f16 = false;
@@ -353,6 +355,7 @@ int alloc_buffers(xv_engine* e) {
     want(xv_align(maxc, 4) + 4);      // lrelu_slope
     const size_t ntick = xv_skinny_tickets((int)std::max<size_t>(std::max<size_t>(e->N, 2 * (size_t)e->P), std::max<size_t>(maxc, (size_t)e->Lout))) + 8;
     want(ntick); want(B);             // sk_tickets, xnorm
+    want(B * (size_t)e->P); want(B * (size_t)e->P);           // pool_wpos, pool_amax
     // GEMM split slabs: weight-gradient partials dominate
     size_t ws = 0;
     for (int i = 0; i < e->NL; ++i) {
@@ -455,6 +458,8 @@ int alloc_buffers(xv_engine* e) {
     e->sk_ntickets = ntick;
     e->sk_tickets = (uint32_t*)carve(e, ntick);       // zero (arena memset); every launch leaves them zero
     e->xnorm = carve(e, B);
+    e->pool_wpos = carve(e, B * (size_t)e->P);
+    e->pool_amax = carve(e, B * (size_t)e->P);
     {
         const char* v = getenv("XV_SEGMENT_FUSED");
         e->sk = !(v && v[0] == '0');
@@ -858,7 +863,8 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
     // the last frame layer's BN + ReLU is applied inside the pooling reduction: its [b*t][1500] activation is never written
     {
         ActScope act(e, e->L[F - 1]);
-        rc = xv_stat_pool_forward_bn(s, e->L[F - 1].z, b, cur_t, e->P, e->L[F - 1].scale, e->L[F - 1].shift, 1, frame_w, e->pool);
+        rc = xv_stat_pool_forward_bn_ex(s, e->L[F - 1].z, b, cur_t, e->P, e->L[F - 1].scale, e->L[F - 1].shift, 1, frame_w, e->pool,
+                                        training ? e->pool_wpos : nullptr, e->pool_amax);
     }
     if (rc) return rc;
     // segment-level layers: dense (+ BatchNorm + activation).  With <= XV_SEGMENT_MAX_ROWS chunks the GEMM, its split-K sum and the
@@ -1053,8 +1059,9 @@ int layer_dz(xv_engine* e, hipStream_t s, Affine& a, const float* da, int segs, 
     XV_REQUIRE(Z, "engine_backward: waiting for a dz slot failed");
     if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
         XV_REQUIRE(lidx == e->F - 1 && a.has_bn, "engine_backward: only the last frame layer takes its gradient from the pooling layer");
-        rc = xv_bn_relu_backward_pooled(s, e->pool, e->d_small0, e->att ? e->att_w : nullptr, e->B, e->Tl[e->F], a.z, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale,
-                                        a.shift, 1, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias), e->ws, e->ws_bytes);
+        rc = xv_bn_relu_backward_pooled_ex(s, e->pool, e->d_small0, e->att ? e->att_w : nullptr, e->pool_wpos, e->B, e->Tl[e->F], a.z, a.c_out,
+                                           vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift, 1, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta),
+                                           gptr(e, a.v_bias), e->ws, e->ws_bytes);
     } else if (a.has_bn && pad == 0 && segs * t_out <= XV_BN_SMALL_MAX_ROWS && !is_frame(e, lidx)) {      // segment-level layers: one launch
         rc = xv_bn_small_backward(s, da, a.z, segs * t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift,
                                   a.has_relu ? 1 : 0, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias));
@@ -1162,6 +1169,7 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
         if (!da) {       // tdnn5: the upstream gradient is the (attention-weighted) pooling backward of (pool, d pool)
             XV_REQUIRE(li == e->F - 1, "engine_backward: only the last frame layer takes its gradient from the pooling layer");
             x.pool_out = e->pool; x.dpool = e->d_small0; x.pool_t = e->Tl[e->F]; x.weights = e->att ? e->att_w : nullptr;
+            x.wpos = e->pool_wpos; x.pamax = e->pool_amax;
         } else if (e->bwd_part_layer == li && e->bwd_part_chunks == xv_cdiv(segs * t_out, XV_TILE_M)) {
             // the GEMM that produced `da` already reduced it against this layer's z (xv_affine_dgrad_bnstats_f16x3)
             x.ext_part = e->bwd_part; x.ext_chunks = e->bwd_part_chunks;

@@ -561,6 +561,7 @@ int xv_tn_splits(int M, int N, int R) {
     // 2 workgroups are resident per CU (LDS 64 KB each): keep tiles*splits <= 512 so the whole
     // grid is ONE co-resident round.  (560 workgroups = 512 + a 48-workgroup second round cost
     // 2x on the first build: 61 TF on tdnn2/3, 24 TF on tdnn5.)
+    // [measured, round 2] fewer co-resident workgroups (smaller slabs, cheaper slab sum) lose: 768 -> +0.06 ms/step, 512 -> +0.19 ms
     int splits = XV_RESIDENT_WGS / tiles;
     if (splits > ksteps / 2) splits = ksteps / 2;
     if (splits < 1) splits = 1;

@@ -174,6 +174,14 @@ def stat_pool_forward_bn(z, b, t, scale, shift, relu=True, weights=None):
     return out
 
 
+def stat_pool_forward_bn_aux(z, b, t, scale, shift, relu=True, weights=None):
+    """stat_pool_forward_bn that also returns wpos, amax [b, c] (see xv_stat_pool_forward_bn_aux)."""
+    c = z.shape[1]
+    out, wpos, amax = _f32((b, 2 * c), z), _f32((b, c), z), _f32((b, c), z)
+    _lib.call("xv_stat_pool_forward_bn_aux", _s(), _p(z), b, t, c, _p(scale), _p(shift), int(relu), _p(weights), _p(out), _p(wpos), _p(amax))
+    return out, wpos, amax
+
+
 def att_score(zk, act, query, scale):
     rows, n = zk.shape
     score = _f32((rows,), zk)
@@ -224,6 +232,17 @@ def bn_relu_backward_pooled(pool_out, dpool, b, t, z, gamma, mean, invstd, scale
     wp, wb = _ws(z)
     _lib.call("xv_bn_relu_backward_pooled", _s(), _p(pool_out), _p(dpool), _p(weights), b, t, _p(z), n, _p(gamma), _p(mean), _p(invstd), _p(scale),
               _p(shift), int(relu), _p(dz), _p(dgamma), _p(dbeta), _p(dbias), wp, wb)
+    return dz, dgamma, dbeta, dbias
+
+
+def bn_relu_backward_pooled_aux(pool_out, dpool, wpos, b, t, z, gamma, mean, invstd, scale, shift, relu=True, weights=None):
+    """bn_relu_backward_pooled with the reductions in closed form from (pool_out, dpool, wpos): no reduction pass over z."""
+    n = z.shape[1]
+    dz = _f32((b * t, n), z)
+    dgamma, dbeta, dbias = _f32((n,), z), _f32((n,), z), _f32((n,), z)
+    wp, wb = _ws(z)
+    _lib.call("xv_bn_relu_backward_pooled_aux", _s(), _p(pool_out), _p(dpool), _p(weights), _p(wpos), b, t, _p(z), n, _p(gamma), _p(mean),
+              _p(invstd), _p(scale), _p(shift), int(relu), _p(dz), _p(dgamma), _p(dbeta), _p(dbias), wp, wb)
     return dz, dgamma, dbeta, dbias
 
 
