@@ -866,8 +866,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split_kernel(const float* __
 // there; off frames contribute nothing.  Summed over the frames of the chunk, with W+ = the weight on active frames (pooling forward):
 //   sum dd        = dm*W+ + q*mu*(1 - W+)
 //   sum dd*xhat   = (dm*(mu - beta*W+) + q*(var - beta*mu*(1 - W+))) / gamma
-// (sum_on omega*a = mu and sum_on omega*a^2 = var + mu^2 because a = 0 off).  One workgroup = 16 channel quads x 16 chunk lanes, chunks
-// summed in a fixed order; also does bn_bwd_finalize_kernel's job.  gamma == 0 (xhat not recoverable from a) yields inf / nan - loudly.
+// (sum_on omega*a = mu and sum_on omega*a^2 = var + mu^2 because a = 0 off).  One workgroup = 4 channel quads x 64 chunk lanes (the
+// kernel is a handful of dependent memory round trips: 16 quads x 16 lanes, 8 chunks per lane, took 20 us), chunks summed in a fixed
+// order; also does bn_bwd_finalize_kernel's job.  gamma == 0 (xhat not recoverable from a) yields inf / nan - loudly.
+#define PS_QUADS 4
+#define PS_LANES 64
 __global__ __launch_bounds__(256) void bn_bwd_pooled_stats_kernel(PoolGrad pg, int segs, int n, int rows, const float* __restrict__ gamma,
                                                                   const float* __restrict__ shift, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, const float* __restrict__ scale,
@@ -875,16 +878,16 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_stats_kernel(PoolGrad pg, i
                                                                   float* __restrict__ coef, float* __restrict__ dbias,
                                                                   const float* __restrict__ zmin, const float* __restrict__ zmax,
                                                                   unsigned* __restrict__ dz_amax) {
-    __shared__ f32x4 r1[16][16], r2[16][16], r3[16][16];
-    const int cq = threadIdx.x & 15, bl = threadIdx.x >> 4;
-    const int col = (blockIdx.x * 16 + cq) * 4;
+    __shared__ f32x4 r1[PS_LANES][PS_QUADS], r2[PS_LANES][PS_QUADS], r3[PS_LANES][PS_QUADS];
+    const int cq = threadIdx.x & (PS_QUADS - 1), bl = threadIdx.x / PS_QUADS;
+    const int col = (blockIdx.x * PS_QUADS + cq) * 4;
     const bool cv = col < n;
     f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0};
     const float invT = 1.f / (float)pg.t;
     if (cv) {
         // beta = shift + mean*scale (shift = beta - mean*scale, bn_finalize)
         const f32x4 bt = *(const f32x4*)(shift + col) + *(const f32x4*)(mean + col) * *(const f32x4*)(scale + col);
-        for (int b = bl; b < segs; b += 16) {
+        for (int b = bl; b < segs; b += PS_LANES) {
             const PoolCoef pc = pool_coef(pg, b, n, col);
             const f32x4 sd = *(const f32x4*)(pg.out + (long)b * 2 * n + n + col);
             const f32x4 wp = *(const f32x4*)(pg.wpos + (long)b * n + col);
@@ -904,8 +907,7 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_stats_kernel(PoolGrad pg, i
     __syncthreads();
     if (bl != 0 || !cv) return;
     s1 = r1[0][cq]; s2 = r2[0][cq];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) {
+    for (int k = 1; k < PS_LANES; ++k) {
         s1 += r1[k][cq]; s2 += r2[k][cq];
         s3.x = fmaxf(s3.x, r3[k][cq].x); s3.y = fmaxf(s3.y, r3[k][cq].y); s3.z = fmaxf(s3.z, r3[k][cq].z); s3.w = fmaxf(s3.w, r3[k][cq].w);
     }
@@ -950,7 +952,7 @@ static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, co
     const bool pooled = pg.out != nullptr;
     if (pooled && pg.wpos && !(relu && act.slope)) {
         // closed form from the pooled statistics: no pass over z, no finalize launch
-        hipLaunchKernelGGL(bn_bwd_pooled_stats_kernel, dim3(xv_cdiv(n / 4, 16)), dim3(256), 0, s, pg, rows / pg.t, n, rows, gamma, shift, mean,
+        hipLaunchKernelGGL(bn_bwd_pooled_stats_kernel, dim3(xv_cdiv(n / 4, PS_QUADS)), dim3(256), 0, s, pg, rows / pg.t, n, rows, gamma, shift, mean,
                            invstd, scale, dgamma, dbeta, coef, dbias, (const float*)nullptr, (const float*)nullptr, (unsigned*)nullptr);
         XV_LAUNCH_CHECK();
     } else {
@@ -992,7 +994,7 @@ static int bn_relu_backward_split_impl(hipStream_t s, const float* da, PoolGrad 
     if (zero_amax) XV_CHECK_HIP(hipMemsetAsync(dz_amax, 0, sizeof(uint32_t), s));
     if (pooled && pg.wpos && pg.amax && !pg.w && !ext_part && !(relu && act.slope)) {
         // statistics pooling, plain ReLU: reductions, finalize and the |dz| bound in closed form from the pooled statistics (no pass over z)
-        hipLaunchKernelGGL(bn_bwd_pooled_stats_kernel, dim3(xv_cdiv(n / 4, 16)), dim3(256), 0, s, pg, rows / pg.t, n, rows, gamma, shift, mean,
+        hipLaunchKernelGGL(bn_bwd_pooled_stats_kernel, dim3(xv_cdiv(n / 4, PS_QUADS)), dim3(256), 0, s, pg, rows / pg.t, n, rows, gamma, shift, mean,
                            invstd, scale, dgamma, dbeta, coef, dbias, zmin, zmax, (unsigned*)dz_amax);
         XV_LAUNCH_CHECK();
     } else {
