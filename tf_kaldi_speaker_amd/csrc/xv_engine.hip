@@ -121,6 +121,7 @@ struct xv_engine {
     float* xnorm = nullptr;         // [B] ||out[r]||, written with the loss rows
     float* pool_wpos = nullptr;     // [B][P] share of each chunk's frame weights on ReLU-active frames (pooling forward -> BN backward)
     float* pool_amax = nullptr;     // [B][P] each chunk's largest pooled activation
+    bool pool_closed_form = true;   // XV_POOLED_CLOSED_FORM=0: the last frame layer's BN backward reduces over z directly (A/B)
     float* lrelu_slope = nullptr;   // network_relu_type lrelu: a constant 0.2 vector as wide as the widest layer
     // split precision state
     bool f16 = false;
@@ -128,6 +129,7 @@ struct xv_engine {
     unsigned short* dzh[2] = {nullptr, nullptr};
     size_t dzh_halfs = 0;                     // halfs per plane of a dz buffer
     uint32_t* amax = nullptr;                 // [AMAX_SLOTS] float bits, see amax_slot()
+    bool amax_wt_clean = false, amax_dz_clean = false;   // zeroed by the forward pass's one memset over the whole table
     void* ws = nullptr;
     size_t ws_bytes = 0;
     int32_t* labels_dev = nullptr;   // caller's pointer of the current step
@@ -463,6 +465,8 @@ int alloc_buffers(xv_engine* e) {
     {
         const char* v = getenv("XV_SEGMENT_FUSED");
         e->sk = !(v && v[0] == '0');
+        v = getenv("XV_POOLED_CLOSED_FORM");
+        e->pool_closed_form = !(v && v[0] == '0');
     }
     e->ws = carve(e, ws / sizeof(float));
     e->ws_side = carve(e, ws / sizeof(float));
@@ -533,7 +537,9 @@ int prep_layers(xv_engine* e, hipStream_t s, int first, int last) {
         // one memset over the slot range of these layers (tdnn first..F-1 -> slots first..F-1, key layers -> F, F+1: contiguous)
         unsigned *lo = A.out[0], *hi = A.out[0];
         for (int j = 1; j < A.n; ++j) { lo = std::min(lo, A.out[j]); hi = std::max(hi, A.out[j]); }
-        if (first == 0 && last == 1) {
+        if (e->amax_wt_clean) {
+            // the forward pass zeroed the whole table in one memset (ahead of this point on `s`, and of the event the side stream waits for)
+        } else if (first == 0 && last == 1) {
             XV_CHECK_HIP(hipMemsetAsync(lo, 0, sizeof(uint32_t), s));                    // layer 0 alone (its neighbours belong to the side-stream half)
         } else {
             XV_CHECK_HIP(hipMemsetAsync(lo, 0, (size_t)(hi - lo + 1) * sizeof(uint32_t), s));
@@ -721,14 +727,22 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
     e->last_stream = s;
     e->B = b; e->T = t; e->training = training;
     // training steps only: there xv_engine_loss_forward always follows and picks up the loss head's event
+    // split precision: one memset for every max-|x| slot of the step (input, activations, and - when the weight copies are rebuilt, i.e.
+    // on every training step - weights and dz) instead of four ~5 us fill launches along the step
+    const bool zero_all = e->f16 && e->weights_dirty;
+    if (zero_all) {
+        XV_CHECK_HIP(hipMemsetAsync(e->amax, 0, AMAX_SLOTS * sizeof(uint32_t), s));
+        e->amax_wt_clean = e->amax_dz_clean = true;
+    }
     int rc = ensure_weights(e, s, training != 0 && e->N > 0);
+    e->amax_wt_clean = false;
     if (rc) return rc;
     int cur_t = t;
     e->Tl[0] = t;
     const int F = e->F;
     if (e->f16) {
         // split precision: every frame-level operand travels as two fp16 planes + a device-side max |x|
-        XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_X, 0, (4 + xv_align(F, 4)) * sizeof(uint32_t), s));      // x and every BN+ReLU output slot
+        if (!zero_all) XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_X, 0, (4 + xv_align(F, 4)) * sizeof(uint32_t), s));      // x and every BN+ReLU output slot
         rc = xv_amax(s, features, (size_t)b * t * e->cfg.feat_dim, e->amax + AMAX_X);
         if (rc) return rc;
         rc = xv_split_planes(s, features, b * t, e->cfg.feat_dim, e->cfg.feat_dim, e->xh, e->c_pad0, (size_t)b * t * e->c_pad0,
@@ -1059,7 +1073,7 @@ int layer_dz(xv_engine* e, hipStream_t s, Affine& a, const float* da, int segs, 
     XV_REQUIRE(Z, "engine_backward: waiting for a dz slot failed");
     if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
         XV_REQUIRE(lidx == e->F - 1 && a.has_bn, "engine_backward: only the last frame layer takes its gradient from the pooling layer");
-        rc = xv_bn_relu_backward_pooled_ex(s, e->pool, e->d_small0, e->att ? e->att_w : nullptr, e->pool_wpos, e->B, e->Tl[e->F], a.z, a.c_out,
+        rc = xv_bn_relu_backward_pooled_ex(s, e->pool, e->d_small0, e->att ? e->att_w : nullptr, e->pool_closed_form ? e->pool_wpos : nullptr, e->B, e->Tl[e->F], a.z, a.c_out,
                                            vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift, 1, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta),
                                            gptr(e, a.v_bias), e->ws, e->ws_bytes);
     } else if (a.has_bn && pad == 0 && segs * t_out <= XV_BN_SMALL_MAX_ROWS && !is_frame(e, lidx)) {      // segment-level layers: one launch
@@ -1169,7 +1183,7 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
         if (!da) {       // tdnn5: the upstream gradient is the (attention-weighted) pooling backward of (pool, d pool)
             XV_REQUIRE(li == e->F - 1, "engine_backward: only the last frame layer takes its gradient from the pooling layer");
             x.pool_out = e->pool; x.dpool = e->d_small0; x.pool_t = e->Tl[e->F]; x.weights = e->att ? e->att_w : nullptr;
-            x.wpos = e->pool_wpos; x.pamax = e->pool_amax;
+            if (e->pool_closed_form) { x.wpos = e->pool_wpos; x.pamax = e->pool_amax; }
         } else if (e->bwd_part_layer == li && e->bwd_part_chunks == xv_cdiv(segs * t_out, XV_TILE_M)) {
             // the GEMM that produced `da` already reduced it against this layer's z (xv_affine_dgrad_bnstats_f16x3)
             x.ext_part = e->bwd_part; x.ext_chunks = e->bwd_part_chunks;
@@ -1273,7 +1287,8 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
     const int b = e->B;
     int rc;
     if (stage == -1 || stage == 0) {
-        if (e->f16) XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_DZ, 0, xv_align(e->F + 2, 4) * sizeof(uint32_t), s));   // every layer's dz scale slot
+        if (e->f16 && !e->amax_dz_clean) XV_CHECK_HIP(hipMemsetAsync(e->amax + AMAX_DZ, 0, xv_align(e->F + 2, 4) * sizeof(uint32_t), s));   // every layer's dz scale slot
+        e->amax_dz_clean = false;
         // d wn = out^T . dlogits and the gradient through l2_normalize: on a stream of its own (it only reads dlogits / out / wn, which
         // the main chain never rewrites during backward), started before anything else of the backward pass.  [measured, same box]
         // on the weight-gradient stream, BEHIND the segment layers' weight gradients, it cost fp32 mode 0.2 ms/step (it then ran beside

@@ -16,7 +16,7 @@ gamma, beta = rnd(n).abs() + 0.5, rnd(n)
 mm, mv = torch.zeros(n).cuda(), torch.ones(n).cuda()
 part = ops.col_stats(z)
 mean, invstd, scale, shift, zmin, zmax, amax = ops.bn_finalize(part, B * T, gamma, beta, 1e-3, 0.99, 0, mm, mv, with_range=True)
-pool = ops.stat_pool_forward_bn(z, B, T, scale, shift, True)
+pool, wpos, _ = ops.stat_pool_forward_bn_aux(z, B, T, scale, shift, True)
 dpool = rnd(B, 2 * n)
 flush = torch.empty(300 << 18, dtype=torch.float32, device="cuda")      # 300 MB: evicts the Infinity Cache
 
@@ -39,7 +39,8 @@ for name, fn, bytes_mb in (("amax (plain streaming read, for reference)", lambda
                            ("torch.sum (vendor streaming read)", lambda: torch.sum(z), mb),
                            ("stat_pool_forward_bn", lambda: ops.stat_pool_forward_bn(z, B, T, scale, shift, True), mb),
                            ("bn_relu_backward_pooled (reduce+finalize+apply)", lambda: ops.bn_relu_backward_pooled(pool, dpool, B, T, z, gamma, mean, invstd, scale, shift, True), 3 * mb),
+                           ("bn_relu_backward_pooled_aux (closed-form statistics + apply)", lambda: ops.bn_relu_backward_pooled_aux(pool, dpool, wpos, B, T, z, gamma, mean, invstd, scale, shift, True), 2 * mb),
                            ("bn_relu_backward_pooled_split", lambda: ops.bn_relu_backward_pooled_split(pool, dpool, B, T, z, gamma, mean, invstd, scale, shift, zmin, zmax, True), 3 * mb)):
     for cold in (False, True):
         us = timed(fn, cold)
-        print("%-50s %s  %7.1f us  %6.1f MB  %.2f TB/s" % (name, "cold" if cold else "warm", us, bytes_mb, bytes_mb / us))
+        print("%-62s %s  %7.1f us  %6.1f MB  %.2f TB/s" % (name, "cold" if cold else "warm", us, bytes_mb, bytes_mb / us))
