@@ -289,6 +289,42 @@ def test_train_driver_with_two_ranks_sharing_the_gpu(tmp_path, xv_precision):
     assert float(np.abs(ck["tdnn/tdnn1_bn/moving_mean"]).max()) > 0
 
 
+def test_finetune_driver_with_two_ranks_sharing_the_gpu(tmp_path, xv_precision):
+    """nnet/lib/finetune.py under torch.distributed.run with WORLD_SIZE=2 (the step-0 checkpoint of the pre-trained model is
+    written by rank 0 alone while the other rank waits in a barrier, so that save must not issue a collective): the run finishes, the
+    frozen layers stay bit-identical to the pre-trained model and the new loss layer is trained."""
+    if xv_precision == "f32":
+        pytest.skip("one precision is enough for the process wiring")
+    data, spklist, _ = make_data_dir(str(tmp_path / "train"), num_spk=6, utts_per_spk=3, min_frames=60, max_frames=110)
+    vdata, vspk, _ = make_data_dir(str(tmp_path / "valid"), num_spk=6, utts_per_spk=2, min_frames=60, max_frames=110, seed=5)
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps(dict(CONFIG, num_epochs=1)))
+    model = str(tmp_path / "exp")
+    os.makedirs(model)
+    env = dict(os.environ, TF_KALDI_ROOT=PKG, PYTHONPATH=PKG, XV_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    lib = os.path.join(PKG, "nnet", "lib")
+    r = subprocess.run([sys.executable, os.path.join(lib, "train.py"), "--config", str(cfg_path), data, spklist, vdata, vspk, model],
+                       env=env, cwd=PKG, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ck = np.load(os.path.join(model, "nnet", "model-6.npz"))
+    ft_path = tmp_path / "finetune.json"
+    ft_path.write_text(json.dumps(dict(CONFIG, num_epochs=1, noupdate_var_list=["tdnn1", "tdnn2", "tdnn3"], noload_var_list=["softmax"])))
+    ft_model = str(tmp_path / "exp_ft")
+    os.makedirs(ft_model)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + os.getpid() % 150), os.path.join(lib, "finetune.py"), "--checkpoint", "last", "--config", str(ft_path),
+           data, spklist, vdata, vspk, model, ft_model]
+    r = subprocess.run(cmd, env=env, cwd=lib, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    nnet = os.path.join(ft_model, "nnet")
+    assert os.path.isfile(os.path.join(nnet, "model-0.npz"))                                           # the pre-trained model as step 0
+    ft = np.load(os.path.join(nnet, "model-6.npz"))
+    assert all(np.isfinite(ft[k]).all() for k in ft.files)
+    assert np.array_equal(ft["tdnn/tdnn2_conv/kernel"], ck["tdnn/tdnn2_conv/kernel"])                   # frozen on both ranks
+    assert not np.array_equal(ft["tdnn/tdnn5_dense/kernel"], ck["tdnn/tdnn5_dense/kernel"])
+    assert not np.array_equal(ft["softmax/output/kernel"], ck["softmax/output/kernel"])
+
+
 @pytest.mark.parametrize("optimizer", ["momentum", "adam"])
 def test_resume_from_checkpoint_is_bit_identical(tmp_path, optimizer):
     """Four optimiser steps in one go == two steps, save, a fresh Trainer that loads the checkpoint, two more steps: variables,
