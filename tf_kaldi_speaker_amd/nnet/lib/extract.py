@@ -8,32 +8,20 @@ Reads an ark / input pipe of feature matrices, writes a Kaldi float-vector ark o
 half-overlapping chunks whose embeddings are length-weighted averaged (reference extract.py:65-94).
 -g selects the HIP device (the reference's CPU mode `-g -1` maps to device 0: there is no CPU path).
 """
-import argparse
-import logging
 import os
 import sys
 
 import numpy as np
 
+import _cli
 from model.trainer import Trainer
 from misc.utils import Params, split_into_chunks, average_chunk_embeddings
 from dataset.kaldi_io import open_or_fd, read_mat_ark, write_vec_flt
 
-parser = argparse.ArgumentParser()
-parser.add_argument("-g", "--gpu", type=int, default=-1, help="The GPU id (-1: device 0).")
-parser.add_argument("-m", "--min-chunk-size", type=int, default=25, help="Segments shorter than this are skipped.")
-parser.add_argument("-s", "--chunk-size", type=int, default=10000, help="Longer segments are split and averaged.")
-parser.add_argument("-n", "--normalize", action="store_true", help="Normalize the embedding before averaging and output.")
-parser.add_argument("--node", type=str, default="", help="The node to output the embeddings.")
-parser.add_argument("model_dir", type=str, help="The model directory.")
-parser.add_argument("rspecifier", type=str, help="Kaldi feature rspecifier (or ark file).")
-parser.add_argument("wspecifier", type=str, help="Kaldi output wspecifier (or ark file).")
-
 
 def main():
-    logging.basicConfig(level=logging.INFO, format="%(levelname)s:%(name)s:%(message)s")
-    log = logging.getLogger("tf_kaldi_speaker_amd")
-    args = parser.parse_args()
+    log = _cli.logger()
+    args = _cli.parser_for("gpu", "min_chunk_size", "chunk_size", "normalize", "node", "model_dir", "rspecifier", "wspecifier").parse_args()
     # -g is an enable flag in the reference ("an arbitrary number except -1"; run_extract_embeddings.sh passes the JOB
     # number with --gpuid), device choice being left to CUDA_VISIBLE_DEVICES.  Here: among the devices HIP_VISIBLE_DEVICES
     # leaves visible, job N takes device N modulo their count, so `nj` parallel jobs spread over the GPUs of the node and

@@ -8,31 +8,17 @@ learning_rate,valid_loss} behave as the reference's (train.py:26-143; the bookke
 misc.utils.EpochLedger); the graph runs on the MI355X engine.  Under torch.distributed.run (WORLD_SIZE > 1) every rank trains on
 its own batches and gradients are all-reduced over RCCL; rank 0 owns the model directory.
 """
-import argparse
-import logging
 import os
-import random
 import sys
 
-import numpy as np
-
+import _cli
 from misc.utils import save_codes_and_config, compute_cos_pairwise_eer, Params, EpochLedger, checkpoint_step
 from model.trainer import Trainer
 from dataset.data_loader import KaldiDataRandomQueue
-from dataset.kaldi_io import FeatureReader
-
-parser = argparse.ArgumentParser()
-parser.add_argument("-c", "--cont", action="store_true", help="Continue training from an existing model.")
-parser.add_argument("--config", type=str, help="The configuration file.")
-parser.add_argument("train_dir", type=str, help="The data directory of the training set.")
-parser.add_argument("train_spklist", type=str, help="The spklist file maps the TRAINING speakers to the indices.")
-parser.add_argument("valid_dir", type=str, help="The data directory of the validation set.")
-parser.add_argument("valid_spklist", type=str, help="The spklist maps the VALID speakers to the indices.")
-parser.add_argument("model", type=str, help="The output model directory.")
 
 
 def main():
-    run(parser.parse_args())
+    run(_cli.parser_for("cont", "config", "train_dir", "train_spklist", "valid_dir", "valid_spklist", "model").parse_args())
 
 
 class _Ranks(object):
@@ -78,8 +64,7 @@ def run(args, finetune=False):
     params.noupdate_var_list frozen, params.noload_var_list re-initialised, one evaluation before the first epoch).
     args.model is the (fine-tuned) model directory.  Rank 0 owns the directory, evaluates and decides; its decision is
     shared, every rank trains."""
-    logging.basicConfig(level=logging.INFO, format="%(levelname)s:%(name)s:%(message)s")
-    log = logging.getLogger("tf_kaldi_speaker_amd")
+    log = _cli.logger()
     ranks = _Ranks()
     if ranks.first:
         params = save_codes_and_config(args.cont, args.model, args.config)
@@ -87,8 +72,7 @@ def run(args, finetune=False):
     if not ranks.first:
         params = Params(os.path.join(args.model, "nnet/config.json"))
     model_dir = os.path.join(args.model, "nnet")
-    random.seed(params.seed + ranks.rank)
-    np.random.seed(params.seed + ranks.rank)
+    _cli.seed_from(params, offset=ranks.rank)      # every rank draws its own batches
 
     first_epoch = 0
     if args.cont:
@@ -103,7 +87,7 @@ def run(args, finetune=False):
         ranks.barrier()
 
     ledger = EpochLedger(model_dir, params, first_epoch, default_early_stop=5 if finetune else 10)      # finetune.py:117 / train.py:101
-    dim = FeatureReader(args.train_dir).get_dim()
+    dim = _cli.feature_dim(args.train_dir)
     if ranks.first:
         ledger.write_feature_dim(dim)
     num_total_train_speakers = KaldiDataRandomQueue(args.train_dir, args.train_spklist).num_total_speakers

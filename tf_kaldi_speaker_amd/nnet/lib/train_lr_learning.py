@@ -6,52 +6,40 @@ range test of Trainer.train_tune_lr; writes <model>/nnet/learning_rate_tuning ("
     python nnet/lib/train_lr_learning.py [--tune_period N] [--checkpoint C] --config CFG train_dir train_spklist valid_dir \
         valid_spklist pretrain_model finetune_model          (seven positionals: the fine-tuning form)
 """
-import argparse
-import logging
 import os
-import random
 import sys
 
-import numpy as np
-
+import _cli
 from misc.utils import save_codes_and_config, get_pretrain_model
 from model.trainer import Trainer
 from dataset.data_loader import KaldiDataRandomQueue
-from dataset.kaldi_io import FeatureReader
 
-parser = argparse.ArgumentParser()
-parser.add_argument("--tune_period", type=int, default=100, help="How many steps per learning rate.")
-parser.add_argument("--checkpoint", type=str, default="-1", help="The checkpoint in the pre-trained model (fine-tuning form).")
-parser.add_argument("--config", type=str, help="The configuration file.")
-parser.add_argument("train_dir", type=str, help="The data directory of the training set.")
-parser.add_argument("train_spklist", type=str, help="The spklist file maps the TRAINING speakers to the indices.")
-parser.add_argument("valid_dir", type=str, help="The data directory of the validation set.")
-parser.add_argument("valid_spklist", type=str, help="The spklist maps the VALID speakers to the indices.")
-parser.add_argument("model", type=str, nargs="+", help="model   |   pretrain_model finetune_model")
 
-if __name__ == "__main__":
-    logging.basicConfig(level=logging.INFO, format="%(levelname)s:%(name)s:%(message)s")
-    log = logging.getLogger("tf_kaldi_speaker_amd")
-    args = parser.parse_args()
+def main():
+    log = _cli.logger()
+    args = _cli.parser_for("tune_period", "checkpoint", "config", "train_dir", "train_spklist", "valid_dir", "valid_spklist", "models").parse_args()
     if len(args.model) not in (1, 2):
         sys.exit("expected `model` or `pretrain_model finetune_model`")
-    model = args.model[-1]
+    finetune, model = len(args.model) == 2, args.model[-1]
     params = save_codes_and_config(False, model, args.config)
-    model_dir = os.path.join(model, "nnet")
-    if len(args.model) == 2:
-        get_pretrain_model(os.path.join(args.model[0], "nnet"), model_dir, args.checkpoint)
-    random.seed(params.seed)
-    np.random.seed(params.seed)
-    dim = FeatureReader(args.train_dir).get_dim()
-    with open(os.path.join(model_dir, "feature_dim"), "w") as f:
+    nnet = os.path.join(model, "nnet")
+    if finetune:
+        get_pretrain_model(os.path.join(args.model[0], "nnet"), nnet, args.checkpoint)
+    _cli.seed_from(params)
+    dim = _cli.feature_dim(args.train_dir)
+    with open(os.path.join(nnet, "feature_dim"), "w") as f:
         f.write("%d\n" % dim)
-    num_total_train_speakers = KaldiDataRandomQueue(args.train_dir, args.train_spklist).num_total_speakers
-    log.info("There are %d speakers in the training set and the dim is %d" % (num_total_train_speakers, dim))
+    speakers = KaldiDataRandomQueue(args.train_dir, args.train_spklist).num_total_speakers
+    log.info("There are %d speakers in the training set and the dim is %d" % (speakers, dim))
     trainer = Trainer(params, model)
-    trainer.build("train", dim=dim, loss_type=params.loss_func, num_speakers=num_total_train_speakers)
-    trainer.build("valid", dim=dim, loss_type=params.loss_func, num_speakers=num_total_train_speakers)
-    if len(args.model) == 2:
+    for mode in ("train", "valid"):
+        trainer.build(mode, dim=dim, loss_type=params.loss_func, num_speakers=speakers)
+    if finetune:
         trainer.get_finetune_model(params.noload_var_list)
     trainer.train_tune_lr(args.train_dir, args.train_spklist, args.tune_period)
     trainer.close()
     log.info("Finish tuning.")
+
+
+if __name__ == "__main__":
+    main()
