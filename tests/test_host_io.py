@@ -255,6 +255,23 @@ def test_chunk_split_and_weighted_average():
     e = np.array([[1.0, 0.0], [0.0, 2.0]], np.float32)
     assert np.allclose(U.average_chunk_embeddings(e, [10000, 5000], False), [2 / 3, 2 / 3])
     assert np.allclose(U.average_chunk_embeddings(e, [10000, 5000], True), [2 / 3, 1 / 3])
+    # the per-utterance driver of extract.py: one piece up to chunk_size, else full-length chunks as one batch + the shorter tail
+    calls = []
+
+    def predict(x):       # "embedding" = (first frame's first value, number of frames); batch in -> batch out
+        x = np.asarray(x)
+        calls.append(x.shape)
+        return np.array([x[0, 0], x.shape[0]], np.float32) if x.ndim == 2 else np.stack([[c[0, 0], c.shape[0]] for c in x]).astype(np.float32)
+
+    feat = np.arange(130, dtype=np.float32)[:, None] * np.ones((1, 3), np.float32)
+    emb, pieces = U.utterance_embedding(predict, feat[:60], 60, False)
+    assert pieces == 1 and calls == [(60, 3)] and np.allclose(emb, [0, 60])
+    del calls[:]
+    emb, pieces = U.utterance_embedding(predict, feat, 60, False)        # chunks (0,60) (30,60) (60,60) (90,40)
+    assert pieces == 4 and calls == [(3, 60, 3), (40, 3)]
+    assert np.allclose(emb, [(0 * 60 + 30 * 60 + 60 * 60 + 90 * 40) / 220.0, (3 * 60 * 60 + 40 * 40) / 220.0])
+    emb, _ = U.utterance_embedding(predict, feat, 60, True)
+    assert abs(np.linalg.norm(emb) - 1.0) < 1e-6
 
 
 def test_cos_pairwise_eer():

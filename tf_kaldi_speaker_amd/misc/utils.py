@@ -375,3 +375,20 @@ def average_chunk_embeddings(embeddings, lengths, normalize):
     if normalize:
         embeddings = embeddings / np.sqrt(np.sum(np.square(embeddings), axis=1, keepdims=True))
     return np.sum(embeddings * lengths, axis=0) / np.sum(lengths)
+
+
+def utterance_embedding(predict, feature, chunk_size, normalize):
+    """One embedding per utterance the way extract.py:65-94 produces it: utterances of at most chunk_size frames in one piece, longer
+    ones as the length-weighted mean over half-overlapping chunks (the full-length chunks go through `predict` as one batch, the
+    shorter last one on its own); optionally L2-normalised per chunk and at the end.  Returns (embedding, number of chunks)."""
+    chunks = split_into_chunks(feature.shape[0], chunk_size)
+    if len(chunks) == 1:
+        embedding = predict(feature)
+    else:
+        body = predict(np.array([feature[s:s + n] for s, n in chunks[:-1]], dtype=np.float32))
+        s, n = chunks[-1]
+        tail = predict(feature[s:s + n])
+        embedding = average_chunk_embeddings(np.concatenate([body, tail[None]], axis=0), [n for _, n in chunks], normalize)
+    if normalize:
+        embedding = embedding / np.sqrt(np.sum(np.square(embedding)))
+    return np.asarray(embedding, np.float32), len(chunks)

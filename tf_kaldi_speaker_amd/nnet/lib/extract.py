@@ -11,11 +11,9 @@ half-overlapping chunks whose embeddings are length-weighted averaged (reference
 import os
 import sys
 
-import numpy as np
-
 import _cli
 from model.trainer import Trainer
-from misc.utils import Params, split_into_chunks, average_chunk_embeddings
+from misc.utils import Params, utterance_embedding
 from dataset.kaldi_io import open_or_fd, read_mat_ark, write_vec_flt
 
 
@@ -44,25 +42,14 @@ def main():
     if "." in args.rspecifier and args.rspecifier.rsplit(".", 1)[1] == "scp":
         sys.exit("The rspecifier must be ark or input pipe")
     fp_out = open_or_fd(args.wspecifier, "wb")
-    for index, (key, feature) in enumerate(read_mat_ark(args.rspecifier)):
-        if feature.shape[0] < args.min_chunk_size:
-            log.info("[INFO] Key %s length too short, %d < %d, skip." % (key, feature.shape[0], args.min_chunk_size))
+    for key, feature in read_mat_ark(args.rspecifier):
+        frames = feature.shape[0]
+        if frames < args.min_chunk_size:
+            log.info("[INFO] Key %s length too short, %d < %d, skip." % (key, frames, args.min_chunk_size))
             continue
-        if feature.shape[0] > args.chunk_size:
-            chunks = split_into_chunks(feature.shape[0], args.chunk_size)
-            log.info("[INFO] Key %s length %d > %d, split to %d segments." % (key, feature.shape[0], args.chunk_size, len(chunks)))
-            full = np.array([feature[s:s + n] for s, n in chunks[:-1]], dtype=np.float32)
-            embeddings = trainer.predict(full)
-            s, n = chunks[-1]
-            last = trainer.predict(feature[s:s + n])
-            embeddings = np.concatenate([embeddings, np.expand_dims(last, axis=0)], axis=0)
-            embedding = average_chunk_embeddings(embeddings, [n for _, n in chunks], args.normalize)
-        else:
-            log.info("[INFO] Key %s length %d." % (key, feature.shape[0]))
-            embedding = trainer.predict(feature)
-        if args.normalize:
-            embedding = embedding / np.sqrt(np.sum(np.square(embedding)))
-        write_vec_flt(fp_out, np.asarray(embedding, np.float32), key=key)
+        embedding, pieces = utterance_embedding(trainer.predict, feature, args.chunk_size, args.normalize)
+        log.info("[INFO] Key %s length %d%s." % (key, frames, "" if pieces == 1 else " > %d, split to %d segments" % (args.chunk_size, pieces)))
+        write_vec_flt(fp_out, embedding, key=key)
     fp_out.close()
     trainer.close()
 
