@@ -415,17 +415,25 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     s_cnt[tl][cx] = cnt; s_mean[tl][cx] = mean; s_m2[tl][cx] = m2;
     s_mn[tl][cx] = zmn; s_mx[tl][cx] = zmx;
     __syncthreads();
-    if (tl != 0 || c >= n) return;
-    for (int k = 1; k < FIN_LANES; ++k) { zmn = fminf(zmn, s_mn[k][cx]); zmx = fmaxf(zmx, s_mx[k][cx]); }
-    for (int k = 1; k < FIN_LANES; ++k) {
-        double cb = s_cnt[k][cx];
-        if (cb > 0.0) {
-            double nn = cnt + cb, d = s_mean[k][cx] - mean;
-            mean += d * (cb / nn);
-            m2 += s_m2[k][cx] + d * d * (cnt * cb / nn);
-            cnt = nn;
+    // fold the 32 lanes of a channel as a tree (lane l takes lane l + stride: a fixed order): the serial fold by lane 0 was 31 dependent
+    // Chan merges with two fp64 divisions each - 4 of the kernel's 12 us
+    for (int stride = FIN_LANES / 2; stride >= 1; stride >>= 1) {
+        if (tl < stride) {
+            const double cb = s_cnt[tl + stride][cx];
+            if (cb > 0.0) {
+                const double nn = cnt + cb, d = s_mean[tl + stride][cx] - mean;
+                mean += d * (cb / nn);
+                m2 += s_m2[tl + stride][cx] + d * d * (cnt * cb / nn);
+                cnt = nn;
+            }
+            zmn = fminf(zmn, s_mn[tl + stride][cx]);
+            zmx = fmaxf(zmx, s_mx[tl + stride][cx]);
+            s_cnt[tl][cx] = cnt; s_mean[tl][cx] = mean; s_m2[tl][cx] = m2;
+            s_mn[tl][cx] = zmn; s_mx[tl][cx] = zmx;
         }
+        __syncthreads();
     }
+    if (tl != 0 || c >= n) return;
     float var = (float)(m2 / (double)rows);
     float meanf = (float)mean;
     float invstd = 1.0f / sqrtf(var + eps);
