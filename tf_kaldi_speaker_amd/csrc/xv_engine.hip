@@ -1293,8 +1293,11 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
         // the main chain never rewrites during backward), started before anything else of the backward pass.  [measured, same box]
         // on the weight-gradient stream, BEHIND the segment layers' weight gradients, it cost fp32 mode 0.2 ms/step (it then ran beside
         // the big data-gradient GEMMs, 10x slower, with the frame layers' weight gradients queued behind it); IN FRONT of them the
-        // last frame layer's BN backward waited ~80 us for the dz slot tdnn7's weight gradient still had to read
-        {
+        // last frame layer's BN backward waited ~80 us for the dz slot tdnn7's weight gradient still had to read; on its own stream but
+        // launched at the END of this stage (it has 3 ms of slack, and d out runs 23 instead of 49 us without it alongside) it again
+        // costs fp32 0.24 ms: its many-workgroup TN kernel then competes with the first big data-gradient GEMMs
+        auto loss_head_wgrad = [&]() -> int {
+            int rc = 0;
             hipStream_t ss = e->concurrent ? e->side2 : s;
             void* lws = e->concurrent ? e->ws_side2 : e->ws_side;
             if (e->concurrent) {
@@ -1328,7 +1331,10 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
                 XV_CHECK_HIP(hipEventRecord(e->ev_lw, ss));
                 e->lw_pending = true;
             }
-        }
+            return 0;
+        };
+        rc = loss_head_wgrad();
+        if (rc) return rc;
         // d out = dlogits . wn^T   (pad column of both is zero, so K = ldl is exact), + the gradient through ||out|| (loss.py:122,147).
         // Fused form (xv_skinny.hip): one launch, and with a BatchNorm in tdnn7 and no l2_scaling in between, tdnn7's BN backward too
         Affine &l6 = e->L[e->S0()], &l7 = e->L[e->S1()];
