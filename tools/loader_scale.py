@@ -19,6 +19,9 @@ sys.path.insert(0, ROOT)
 
 def _worker(rank, root, spklist, threads, batches, chunks, start_evt, q):
     import numpy as np
+    pin = int(os.environ.get("XV_LOADER_PIN", "0"))          # > 0: rank r keeps to CPUs [r * pin, (r + 1) * pin) (NUMA / CCD locality experiment)
+    if pin > 0:
+        os.sched_setaffinity(0, set(range(rank * pin, (rank + 1) * pin)))
     from tf_kaldi_speaker_amd.dataset.native_loader import NativeRandomQueue
     spk, seg = (chunks // 2, 2) if chunks % 2 == 0 else (chunks, 1)
     ld = NativeRandomQueue(root, spklist, num_parallel=threads, max_qsize=8, num_speakers=spk, num_segments=seg, min_len=200, max_len=400,
