@@ -204,6 +204,7 @@ def test_train_step_matches_oracle_unfused_segment_layers(kw, form, monkeypatch)
 ODD_DIMS = [
     dict(D=23, P=600, L=256, N=101, B=5, T=33, kw=dict(loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True)),
     dict(D=40, P=3000, L=512, N=53, B=5, T=27, kw=dict(loss_func="softmax")),
+    dict(D=30, P=600, L=128, N=20011, B=7, T=25, kw=dict(loss_func="additive_angular_margin_softmax", margin_m=0.2, last_layer_linear=True)),   # 626 column tiles of logits
     dict(D=23, P=1500, L=128, N=19, B=4, T=22, kw=dict(loss_func="asoftmax", margin_m=2, lambda_min=5, lambda_gamma=1e-3,
                                                          last_layer_linear=True, pooling_type="self_attention",
                                                          att_key_num_nodes=(100, 60))),

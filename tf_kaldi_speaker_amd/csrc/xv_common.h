@@ -57,10 +57,10 @@ static inline size_t xv_align(size_t x, size_t a) { return (x + a - 1) / a * a; 
 #endif
 #define XV_RESIDENT_WGS (256 * XV_WGS_PER_CU)
 
-// A device page of XV_ZERO_PAGE_FLOATS zeros (xv_gemm.hip): out-of-range rows / k of a GEMM operand are redirected to it (the select
-// is on the address, loads stay unconditional); "base + k" stays inside the page for every k < K <= XV_ZERO_PAGE_FLOATS
+// A device page of at least `floats` (and XV_ZERO_PAGE_FLOATS) zeros (xv_gemm.hip): out-of-range rows / k of a GEMM operand are redirected
+// to it (the select is on the address, loads stay unconditional); "base + k" stays inside the page for every k < K <= floats
 #define XV_ZERO_PAGE_FLOATS 16384
-const float* xv_zero_page();
+const float* xv_zero_page(size_t floats = XV_ZERO_PAGE_FLOATS);
 
 // Internal GEMM launchers (xv_gemm.hip).
 // C[m][n] (+)= sum_k A[rowmap(m)][k] * Bt[n][k]   ("NT", both operands k-contiguous)

@@ -62,13 +62,21 @@ struct NTArgs {
 // The page is XV_ZERO_PAGE_FLOATS long: an out-of-range ROW is redirected to it ONCE (its base pointer), after which "base + k"
 // stays inside the page for every k < K <= XV_ZERO_PAGE_FLOATS - so full K-steps stage with no per-step select at all.
 static float* g_zero_page = nullptr;
-static int ensure_zero_page() {
-    if (g_zero_page) return 0;
-    XV_CHECK_HIP(hipMalloc((void**)&g_zero_page, XV_ZERO_PAGE_FLOATS * sizeof(float)));
-    XV_CHECK_HIP(hipMemset(g_zero_page, 0, XV_ZERO_PAGE_FLOATS * sizeof(float)));
+static size_t g_zero_page_floats = 0;
+// Grows on demand (a reduction longer than the page, e.g. the gradient through a 20 000-speaker loss head: K = the speaker count).
+// The old page is left alive: launches already enqueued may still read it, and a page is a few hundred KB at most.
+static int ensure_zero_page(size_t floats = XV_ZERO_PAGE_FLOATS) {
+    if (g_zero_page && floats <= g_zero_page_floats) return 0;
+    size_t want = XV_ZERO_PAGE_FLOATS;
+    while (want < floats) want *= 2;
+    float* p = nullptr;
+    XV_CHECK_HIP(hipMalloc((void**)&p, want * sizeof(float)));
+    XV_CHECK_HIP(hipMemset(p, 0, want * sizeof(float)));
+    g_zero_page = p;
+    g_zero_page_floats = want;
     return 0;
 }
-const float* xv_zero_page() { return ensure_zero_page() ? nullptr : g_zero_page; }
+const float* xv_zero_page(size_t floats) { return ensure_zero_page(floats) ? nullptr : g_zero_page; }
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     // blocks b and b+8 share an XCD (round-robin dispatch): hand each XCD a contiguous run of
@@ -366,8 +374,7 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     XV_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm_nt: K/lda/ldb must be multiples of 4 (K=%d lda=%ld ldb=%ld)", g.K, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0, "gemm_nt: operands must be 16-byte aligned");
     XV_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.a_rps > 0, "gemm_nt: empty problem");
-    XV_REQUIRE(g.K <= XV_ZERO_PAGE_FLOATS, "gemm_nt: K = %d exceeds the zero page (%d)", g.K, XV_ZERO_PAGE_FLOATS);
-    if (ensure_zero_page()) return 1;
+    if (ensure_zero_page((size_t)g.K)) return 1;
     NTArgs p;
     p.zero = g_zero_page;
     p.A = g.A; p.lda = g.lda; p.a_rps = g.a_rps; p.a_pitch = g.a_pitch;

@@ -305,10 +305,9 @@ int xv_launch_skinny(hipStream_t s, const XvSkinny& g) {
     XV_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0, "segment gemm: K/lda/ldb must be multiples of 4 (K=%d lda=%ld ldb=%ld)", g.K, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0, "segment gemm: operands must be 16-byte aligned");
     XV_REQUIRE(g.epi >= XV_SK_PLAIN && g.epi <= XV_SK_BN_BWD, "segment gemm: bad epilogue %d", g.epi);
-    XV_REQUIRE(g.K <= XV_ZERO_PAGE_FLOATS, "segment gemm: K = %d exceeds the zero page (%d)", g.K, XV_ZERO_PAGE_FLOATS);
     SkArgs p;
     p.g = g;
-    p.zero = xv_zero_page();
+    p.zero = xv_zero_page((size_t)g.K);
     if (!p.zero) return 1;
     p.tiles_n = xv_cdiv(g.N, SK_COLS);
     // two stages (64 k) per workgroup at least; as many splits as fill the chip once
