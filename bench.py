@@ -178,9 +178,13 @@ def run_mode(precision, args, dev, rank, world, dist, chunks, t_lo, t_hi, h2d=Fa
         # recycle fixed staging buffers) cost 0.2 - 1.9 ms/step depending on which hardware queue the streams happened to share
         hx, hy = [t.pin_memory() for t in hx], [t.pin_memory() for t in hy]
         copy_stream = torch.cuda.Stream(device=dev)
+        import collections
+        consumed = collections.deque()      # as the loader: the host stays at most 4 batches ahead of the compute stream
 
         def feed(i):
             j = i % nb
+            if len(consumed) > 4:
+                consumed.popleft().synchronize()
             with torch.cuda.stream(copy_stream):
                 x = hx[j].to(dev, non_blocking=True)
                 y = hy[j].to(dev, non_blocking=True)
@@ -201,6 +205,9 @@ def run_mode(precision, args, dev, rank, world, dist, chunks, t_lo, t_hi, h2d=Fa
         if h2d:
             x, y = feed(i)
             eng.train_step(x, y, lr, i, allreduce=allreduce)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+            consumed.append(done)
         else:
             eng.train_step(xs[j], ys[j], lr, i, allreduce=allreduce)
 
