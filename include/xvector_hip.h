@@ -70,6 +70,12 @@ size_t xv_op_workspace_bytes(int rows, int cols_in, int cols_out);
  * the 30-dim MFCC rows (dataset feed of trainer.py:491) to a 16-byte-aligned pitch. */
 int xv_pad_channels(void* stream, const float* src, int rows, int c_src, float* dst, int c_dst);
 
+/* Kaldi 'CM ' compressed-matrix decode (dataset/kaldi_io.py:768-812 the codec, :814-867 the row sub-range) of a batch the native loader
+ * delivers undecoded (include/xvector_io.h, xvio_config.packed): b chunks of chunk_stride bytes, each
+ *   [min f32][range f32][d x (p0, p25, p75, p100) u16][d x t u8, column after column]
+ * -> out [b][t][d] float32, bit-identical to the host decoder and the reference reader.  d <= 128. */
+int xv_cm_decode(void* stream, const uint8_t* packed, int b, int t, int d, size_t chunk_stride, float* out);
+
 /* Kernel-layout weights for xv_affine_forward: wt[o][j*c_pad + c] = kernel[j][c][o]
  * (TF layout [k][C][O] of tdnn/tdnnX_{conv,dense}/kernel, tdnn.py:39,57,75,96,115,147,166);
  * columns c in [C, c_pad) are zero. */

@@ -1,6 +1,6 @@
 /* C-ABI of libxvector_io.so - the native Kaldi minibatch loader that feeds the MI355X x-vector engine.
  *
- * Host-only C++ (threads + pread), no HIP: it replaces the reference's pickle-over-multiprocessing loader
+ * Host-only C++ (threads over memory-mapped arks), no HIP: it replaces the reference's pickle-over-multiprocessing loader
  *   dataset/data_loader.py:229-307 (batch_random), :310-414 (KaldiDataRandomQueue)
  *   dataset/kaldi_io.py:743-749, 814-867 (read_mat_from_segment / _read_compressed_submat: rows [start, start+T) of a
  *   Kaldi 'CM ' compressed matrix), :768-812 (the codec)
@@ -31,6 +31,9 @@ typedef struct xvio_config {
     int32_t num_threads;       /* decoder threads */
     int32_t queue_depth;       /* batches prepared ahead */
     uint64_t seed;             /* batch i is a pure function of (seed, i): same stream for any thread count */
+    int32_t packed;            /* 1: the threads do not decode - a batch is delivered as the undecoded 'CM ' pieces of its rows
+                                * (xvio_loader_next_packed) and decoded on the GPU (xv_cm_decode, xvector_hip.h): 1/4 of the host
+                                * memory traffic and of the PCIe bytes.  'CM ' matrices only. */
 } xvio_config;
 
 const char* xvio_last_error(void);
@@ -47,6 +50,12 @@ int xvio_loader_num_utterances(const xvio_loader* l);
 /* Blocks until the next batch (in batch-index order) is ready and copies it out.
  * features: capacity >= B * max_len * dim floats, written as [B][*frames][dim]; labels: B ints. */
 int xvio_loader_next(xvio_loader* l, float* features, int32_t* labels, int32_t* frames);
+
+/* Packed mode.  One chunk = rows [start, start+frames) of one 'CM ' matrix (kaldi_io.py:814-867), undecoded:
+ *   [min f32][range f32][dim x (p0, p25, p75, p100) u16][dim x frames u8, column after column], padded to a multiple of 16 bytes
+ * = xvio_packed_chunk_bytes(dim, frames) bytes; a batch is B such chunks back to back.  packed: capacity >= B * chunk bytes at max_len. */
+int64_t xvio_packed_chunk_bytes(int32_t dim, int32_t frames);
+int xvio_loader_next_packed(xvio_loader* l, uint8_t* packed, int32_t* labels, int32_t* frames);
 
 /* Batches decoded so far and the time the decoder threads spent on them (throughput reporting). */
 int xvio_loader_stats(const xvio_loader* l, int64_t* batches, double* decode_seconds);

@@ -90,6 +90,28 @@ def test_trainer_api_roundtrip(tmp_path):
     tr2.close()
 
 
+def test_trainer_trains_from_gpu_decoded_batches(tmp_path, monkeypatch):
+    """XV_LOADER=gpu_decode: Trainer.train fed by the packed loader + xv_cm_decode (same features bit for bit, tests/test_gpu_loader.py):
+    an epoch runs, moves the weights and writes its checkpoint."""
+    from tf_kaldi_speaker_amd.misc.utils import Params
+    from tf_kaldi_speaker_amd.model.trainer import Trainer
+    monkeypatch.setenv("XV_LOADER", "gpu_decode")
+    data, spklist, _ = make_data_dir(str(tmp_path / "train"), num_spk=6, utts_per_spk=3, min_frames=60, max_frames=110)
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps(CONFIG))
+    model = str(tmp_path / "exp")
+    os.makedirs(os.path.join(model, "nnet"))
+    tr = Trainer(Params(str(cfg_path)), model)
+    tr.build("train", dim=30, loss_type=CONFIG["loss_func"], num_speakers=6)
+    before = tr.engine.get_variables()
+    tr.train(data, spklist, 0.01)
+    after = tr.engine.get_variables()
+    assert all(np.isfinite(v).all() for v in after.values())
+    assert np.abs(after["tdnn/tdnn1_conv/kernel"] - before["tdnn/tdnn1_conv/kernel"]).max() > 0
+    assert os.path.isfile(os.path.join(model, "nnet", "model-6.npz"))
+    tr.close()
+
+
 ATT_KEYS = {   # the attention block of egs/voxceleb/v1/nnet_conf/tdnn_amsoftmax_m0.20_linear_bn_1e-2_tdnn4_att.json:17-28 (key widths shrunk)
     "pooling_type": "self_attention", "att_key_input": "tdnn4_relu", "att_key_num_nodes": [96, 64], "att_key_network_type": 3,
     "att_value_input": "tdnn5_relu", "att_value_num_nodes": [], "att_value_network_type": 0, "att_apply_nonlinear": False,

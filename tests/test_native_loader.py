@@ -34,7 +34,7 @@ def test_abi_matches_header(nl):
     lib = ctypes.CDLL(nl.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), "libxvector_io.so does not export %s" % n
-    assert nl.load().xvio_abi_version() == 1
+    assert nl.load().xvio_abi_version() == 2
     body = src[src.index("typedef struct xvio_config {") + len("typedef struct xvio_config {"):src.index("} xvio_config;")]
     fields = []
     for line in body.split(";"):
@@ -154,6 +154,42 @@ def test_stream_is_a_function_of_seed_and_index_only(nl, data):
         assert np.array_equal(fa, fb) and np.array_equal(la, lb)
     c, _ = _collect(nl, root, spklist, threads=2, n=3, seed=12)
     assert not all(np.array_equal(x[1], y[1]) and x[0].shape == y[0].shape for x, y in zip(a, c))
+
+
+def test_packed_batches_decode_to_the_host_decoded_ones(nl, data, tmp_path):
+    """xvio_config.packed: the threads deliver the rows' undecoded 'CM ' pieces (for xv_cm_decode on the GPU).  Decoded with the NumPy
+    restatement of that kernel, batch i is bit-identical to batch i of the host-decoding loader with the same seed - odd lengths (a
+    chunk stride that needs its 16-byte padding) included; FM / DM data is refused by name."""
+    root, spklist, _ = data
+    a, _ = _collect(nl, root, spklist, threads=2, n=8)
+    b, _ = _collect(nl, root, spklist, threads=3, n=8, packed=True)
+    assert {x[0].shape[1] % 2 for x in a} == {0, 1}
+    for (fa, la), (fb, lb) in zip(a, b):
+        assert fa.shape == fb.shape and fb.dtype == np.float32
+        assert np.array_equal(fa, fb) and np.array_equal(la, lb)
+    assert nl.packed_chunk_bytes(30, 41) == (8 + 240 + 30 * 41 + 15) // 16 * 16
+    # an uncompressed ark: the packed loader says what it needs instead of decoding garbage
+    from tf_kaldi_speaker_amd.dataset import kaldi_io
+    d = tmp_path / "fm"
+    d.mkdir()
+    with open(d / "feats.ark", "wb") as f:
+        f.write(b"s1-u1 ")
+        off = f.tell()
+        kaldi_io.write_mat(f, np.random.RandomState(0).randn(90, 30).astype(np.float32))
+    (d / "feats.scp").write_text("s1-u1 %s:%d\n" % (d / "feats.ark", off))
+    (d / "spk2utt").write_text("s1 s1-u1\n")
+    (d / "utt2num_frames").write_text("s1-u1 90\n")
+    (d / "spklist").write_text("s1 0\n")
+    q = nl.NativeRandomQueue(str(d), str(d / "spklist"), num_parallel=1, max_qsize=2, num_speakers=1, num_segments=1, min_len=40, max_len=50, seed=1,
+                             packed=True)
+    q.start()
+    with pytest.raises(nl.XvioError, match="needs 'CM ' compressed matrices"):
+        q.fetch()
+    q.stop()
+    plain = nl.NativeRandomQueue(str(d), str(d / "spklist"), num_parallel=1, max_qsize=2, num_speakers=1, num_segments=1, min_len=40, max_len=50, seed=1)
+    plain.start()
+    assert plain.fetch()[0].shape[2] == 30
+    plain.stop()
 
 
 def test_no_shuffle_starts_at_frame_zero_and_few_speakers_are_duplicated(nl, data):

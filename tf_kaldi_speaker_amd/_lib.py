@@ -139,6 +139,7 @@ SIGNATURES = {
     "xv_l2_scaling_backward": (_I, [_VP, _VP, _VP, _I, _I, _F, _VP]),
     "xv_loss_prep_weight": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP]),
     "xv_margin_softmax_rows": (_I, [_VP, _I, _VP, _I, _I, _I, _VP, _I, _VP, _F, _F, _VP, _VP, _VP, _VP]),
+    "xv_cm_decode": (_I, [_VP, _VP, _I, _I, _I, _SZ, _VP]),
     "xv_add_norm_grad": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
     "xv_segment_gemm": (_I, [_VP, _VP, C.c_long, _VP, C.c_long, _I, _I, _I, _VP, _VP, _VP, _VP, C.c_long, _VP, C.c_long, _VP, _SZ, _VP]),
     "xv_segment_affine_bn_forward": (_I, [_VP, _VP, C.c_long, _VP, C.c_long, _I, _I, _I, _VP, _VP, _VP, _F, _F, _I, _VP, _VP, _VP, _VP, _VP,

@@ -60,6 +60,70 @@ extern "C" int xv_pad_channels(void* stream, const float* src, int rows, int c_s
     return 0;
 }
 
+// ------------------------------------------------------------------------------------
+// Kaldi 'CM ' compressed-matrix decode on the GPU (kaldi_io.py:768-867 / compressed-matrix.h) for batches the native loader delivers
+// packed (include/xvector_io.h: per chunk [min f32][range f32][D x (p0, p25, p75, p100) u16][D x T u8, column after column], padded to
+// `stride` bytes).  One workgroup per chunk: the column parameters once, then tiles of CMD_TT frames - bytes in along the frame axis
+// (how they are stored), floats out along the feature axis (how [b][t][d] is stored), transposed through LDS.
+// The arithmetic is the reference codec's, operation by operation in float with no contraction (fp contract off), so the result is
+// bit-identical to the host decoder (xv_loader.cpp, -ffp-contract=off) and to the reference reader.
+// ------------------------------------------------------------------------------------
+#define CMD_MAX_D 128
+#define CMD_TT 128
+__global__ __launch_bounds__(256) void cm_decode_kernel(const uint8_t* __restrict__ packed, long stride, int T, int D, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    __shared__ float prm[6][CMD_MAX_D];                  // p0, p25, p75, s_lo, s_mid, s_hi per column
+    __shared__ uint8_t tile[CMD_MAX_D][CMD_TT + 4];
+    const uint8_t* chunk = packed + (long)blockIdx.x * stride;
+    const int tid = threadIdx.x;
+    float minv, range;
+    memcpy(&minv, chunk, 4);
+    memcpy(&range, chunk + 4, 4);
+    // plain operators under "fp contract(off)": HIP's __fmul_rn / __fadd_rn are inline functions compiled with the default contraction,
+    // and their multiply-adds get fused into v_fma_f32 after inlining (1 ulp off the codec)
+    const float gs = range * 1.52590218966964e-05f;        // 1/65535
+    if (tid < D) {
+        unsigned short h[4];
+        memcpy(h, chunk + 8 + 8 * tid, 8);
+        const float p0 = minv + gs * (float)h[0], p25 = minv + gs * (float)h[1];
+        const float p75 = minv + gs * (float)h[2], p100 = minv + gs * (float)h[3];
+        prm[0][tid] = p0; prm[1][tid] = p25; prm[2][tid] = p75;
+        prm[3][tid] = (p25 - p0) / 64.0f;
+        prm[4][tid] = (p75 - p25) / 128.0f;
+        prm[5][tid] = (p100 - p75) / 63.0f;
+    }
+    const uint8_t* bytes = chunk + 8 + 8 * (long)D;
+    float* o = out + (long)blockIdx.x * T * D;
+    for (int t0 = 0; t0 < T; t0 += CMD_TT) {
+        const int tt_n = min(CMD_TT, T - t0);
+        __syncthreads();
+        for (int idx = tid; idx < D * CMD_TT; idx += 256) {
+            const int d = idx / CMD_TT, tt = idx - d * CMD_TT;
+            if (tt < tt_n) tile[d][tt] = bytes[(long)d * T + t0 + tt];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < tt_n * D; idx += 256) {
+            const int tt = idx / D, d = idx - tt * D;
+            const uint8_t b = tile[d][tt];
+            const float v = (float)b;
+            float y;
+            if (b <= 64) y = prm[0][d] + prm[3][d] * v;
+            else if (b <= 192) y = prm[1][d] + prm[4][d] * (v - 64.0f);
+            else y = prm[2][d] + prm[5][d] * (v - 192.0f);
+            o[(long)(t0 + tt) * D + d] = y;
+        }
+    }
+}
+
+extern "C" int xv_cm_decode(void* stream, const uint8_t* packed, int b, int t, int d, size_t chunk_stride, float* out) {
+    XV_REQUIRE(packed && out && b > 0 && t > 0 && d > 0, "cm_decode: bad arguments");
+    XV_REQUIRE(d <= CMD_MAX_D, "cm_decode: at most %d feature dimensions (got %d)", CMD_MAX_D, d);
+    XV_REQUIRE(chunk_stride >= (size_t)8 + 8 * (size_t)d + (size_t)d * t, "cm_decode: chunk stride %zu is smaller than a chunk", chunk_stride);
+    hipLaunchKernelGGL(cm_decode_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, packed, (long)chunk_stride, t, d, out);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
 // wt[o][j*c_pad + c] = kernel[(j*C + c)*O + o], zero for c >= C.  32x32 LDS-tiled transpose:
 // reads run along o (contiguous in kernel), writes run along the padded k axis (contiguous in wt).
 __global__ void prep_weight_fwd_kernel(const float* __restrict__ w, int k, int C, int O, float* __restrict__ wt, int c_pad) {

@@ -159,6 +159,29 @@ int read_rows_fd(const Source& src, const char* name, int64_t off, int start, in
     return 0;
 }
 
+// Packed form of rows [start, start+length) of a 'CM ' matrix, for decoding on the GPU (xv_cm_decode, include/xvector_hip.h): the
+// matrix header's (min, range), the per-column percentile headers and the rows' bytes, column after column - nothing is decoded here:
+//   [min f32][range f32][cols x (p0, p25, p75, p100) u16][cols x length u8]      (xvio_packed_chunk_bytes: padded to 16 bytes)
+int read_rows_packed(const Source& src, const char* name, int64_t off, int start, int length, uint8_t* out, int dim) {
+    char head[5];
+    if (!src.get(head, 5, off)) return fail("%s:%lld: cannot read the matrix header", name, (long long)off);
+    if (head[0] != '\0' || head[1] != 'B') return fail("%s:%lld: not a binary Kaldi object", name, (long long)off);
+    if (memcmp(head + 2, "CM ", 3) != 0) return fail("%s: the packed (GPU-decoded) loader needs 'CM ' compressed matrices, found '%.3s'", name, head + 2);
+    off += 5;
+    struct { float minv, range; int32_t rows, cols; } g;
+    if (!src.get(&g, 16, off)) return fail("%s: truncated CM header", name);
+    off += 16;
+    if (g.cols != dim) return fail("feature dimension changes inside %s", name);
+    if (start < 0 || length < 0 || start + length > g.rows) return fail("The number of frames is not enough for length %d (%s: %d rows, start %d)", length, name, g.rows, start);
+    memcpy(out, &g.minv, 4); memcpy(out + 4, &g.range, 4);
+    if (!src.get(out + 8, (size_t)dim * 8, off)) return fail("%s: truncated CM column headers", name);
+    off += (int64_t)dim * 8;
+    uint8_t* dst = out + 8 + (size_t)dim * 8;
+    for (int c = 0; c < dim; ++c)
+        if (!src.get(dst + (size_t)c * length, (size_t)length, off + (int64_t)c * g.rows + start)) return fail("%s: truncated CM data", name);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // random numbers: splitmix64-seeded xoshiro256**, one generator per batch index
 // ---------------------------------------------------------------------------------------------
@@ -194,6 +217,7 @@ struct Utt { int fd_index; int64_t offset; int num_frames; };
 
 struct Slot {
     std::vector<float> features;
+    std::vector<uint8_t> packed;      // packed mode: the chunks' undecoded 'CM ' pieces instead of `features`
     std::vector<int32_t> labels;
     int frames = 0;
     int64_t index = -1;     // batch index held (READY) or being filled
@@ -271,10 +295,19 @@ int xvio_loader::fill(Slot& s, int64_t index, std::vector<uint8_t>& scratch) {
             const Utt& u = utts[picks[j]];
             const int start = cfg.shuffle ? rng.range(0, u.num_frames - T) : 0;
             int rows = 0, cols = 0;
-            float* dst = s.features.data() + (size_t)(i * G + j) * T * dim;
-            if (read_rows_fd(fds[u.fd_index], ark_names[u.fd_index].c_str(), u.offset, start, T, dst, (int64_t)T * dim, &rows, &cols, scratch)) {
-                s.error = g_err;
-                return 1;
+            if (cfg.packed) {
+                uint8_t* dstp = s.packed.data() + (size_t)(i * G + j) * xvio_packed_chunk_bytes(dim, T);
+                if (read_rows_packed(fds[u.fd_index], ark_names[u.fd_index].c_str(), u.offset, start, T, dstp, dim)) {
+                    s.error = g_err;
+                    return 1;
+                }
+                cols = dim;
+            } else {
+                float* dst = s.features.data() + (size_t)(i * G + j) * T * dim;
+                if (read_rows_fd(fds[u.fd_index], ark_names[u.fd_index].c_str(), u.offset, start, T, dst, (int64_t)T * dim, &rows, &cols, scratch)) {
+                    s.error = g_err;
+                    return 1;
+                }
             }
             if (cols != dim) { s.error = "feature dimension changes inside " + ark_names[u.fd_index]; return 1; }
             s.labels[i * G + j] = spk_label[spk];
@@ -308,7 +341,7 @@ void xvio_loader::worker() {
 }
 
 extern "C" const char* xvio_last_error(void) { return g_err; }
-extern "C" int xvio_abi_version(void) { return 1; }
+extern "C" int xvio_abi_version(void) { return 2; }
 
 extern "C" int xvio_read_rows(const char* ark_path, int64_t offset, int32_t start, int32_t length, float* out, int64_t capacity,
                               int32_t* rows_out, int32_t* cols_out) {
@@ -435,7 +468,8 @@ extern "C" int xvio_loader_create(const xvio_config* cfg, xvio_loader** out) {
     const size_t B = (size_t)cfg->num_speakers * cfg->num_segments;
     l->slots.resize(depth);
     for (auto& s : l->slots) {
-        s.features.resize(B * (size_t)cfg->max_len * l->dim);
+        if (cfg->packed) s.packed.resize(B * (size_t)xvio_packed_chunk_bytes(l->dim, cfg->max_len));
+        else s.features.resize(B * (size_t)cfg->max_len * l->dim);
         s.labels.resize(B);
     }
     const int nt = std::max(1, cfg->num_threads);
@@ -462,7 +496,23 @@ extern "C" int xvio_loader_dim(const xvio_loader* l) { return l ? l->dim : 0; }
 extern "C" int xvio_loader_total_speakers(const xvio_loader* l) { return l ? l->total_speakers : 0; }
 extern "C" int xvio_loader_num_utterances(const xvio_loader* l) { return l ? (int)l->utts.size() : 0; }
 
+extern "C" int64_t xvio_packed_chunk_bytes(int32_t dim, int32_t frames) {
+    return ((int64_t)8 + (int64_t)dim * 8 + (int64_t)dim * frames + 15) / 16 * 16;
+}
+
+static int loader_next_any(xvio_loader* l, void* features, int32_t* labels, int32_t* frames, bool packed);
+
 extern "C" int xvio_loader_next(xvio_loader* l, float* features, int32_t* labels, int32_t* frames) {
+    if (l && l->cfg.packed) return fail("loader_next: this loader was created in packed mode (use xvio_loader_next_packed)");
+    return loader_next_any(l, features, labels, frames, false);
+}
+
+extern "C" int xvio_loader_next_packed(xvio_loader* l, uint8_t* packed, int32_t* labels, int32_t* frames) {
+    if (l && !l->cfg.packed) return fail("loader_next_packed: this loader decodes on the host (xvio_config.packed = 0)");
+    return loader_next_any(l, packed, labels, frames, true);
+}
+
+static int loader_next_any(xvio_loader* l, void* features, int32_t* labels, int32_t* frames, bool packed) {
     if (!l || !features || !labels || !frames) return fail("loader_next: null argument");
     Slot& s = l->slots[l->consume_index % l->slots.size()];
     {
@@ -474,7 +524,8 @@ extern "C" int xvio_loader_next(xvio_loader* l, float* features, int32_t* labels
     if (s.state == 3) rc = fail("%s", s.error.c_str());
     else {
         const size_t B = s.labels.size();
-        memcpy(features, s.features.data(), B * (size_t)s.frames * l->dim * sizeof(float));
+        if (packed) memcpy(features, s.packed.data(), B * (size_t)xvio_packed_chunk_bytes(l->dim, s.frames));
+        else memcpy(features, s.features.data(), B * (size_t)s.frames * l->dim * sizeof(float));
         memcpy(labels, s.labels.data(), B * sizeof(int32_t));
         *frames = s.frames;
     }

@@ -289,10 +289,10 @@ class KaldiDataRandomQueue(NativeRandomQueue):
     class name.  `num_total_speakers` is available before start() (train.py:74 reads it from a bare instance)."""
 
     def __init__(self, data_dir, spklist, num_parallel=1, max_qsize=10, num_speakers=None, num_segments=None,
-                 min_len=None, max_len=None, shuffle=True, seed=None):
+                 min_len=None, max_len=None, shuffle=True, seed=None, packed=False):
         NativeRandomQueue.__init__(self, data_dir, spklist, num_parallel=num_parallel, max_qsize=max_qsize,
                                    num_speakers=num_speakers, num_segments=num_segments, min_len=min_len, max_len=max_len,
-                                   shuffle=shuffle, seed=seed)
+                                   shuffle=shuffle, seed=seed, packed=packed)
         with open(spklist) as f:
             self.num_total_speakers = sum(1 for line in f if line.strip())
 

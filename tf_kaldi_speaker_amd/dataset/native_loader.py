@@ -32,6 +32,7 @@ class XvioConfig(C.Structure):
         ("num_threads", C.c_int32),
         ("queue_depth", C.c_int32),
         ("seed", C.c_uint64),
+        ("packed", C.c_int32),
     ]
 
 
@@ -49,6 +50,8 @@ SIGNATURES = {
     "xvio_loader_num_utterances": (_I, [_VP]),
     "xvio_loader_next": (_I, [_VP, _VP, _VP, _VP]),
     "xvio_loader_stats": (_I, [_VP, _VP, _VP]),
+    "xvio_packed_chunk_bytes": (_I64, [C.c_int32, C.c_int32]),
+    "xvio_loader_next_packed": (_I, [_VP, _VP, _VP, _VP]),
     "xvio_read_rows": (_I, [C.c_char_p, _I64, C.c_int32, C.c_int32, _VP, _I64, _VP, _VP]),
 }
 
@@ -83,11 +86,38 @@ def read_rows(ark_path, offset, start=0, length=-1, max_elems=1 << 24):
     return out[:rows.value * cols.value].reshape(rows.value, cols.value).copy()
 
 
+def packed_chunk_bytes(dim, frames):
+    return int(load().xvio_packed_chunk_bytes(int(dim), int(frames)))
+
+
+def decode_packed(packed, batch, frames, dim):
+    """NumPy restatement of xv_cm_decode (the GPU kernel) on a packed batch: [batch, frames, dim] float32, the arithmetic of the
+    reference codec (kaldi_io.py:768-812) in float32 - what the host-decoding loader delivers for the same (seed, index)."""
+    stride = packed_chunk_bytes(dim, frames)
+    raw = np.frombuffer(np.ascontiguousarray(packed, np.uint8)[:batch * stride].tobytes(), np.uint8).reshape(batch, stride)
+    out = np.empty((batch, frames, dim), np.float32)
+    f32 = np.float32
+    for i in range(batch):
+        minv, rng = np.frombuffer(raw[i, :8].tobytes(), np.float32)
+        hdr = np.frombuffer(raw[i, 8:8 + 8 * dim].tobytes(), np.uint16).reshape(dim, 4).astype(np.float32)
+        b = raw[i, 8 + 8 * dim:8 + 8 * dim + dim * frames].reshape(dim, frames)
+        gs = f32(rng) * f32(1.52590218966964e-05)
+        p0, p25, p75, p100 = (f32(minv) + gs * hdr[:, j] for j in range(4))
+        s_lo, s_mid, s_hi = (p25 - p0) / f32(64.0), (p75 - p25) / f32(128.0), (p100 - p75) / f32(63.0)
+        v = b.astype(np.float32)
+        y = np.where(b <= 64, p0[:, None] + s_lo[:, None] * v,
+                     np.where(b <= 192, p25[:, None] + s_mid[:, None] * (v - f32(64.0)), p75[:, None] + s_hi[:, None] * (v - f32(192.0))))
+        out[i] = y.astype(np.float32).T
+    return out
+
+
 class NativeRandomQueue(object):
-    """Endless stream of random (features [B,T,D] f32, labels [B] i32) batches from C++ decoder threads."""
+    """Endless stream of random (features [B,T,D] f32, labels [B] i32) batches from C++ decoder threads.
+    packed=True: the threads only gather the rows' undecoded 'CM ' bytes (a quarter of the traffic); `device_batches` then decodes on
+    the GPU (xv_cm_decode), `fetch` through the NumPy restatement - same values either way."""
 
     def __init__(self, data_dir, spklist, num_parallel=1, max_qsize=10, num_speakers=None, num_segments=None,
-                 min_len=None, max_len=None, shuffle=True, seed=None):
+                 min_len=None, max_len=None, shuffle=True, seed=None, packed=False):
         self.data = data_dir
         self.spklist = spklist
         self.num_speakers = num_speakers
@@ -98,6 +128,7 @@ class NativeRandomQueue(object):
         self.max_qsize = max_qsize
         self.shuffle = shuffle
         self.seed = int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)
+        self.packed = bool(packed)
         self.h = None
         self.dim = None
         self.num_total_speakers = None
@@ -115,7 +146,7 @@ class NativeRandomQueue(object):
         lib = load()
         cfg = XvioConfig(self.data.encode(), self.spklist.encode(), int(self.num_speakers), int(self.num_segments), int(self.min_len),
                          int(self.max_len), 1 if self.shuffle else 0, max(1, int(self.num_parallel_datasets)), max(1, int(self.max_qsize)),
-                         self.seed & 0xFFFFFFFFFFFFFFFF)
+                         self.seed & 0xFFFFFFFFFFFFFFFF, 1 if self.packed else 0)
         h = C.c_void_p()
         _check(lib.xvio_loader_create(C.byref(cfg), C.byref(h)), "xvio_loader_create")
         self.h = h
@@ -128,6 +159,10 @@ class NativeRandomQueue(object):
         """Staging buffers the decoder copies into: pinned when torch + a GPU are around (async H2D), plain otherwise."""
         shape = (self.batch, int(self.max_len), self.dim)
         self._pinned = None
+        if self.packed:
+            self._pk = np.empty(self.batch * packed_chunk_bytes(self.dim, self.max_len), np.uint8)
+            self._lab = np.empty(self.batch, np.int32)
+            return
         try:
             import torch
             if torch.cuda.is_available():
@@ -144,8 +179,17 @@ class NativeRandomQueue(object):
         _check(load().xvio_loader_next(self.h, features.ctypes.data, labels.ctypes.data, C.byref(frames)), "xvio_loader_next")
         return frames.value
 
+    def fetch_packed_into(self, packed, labels):
+        """Packed mode: the next batch's undecoded bytes into caller buffers (uint8 >= B*packed_chunk_bytes(dim, max_len), int32 >= B); returns T."""
+        frames = C.c_int32()
+        _check(load().xvio_loader_next_packed(self.h, packed.ctypes.data, labels.ctypes.data, C.byref(frames)), "xvio_loader_next_packed")
+        return frames.value
+
     def fetch(self):
         """(features [B,T,D], labels [B]) as fresh NumPy arrays, like the reference queue."""
+        if self.packed:
+            t = self.fetch_packed_into(self._pk, self._lab)
+            return decode_packed(self._pk, self.batch, t, self.dim), self._lab.copy()
         t = self.fetch_into(self._feat.reshape(-1), self._lab)
         feats = self._feat.reshape(-1)[:self.batch * t * self.dim].reshape(self.batch, t, self.dim).copy()
         return feats, self._lab.copy()
@@ -162,15 +206,26 @@ class NativeRandomQueue(object):
         consumed = collections.deque()
         copy_stream = torch.cuda.Stream(device=dev)
         shape = (self.batch, int(self.max_len), self.dim)
-        ring = [(torch.empty(shape, dtype=torch.float32).pin_memory(), torch.empty(self.batch, dtype=torch.int32).pin_memory(),
-                 torch.cuda.Event()) for _ in range(depth)]
+        if self.packed:
+            from .. import ops
+            shape = (self.batch * packed_chunk_bytes(self.dim, self.max_len),)
+        ring = [(torch.empty(shape, dtype=torch.uint8 if self.packed else torch.float32).pin_memory(),
+                 torch.empty(self.batch, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(depth)]
         i = 0
         while True:
             pf, pl, ev = ring[i % depth]
             ev.synchronize()                       # the copy that last read this staging buffer has finished
-            t = self.fetch_into(pf.numpy().reshape(-1), pl.numpy())
+            if self.packed:
+                t = self.fetch_packed_into(pf.numpy(), pl.numpy())
+            else:
+                t = self.fetch_into(pf.numpy().reshape(-1), pl.numpy())
             with torch.cuda.stream(copy_stream):
-                x = pf.view(-1)[:self.batch * t * self.dim].view(self.batch, t, self.dim).to(dev, non_blocking=True)
+                if self.packed:       # a quarter of the PCIe bytes; decoded by xv_cm_decode on the copy stream, off the step's critical path
+                    raw = pf[:self.batch * packed_chunk_bytes(self.dim, t)].to(dev, non_blocking=True)
+                    x = ops.cm_decode(raw, self.batch, t, self.dim)
+                    raw.record_stream(copy_stream)
+                else:
+                    x = pf.view(-1)[:self.batch * t * self.dim].view(self.batch, t, self.dim).to(dev, non_blocking=True)
                 y = pl.to(dev, non_blocking=True)
                 ev.record(copy_stream)
             cur = torch.cuda.current_stream(dev)

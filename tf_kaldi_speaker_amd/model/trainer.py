@@ -270,10 +270,14 @@ class Trainer(object):
             self.engine.lib.xv_engine_invalidate_weights(self.engine.h)
         # KaldiDataRandomQueue = the C++ loader (libxvector_io.so: planning + decoding in native threads); XV_LOADER=python
         # plans the batches in Python and only decodes natively (dataset/data_loader.py) - same rules, same batch contract
-        queue_cls = PlannedRandomQueue if os.environ.get("XV_LOADER", "native") == "python" else KaldiDataRandomQueue
+        # XV_LOADER=gpu_decode: the native threads only gather the rows' 'CM ' bytes, the batch is decoded on the GPU (xv_cm_decode) -
+        # a quarter of the host memory traffic and PCIe bytes, bit-identical features ('CM ' archives only)
+        which = os.environ.get("XV_LOADER", "native")
+        queue_cls = PlannedRandomQueue if which == "python" else KaldiDataRandomQueue
+        extra = {"packed": True} if which == "gpu_decode" else {}
         loader = queue_cls(data, spklist, num_parallel=p.num_parallel_datasets, max_qsize=p.max_queue_size,
                            num_speakers=p.num_speakers_per_batch, num_segments=p.num_segments_per_speaker,
-                           min_len=p.min_segment_len, max_len=p.max_segment_len, shuffle=True)
+                           min_len=p.min_segment_len, max_len=p.max_segment_len, shuffle=True, **extra)
         loader.start()
         try:
             if hasattr(loader, "device_batches"):        # pinned staging + asynchronous H2D on a copy stream

@@ -50,6 +50,14 @@ def pad_channels(x2d, c_dst):
     return out
 
 
+def cm_decode(packed, b, t, d):
+    """packed: uint8 device tensor of b chunks (xvector_io.h packed layout) -> [b, t, d] float32 (Kaldi 'CM ' decode on the GPU)."""
+    out = torch.empty((b, t, d), dtype=torch.float32, device=packed.device)
+    stride = (8 + 8 * d + d * t + 15) // 16 * 16
+    _lib.call("xv_cm_decode", _s(), _p(packed), b, t, d, C.c_size_t(stride), _p(out))
+    return out
+
+
 def prep_weight_fwd(kernel, c_pad):
     """kernel: [k, C, O] -> [O, k*c_pad]"""
     k, c, o = kernel.shape

@@ -15,7 +15,8 @@ N = 7351
 cfg = E.make_config(30, N, loss_func="additive_margin_softmax", margin_m=0.2, last_layer_linear=True, max_batch=128, max_frames=400)
 eng = E.Engine(cfg, device="cuda:0")
 eng.init_variables(seed=0)
-q = NativeRandomQueue(root, spklist, num_parallel=threads, max_qsize=8, num_speakers=64, num_segments=2, min_len=200, max_len=400, seed=5)
+q = NativeRandomQueue(root, spklist, num_parallel=threads, max_qsize=8, num_speakers=64, num_segments=2, min_len=200, max_len=400, seed=5,
+                      packed=os.environ.get("XV_LOADER", "native") == "gpu_decode")      # XV_LOADER=gpu_decode: 'CM ' bytes over PCIe, xv_cm_decode on the GPU
 q.start()
 it = q.device_batches("cuda:0")
 def run(batches, n):

@@ -24,11 +24,17 @@ def _worker(rank, root, spklist, threads, batches, chunks, start_evt, q):
         os.sched_setaffinity(0, set(range(rank * pin, (rank + 1) * pin)))
     from tf_kaldi_speaker_amd.dataset.native_loader import NativeRandomQueue
     spk, seg = (chunks // 2, 2) if chunks % 2 == 0 else (chunks, 1)
+    packed = os.environ.get("XV_LOADER", "native") == "gpu_decode"      # the threads only gather 'CM ' bytes (decode happens on the GPU)
     ld = NativeRandomQueue(root, spklist, num_parallel=threads, max_qsize=8, num_speakers=spk, num_segments=seg, min_len=200, max_len=400,
-                           seed=100 + rank)
+                           seed=100 + rank, packed=packed)
     ld.start()
-    feat = np.empty(chunks * 400 * ld.dim, np.float32)
     lab = np.empty(chunks, np.int32)
+    if packed:
+        from tf_kaldi_speaker_amd.dataset.native_loader import packed_chunk_bytes
+        feat = np.empty(chunks * packed_chunk_bytes(ld.dim, 400), np.uint8)
+        ld.fetch_into = ld.fetch_packed_into
+    else:
+        feat = np.empty(chunks * 400 * ld.dim, np.float32)
     ld.fetch_into(feat, lab)                      # warm: threads running, files open
     q.put(("ready", rank))
     start_evt.wait()
