@@ -274,6 +274,24 @@ def test_chunk_split_and_weighted_average():
     assert abs(np.linalg.norm(emb) - 1.0) < 1e-6
 
 
+def test_prefetch_iter_keeps_order_and_forwards_errors():
+    assert list(U.prefetch_iter(iter(range(100)), depth=3)) == list(range(100))
+    assert list(U.prefetch_iter(iter([]))) == []
+
+    def broken():
+        yield 1
+        yield 2
+        raise ValueError("truncated ark")
+
+    it = U.prefetch_iter(broken(), depth=2)
+    assert next(it) == 1 and next(it) == 2
+    with pytest.raises(ValueError, match="truncated ark"):
+        next(it)
+    it = U.prefetch_iter(iter(range(10 ** 9)), depth=2)      # abandoning the iterator stops the producer
+    assert next(it) == 0
+    it.close()
+
+
 def test_cos_pairwise_eer():
     rs = np.random.RandomState(0)
     centres = rs.randn(10, 16) * 3

@@ -392,3 +392,40 @@ def utterance_embedding(predict, feature, chunk_size, normalize):
     if normalize:
         embedding = embedding / np.sqrt(np.sum(np.square(embedding)))
     return np.asarray(embedding, np.float32), len(chunks)
+
+
+def prefetch_iter(iterable, depth=8):
+    """The items of `iterable`, produced by a background thread up to `depth` ahead of the consumer (extract.py: reading and decoding
+    utterance i+1.. from the ark while the GPU runs utterance i - the host side was half of the 0.63 ms per utterance).  Exceptions of
+    the producer are re-raised in the consumer; the thread is a daemon and stops with the iterator."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=max(1, int(depth)))
+    end, stop = object(), threading.Event()
+
+    def produce():
+        try:
+            for item in iterable:
+                while not stop.is_set():
+                    try:
+                        q.put((item, None), timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
+                if stop.is_set():
+                    return
+            q.put((end, None))
+        except BaseException as exc:       # noqa: B902 - handed to the consumer
+            q.put((end, exc))
+
+    threading.Thread(target=produce, name="prefetch", daemon=True).start()
+    try:
+        while True:
+            item, exc = q.get()
+            if item is end:
+                if exc is not None:
+                    raise exc
+                return
+            yield item
+    finally:
+        stop.set()

@@ -13,7 +13,7 @@ import sys
 
 import _cli
 from model.trainer import Trainer
-from misc.utils import Params, utterance_embedding
+from misc.utils import Params, utterance_embedding, prefetch_iter
 from dataset.kaldi_io import open_or_fd, read_mat_ark, write_vec_flt
 
 
@@ -42,7 +42,7 @@ def main():
     if "." in args.rspecifier and args.rspecifier.rsplit(".", 1)[1] == "scp":
         sys.exit("The rspecifier must be ark or input pipe")
     fp_out = open_or_fd(args.wspecifier, "wb")
-    for key, feature in read_mat_ark(args.rspecifier):
+    for key, feature in prefetch_iter(read_mat_ark(args.rspecifier)):       # the reader runs ahead of the GPU in its own thread
         frames = feature.shape[0]
         if frames < args.min_chunk_size:
             log.info("[INFO] Key %s length too short, %d < %d, skip." % (key, frames, args.min_chunk_size))

@@ -11,7 +11,7 @@ python3 tools/elementwise_summary.py $(find $O/ew -name "*kernel_trace.csv" | he
 python3 tools/pool_bench.py 2>&1 | grep -v amdgpu.ids > $O/pool_bench.txt
 python3 tools/segment_bench.py 2>&1 | grep -v amdgpu.ids > $O/segment_bench.txt
 python3 tools/e2e_ab.py --rounds 2 2>&1 | grep -v amdgpu.ids > $O/e2e_ab.txt
-python3 tools/extract_bench.py 2>&1 | grep -v amdgpu.ids > $O/extract_bench.txt; tail -3 $O/extract_bench.txt
+python3 tools/extract_bench.py 2>&1 | grep -v amdgpu.ids > $O/extract_bench.txt; python3 tools/extract_driver_bench.py 2>&1 | grep -v amdgpu.ids >> $O/extract_bench.txt; tail -4 $O/extract_bench.txt
 python3 bench.py --extended --frames 400 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_extended.json
 python3 tools/bench_summary.py $O/bench_extended.json | grep -E "^f32|^f16x3"
 python3 tools/shape_sweep.py --precision f32 2>/dev/null > $O/shapes_f32.json
