@@ -16,5 +16,5 @@ python3 bench.py --extended --frames 400 --steps 20 --warmup 5 --no-cpu-baseline
 python3 tools/bench_summary.py $O/bench_extended.json | grep -E "^f32|^f16x3"
 python3 tools/shape_sweep.py --precision f32 2>/dev/null > $O/shapes_f32.json
 python3 tools/shape_sweep.py --precision f16x3 2>/dev/null > $O/shapes_f16x3.json
-python3 tools/loader_scale.py 2>/dev/null | tail -1 > $O/loader_scale.json
+python3 tools/loader_scale.py --batches 400 --need 22800 2>/dev/null | tail -1 > $O/loader_scale.json
 ls -la $O
