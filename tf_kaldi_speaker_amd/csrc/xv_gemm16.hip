@@ -870,12 +870,15 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
             tt = r - seg * p.rps;
             const long ao = ((long)seg * p.a_pitch + tt) * p.lda + m0 + scol;
             const long bo = ((long)seg * p.b_pitch + tt) * p.ldb + n0 + scol;
+#ifndef XV16_TN_ABLATE
+#define XV16_TN_ABLATE 0      // diagnostics only (tools/variant_libs.sh; wrong results): 1 = the A (x) planes are staged for the first stage only, 2 = the B (dz) planes
+#endif
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
                 const u16* pa = (rv && a_cv) ? p.A + pl * p.a_plane + ao : p.zero;
                 const u16* pb = (rv && b_cv) ? p.B + pl * p.b_plane + bo : p.zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(base + pl * PH + 4 * rg * 128), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + (2 + pl) * PH + 4 * rg * 128), 16, 0, 0);
+                if (!(XV16_TN_ABLATE & 1) || kt < 2) __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(base + pl * PH + 4 * rg * 128), 16, 0, 0);
+                if (!(XV16_TN_ABLATE & 2) || kt < 2) __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + (2 + pl) * PH + 4 * rg * 128), 16, 0, 0);
             }
         }
     };

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 src=$R/tf_kaldi_speaker_amd/csrc
 W=/tmp/xv_variants; mkdir -p $W/base
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R/include -I$src -Wall -Wno-unused-function"
-for f in xv_gemm xv_gemm16 xv_elementwise xv_loss xv_attention xv_engine; do
+for f in xv_gemm xv_gemm16 xv_skinny xv_elementwise xv_loss xv_attention xv_engine; do
   [ -f $W/base/$f.o ] || hipcc $FL -c $src/$f.hip -o $W/base/$f.o &
 done
 wait
@@ -17,7 +17,7 @@ for v in "$@"; do
   mkdir -p $W/$name
   hipcc $FL $flags -c $src/$unit -o $W/$name/unit.o 2>&1 | grep -E "error|warning: .*spill" 
   objs=""
-  for f in xv_gemm xv_gemm16 xv_elementwise xv_loss xv_attention xv_engine; do
+  for f in xv_gemm xv_gemm16 xv_skinny xv_elementwise xv_loss xv_attention xv_engine; do
     if [ "$f.hip" == "$unit" ]; then objs="$objs $W/$name/unit.o"; else objs="$objs $W/base/$f.o"; fi
   done
   hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $W/$name/libxvector_hip.so
