@@ -2,7 +2,9 @@
 """Headline benchmark: utterance-chunks/sec of full x-vector optimiser steps on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; called WITHOUT a launcher
+   - no WORLD_SIZE in the environment - `--gpus N` starts that command itself as a child process, before anything touches the GPU,
+   relays rank 0's JSON line and exits with the child's status)
 
 Workload (BASELINE.json configs[1], SURVEY.md section 8d shape S1): standard 5-layer TDNN
 x-vector + AM-Softmax (m = 0.2), 128 chunks x 200 frames x 30-dim MFCC per GPU, 7351 speakers,
@@ -331,6 +333,28 @@ def summarize(res, args, world, chunks):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start one rank per GPU as CHILD processes (torch.distributed.run) and
+    relay their output.  Nothing in this process has touched the GPU yet (`import torch` and `device_count()` do not initialise
+    HIP on this image), and the children are spawned, never exec'd over this process."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("XV_SHARE_GPU") != "1":
+        print("bench.py --gpus %d: only %d device(s) visible (XV_SHARE_GPU=1 runs the ranks on shared devices over gloo - a wiring "
+              "check, not a measurement)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -350,11 +374,13 @@ def main():
     ap.add_argument("--single-mode", action="store_true", help="time only --precision (no second mode, no e2e leg)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d was launched with WORLD_SIZE=%d (torch.distributed.run --nproc-per-node must equal --gpus)" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     # XV_SHARE_GPU=1 (tests on a 1-GPU box): ranks share the visible devices round-robin and talk over gloo - RCCL refuses
@@ -391,7 +417,7 @@ def main():
     if dist is not None:       # per-rank communication report, gathered on every rank (collective), printed by rank 0
         try:
             mine = {"rank": rank, "backend": dist.get_backend(), "world_size": dist.get_world_size(), "device": torch.cuda.get_device_name(dev),
-                    "report": head["comm"]}
+                    "device_index": dev_index, "data_seed": 1000 + rank, "report": head["comm"]}
             comm_all = [None] * world
             dist.all_gather_object(comm_all, mine)
         except Exception as exc:       # the report must never cost the bench line

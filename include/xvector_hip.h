@@ -148,6 +148,16 @@ int xv_bn_relu_backward(void* stream, const float* da, const float* z, int segs,
 /* prelu, common.py:27-42: y[r][c] = relu(x) + alpha[c] * (x - |x|) / 2 = x > 0 ? x : alpha[c] * x  (tf.nn.leaky_relu: alpha = 0.2 everywhere).
  * Inside the engine the same non-linearity follows every BatchNorm when xv_config.relu_type says so. */
 int xv_prelu_forward(void* stream, const float* x, int rows, int n, const float* alpha, float* y);
+/* The activation that follows a BatchNorm in every op-level entry point that takes a `relu` flag (xv_bn_apply, xv_bn_apply_split,
+ * xv_bn_relu_backward[_split|_pooled*], xv_stat_pool_forward_bn*, xv_segment_affine_bn_forward, xv_segment_dgrad_bn_backward,
+ * xv_att_pool_backward_weights): network_relu_type of tdnn.py:24-30.
+ *   slope == NULL (the default): tf.nn.relu.
+ *   slope != NULL: y > 0 ? y : slope[c] * y with one device float per channel - prelu (common.py:27-42, slope = the layer's
+ *     <layer>_relu/alpha variable; dalpha, if not NULL, receives d alpha[c] = sum over rows of da * min(y, 0) from the backward
+ *     entry points) or lrelu (a constant 0.2 vector, dalpha = NULL).
+ * The setting belongs to the CALLING THREAD and stays until the next call; set it around the calls of one layer and reset it with
+ * (NULL, NULL).  The engine does exactly that per layer, so engine-level calls ignore and clear whatever was set here. */
+int xv_set_activation(const float* slope, float* dalpha);
 /* Backward of a bare ReLU (no BN in front): dz = da * (a > 0). */
 int xv_relu_backward(void* stream, const float* da, const float* a, size_t count, float* dz);
 

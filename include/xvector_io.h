@@ -9,6 +9,10 @@
  * batch, exactly what Trainer.train feeds (model/trainer.py:491-508).
  *
  * Every function returns 0 on success; on failure a message is available from xvio_last_error() (thread-local).
+ *
+ * Arks are read through read-only shared mappings and must be IMMUTABLE while a loader that opened them is alive: truncating or
+ * replacing a mapped ark (feature preparation re-run, NFS) ends the process with SIGBUS in a decoder thread.  XVIO_NO_MMAP=1 in the
+ * environment keeps every read on pread(), which reports such a file as a clean "truncated" error instead.
  */
 #ifndef XVECTOR_IO_H
 #define XVECTOR_IO_H
@@ -38,6 +42,10 @@ typedef struct xvio_config {
 
 const char* xvio_last_error(void);
 int xvio_abi_version(void);
+
+/* CRC32C (Castagnoli) of n bytes continuing from `crc` (0 to start): the checksum of TensorFlow V2 checkpoint files - the payload
+ * tf.train.Saver writes at reference model/trainer.py:318,444 - which tf_kaldi_speaker_amd/misc/tf_checkpoint.py reads and writes. */
+uint32_t xvio_crc32c(uint32_t crc, const void* data, uint64_t n);
 
 /* Parses the directory (feats.scp / spk2utt / utt2num_frames / spklist), opens every ark once and starts the threads. */
 int xvio_loader_create(const xvio_config* cfg, xvio_loader** out);

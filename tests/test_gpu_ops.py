@@ -142,6 +142,39 @@ def test_bn_relu_backward(ops, relu, pad):
     assert_close(host(db), db_ref, 2e-5, 1e-4, "dbeta")
 
 
+@pytest.mark.parametrize("kind", ["prelu", "lrelu"])
+def test_bn_activation_through_the_op_level_abi(ops, kind):
+    """network_relu_type prelu / lrelu (tdnn.py:24-30, common.py:27-42) on the OP-level entry points: the slope travels through
+    xv_set_activation (include/xvector_hip.h), as a foreign binding would pass it - not only through the engine."""
+    rs = np.random.RandomState(11)
+    segs, t, n = 5, 41, 512
+    z = (rs.randn(segs * t, n) * 2 + 0.3).astype(np.float32)
+    da = rs.randn(segs * t, n).astype(np.float32)
+    gamma, beta = (rs.rand(n) + 0.5).astype(np.float32), (0.3 * rs.randn(n)).astype(np.float32)
+    alpha = (0.01 + 0.3 * rs.rand(n)).astype(np.float32) if kind == "prelu" else np.full(n, O.LRELU_ALPHA, np.float32)
+    y, cache = O.batchnorm_train_fwd(z.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64))
+    a_ref = O.act_fwd(y, kind, alpha.astype(np.float64))
+    dy, dalpha_ref = O.act_bwd(y, a_ref, da.astype(np.float64), kind, alpha.astype(np.float64))
+    dz_ref, dg_ref, db_ref = O.batchnorm_train_bwd(dy, cache, gamma.astype(np.float64))
+    part = ops.col_stats(dev(z))
+    mean, invstd, scale, shift = ops.bn_finalize(part, segs * t, dev(gamma), dev(beta), 1e-3, 0.99, False, None, None)
+    d_alpha = dev(alpha)
+    d_dalpha = dev(np.zeros(n, np.float32)) if kind == "prelu" else None
+    with ops.activation(d_alpha, d_dalpha):
+        a = ops.bn_apply(dev(z), scale, shift, 1)
+        dz, dg, db = ops.bn_relu_backward(dev(da), dev(z), segs, t, dev(gamma), mean, invstd, scale, shift, 1, 0)
+    assert_close(host(a), a_ref, 2e-5, 2e-4, "bn + %s" % kind)
+    assert (host(a) < 0).any()                                             # the negative side is really there
+    assert_close(host(dz).reshape(-1, n), dz_ref, 2e-5, 2e-4, "bn dz (%s)" % kind)
+    assert_close(host(dg), dg_ref, 2e-5, 1e-4, "dgamma")
+    assert_close(host(db), db_ref, 2e-5, 1e-4, "dbeta")
+    if kind == "prelu":
+        assert_close(host(d_dalpha), dalpha_ref, 2e-5, 1e-4, "dalpha")
+    # outside the scope the same calls are plain ReLU again
+    a0 = ops.bn_apply(dev(z), scale, shift, 1)
+    assert_close(host(a0), np.maximum(y, 0), 2e-5, 2e-4, "bn + relu after the scope")
+
+
 def test_statistics_pooling_adversarial(ops):
     """Rows from the reference's pooling self-test (pooling.py:478-510 style): tiny, zero, huge, constant."""
     rs = np.random.RandomState(9)
@@ -465,6 +498,45 @@ def test_auxiliary_losses_against_reference_golden_vectors(ops):
 # plus ragged rows / columns / K tails (K % 8 == 4, N % 32 != 0, one row, a single split)
 SEGMENT_CASES = [(128, 512, 3000), (64, 512, 512), (128, 7351, 512), (128, 512, 7352), (128, 3000, 512),
                  (1, 512, 3000), (37, 100, 68), (128, 33, 4), (2, 600, 1204)]
+
+
+def test_split_handoff_stress(ops):
+    """The split-K hand-over of the one-launch segment kernels (relaxed agent-scope stores / ticket / loads: the xv_handoff_* contract of
+    csrc/xv_common.h, an architecture property of gfx950 rather than a HIP memory-model guarantee - ADVICE r02) replayed many times
+    back to back, the consumer L1-warm, under UNEVEN load (a large GEMM on another stream occupies part of the chip): every launch must
+    reproduce the first result bit for bit - a stale slab word would show as a different sum - and leave its tickets at zero."""
+    import torch
+    rs = np.random.RandomState(3)
+    rows, n, k = 128, 512, 3000                        # tdnn6: the largest split count of the chain
+    x, wt, bias = rs.randn(rows, k).astype(np.float32), (rs.randn(n, k) / 50).astype(np.float32), rs.randn(n).astype(np.float32)
+    dx, dw, db = dev(x), dev(wt), dev(bias)
+    first = ops.segment_gemm(dx, dw, db).clone()
+    torch.cuda.synchronize()
+    assert_close(host(first), x.astype(np.float64) @ wt.astype(np.float64).T + bias, name="segment_gemm")
+    side = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device="cuda")
+    bad = 0
+    for rep in range(8):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                big @ big                               # uneven load beside the hand-overs
+        outs = [ops.segment_gemm(dx, dw, db).clone() for _ in range(150)]
+        torch.cuda.synchronize()
+        bad += sum(int(not torch.equal(o, first)) for o in outs)
+    assert bad == 0, "%d of 1200 launches differ from the first" % bad
+    # the fused BatchNorm form consumes the summed columns inside the same launch: same replay on it
+    gamma, beta = dev((rs.rand(n) + 0.5).astype(np.float32)), dev((0.3 * rs.randn(n)).astype(np.float32))
+    def bn():
+        mm, mv = dev(np.zeros(n)), dev(np.ones(n))
+        return ops.segment_affine_bn_forward(dx, dw, db, gamma, beta, 1e-3, 0.99, True, mm, mv, 1)[1].clone()
+    a0 = bn()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            big @ big
+    outs = [bn() for _ in range(200)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, a0) for o in outs)
 
 
 @pytest.mark.parametrize("rows,n,k", SEGMENT_CASES)

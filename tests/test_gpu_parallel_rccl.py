@@ -163,3 +163,26 @@ def test_bench_two_ranks_sharing_the_gpu():
         assert "error" not in rep and rep["steps"] == 3 and len(rep["slices"]) == 4, rep
         assert abs(sum(sl["mbytes"] for sl in rep["slices"]) - 39.3) < 0.3               # the whole 9.83 M-float gradient buffer
         assert rep["allreduce_ms_per_step"] > 0 and 0.0 <= rep["overlap_frac"] <= 1.0
+
+
+def test_bench_gpus8_launches_itself_with_eight_ranks_sharing_the_gpu():
+    """`python bench.py --gpus 8` exactly as the driver calls it for N = 1 (no torch.distributed.run around it, no WORLD_SIZE): bench.py
+    starts the 8 ranks itself as child processes.  On this 1-GPU box the ranks share the device over gloo (XV_SHARE_GPU=1): eight
+    engines, eight seeded feeds, the staged all-reduce with world 8 - so the first real 8-GPU run is not the first 8-rank run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", XV_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["parallelism"] == "dp8" and line["scaling"] == "weak" and np.isfinite(line["loss"])
+    assert line["value"] > 100 and abs(line["value"] - 8 * 128 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-2 * line["value"]
+    comm = sorted(line["comm"], key=lambda c: c["rank"])
+    assert [c["rank"] for c in comm] == list(range(8))
+    assert len({c["data_seed"] for c in comm}) == 8                      # every rank draws its own minibatches
+    for c in comm:
+        assert c["world_size"] == 8 and c["backend"] == "gloo", c
+        rep = c["report"]
+        assert "error" not in rep and rep["steps"] == 3 and len(rep["slices"]) == 4, rep

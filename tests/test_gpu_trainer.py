@@ -383,3 +383,36 @@ def test_resume_from_checkpoint_is_bit_identical(tmp_path, optimizer):
     got_opt = c.engine.opt_state.cpu().numpy()
     assert np.array_equal(got, want) and np.array_equal(got_opt, want_opt) and np.abs(want_opt).max() > 0
     c.close()
+
+
+def test_trainer_reads_and_writes_tensorflow_checkpoints(tmp_path, xv_precision):
+    """`save_tf_checkpoint: true` writes the reference's payload format (tf.train.Saver V2, reference trainer.py:318,444) beside the
+    .npz, and Trainer.load() restores from such a checkpoint when no .npz is there - the path a pretrained upstream model
+    (reference README.md:86-104) takes.  Format restated in misc/tf_checkpoint.py (pinned by tests/test_tf_checkpoint.py)."""
+    if xv_precision != "f32":
+        pytest.skip("checkpoint I/O does not depend on the GEMM precision")
+    from tf_kaldi_speaker_amd.misc.utils import Params
+    from tf_kaldi_speaker_amd.misc import tf_checkpoint
+    from tf_kaldi_speaker_amd.model.trainer import Trainer
+    data, spklist, mats = make_data_dir(str(tmp_path / "train"), num_spk=5, utts_per_spk=3, min_frames=60, max_frames=90)
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps(dict(CONFIG, save_tf_checkpoint=True, num_steps_per_epoch=3)))
+    model = str(tmp_path / "exp")
+    os.makedirs(os.path.join(model, "nnet"))
+    tr = Trainer(Params(str(cfg_path)), model)
+    tr.build("train", dim=30, loss_type="additive_margin_softmax", num_speakers=5)
+    tr.train(data, spklist, 0.01)
+    want = tr.engine.get_variables()
+    tr.close()
+    prefix = os.path.join(model, "nnet", "model-3")
+    assert os.path.isfile(prefix + ".index") and os.path.isfile(prefix + ".data-00000-of-00001")
+    stored = tf_checkpoint.read_checkpoint(prefix, verify=True)
+    assert set(stored) == set(want) and stored["tdnn/tdnn1_conv/kernel"].shape == (1, 5, 30, 512)
+    os.remove(prefix + ".npz")                                   # only the TensorFlow payload is left, as in an upstream model directory
+    tr2 = Trainer(Params(str(cfg_path)), model)
+    tr2.build("predict", dim=30)
+    assert tr2.load() == 3
+    got = tr2.engine.get_variables()
+    for k, v in want.items():
+        assert np.array_equal(got[k], v), k
+    tr2.close()

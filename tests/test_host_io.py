@@ -110,9 +110,11 @@ def test_random_batch_sampling_rules(tmp_path):
         for j in (0, 5):
             ref, _ = rd.read_segment(index.feature_name(int(plan.utts[j])), plan.length, shuffle=False, start=int(plan.starts[j]))
             assert np.array_equal(feats[j], ref)
-    # every speaker too short for T: the plan replaces speakers until none is left, then gives up loudly
-    with pytest.raises(DataOutOfRange):
+    # every speaker too short for T: the plan replaces speakers until none is left, then gives up loudly - and NOT with
+    # DataOutOfRange, which Trainer.train takes for the regular end of the data
+    with pytest.raises(ValueError) as ei:
         plan_random_batch(index, rng, 8, 1, 95, 95, True)
+    assert not isinstance(ei.value, DataOutOfRange)
     # a T only some speakers can serve: the others are replaced from outside the batch's first pick
     long_spk = {int(index.speaker[u]) for u in range(len(index)) if index.frames[u] > 80}
     if 0 < len(long_spk) < 8:
@@ -120,6 +122,18 @@ def test_random_batch_sampling_rules(tmp_path):
         assert set(plan.labels.tolist()) <= long_spk
     reader.close()
     rd.close()
+
+
+def test_random_queue_failure_is_sticky_and_not_an_end_of_data(tmp_path):
+    """A random queue whose data cannot serve the requested length fails in fetch() with the planner's error, and every later
+    fetch() raises it again instead of waiting for ever on the dead prefetch thread."""
+    data, spklist, _ = make_data_dir(str(tmp_path / "short"), num_spk=4, utts_per_spk=2, min_frames=30, max_frames=40)
+    q = PlannedRandomQueue(data, spklist, num_parallel=1, max_qsize=2, num_speakers=3, num_segments=1, min_len=90, max_len=95)
+    q.start()
+    for _ in range(3):
+        with pytest.raises(ValueError):
+            q.fetch()
+    q.stop()
 
 
 def test_queues_end_to_end(tmp_path):

@@ -108,6 +108,31 @@ def test_errors_are_reported(nl, data, tmp_path):
     q.stop()
 
 
+def test_pread_path_without_mmap(nl, data, tmp_path, monkeypatch):
+    """XVIO_NO_MMAP=1 (include/xvector_io.h): no mapping, every read through pread - same rows bit for bit, and an ark that was cut
+    short after it was indexed is a clean error, not a SIGBUS."""
+    import shutil
+    root, spklist, mats = data
+    scp = _scp(root)
+    utt, (path, off) = list(scp.items())[-1]              # a matrix near the end of its ark
+    want = nl.read_rows(path, off)
+    monkeypatch.setenv("XVIO_NO_MMAP", "1")
+    assert np.array_equal(nl.read_rows(path, off), want)
+    assert np.array_equal(nl.read_rows(path, off, 3, 20), want[3:23])
+    out, _ = _collect(nl, root, spklist, 2, 3)
+    monkeypatch.delenv("XVIO_NO_MMAP")
+    ref, _ = _collect(nl, root, spklist, 2, 3)
+    for (f, l), (g, m) in zip(out, ref):
+        assert np.array_equal(f, g) and np.array_equal(l, m)
+    monkeypatch.setenv("XVIO_NO_MMAP", "1")
+    cut = str(tmp_path / "cut.ark")
+    shutil.copyfile(path, cut)
+    with open(cut, "r+b") as fh:
+        fh.truncate(off + 40)                             # header and a few column headers survive, the data do not
+    with pytest.raises(nl.XvioError, match="truncated"):
+        nl.read_rows(cut, off)
+
+
 def _collect(nl, root, spklist, threads, n, seed=11, **kw):
     args = dict(num_speakers=5, num_segments=3, min_len=40, max_len=65, shuffle=True)
     args.update(kw)

@@ -104,6 +104,7 @@ SIGNATURES = {
     "xv_bn_apply": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP, _I]),
     "xv_bn_relu_backward": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _SZ]),
     "xv_prelu_forward": (_I, [_VP, _VP, _I, _I, _VP, _VP]),
+    "xv_set_activation": (_I, [_VP, _VP]),
     "xv_relu_backward": (_I, [_VP, _VP, _VP, _SZ, _VP]),
     "xv_amax": (_I, [_VP, _VP, _SZ, _VP]),
     "xv_split_planes": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _SZ, _VP]),

@@ -44,6 +44,32 @@ void xv_set_error(const char* fmt, ...);
 static inline int xv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t xv_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- cross-workgroup hand-over inside one launch (split sums, last-arriver epilogues) --------------------------------------------
+// Protocol (xv_skinny.hip, xv_loss.hip, xv_gemm.hip): a producer workgroup writes its partial results with xv_handoff_store, every
+// storing wave drains them (xv_handoff_drain), the workgroup meets at a barrier, ONE lane takes a ticket (xv_ticket_take); the workgroup
+// whose ticket is the last one reads every partial with xv_handoff_load after a second barrier.  All three are RELAXED agent-scope
+// atomics: on gfx950 that is `global_store/load ... sc1` (written through to / read from the memory level all XCDs share) and a
+// device-scope RMW - exactly the hand-off MI355X_MICROARCH.md ("Valid forms", first row of the sc1 table) measures as valid, and the
+// only one that does not pay `buffer_wbl2 sc1` (a write-back of the XCD's WHOLE L2, 12 us per split on the segment kernels) per
+// workgroup, which is what a release fence / release RMW lowers to.  Under the HIP memory model alone a relaxed ticket carries no
+// happens-before edge, so this is an ARCHITECTURE contract, not a language one: the guard below stops any other target from
+// compiling it silently, and tests/test_gpu_ops.py::test_split_handoff_stress replays the hand-over thousands of times
+// against the unsplit result.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "xv_handoff_* relies on gfx950 sc1 write-through stores / L2-bypassing loads; re-derive the hand-over for this target"
+#endif
+__device__ __forceinline__ void xv_handoff_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float xv_handoff_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xv_handoff_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// one lane per workgroup, after xv_handoff_drain + __syncthreads(): true for the workgroup that arrives last of `expected`; that
+// lane also re-arms the ticket for the next launch (every other arrival has already been counted)
+__device__ __forceinline__ bool xv_ticket_take(unsigned* ticket, unsigned expected) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = (t == expected - 1u);
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return last;
+}
+
 // ---- GEMM geometry shared between launchers and the engine -------------------------
 #define XV_TILE_M 128
 #define XV_TILE_N 128

@@ -407,6 +407,11 @@ extern "C" int xv_col_stats(void* stream, const float* z, int rows, int n, int l
 static thread_local XvActContext g_act = {nullptr, nullptr};
 void xv_set_act_context(const float* slope, float* dalpha) { g_act.slope = slope; g_act.dalpha = dalpha; }
 XvActContext xv_act_context() { return g_act; }
+extern "C" int xv_set_activation(const float* slope, float* dalpha) {
+    XV_REQUIRE(slope || !dalpha, "set_activation: a d alpha buffer needs a slope vector");
+    xv_set_act_context(slope, dalpha);
+    return 0;
+}
 
 __device__ __forceinline__ float act1(float y, float sl) { return y > 0.f ? y : y * sl; }
 __device__ __forceinline__ f32x4 act4(f32x4 y, f32x4 sl) {

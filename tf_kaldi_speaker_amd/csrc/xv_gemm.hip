@@ -14,8 +14,9 @@
 // therefore re-reads the same (128+k-1) x C window k times from L2, never from HBM.
 //
 // Both kernels: 128x128 output tile, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile
-// as 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 acc VGPRs), K-step 32, register-staged
-// double-buffered LDS, one barrier per K-step, 2 workgroups per CU.
+// as 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 acc VGPRs), K-step XV_TILE_K = 16, operand tiles
+// staged by LDS-DMA (global_load_lds_dwordx4) into a double-buffered 32 KB LDS image, one barrier per
+// K-step, XV_WGS_PER_CU = 4 workgroups per CU (xv_common.h).
 //
 // MFMA operand maps (cdna_hip_programming.md section 3): lane l supplies A[i=l&31][k=l>>5] and
 // B[k=l>>5][j=l&31]; D register r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), column l&31.
@@ -50,6 +51,7 @@ struct NTArgs {
     const float* bias;
     float* part_sum; float* part_m2;
     const float* zero;
+    int stamp_half;      // diagnostics (XV_NT_STAMP)
 };
 
 // Out-of-range rows / k read this 16-byte zero page instead of being masked after the load: the
@@ -142,12 +144,48 @@ __device__ __forceinline__ void nt_store_tile(f32x16 (&acc)[2][2], float* __rest
 // half K-step read before the current half's MFMAs, K-step 32; per-wave private staging without any barrier was 20 % slower.
 #define XV_NT_ABLATE 0
 #endif
+#ifndef XV_NT_STAMP
+#define XV_NT_STAMP 0
+#endif
+#ifndef XV_NT_BARRIER_END
+#define XV_NT_BARRIER_END 0
+#endif
+#if XV_NT_STAMP
+// diagnostics only (tools/gemm_probe.cpp): per-workgroup s_memtime / s_memrealtime stamps and the hardware placement of every
+// workgroup of the LAST NT launch: [wg][8] = {entry, loop start, loop end, exit, HW_ID | XCC_ID << 32, realtime at entry,
+// realtime at exit, cycles wave 0 spent in the per-K-step wait + barrier}
+#define XV_DBG_STAMP_WGS 4096
+__device__ unsigned long long xv_dbg_stamps[2 * XV_DBG_STAMP_WGS * 8];      // two halves, alternating per launch
+static int g_stamp_half = 0;
+static int read_stamps(void* dst, size_t bytes, int half) {
+    XV_REQUIRE(bytes <= sizeof(unsigned long long) * XV_DBG_STAMP_WGS * 8, "debug_read_stamps: at most %d workgroups", XV_DBG_STAMP_WGS);
+    XV_CHECK_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(xv_dbg_stamps), bytes, sizeof(unsigned long long) * XV_DBG_STAMP_WGS * 8 * half));
+    return 0;
+}
+extern "C" int xv_debug_read_stamps(void* dst, size_t bytes) { return read_stamps(dst, bytes, g_stamp_half ^ 1); }        // the last launch
+extern "C" int xv_debug_read_stamps_prev(void* dst, size_t bytes) { return read_stamps(dst, bytes, g_stamp_half); }    // the one before it
+#define XV_STAMP(slot) do { if (tid == 0 && blockIdx.x < XV_DBG_STAMP_WGS) xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XV_STAMP(slot) ((void)0)
+#endif
 template <bool STATS>
 __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * NT_PITCH];
+#ifndef XV_NT_LDS_PAD_KB
+#define XV_NT_LDS_PAD_KB 0      // diagnostics: extra LDS per workgroup = fewer co-resident workgroups per CU
+#endif
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * NT_PITCH + XV_NT_LDS_PAD_KB * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
+#if XV_NT_STAMP
+    XV_STAMP(0);
+    if (tid == 0 && blockIdx.x < XV_DBG_STAMP_WGS) {
+        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
+                                            ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    }
+    unsigned long long stall = 0;
+#endif
 
     const int t = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
@@ -267,6 +305,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
     const int fsw = NT_SWZ(li);     // rows wr*64 + a*32 + li share f(li): the offsets are multiples of 16
     if (nk > 0) NT_STAGE_FIRST();
     __syncthreads();
+    XV_STAMP(1);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
 #if !(XV_NT_ABLATE & 2)
@@ -296,14 +335,32 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
             }
         }
         if (kt + 1 < nk) NT_COMMIT(buf);
+#if XV_NT_BARRIER_END
+        __builtin_amdgcn_sched_barrier(0);      // keeps hipcc from hoisting the barrier above the second MFMA group
+#endif
+#if XV_NT_STAMP >= 2
+        const unsigned long long tw = __builtin_amdgcn_s_memtime();
         __syncthreads();
+        stall += __builtin_amdgcn_s_memtime() - tw;
+#else
+        __syncthreads();
+#endif
     }
+    XV_STAMP(2);
 
     // ---- epilogue
     float* C = p.C + (long)blockIdx.z * p.c_split_stride;
     nt_store_tile(acc, C, p.ldc, p.bias, m0, n0, p.M, p.N, wr, wc, li, lh);
 
     if (STATS) xv_tile_stats_epilogue(acc, smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part_sum);
+#if XV_NT_STAMP
+    __builtin_amdgcn_s_waitcnt(0);      // stores issued; exit stamp = the wave is about to retire
+    XV_STAMP(3);
+    if (tid == 0 && blockIdx.x < XV_DBG_STAMP_WGS) {
+        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 7] = stall;
+    }
+#endif
 }
 
 // out[m][n] = sum_z slab[z][m][n] (+ bias[n])
@@ -377,6 +434,10 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     if (ensure_zero_page((size_t)g.K)) return 1;
     NTArgs p;
     p.zero = g_zero_page;
+    p.stamp_half = 0;
+#if XV_NT_STAMP
+    p.stamp_half = g_stamp_half; g_stamp_half ^= 1;
+#endif
     p.A = g.A; p.lda = g.lda; p.a_rps = g.a_rps; p.a_pitch = g.a_pitch;
     p.Bt = g.Bt; p.ldb = g.ldb;
     p.M = g.M; p.N = g.N; p.K = g.K;
@@ -565,9 +626,9 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p
 int xv_tn_splits(int M, int N, int R) {
     int tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
     int ksteps = xv_cdiv(R, BK);
-    // 2 workgroups are resident per CU (LDS 64 KB each): keep tiles*splits <= 512 so the whole
-    // grid is ONE co-resident round.  (560 workgroups = 512 + a 48-workgroup second round cost
-    // 2x on the first build: 61 TF on tdnn2/3, 24 TF on tdnn5.)
+    // XV_WGS_PER_CU (4) workgroups are resident per CU (LDS 32 KB each): keep tiles*splits <= XV_RESIDENT_WGS (1 024) so the
+    // whole grid is ONE co-resident round.  (On the first build - 2 per CU - 560 workgroups = 512 + a 48-workgroup second
+    // round cost 2x: 61 TF on tdnn2/3, 24 TF on tdnn5.)
     // [measured, round 2] fewer co-resident workgroups (smaller slabs, cheaper slab sum) lose: 768 -> +0.06 ms/step, 512 -> +0.19 ms
     int splits = XV_RESIDENT_WGS / tiles;
     if (splits > ksteps / 2) splits = ksteps / 2;

@@ -20,6 +20,7 @@
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -79,7 +80,12 @@ struct Source {
         scratch.resize(n);
         return pread_all(fd, scratch.data(), n, (off_t)off) ? scratch.data() : nullptr;
     }
+    // XVIO_NO_MMAP=1 keeps every read on pread: a mapped ark that is truncated or replaced while training runs (feature preparation
+    // re-run, NFS) ends the process with SIGBUS in a decoder thread, pread returns a clean "truncated" error instead.  Arks must be
+    // immutable while a loader that maps them is open (include/xvector_io.h).
     void open_map() {
+        const char* no = getenv("XVIO_NO_MMAP");
+        if (no && no[0] && no[0] != '0') return;
         struct stat st;
         if (fd < 0 || fstat(fd, &st) != 0 || st.st_size <= 0) return;
         void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
@@ -342,6 +348,35 @@ void xvio_loader::worker() {
 
 extern "C" const char* xvio_last_error(void) { return g_err; }
 extern "C" int xvio_abi_version(void) { return 2; }
+
+// CRC32C, slice-by-8 (tables built once, thread-safe static init)
+extern "C" uint32_t xvio_crc32c(uint32_t crc, const void* data, uint64_t n) {
+    struct Tables {
+        uint32_t t[8][256];
+        Tables() {
+            for (uint32_t i = 0; i < 256; ++i) {
+                uint32_t c = i;
+                for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+                t[0][i] = c;
+            }
+            for (uint32_t i = 0; i < 256; ++i)
+                for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
+        }
+    };
+    static const Tables T;
+    const uint8_t* p = (const uint8_t*)data;
+    uint32_t c = ~crc;
+    while (n >= 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        w ^= c;
+        c = T.t[7][w & 0xFF] ^ T.t[6][(w >> 8) & 0xFF] ^ T.t[5][(w >> 16) & 0xFF] ^ T.t[4][(w >> 24) & 0xFF] ^
+            T.t[3][(w >> 32) & 0xFF] ^ T.t[2][(w >> 40) & 0xFF] ^ T.t[1][(w >> 48) & 0xFF] ^ T.t[0][(w >> 56) & 0xFF];
+        p += 8; n -= 8;
+    }
+    while (n--) c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return ~c;
+}
 
 extern "C" int xvio_read_rows(const char* ark_path, int64_t offset, int32_t start, int32_t length, float* out, int64_t capacity,
                               int32_t* rows_out, int32_t* cols_out) {

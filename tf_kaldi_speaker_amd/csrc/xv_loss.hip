@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void margin_softmax_rows_kernel(int kind, cons
         dnorm[r] = margin ? s_dn * (py - 1.f) * inv_rows : 0.f;
         if (ticket) {
             // the mean over the rows in the same launch: the last workgroup to finish sums row_loss in index order (mean_kernel's
-            // arithmetic).  Hand-over by agent-scope atomics, not __threadfence() (a whole-L2 write-back per workgroup on gfx950)
+            // arithmetic).  Hand-over by agent-scope atomics (the xv_handoff_* contract of xv_common.h), not __threadfence() (a
+            // whole-L2 write-back per workgroup on gfx950)
             __hip_atomic_store(row_loss + r, rl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void xv_skinny_kernel(SkArgs p) {
     // accumulator r of lane (li, lh) is C[row(r)][n0 + li], row(r) = 32 wave + (r & 3) + 8 (r >> 2) + 4 lh
     const int row0 = wave * 32 + 4 * lh;
     if (p.splits > 1) {
-        // Slab hand-over without a device-wide fence.  __threadfence() here is "buffer_wbl2 sc1": every wave writes back its XCD's
+        // Slab hand-over without a device-wide fence (the xv_handoff_* contract of xv_common.h, gfx950 only).  __threadfence() here is "buffer_wbl2 sc1": every wave writes back its XCD's
         // whole L2 - measured 12 us per split on this kernel.  Instead the slab values are stored and loaded as relaxed agent-scope
         // atomics (sc1: written through to / read from the level all XCDs share), the stores are drained (vmcnt(0)) in front of the
         // workgroup barrier, and only then does thread 0 take the ticket.

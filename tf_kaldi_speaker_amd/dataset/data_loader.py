@@ -145,7 +145,11 @@ def plan_random_batch(index, rng, num_speakers, num_segments, min_len, max_len, 
             if len(ok):
                 break
             if len(spare) == 0:
-                raise DataOutOfRange("no utterance longer than %d frames outside the sampled speakers" % length)
+                # NOT DataOutOfRange: Trainer.train_batches takes that as the regular end of a sequence queue's data, so a data
+                # directory whose utterances are all too short would end every epoch silently (and hang the other ranks of a
+                # data-parallel run in their all-reduce).  The reference loops forever here (data_loader.py:281-290).
+                raise ValueError("no utterance longer than %d frames outside the sampled speakers: max_segment_len is larger than the "
+                                 "data allows" % length)
             s = int(rng.choice(spare))
             spare = spare[spare != s]      # in the batch now (or found too short): not a candidate for a later replacement
         if len(ok) < num_segments:
@@ -202,6 +206,8 @@ class _Prefetcher(threading.Thread):
         self.plans, self.reader = plans, reader
         self.out = _queue.Queue(max(1, int(depth)))
         self.halt = threading.Event()
+        self.failure = None          # the exception that ended the pipeline: raised again by every later get()
+        self.ended = False
 
     def run(self):
         try:
@@ -220,9 +226,16 @@ class _Prefetcher(threading.Thread):
             self.out.put(exc)
 
     def get(self):
+        if self.failure is not None:       # the thread is gone: a second get() would wait on an empty queue for ever
+            raise self.failure
+        if self.ended:
+            return None
         item = self.out.get()
         if isinstance(item, Exception):
+            self.failure = item
             raise item
+        if item is None:
+            self.ended = True
         return item
 
 

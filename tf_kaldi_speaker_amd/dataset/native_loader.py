@@ -43,6 +43,7 @@ _I64 = C.c_int64
 SIGNATURES = {
     "xvio_last_error": (C.c_char_p, []),
     "xvio_abi_version": (_I, []),
+    "xvio_crc32c": (C.c_uint32, [C.c_uint32, _VP, C.c_uint64]),
     "xvio_loader_create": (_I, [_VP, _VP]),
     "xvio_loader_destroy": (None, [_VP]),
     "xvio_loader_dim": (_I, [_VP]),

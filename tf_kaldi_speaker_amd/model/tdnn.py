@@ -158,8 +158,11 @@ def tdnn(features, params, is_training=None, reuse_variables=None, aux_features=
     assert x.dim() == 3, "features must be [batch, length, dim]"
     b, t, dim = x.shape
     check_params(params)
+    # everything that changes the graph tdnn() builds: two graphs in one process that differ in any of these must not share an engine
     key = (dim, params.dict["num_nodes_pooling_layer"], params.dict["num_nodes_last_layer"],
-           bool(params.last_layer_no_bn), bool(params.last_layer_linear), frame_layer_table(params))
+           bool(params.last_layer_no_bn), bool(params.last_layer_linear), frame_layer_table(params),
+           params.dict.get("network_relu_type", "relu"), params.dict.get("pooling_type", "statistics_pooling"),
+           tuple(sorted((k, repr(v)) for k, v in params.dict.items() if k.startswith("att_"))))
     eng = _GRAPH["engine"]
     if eng is None:
         if reuse_variables is True:

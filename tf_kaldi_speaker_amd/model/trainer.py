@@ -29,6 +29,7 @@ try:
     from ..parallel import GradAllReduce, average_bn_statistics, broadcast_variables
     from ..dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, PlannedRandomQueue, DataOutOfRange
     from ..misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state
+    from ..misc import tf_checkpoint
     from .tdnn import tdnn, extended_tdnn, engine_config, collect_endpoints, check_params
     from . import loss as _loss
 except (ImportError, ValueError):      # drop-in layout: PYTHONPATH=$TF_KALDI_ROOT
@@ -37,6 +38,7 @@ except (ImportError, ValueError):      # drop-in layout: PYTHONPATH=$TF_KALDI_RO
     from parallel import GradAllReduce, average_bn_statistics, broadcast_variables
     from dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, PlannedRandomQueue, DataOutOfRange
     from misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state
+    from misc import tf_checkpoint
     from model.tdnn import tdnn, extended_tdnn, engine_config, collect_endpoints, check_params
     from model import loss as _loss
 
@@ -220,6 +222,10 @@ class Trainer(object):
         tmp = path + ".tmp.npz"
         np.savez(tmp, **arrays)
         os.replace(tmp, path + ".npz")
+        if self.params.dict.get("save_tf_checkpoint", False):
+            # the same variables as a TensorFlow V2 checkpoint (model-<step>.index / .data-00000-of-00001) the reference's
+            # tf.train.Saver restores (trainer.py:142-158): an upstream user can pick the model up without this package
+            tf_checkpoint.write_checkpoint(path, self.engine.get_variables())
         # the index keeps BASENAMES (TF's save_relative_paths form): the model directory can be moved or copied and pruning
         # / loading still find the payloads; entries written with a directory part by older runs are read by basename
         name = os.path.basename(path)
@@ -228,8 +234,9 @@ class Trainer(object):
         keep = int(self.params.dict.get("keep_checkpoint_max", 5))
         while keep > 0 and len(names) > keep:
             old = os.path.join(self.model, names.pop(0))
-            if os.path.exists(old + ".npz"):
-                os.remove(old + ".npz")
+            for ext in (".npz", ".index", ".data-00000-of-00001"):
+                if os.path.exists(old + ext):
+                    os.remove(old + ext)
         write_checkpoint_state(self.model, name, names)
 
     def load(self):
@@ -241,6 +248,19 @@ class Trainer(object):
         step = int(next(re.finditer(r"(\d+)(?!.*\d)", ckpt_name)).group(0))
         path = os.path.join(self.model, ckpt_name + ".npz")
         if not os.path.isfile(path):
+            prefix = os.path.join(self.model, ckpt_name)
+            if os.path.isfile(prefix + ".index"):
+                # a checkpoint written by the reference's tf.train.Saver (trainer.py:318,444; the pretrained models of README.md:86-104):
+                # same variable names and shapes, read without TensorFlow (misc/tf_checkpoint.py).  Optimiser slots are not taken over.
+                tf_vars = tf_checkpoint.read_checkpoint(prefix)
+                values = {k: v for k, v in tf_vars.items() if k in self.engine.table}
+                missing = [k for k in self.engine.table if k not in values]
+                if missing:
+                    sys.exit("Checkpoint %s.index lacks variables: %s" % (prefix, ", ".join(missing[:5])))
+                self.engine.set_variables(values)
+                log.info("Succeed to load TensorFlow checkpoint {}".format(ckpt_name))
+                self.is_loaded = True
+                return step
             sys.exit("Failed to find a checkpoint in {}".format(self.model))
         data = np.load(path)
         values = {k: data[k] for k in data.files if not k.startswith("__") and k in self.engine.table}

@@ -154,6 +154,22 @@ def bn_relu_backward(da, z, segs, t, gamma, mean, invstd, scale, shift, relu, pa
     return (dz, dgamma, dbeta, dbias) if with_dbias else (dz, dgamma, dbeta)
 
 
+class activation:
+    """`with ops.activation(slope, dalpha=None):` - the op-level calls inside take y > 0 ? y : slope[c] * y (prelu / lrelu,
+    tdnn.py:24-30) wherever their `relu` flag is set, through the ABI's xv_set_activation; plain ReLU again on exit."""
+
+    def __init__(self, slope, dalpha=None):
+        self.slope, self.dalpha = slope, dalpha
+
+    def __enter__(self):
+        _lib.call("xv_set_activation", _p(self.slope), _p(self.dalpha))
+        return self
+
+    def __exit__(self, *exc):
+        _lib.call("xv_set_activation", None, None)
+        return False
+
+
 def prelu_forward(x2d, alpha):
     """x > 0 ? x : alpha[c] * x over the last axis."""
     y = torch.empty_like(x2d)
