@@ -61,6 +61,35 @@ static inline size_t xv_align(size_t x, size_t a) { return (x + a - 1) / a * a; 
 __device__ __forceinline__ void xv_handoff_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float xv_handoff_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void xv_handoff_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// 16-byte forms for tile-sized partials (64 KB per workgroup): `global_store_dwordx4 ... sc1` / `global_load_dwordx4 ... sc1` (the widths
+// the guide's hand-off table rates fastest: a 4-byte sc1 store costs ~6x the time per byte).  HIP has no 16-byte atomic, so these are
+// inline assembly: the compiler does not count them in its own s_waitcnt bookkeeping, which only ever makes ITS waits longer (vmcnt
+// retires in issue order); the loads wait for themselves, the stores are drained by xv_handoff_drain.
+__device__ __forceinline__ void xv_handoff_store4(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// four loads in flight: p + {0, 4, 8, 12} floats
+__device__ __forceinline__ void xv_handoff_load4x4(const float* p, f32x4 (&v)[4]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+        : "v"(p)
+        : "memory");
+}
+// eight loads in flight: p + {0, 4, 8, 12} floats and q + the same
+__device__ __forceinline__ void xv_handoff_load4x8(const float* p, const float* q, f32x4 (&v)[8]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %2, %8, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
+        "global_load_dwordx4 %4, %9, off sc1\n\tglobal_load_dwordx4 %5, %9, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %6, %9, off offset:32 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:48 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(p), "v"(q)
+        : "memory");
+}
 // one lane per workgroup, after xv_handoff_drain + __syncthreads(): true for the workgroup that arrives last of `expected`; that
 // lane also re-arms the ticket for the next launch (every other arrival has already been counted)
 __device__ __forceinline__ bool xv_ticket_take(unsigned* ticket, unsigned expected) {
@@ -102,15 +131,21 @@ struct XvGemmNT {
 };
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g);
 
-// P[z][m][n] = sum_{r in chunk z} A[amap(r)][m] * B[bmap(r)][n]   ("TN", reduction over rows)
+// out[(j*C + c)][n] = sum_r A[amap(r)][j*c_pad + c] * B[bmap(r)][n]  (+ l2 * w[(j*C + c)][n])   ("TN", reduction over rows; rows with
+// c >= C - padded input channels - are dropped).  The reduction is split over `splits` workgroups per output tile; the workgroup that
+// finishes a tile last sums the partials in split order inside the same launch (xv_gemm.hip).
 struct XvGemmTN {
     const float* A; long lda; int a_rps; int a_pitch;   // [R] rows mapped, M columns used
     const float* B; long ldb; int b_rps; int b_pitch;   // [R] rows mapped, N columns used
     int M, N, R;
-    float* P;            // slabs [splits][M][N]
+    float* P;            // scratch for the split partials: xv_tn_slab_bytes(M, N, R) bytes
     int splits;          // chosen by xv_tn_splits
+    float* out; long ldo;             // [(M / c_pad) * C][ldo]
+    int C, c_pad;                     // M = k * c_pad; C == c_pad == M for a plain matrix
+    const float* w; long ldw; float l2;      // optional regulariser term
 };
 int xv_tn_splits(int M, int N, int R);
+size_t xv_tn_slab_bytes(int M, int N, int R);
 int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g);
 int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int C, int c_pad, int n_in, int n_out, const float* w,
                            long ldw, float l2, float* out, long ldo);

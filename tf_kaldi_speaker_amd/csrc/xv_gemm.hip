@@ -24,6 +24,11 @@
 // lane-half h own 4 CONSECUTIVE k of every 8 (one ds_read_b128 feeds 4 MFMAs).
 #include "xv_common.h"
 #include "xv_epilogue.h"
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #define BM XV_TILE_M
 #define BN XV_TILE_N
@@ -169,11 +174,14 @@ extern "C" int xv_debug_read_stamps_prev(void* dst, size_t bytes) { return read_
 #define XV_STAMP(slot) ((void)0)
 #endif
 template <bool STATS>
-__global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p) {
+__global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(128))) void xv_gemm_nt_kernel(NTArgs p) {
 #ifndef XV_NT_LDS_PAD_KB
 #define XV_NT_LDS_PAD_KB 0      // diagnostics: extra LDS per workgroup = fewer co-resident workgroups per CU
 #endif
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * NT_PITCH + XV_NT_LDS_PAD_KB * 256];
+#ifndef XV_NT_STAGES
+#define XV_NT_STAGES 2          // LDS ring depth: 2 = the next K-step's DMA is in flight during this one, 3 = the next two
+#endif
+    __shared__ __attribute__((aligned(16))) float smem[XV_NT_STAGES * 2 * BM * NT_PITCH + XV_NT_LDS_PAD_KB * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -303,6 +311,60 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
     const int a_off = (wr * 64 + li) * NT_PITCH;
     const int b_off = (wc * 64 + li) * NT_PITCH;
     const int fsw = NT_SWZ(li);     // rows wr*64 + a*32 + li share f(li): the offsets are multiples of 16
+#if XV_NT_STAGES >= 3
+    // Ring of XV_NT_STAGES slots: the DMA of K-step kt + STAGES - 1 is issued at the top of K-step kt (its slot was last read in K-step
+    // kt - 1, which every wave has left: the barrier at its end), so a transfer has STAGES - 1 K-steps to land instead of one.  In front of
+    // the one barrier per K-step each wave waits for its OWN transfers of K-step kt + 1, i.e. for all but the 2 * NT_RPT instructions of
+    // each younger K-step in flight (s_waitcnt counts a wave's vector-memory operations in issue order).
+    static_assert(XV_GLDS, "the ring is built on LDS-DMA staging");
+    static_assert(XV_NT_STAGES <= 4, "s_waitcnt immediates are spelled out for at most 4 slots");
+    auto wait_younger = [&](int younger) {      // younger: K-steps issued after the one being waited for (uniform)
+        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NT_RPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NT_RPT) : "memory");
+    };
+    for (int j = 0; j < XV_NT_STAGES - 1; ++j)
+        if (j < nk) gstage(j, j);
+    wait_younger(min(nk, XV_NT_STAGES - 1) - 1);
+    __builtin_amdgcn_s_barrier();
+    XV_STAMP(1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nbuf = buf == 0 ? XV_NT_STAGES - 1 : buf - 1;      // (kt + STAGES - 1) % STAGES
+#if !(XV_NT_ABLATE & 2)
+        if (kt + XV_NT_STAGES - 1 < nk) gstage(kt + XV_NT_STAGES - 1, nbuf);
+#endif
+        const float* sa = smem + buf * (2 * BM * NT_PITCH);
+        const float* sb = sa + BM * NT_PITCH;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            f32x4 af[2], bf[2];
+            const int pos = (((2 * q + lh) ^ fsw) << 2);
+#if XV_NT_ABLATE & 1
+            af[0] = af[1] = bf[0] = bf[1] = f32x4{(float)pos, 1.f, 2.f, (float)kt};
+            asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(bf[0]), "+v"(bf[1]));
+#else
+            af[0] = *(const f32x4*)(sa + a_off + pos);
+            af[1] = *(const f32x4*)(sa + a_off + 32 * NT_PITCH + pos);
+            bf[0] = *(const f32x4*)(sb + b_off + pos);
+            bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
+#endif
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[0][e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[1][e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[0][e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[1][e], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) {
+            wait_younger(min(nk - 1, kt + XV_NT_STAGES - 1) - (kt + 1));
+            __builtin_amdgcn_s_barrier();
+        }
+        buf = buf == XV_NT_STAGES - 1 ? 0 : buf + 1;
+    }
+    __syncthreads();      // the statistics epilogue reuses the ring as scratch
+#else
     if (nk > 0) NT_STAGE_FIRST();
     __syncthreads();
     XV_STAMP(1);
@@ -346,6 +408,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
         __syncthreads();
 #endif
     }
+#endif
     XV_STAMP(2);
 
     // ---- epilogue
@@ -363,6 +426,171 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_nt_kernel(NTArgs p
 #endif
 }
 
+// -------------------------------------------------------------------------------------
+// NT, evenly scheduled ("stream-K"): the launch has P persistent workgroups (one co-resident round) and every one of them runs the
+// same number of K-steps.  The (tile, K-step) pairs are numbered tile-major, u = tile * nk + kt; workgroup w owns the units
+// [w * total / P, (w + 1) * total / P) - a run that may start and end in the middle of a tile.  A tile whose K-steps were shared
+// stores its partial accumulators as slabs (the lane-order layout of the TN kernel), and the workgroup that finishes its share
+// LAST sums them in K order (xv_handoff_* contract) and runs the ordinary epilogue (bias, store, BatchNorm statistics).
+// Why [measured, round 3, tools/gemm_probe]: with one workgroup per tile the time of a launch is set by the CU with the most tiles:
+// tdnn2's data gradient at S1 (784 tiles = 768 + 16: sixteen CUs run a fourth tile) ran at 101 TF against 134 TF for tdnn3's
+// (768 tiles), and the shipped batch shape (64 x T~300: 584 / 572 tiles = 2.3 per CU, some CUs 3) ran tdnn2 / tdnn3 forward in the
+// time of the 128 x 200 batch (100 TF).  It also replaces the launcher's split-K + xv_splitk_reduce_kernel for few-tile problems.
+struct NTSKArgs {
+    NTArgs g;
+    int P;                    // workgroups (grid size)
+    int nk;                   // K-steps per tile
+    long total;               // tiles * nk
+    float* slab;              // [P][2][128*128]: first / last partial tile of each workgroup
+    unsigned* tickets;        // one per tile, zero between launches
+};
+
+__device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (int)((((u + 1) * P) - 1) / total); }
+
+template <bool STATS>
+__global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(128))) void xv_gemm_nt_sk_kernel(NTSKArgs q) {
+    const NTArgs& p = q.g;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * NT_PITCH];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int w = xcd_swizzle(blockIdx.x, gridDim.x);
+    const long u_end = (long)(w + 1) * q.total / q.P;
+    long u = (long)w * q.total / q.P;
+    const int first_tile = (int)(u / q.nk);
+
+    constexpr int NT_RPI = 64 / NT_KQ;          // tile rows per wave-instruction (16 at BK=16)
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int lrow = lane / NT_KQ, lpos = lane % NT_KQ;
+    const float* __restrict__ zp = p.zero;
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int a_off = (wr * 64 + li) * NT_PITCH;
+    const int b_off = (wc * 64 + li) * NT_PITCH;
+    const int fsw = NT_SWZ(li);
+
+    while (u < u_end) {
+        const int tile = (int)(u / q.nk);
+        const int kt0 = (int)(u - (long)tile * q.nk);
+        const int kt1 = (int)min((long)q.nk, kt0 + (u_end - u));
+        const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+        // per-lane source pointers of this tile (swizzled chunk folded in; out-of-range rows -> zero page)
+        const float* ap[NT_RPT];
+        const float* bp[NT_RPT];
+        int ksrc[NT_RPT];
+#pragma unroll
+        for (int i = 0; i < NT_RPT; ++i) {
+            const int row = NT_RPI * (NT_RPT * wave + i) + lrow;
+            ksrc[i] = ((lpos ^ NT_SWZ(row)) << 2);
+            const int m = m0 + row;
+            const int mm = m < p.M ? m : 0;
+            const int seg = mm / p.a_rps, tt = mm - seg * p.a_rps;
+            ap[i] = (m < p.M ? p.A + ((long)seg * p.a_pitch + tt) * p.lda : zp) + ksrc[i];
+            const int n = n0 + row;
+            bp[i] = (n < p.N ? p.Bt + (long)n * p.ldb : zp) + ksrc[i];
+        }
+        auto gstage = [&](int kt, int buf) {
+            float* sa = smem + buf * (2 * BM * NT_PITCH) + NT_RPI * NT_RPT * uwave * NT_PITCH;
+            float* sb = sa + BM * NT_PITCH;
+            const int k0 = kt * BK;
+            if (k0 + BK <= p.K) {
+#pragma unroll
+                for (int i = 0; i < NT_RPT; ++i) {
+                    __builtin_amdgcn_global_load_lds((gptr_t)(ap[i] + k0), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(bp[i] + k0), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                }
+            } else {                       // ragged last step of a row: chunks at or beyond K come from the zero page
+#pragma unroll
+                for (int i = 0; i < NT_RPT; ++i) {
+                    const bool kv = k0 + ksrc[i] < p.K;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(kv ? ap[i] + k0 : zp), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(kv ? bp[i] + k0 : zp), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                }
+            }
+        };
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        gstage(kt0, 0);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            if (kt + 1 < kt1) gstage(kt + 1, buf ^ 1);
+            const float* sa = smem + buf * (2 * BM * NT_PITCH);
+            const float* sb = sa + BM * NT_PITCH;
+#pragma unroll
+            for (int qq = 0; qq < BK / 8; ++qq) {
+                f32x4 af[2], bf[2];
+                const int pos = (((2 * qq + lh) ^ fsw) << 2);
+                af[0] = *(const f32x4*)(sa + a_off + pos);
+                af[1] = *(const f32x4*)(sa + a_off + 32 * NT_PITCH + pos);
+                bf[0] = *(const f32x4*)(sb + b_off + pos);
+                bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[0][e], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[1][e], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[0][e], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[1][e], acc[1][1], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        u += kt1 - kt0;
+
+        if (kt0 != 0 || kt1 != q.nk) {
+            // a shared tile: publish this share, take a ticket, and only the last of the tile's workgroups goes on
+            float* mine = q.slab + ((long)w * 2 + (tile == first_tile ? 0 : 1)) * (BM * BN) + tid * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 v = {acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]};
+                xv_handoff_store4(mine + (r >> 2) * (256 * 16) + (r & 3) * 4, v);
+            }
+            xv_handoff_drain();
+            __syncthreads();
+            const long t_first = (long)tile * q.nk;
+            const int w_first = ntsk_owner(t_first, q.P, q.total), w_last = ntsk_owner(t_first + q.nk - 1, q.P, q.total);
+            if (tid == 0) s_last = xv_ticket_take(q.tickets + tile, (unsigned)(w_last - w_first + 1)) ? 1 : 0;
+            __syncthreads();
+            if (!s_last) continue;                       // (uniform; the next share starts behind the barrier above)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int v = w_first; v <= w_last; ++v) {    // in K order, whoever arrived last
+                const int v_first_tile = (int)(((long)v * q.total / q.P) / q.nk);
+                const float* src = q.slab + ((long)v * 2 + (tile == v_first_tile ? 0 : 1)) * (BM * BN) + tid * 16;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {            // (four loads at a time: the register budget of this kernel is full)
+                    f32x4 x[4];
+                    xv_handoff_load4x4(src + h * (256 * 16), x);
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const int r = 4 * h + k4;
+                        acc[0][0][r] += x[k4][0]; acc[0][1][r] += x[k4][1]; acc[1][0][r] += x[k4][2]; acc[1][1][r] += x[k4][3];
+                    }
+                }
+            }
+        }
+        nt_store_tile(acc, p.C, p.ldc, p.bias, m0, n0, p.M, p.N, wr, wc, li, lh);
+        if (STATS) {
+            xv_tile_stats_epilogue(acc, smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part_sum);
+            __syncthreads();                             // the statistics use the staging buffers as scratch
+        }
+    }
+}
+
 // out[m][n] = sum_z slab[z][m][n] (+ bias[n])
 __global__ void xv_splitk_reduce_kernel(const float* __restrict__ slab, int splits, long split_stride, int M, int N,
                                         int lds, const float* __restrict__ bias, float* __restrict__ out, long ldo) {
@@ -378,8 +606,6 @@ __global__ void xv_splitk_reduce_kernel(const float* __restrict__ slab, int spli
 }
 
 // ---- live launch timing (bench.py roofline leg) ----------------------------------------
-#include <algorithm>
-#include <vector>
 namespace {
 struct ProfRec { hipEvent_t a, b; int kind; double flops; };
 bool g_prof_on = false;
@@ -427,6 +653,29 @@ extern "C" int xv_profile_end(int64_t launches[XV_PROFILE_KINDS], double ms[XV_P
     return 0;
 }
 
+// Tickets of the split hand-over: one zeroed uint32 per output tile, re-armed by the workgroup that takes the last one.  One array per
+// STREAM: launches on a stream run in order, so the array is clean again before the next launch on it reads it, and launches on
+// different streams (the engine runs weight gradients on two side streams) never share one.  Shared by the TN kernel and the
+// evenly scheduled NT kernel: both leave every ticket at zero.
+#define XV_TN_MAX_TILES 16384
+static unsigned* tn_tickets_for(hipStream_t s) {
+    static std::mutex mu;
+    static std::map<hipStream_t, unsigned*> pool;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = pool.find(s);
+    if (it != pool.end()) return it->second;
+    unsigned* t = nullptr;
+    if (hipMalloc((void**)&t, XV_TN_MAX_TILES * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(t, 0, XV_TN_MAX_TILES * sizeof(unsigned)) != hipSuccess) return nullptr;      // (synchronous: visible to every stream)
+    pool[s] = t;
+    return t;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     XV_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm_nt: K/lda/ldb must be multiples of 4 (K=%d lda=%ld ldb=%ld)", g.K, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0, "gemm_nt: operands must be 16-byte aligned");
@@ -445,6 +694,29 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     p.bias = g.bias; p.part_sum = nullptr; p.part_m2 = nullptr;
     const int tiles = p.tiles_m * p.tiles_n;
     const int ksteps = xv_cdiv(g.K, BK);
+    // evenly scheduled path (default): XV_NT_WPC workgroups per CU, each at least 4 K-steps long.  XV_NT_STREAMK=0 keeps the one-
+    // workgroup-per-tile kernel below (diagnostics / A-B runs).
+    static const int use_sk = env_int("XV_NT_STREAMK", 1), wpc = std::min(std::max(env_int("XV_NT_WPC", 3), 1), XV_WGS_PER_CU);
+    if (use_sk) {
+        NTSKArgs q;
+        q.nk = ksteps;
+        q.total = (long)tiles * ksteps;
+        q.P = (int)std::min<long>(256L * wpc, std::max<long>(1, q.total / 4));
+        const bool shared_tiles = q.total % q.P != 0 || (q.total / q.P) % ksteps != 0;
+        if (!shared_tiles || ((size_t)q.P * 2 * BM * BN * sizeof(float) <= g.ws_bytes && g.ws && tiles <= XV_TN_MAX_TILES)) {
+            p.C = g.C; p.ldc = g.ldc; p.c_split_stride = 0; p.k_chunk = ksteps * BK;
+            p.part_sum = g.bn_part; p.part_m2 = nullptr;
+            q.g = p;
+            q.slab = (float*)g.ws;
+            q.tickets = shared_tiles ? tn_tickets_for(s) : nullptr;
+            XV_REQUIRE(!shared_tiles || (q.tickets && ((uintptr_t)q.slab % 16) == 0), "gemm_nt: hand-over buffers unavailable");
+            XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
+            if (g.bn_part) hipLaunchKernelGGL(xv_gemm_nt_sk_kernel<true>, dim3(q.P), dim3(256), 0, s, q);
+            else hipLaunchKernelGGL(xv_gemm_nt_sk_kernel<false>, dim3(q.P), dim3(256), 0, s, q);
+            XV_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     int splits = 1;
     if (!g.bn_part && tiles < XV_RESIDENT_WGS / 2 && ksteps >= 8) {
         splits = XV_RESIDENT_WGS / tiles;
@@ -499,10 +771,16 @@ struct TNArgs {
     const float* A; long lda; int a_pitch;
     const float* B; long ldb; int b_pitch;
     int rps; float inv_rps;
-    float* P;
+    float* P;                 // split partials, [split][tile][16 registers][256 threads] float4 (what each lane holds, as it holds it)
     int M, N, R, r_chunk;
     int tiles_m, tiles_n;
     const float* zero;
+    // epilogue: out[(j*C + c)][n] = sum over the splits of acc[j*c_pad + c][n] (+ l2 * w[(j*C + c)][n]); rows with c >= C are dropped
+    int splits;
+    unsigned* tickets;        // one per tile, zero between launches
+    float* out; long ldo;
+    int C, c_pad;
+    const float* w; long ldw; float l2;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -512,8 +790,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // wave's 64 at reduction row r = 2*ks + half, which feed the two 32x32 accumulators in that
 // direction (the MFMA only needs A and B to agree on r).  So accumulator (a,b) register reg of
 // lane l holds  m = m0 + wr*64 + 2*row(reg,l) + a,  n = n0 + wc*64 + 2*(l&31) + b.
-__global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * BM];   // [buf][A|B][32][128]
+__global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(128))) void xv_gemm_tn_kernel(TNArgs p) {
+#ifndef XV_TN_STAGES
+#define XV_TN_STAGES XV_NT_STAGES
+#endif
+    __shared__ __attribute__((aligned(16))) float smem[XV_TN_STAGES * 2 * BK * BM];   // [slot][A|B][BK][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -567,10 +848,65 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    if (nk > 0) gstage(0, 0);
-    __syncthreads();
     const int a_off = lh * BM + wr * 64 + 2 * li;
     const int b_off = lh * BN + wc * 64 + 2 * li;
+#if XV_TN_STAGES >= 3
+    // the LDS ring of the NT kernel (see there): transfers get XV_TN_STAGES - 1 K-steps to land, one barrier per K-step
+    static_assert(XV_TN_STAGES <= 4, "s_waitcnt immediates are spelled out for at most 4 slots");
+    auto wait_younger = [&](int younger) {
+        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN_RPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TN_RPT) : "memory");
+    };
+    for (int j = 0; j < XV_TN_STAGES - 1; ++j)
+        if (j < nk) gstage(j, j);
+    wait_younger(min(nk, XV_TN_STAGES - 1) - 1);
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nbuf = buf == 0 ? XV_TN_STAGES - 1 : buf - 1;
+        if (kt + XV_TN_STAGES - 1 < nk) gstage(kt + XV_TN_STAGES - 1, nbuf);
+        const float* sa = smem + buf * (2 * BK * BM) + a_off;
+        const float* sb = smem + buf * (2 * BK * BM) + BK * BM + b_off;
+        // Software pipeline over the two halves of the K-step: the second half's 16 fragment reads
+        // are issued BEFORE the first half's 32 MFMAs.  sched_barrier pins that order - hipcc's
+        // scheduler otherwise sinks every ds_read to just in front of its use and exposes the LDS
+        // latency once per 8 MFMAs.
+        f32x2 af[BK / 4], bf[BK / 4], an[BK / 4], bn[BK / 4];
+#pragma unroll
+        for (int j = 0; j < BK / 4; ++j) {
+            af[j] = *(const f32x2*)(sa + 2 * j * BM);
+            bf[j] = *(const f32x2*)(sb + 2 * j * BN);
+        }
+#pragma unroll
+        for (int j = 0; j < BK / 4; ++j) {
+            an[j] = *(const f32x2*)(sa + 2 * (BK / 4 + j) * BM);
+            bn[j] = *(const f32x2*)(sb + 2 * (BK / 4 + j) * BN);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < BK / 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BK / 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].y, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            wait_younger(min(nk - 1, kt + XV_TN_STAGES - 1) - (kt + 1));
+            __builtin_amdgcn_s_barrier();
+        }
+        buf = buf == XV_TN_STAGES - 1 ? 0 : buf + 1;
+    }
+#else
+    if (nk > 0) gstage(0, 0);
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
@@ -608,18 +944,81 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p
         }
         __syncthreads();
     }
+#endif
 
-    float* P = p.P + (long)split * p.M * p.N;
+    // ---- epilogue: the split partials are summed by the workgroup that finishes its tile LAST (xv_handoff_* contract, xv_common.h) - in
+    // split order, so the result does not depend on which one that is - and the sum goes straight to the gradient tensor with the
+    // regulariser's l2 * w folded in.  (Round 2 wrote row-major slabs and summed them in a second kernel: 8 more launches per step and
+    // the slabs read back through HBM; here every lane stores and reloads exactly the registers it holds, 16 bytes per lane and 1 KB
+    // contiguous per wave instruction.)
+    // Slab of one (split, tile): [group g = register / 4][thread][register % 4] float4 - a lane's four float4 of one group are 64 contiguous
+    // bytes (one base address + immediate offsets), a wave instruction covers 4 KB with every 128-byte line half used and its neighbour
+    // instruction using the other half.
+    __shared__ int s_last;
+    if (p.splits > 1) {
+        float* mine = p.P + ((long)split * tiles + t) * (BM * BN) + tid * 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x4 v = {acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]};
+            xv_handoff_store4(mine + (r >> 2) * (256 * 16) + (r & 3) * 4, v);
+        }
+        xv_handoff_drain();
+        __syncthreads();
+        if (tid == 0) s_last = xv_ticket_take(p.tickets + t, (unsigned)p.splits) ? 1 : 0;
+        __syncthreads();
+        if (!s_last) return;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        const float* all = p.P + (long)t * (BM * BN) + tid * 16;
+        const long zstride = (long)tiles * (BM * BN);
+        for (int z = 0; z < p.splits; ++z) {
+            const float* src = all + z * zstride;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 v[8];
+                xv_handoff_load4x8(src + (2 * h) * (256 * 16), src + (2 * h + 1) * (256 * 16), v);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = 8 * h + u;
+                    acc[0][0][r] += v[u][0]; acc[0][1][r] += v[u][1]; acc[1][0][r] += v[u][2]; acc[1][1][r] += v[u][3];
+                }
+            }
+        }
+    }
+    // the tile's sum -> out (TF layout [k][C][n]: padded channel rows dropped), + l2 * w.  The regulariser's weights are fetched 16 rows
+    // at a time in front of the stores (a load inside each predicated store block would make every store wait for its own load:
+    // the serialised tail nt_store_tile describes); invalid positions read the zero page.
     const int n = n0 + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int m = m0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;
-            if (m < p.M && n < p.N) {
-                f32x2 v = {acc[a][0][r], acc[a][1][r]};
-                *(f32x2*)(P + (long)m * p.N + n) = v;
+        for (int g = 0; g < 2; ++g) {      // 8 registers at a time (register budget: 128)
+            int row[8];                    // output row, -1 = not stored
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = 8 * g + u;
+                const int m = m0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;
+                const int j = m / p.c_pad, c = m - j * p.c_pad;
+                row[u] = (m < p.M && n < p.N && c < p.C) ? j * p.C + c : -1;
             }
+            if (p.w) {
+                f32x2 wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = *(const f32x2*)(row[u] >= 0 ? p.w + (long)row[u] * p.ldw + n : p.zero);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc[a][0][8 * g + u] += p.l2 * wv[u].x; acc[a][1][8 * g + u] += p.l2 * wv[u].y; }
+                asm volatile("" : "+v"(acc[a][0]), "+v"(acc[a][1]));      // keeps hipcc from sinking the loads back into the store blocks
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (row[u] >= 0) {
+                    const f32x2 v = {acc[a][0][8 * g + u], acc[a][1][8 * g + u]};
+                    *(f32x2*)(p.out + (long)row[u] * p.ldo + n) = v;
+                }
         }
 }
 
@@ -637,11 +1036,19 @@ int xv_tn_splits(int M, int N, int R) {
     return xv_cdiv(R, chunk);
 }
 
+size_t xv_tn_slab_bytes(int M, int N, int R) {
+    const int splits = xv_tn_splits(M, N, R);
+    return splits > 1 ? (size_t)splits * xv_cdiv(M, BM) * xv_cdiv(N, BN) * BM * BN * sizeof(float) : 0;
+}
+
 int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     XV_REQUIRE(g.M % 4 == 0 && g.N % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0,
                "gemm_tn: M/N/lda/ldb must be multiples of 4 (M=%d N=%d lda=%ld ldb=%ld)", g.M, g.N, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm_tn: operands must be 16-byte aligned");
     XV_REQUIRE(g.M > 0 && g.N > 0 && g.R > 0 && g.splits >= 1, "gemm_tn: empty problem");
+    XV_REQUIRE(g.out && g.c_pad > 0 && g.C > 0 && g.C <= g.c_pad && g.M % g.c_pad == 0 && g.ldo % 2 == 0 && ((uintptr_t)g.out % 8) == 0,
+               "gemm_tn: bad output description (M=%d C=%d c_pad=%d ldo=%ld)", g.M, g.C, g.c_pad, g.ldo);
+    XV_REQUIRE(!g.w || (g.ldw % 2 == 0 && ((uintptr_t)g.w % 8) == 0), "gemm_tn: the regulariser's weights must be 8-byte aligned rows");
     if (ensure_zero_page()) return 1;
     TNArgs p;
     p.zero = g_zero_page;
@@ -656,7 +1063,15 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     p.r_chunk = xv_cdiv(ksteps, g.splits) * BK;
     int splits = xv_cdiv(g.R, p.r_chunk);
     XV_REQUIRE(splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", splits, g.splits);
-    dim3 grid(p.tiles_m * p.tiles_n * splits, 1, 1);
+    const int tiles = p.tiles_m * p.tiles_n;
+    XV_REQUIRE(tiles <= XV_TN_MAX_TILES, "gemm_tn: %d output tiles (at most %d)", tiles, XV_TN_MAX_TILES);
+    XV_REQUIRE(splits == 1 || (g.P && ((uintptr_t)g.P % 16) == 0), "gemm_tn: the split partials need a 16-byte aligned scratch buffer");
+    p.splits = splits;
+    p.tickets = splits > 1 ? tn_tickets_for(s) : nullptr;
+    XV_REQUIRE(splits == 1 || p.tickets, "gemm_tn: could not allocate the hand-over tickets");
+    p.out = g.out; p.ldo = g.ldo; p.C = g.C; p.c_pad = g.c_pad;
+    p.w = g.l2 != 0.f ? g.w : nullptr; p.ldw = g.ldw; p.l2 = g.l2;
+    dim3 grid(tiles * splits, 1, 1);
     {
         XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
         hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
@@ -669,8 +1084,8 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
 // Public op-level wrappers around the two GEMMs
 // -------------------------------------------------------------------------------------
 extern "C" size_t xv_op_workspace_bytes(int rows, int cols_in, int cols_out) {
-    // split slabs: at most ~512 workgroup tiles of 128x128 floats, plus column partials
-    size_t slabs = (size_t)640 * BM * BN * sizeof(float);
+    // split slabs: at most XV_RESIDENT_WGS (+ one ragged round) workgroup tiles of 128x128 floats, plus column partials
+    size_t slabs = (size_t)(2 * XV_RESIDENT_WGS + 256) * BM * BN * sizeof(float);      // NT: two shared tiles per workgroup
     size_t wg = (size_t)xv_align(cols_in, BM) * xv_align(cols_out, BN) * sizeof(float) * 8;
     size_t part = ((size_t)xv_cdiv(rows > 0 ? rows : 1, 64) * 2 + 2) * (size_t)(cols_out > cols_in ? cols_out : cols_in) * sizeof(float);
     size_t m = slabs > wg ? slabs : wg;
@@ -738,11 +1153,9 @@ extern "C" int xv_affine_wgrad(void* stream, const float* x, int segs, int t_in,
     g.B = dz + (long)dz_row0 * o; g.ldb = o; g.b_rps = t_out; g.b_pitch = dz_seg_pitch;
     g.M = k * c_pad; g.N = o; g.R = segs * t_out;
     g.splits = xv_tn_splits(g.M, g.N, g.R);
-    XV_REQUIRE((size_t)g.splits * g.M * g.N * sizeof(float) <= ws_bytes, "affine_wgrad: workspace too small (%zu needed)",
-               (size_t)g.splits * g.M * g.N * sizeof(float));
+    XV_REQUIRE(xv_tn_slab_bytes(g.M, g.N, g.R) <= ws_bytes, "affine_wgrad: workspace too small (%zu needed)", xv_tn_slab_bytes(g.M, g.N, g.R));
     g.P = (float*)ws;
-    int rc = xv_launch_gemm_tn((hipStream_t)stream, g);
-    if (rc) return rc;
-    return xv_launch_wgrad_reduce((hipStream_t)stream, g.P, g.splits, k, c, c_pad, o, o, l2_scale != 0.f ? kernel : nullptr, o,
-                                  l2_scale, dkernel, o);
+    g.out = dkernel; g.ldo = o; g.C = c; g.c_pad = c_pad;
+    g.w = kernel; g.ldw = o; g.l2 = l2_scale;
+    return xv_launch_gemm_tn((hipStream_t)stream, g);
 }

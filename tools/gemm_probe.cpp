@@ -36,10 +36,17 @@ static float* dev_random(size_t n, float scale, unsigned seed) {
     return p;
 }
 
+// [measured, round 3] a kernel with LDS fragment reads runs 5-15 % slower for the first ~50 ms after the chip was idle (launch periods
+// of one back-to-back burst: 549 -> 519 us, 488 -> 459 us; an MFMA-only body is flat), so every configuration is warmed with >= 150 ms of
+// back-to-back launches before the timed burst, which follows WITHOUT a host synchronisation in between.
 template <class F> static double time_us(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 3; ++i) f();
-    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < 8; ++i) f();
+    CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+    float wms; CK(hipEventElapsedTime(&wms, a, b));
+    const int warm = (int)(150.0 / (wms / 8.0 + 1e-3)) + 1;
+    for (int i = 0; i < warm; ++i) f();
     CK(hipEventRecord(a, 0));
     for (int i = 0; i < reps; ++i) f();
     CK(hipEventRecord(b, 0));
