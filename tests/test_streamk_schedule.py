@@ -1,0 +1,69 @@
+"""The even ("stream-K") schedule of the fp32 NT GEMM (csrc/xv_gemm.hip, xv_gemm_nt_sk_kernel / xv_launch_gemm_nt) restated in Python and
+checked exhaustively on the layer shapes: the kernel's integer formulas must tile the (tile, K-step) units exactly once, agree on who
+shares a tile, and never hand two shares of one workgroup the same slab slot.  (Host logic only; the kernel itself is compared with the
+oracle in tests/test_gpu_ops.py.)"""
+import pytest
+
+
+def schedule(tiles, nk, P):
+    total = tiles * nk
+    begin = [w * total // P for w in range(P + 1)]                       # u = w * total / P
+    owner = lambda u: ((u + 1) * P - 1) // total                         # ntsk_owner
+    shares = []                                                          # (worker, tile, kt0, kt1, slot)
+    for w in range(P):
+        u, u_end = begin[w], begin[w + 1]
+        first_tile = u // nk
+        while u < u_end:
+            tile = u // nk
+            kt0 = u - tile * nk
+            kt1 = min(nk, kt0 + (u_end - u))
+            shares.append((w, tile, kt0, kt1, 0 if tile == first_tile else 1))
+            u += kt1 - kt0
+    return total, begin, owner, shares
+
+
+SHAPES = [  # (rows, cols, K) -> tiles = ceil(rows/128) * ceil(cols/128), nk = ceil(K/16)
+    (24576, 512, 2560), (25088, 512, 2560), (23808, 512, 3584), (24576, 512, 3584), (23808, 512, 512), (23808, 1500, 512), (23808, 512, 1500),
+    (18688, 512, 2560), (18304, 512, 3584), (12544, 512, 160), (128, 7352, 512), (130, 512, 3000), (51200, 1500, 512), (37, 100, 68), (1, 4, 4)]
+
+
+@pytest.mark.parametrize("rows,cols,K", SHAPES)
+@pytest.mark.parametrize("wpc", [3, 4])
+def test_every_unit_once_and_consistent_sharing(rows, cols, K, wpc):
+    tiles = -(-rows // 128) * -(-cols // 128)
+    nk = -(-K // 16)
+    total = tiles * nk
+    P = min(256 * wpc, max(1, total // 4), 8 * tiles)                    # xv_launch_gemm_nt, the evenly scheduled form
+    total, begin, owner, shares = schedule(tiles, nk, P)
+    covered = {}
+    for w, tile, kt0, kt1, slot in shares:
+        assert 0 <= kt0 < kt1 <= nk
+        for kt in range(kt0, kt1):
+            assert (tile, kt) not in covered
+            covered[(tile, kt)] = w
+    assert len(covered) == total
+    # equal work: run lengths differ by at most one K-step
+    lens = [begin[w + 1] - begin[w] for w in range(P)]
+    assert max(lens) - min(lens) <= 1 and min(lens) >= 1
+    # the owner formula is the inverse of the ranges
+    for u in list(range(0, total, max(1, total // 997))) + [0, total - 1]:
+        w = owner(u)
+        assert begin[w] <= u < begin[w + 1]
+    by_tile = {}
+    for w, tile, kt0, kt1, slot in shares:
+        by_tile.setdefault(tile, []).append((w, kt0, kt1, slot))
+    slots = set()
+    for tile, segs in by_tile.items():
+        w_first, w_last = owner(tile * nk), owner(tile * nk + nk - 1)
+        assert [s[0] for s in segs] == list(range(w_first, w_last + 1))   # the ticket count and the reducer's loop
+        assert segs[0][1] == 0 and segs[-1][2] == nk and all(a[2] == b[1] for a, b in zip(segs, segs[1:]))   # K order
+        if len(segs) > 1:
+            for w, kt0, kt1, slot in segs:
+                assert (w, slot) not in slots                            # a workgroup's two shared tiles never collide
+                slots.add((w, slot))
+                assert slot == (0 if tile == begin[w] // nk else 1)       # what the reducer recomputes for workgroup w
+    # a tile is never split into more than a handful of shares (its last workgroup sums them alone)
+    assert max(len(v) for v in by_tile.values()) <= 10
+    # a workgroup has at most two shared tiles
+    for w in range(P):
+        assert sum(1 for (ww, tile, kt0, kt1, slot) in shares if ww == w and (kt0 != 0 or kt1 != nk)) <= 2

@@ -65,8 +65,11 @@ __device__ __forceinline__ void xv_handoff_drain() { asm volatile("s_waitcnt vmc
 // the guide's hand-off table rates fastest: a 4-byte sc1 store costs ~6x the time per byte).  HIP has no 16-byte atomic, so these are
 // inline assembly: the compiler does not count them in its own s_waitcnt bookkeeping, which only ever makes ITS waits longer (vmcnt
 // retires in issue order); the loads wait for themselves, the stores are drained by xv_handoff_drain.
+// The s_nop behind the store is the ISA's "VMEM store of more than 64 bits, then a write of its data VGPRs" hazard (2 wait states):
+// hipcc pads it for its own stores but cannot see through inline assembly, and the very next instruction here usually builds the
+// next float4 in the same registers.  [measured, round 3: without it one register in sixteen of every shared tile arrived corrupted]
 __device__ __forceinline__ void xv_handoff_store4(float* p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 // four loads in flight: p + {0, 4, 8, 12} floats
 __device__ __forceinline__ void xv_handoff_load4x4(const float* p, f32x4 (&v)[4]) {
@@ -131,21 +134,15 @@ struct XvGemmNT {
 };
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g);
 
-// out[(j*C + c)][n] = sum_r A[amap(r)][j*c_pad + c] * B[bmap(r)][n]  (+ l2 * w[(j*C + c)][n])   ("TN", reduction over rows; rows with
-// c >= C - padded input channels - are dropped).  The reduction is split over `splits` workgroups per output tile; the workgroup that
-// finishes a tile last sums the partials in split order inside the same launch (xv_gemm.hip).
+// P[z][m][n] = sum_{r in chunk z} A[amap(r)][m] * B[bmap(r)][n]   ("TN", reduction over rows)
 struct XvGemmTN {
     const float* A; long lda; int a_rps; int a_pitch;   // [R] rows mapped, M columns used
     const float* B; long ldb; int b_rps; int b_pitch;   // [R] rows mapped, N columns used
     int M, N, R;
-    float* P;            // scratch for the split partials: xv_tn_slab_bytes(M, N, R) bytes
+    float* P;            // slabs [splits][M][N]
     int splits;          // chosen by xv_tn_splits
-    float* out; long ldo;             // [(M / c_pad) * C][ldo]
-    int C, c_pad;                     // M = k * c_pad; C == c_pad == M for a plain matrix
-    const float* w; long ldw; float l2;      // optional regulariser term
 };
 int xv_tn_splits(int M, int N, int R);
-size_t xv_tn_slab_bytes(int M, int N, int R);
 int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g);
 int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int C, int c_pad, int n_in, int n_out, const float* w,
                            long ldw, float l2, float* out, long ldo);

@@ -364,7 +364,7 @@ int alloc_buffers(xv_engine* e) {
         Affine& a = e->L[i];
         size_t r = lrows(i);
         int M = a.k * a.c_pad, Nn = a.c_out;
-        size_t s = xv_tn_slab_bytes(M, Nn, (int)r);
+        size_t s = (size_t)xv_tn_splits(M, Nn, (int)r) * M * Nn * sizeof(float);
         if (s > ws) ws = s;
         if (e->f16 && is_frame(e, i)) {
             s = (size_t)xv_tn16_splits(M, a.o_ld, (int)r) * M * a.o_ld * sizeof(float);
@@ -372,7 +372,7 @@ int alloc_buffers(xv_engine* e) {
         }
     }
     if (e->N > 0) {
-        size_t s = xv_tn_slab_bytes(e->Lout, e->ldl, (int)B);
+        size_t s = (size_t)xv_tn_splits(e->Lout, e->ldl, (int)B) * e->Lout * e->ldl * sizeof(float);
         if (s > ws) ws = s;
         s = (size_t)16 * B * e->ldl * sizeof(float);
         if (s > ws) ws = s;
@@ -1138,7 +1138,10 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     bool ring = false;
     int rc = layer_dz(e, s, a, da, segs, t_out, pad, act_out, &dz, &ring);
     if (rc) return rc;
-    rc = layer_wgrad(e, s, a, x, dz, segs, t_in, pad, ring);
+    // the first layer (dx == nullptr) is the end of the chain: nothing is left on `s` to overlap with, and the side stream is still
+    // busy with the layer above's weight gradient - its own (small) weight gradient finishes sooner in line on `s`, beside that one
+    // (round-2 timeline: 166 us of MFMA-idle tail behind tdnn2's weight gradient: tdnn1's, two slab sums, the update)
+    rc = layer_wgrad(e, s, a, x, dz, segs, t_in, pad, ring && dx != nullptr);
     if (rc) return rc;
     if (dx) {
         const float* wf = a.k > 1 ? a.wf : vptr(e, a.v_kernel);
@@ -1309,10 +1312,11 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             w.B = e->dlogits; w.ldb = e->ldl; w.b_rps = b; w.b_pitch = b;
             w.M = e->Lout; w.N = e->ldl; w.R = b;
             w.splits = xv_tn_splits(w.M, w.N, w.R);
-            XV_REQUIRE(xv_tn_slab_bytes(w.M, w.N, w.R) <= e->ws_bytes, "engine_backward: workspace too small for the loss weight gradient");
+            XV_REQUIRE((size_t)w.splits * w.M * w.N * sizeof(float) <= e->ws_bytes, "engine_backward: workspace too small for the loss weight gradient");
             w.P = (float*)lws;
-            w.out = e->dwn; w.ldo = e->ldl; w.C = w.c_pad = e->Lout;
             rc = xv_launch_gemm_tn(ss, w);
+            if (rc) return rc;
+            rc = xv_launch_wgrad_reduce(ss, w.P, w.splits, 1, e->Lout, e->Lout, e->ldl, e->ldl, nullptr, 0, 0.f, e->dwn, e->ldl);
             if (rc) return rc;
             if (e->with_margin && c.aux_mhe) {
                 rc = xv_mhe_add_grad(ss, e->dwn, e->Lout, e->N, e->ldl, e->mhe_coef, e->mhe_counts);

@@ -57,6 +57,7 @@ struct NTArgs {
     float* part_sum; float* part_m2;
     const float* zero;
     int stamp_half;      // diagnostics (XV_NT_STAMP)
+    int taps; long a_rows;      // context-window form: K = taps * channels, rows of the tensor behind A
 };
 
 // Out-of-range rows / k read this 16-byte zero page instead of being masked after the load: the
@@ -447,11 +448,24 @@ struct NTSKArgs {
 
 __device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (int)((((u + 1) * P) - 1) / total); }
 
-template <bool STATS>
-__global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(128))) void xv_gemm_nt_sk_kernel(NTSKArgs q) {
+// CONV = the context-window form for layers with taps > 1 (tdnn.py:39-93 and their data gradients): the K-steps of a tile run channel
+// chunk outer / tap inner, and the rows  xrow(m0) ... xrow(m0 + 127) + taps - 1  of ONE 16-channel chunk of x sit in LDS once for all
+// taps (rows of tap j = rows of tap 0 shifted by j), so x travels L2 -> LDS once instead of once per tap and only the weight tile is
+// staged per K-step.  [r02_pmc_traffic.json: the generic form moved 2.6-2.7 x the algorithmic bytes past L2 on tdnn2 / tdnn3]
+#define NT_WIN_ROWS 192                      // window rows per slot: 128 + (taps - 1) * (1 + chunk boundaries inside a tile), 3 DMA pieces per wave
+template <bool STATS, bool CONV>
+#ifndef XV_SK_VGPR_ATTR
+#define XV_SK_VGPR_ATTR __attribute__((amdgpu_num_vgpr(128)))
+#endif
+#ifndef XV_SK_NOSHARE
+#define XV_SK_NOSHARE 0         // diagnostics: 1 compiles the shared-tile path out (only valid when no tile is shared)
+#endif
+__global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt_sk_kernel(NTSKArgs q) {
     const NTArgs& p = q.g;
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * NT_PITCH];
-    __shared__ int s_last;
+    constexpr int A_SLOT = CONV ? NT_WIN_ROWS * NT_PITCH : BM * NT_PITCH;       // floats per A slot
+    constexpr int B_SLOT = BM * NT_PITCH;
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_SLOT + 2 * B_SLOT];   // [A slot 0 | A slot 1 | B slot 0 | B slot 1]
+    int& s_last = *(int*)smem;      // (the staging buffers are idle when it is used; a variable of its own would be the 40 961st byte: 3 workgroups per CU)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -459,16 +473,29 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     const long u_end = (long)(w + 1) * q.total / q.P;
     long u = (long)w * q.total / q.P;
     const int first_tile = (int)(u / q.nk);
+#if XV_NT_STAMP
+    XV_STAMP(0);
+    if (tid == 0 && blockIdx.x < XV_DBG_STAMP_WGS) {
+        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
+                                            ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 1] = 0;
+    }
+    bool first_seg = true;
+#endif
 
     constexpr int NT_RPI = 64 / NT_KQ;          // tile rows per wave-instruction (16 at BK=16)
+    static_assert(!CONV || (BK == 16 && NT_WIN_ROWS % (4 * NT_RPI) == 0), "the window is staged in whole 16-row pieces, equally by the 4 waves");
+    constexpr int WIN_PIECES = NT_WIN_ROWS / (4 * NT_RPI);      // per wave
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int lrow = lane / NT_KQ, lpos = lane % NT_KQ;
     const float* __restrict__ zp = p.zero;
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    const int a_off = (wr * 64 + li) * NT_PITCH;
     const int b_off = (wc * 64 + li) * NT_PITCH;
     const int fsw = NT_SWZ(li);
+    const int taps = CONV ? p.taps : 1;
+    const int C = p.K / taps;                   // channels per tap (CONV: a multiple of 16)
 
     while (u < u_end) {
         const int tile = (int)(u / q.nk);
@@ -478,36 +505,76 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         const int m0 = tile_m * BM, n0 = tile_n * BN;
 
         // per-lane source pointers of this tile (swizzled chunk folded in; out-of-range rows -> zero page)
-        const float* ap[NT_RPT];
+        const float* ap[CONV ? WIN_PIECES : NT_RPT];
         const float* bp[NT_RPT];
         int ksrc[NT_RPT];
+        int a_row[2];                           // CONV: window row of this lane's two fragment rows at tap 0; else their LDS offset
 #pragma unroll
         for (int i = 0; i < NT_RPT; ++i) {
             const int row = NT_RPI * (NT_RPT * wave + i) + lrow;
             ksrc[i] = ((lpos ^ NT_SWZ(row)) << 2);
-            const int m = m0 + row;
-            const int mm = m < p.M ? m : 0;
-            const int seg = mm / p.a_rps, tt = mm - seg * p.a_rps;
-            ap[i] = (m < p.M ? p.A + ((long)seg * p.a_pitch + tt) * p.lda : zp) + ksrc[i];
             const int n = n0 + row;
             bp[i] = (n < p.N ? p.Bt + (long)n * p.ldb : zp) + ksrc[i];
         }
-        auto gstage = [&](int kt, int buf) {
-            float* sa = smem + buf * (2 * BM * NT_PITCH) + NT_RPI * NT_RPT * uwave * NT_PITCH;
-            float* sb = sa + BM * NT_PITCH;
-            const int k0 = kt * BK;
-            if (k0 + BK <= p.K) {
+        if (CONV) {
+            const int seg0 = m0 / p.a_rps;
+            const long xrow0 = (long)seg0 * p.a_pitch + (m0 - seg0 * p.a_rps);
 #pragma unroll
-                for (int i = 0; i < NT_RPT; ++i) {
-                    __builtin_amdgcn_global_load_lds((gptr_t)(ap[i] + k0), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+            for (int i = 0; i < WIN_PIECES; ++i) {
+                const int wrow = NT_RPI * (WIN_PIECES * wave + i) + lrow;
+                const long xr = xrow0 + wrow;
+                ap[i] = xr < p.a_rows ? p.A + xr * p.lda + ((lpos ^ NT_SWZ(wrow)) << 2) : zp;
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int m = min(m0 + wr * 64 + a * 32 + li, p.M - 1);
+                const int seg = m / p.a_rps;
+                a_row[a] = (int)((long)seg * p.a_pitch + (m - seg * p.a_rps) - xrow0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT_RPT; ++i) {
+                const int row = NT_RPI * (NT_RPT * wave + i) + lrow;
+                const int m = m0 + row;
+                const int mm = m < p.M ? m : 0;
+                const int seg = mm / p.a_rps, tt = mm - seg * p.a_rps;
+                ap[i] = (m < p.M ? p.A + ((long)seg * p.a_pitch + tt) * p.lda : zp) + ksrc[i];
+            }
+            a_row[0] = (wr * 64 + li) * NT_PITCH;
+            a_row[1] = a_row[0] + 32 * NT_PITCH;
+        }
+        // K-step kt of a tile: generic = columns [kt*BK, +BK) of the spliced row; CONV = channel chunk kt / taps of tap kt % taps
+        auto stage_b = [&](int kt, int slot) {
+            float* sb = smem + 2 * A_SLOT + slot * B_SLOT + NT_RPI * NT_RPT * uwave * NT_PITCH;
+            const int k0 = CONV ? (kt % taps) * C + (kt / taps) * BK : kt * BK;
+            if (CONV || k0 + BK <= p.K) {
+#pragma unroll
+                for (int i = 0; i < NT_RPT; ++i)
                     __builtin_amdgcn_global_load_lds((gptr_t)(bp[i] + k0), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
-                }
             } else {                       // ragged last step of a row: chunks at or beyond K come from the zero page
 #pragma unroll
-                for (int i = 0; i < NT_RPT; ++i) {
-                    const bool kv = k0 + ksrc[i] < p.K;
-                    __builtin_amdgcn_global_load_lds((gptr_t)(kv ? ap[i] + k0 : zp), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr_t)(kv ? bp[i] + k0 : zp), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                for (int i = 0; i < NT_RPT; ++i)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(k0 + ksrc[i] < p.K ? bp[i] + k0 : zp), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+            }
+        };
+        auto stage_a = [&](int kt, int slot) {      // generic: the tile's rows of K-step kt; CONV: the window of channel chunk kt / taps
+            if (CONV) {
+                float* sa = smem + slot * A_SLOT + NT_RPI * WIN_PIECES * uwave * NT_PITCH;
+                const int c0 = (kt / taps) * BK;
+#pragma unroll
+                for (int i = 0; i < WIN_PIECES; ++i)      // (a row beyond the tensor points at the zero page, which is at least K floats long: + c0 stays inside)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(ap[i] + c0), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+            } else {
+                float* sa = smem + slot * A_SLOT + NT_RPI * NT_RPT * uwave * NT_PITCH;
+                const int k0 = kt * BK;
+                if (k0 + BK <= p.K) {          // full K-step (uniform): the address is base + k0, nothing else per step
+#pragma unroll
+                    for (int i = 0; i < NT_RPT; ++i)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(ap[i] + k0), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NT_RPT; ++i)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(k0 + ksrc[i] < p.K ? ap[i] + k0 : zp), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
                 }
             }
         };
@@ -520,19 +587,43 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-        gstage(kt0, 0);
+        stage_a(kt0, CONV ? (kt0 / taps) & 1 : 0);
+        stage_b(kt0, 0);
         __syncthreads();
+#if XV_NT_STAMP
+        if (first_seg) { XV_STAMP(1); first_seg = false; }
+#endif
         for (int kt = kt0; kt < kt1; ++kt) {
             const int buf = (kt - kt0) & 1;
-            if (kt + 1 < kt1) gstage(kt + 1, buf ^ 1);
-            const float* sa = smem + buf * (2 * BM * NT_PITCH);
-            const float* sb = sa + BM * NT_PITCH;
+            int tap = 0, aslot = buf;
+            if (CONV) {
+                const int cc = kt / taps;
+                tap = kt - cc * taps;
+                aslot = cc & 1;
+                if (kt + 1 < kt1) {
+                    if (tap + 1 == taps) stage_a(kt + 1, aslot ^ 1);      // the next K-step opens the next channel chunk
+                    stage_b(kt + 1, buf ^ 1);
+                }
+            } else if (kt + 1 < kt1) {
+                stage_a(kt + 1, buf ^ 1);
+                stage_b(kt + 1, buf ^ 1);
+            }
+            const float* sa = smem + aslot * A_SLOT;
+            const float* sb = smem + 2 * A_SLOT + buf * B_SLOT;
 #pragma unroll
             for (int qq = 0; qq < BK / 8; ++qq) {
                 f32x4 af[2], bf[2];
                 const int pos = (((2 * qq + lh) ^ fsw) << 2);
-                af[0] = *(const f32x4*)(sa + a_off + pos);
-                af[1] = *(const f32x4*)(sa + a_off + 32 * NT_PITCH + pos);
+                if (CONV) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const int r = a_row[a] + tap;
+                        af[a] = *(const f32x4*)(sa + r * NT_PITCH + (((2 * qq + lh) ^ NT_SWZ(r)) << 2));
+                    }
+                } else {
+                    af[0] = *(const f32x4*)(sa + a_row[0] + pos);
+                    af[1] = *(const f32x4*)(sa + a_row[1] + pos);
+                }
                 bf[0] = *(const f32x4*)(sb + b_off + pos);
                 bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
 #pragma unroll
@@ -546,8 +637,11 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             __syncthreads();
         }
         u += kt1 - kt0;
+#if XV_NT_STAMP
+        XV_STAMP(2);
+#endif
 
-        if (kt0 != 0 || kt1 != q.nk) {
+        if (!XV_SK_NOSHARE && (kt0 != 0 || kt1 != q.nk)) {
             // a shared tile: publish this share, take a ticket, and only the last of the tile's workgroups goes on
             float* mine = q.slab + ((long)w * 2 + (tile == first_tile ? 0 : 1)) * (BM * BN) + tid * 16;
 #pragma unroll
@@ -562,23 +656,31 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             if (tid == 0) s_last = xv_ticket_take(q.tickets + tile, (unsigned)(w_last - w_first + 1)) ? 1 : 0;
             __syncthreads();
             if (!s_last) continue;                       // (uniform; the next share starts behind the barrier above)
+            // The tile's value is ((s0 + s1) + s2) + ... in K order whoever arrives last.  The first two shares commute, so a workgroup that
+            // holds share 0 or 1 keeps it in its registers and reads only the others (one slab for the usual two-share tile); a later
+            // share is re-read from its slab at its place in the order.
+            const int me = w - w_first;
+            if (me > 1) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-            for (int v = w_first; v <= w_last; ++v) {    // in K order, whoever arrived last
+                        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            }
+            for (int i = 0; i <= w_last - w_first; ++i) {
+                const int v = w_first + (me == 1 ? (i == 0 ? 1 : i == 1 ? 0 : i) : i);      // me == 1: own, share 0, share 2, ...
+                if (v == w && me <= 1) continue;
                 const int v_first_tile = (int)(((long)v * q.total / q.P) / q.nk);
                 const float* src = q.slab + ((long)v * 2 + (tile == v_first_tile ? 0 : 1)) * (BM * BN) + tid * 16;
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {            // (four loads at a time: the register budget of this kernel is full)
-                    f32x4 x[4];
-                    xv_handoff_load4x4(src + h * (256 * 16), x);
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 x[8];
+                    xv_handoff_load4x8(src + (2 * h) * (256 * 16), src + (2 * h + 1) * (256 * 16), x);
 #pragma unroll
-                    for (int k4 = 0; k4 < 4; ++k4) {
-                        const int r = 4 * h + k4;
-                        acc[0][0][r] += x[k4][0]; acc[0][1][r] += x[k4][1]; acc[1][0][r] += x[k4][2]; acc[1][1][r] += x[k4][3];
+                    for (int k8 = 0; k8 < 8; ++k8) {
+                        const int r = 8 * h + k8;
+                        acc[0][0][r] += x[k8][0]; acc[0][1][r] += x[k8][1]; acc[1][0][r] += x[k8][2]; acc[1][1][r] += x[k8][3];
                     }
                 }
             }
@@ -589,6 +691,14 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             __syncthreads();                             // the statistics use the staging buffers as scratch
         }
     }
+#if XV_NT_STAMP
+    __builtin_amdgcn_s_waitcnt(0);
+    XV_STAMP(3);
+    if (tid == 0 && blockIdx.x < XV_DBG_STAMP_WGS) {
+        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 7] = 0;
+    }
+#endif
 }
 
 // out[m][n] = sum_z slab[z][m][n] (+ bias[n])
@@ -694,14 +804,24 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     p.bias = g.bias; p.part_sum = nullptr; p.part_m2 = nullptr;
     const int tiles = p.tiles_m * p.tiles_n;
     const int ksteps = xv_cdiv(g.K, BK);
-    // evenly scheduled path (default): XV_NT_WPC workgroups per CU, each at least 4 K-steps long.  XV_NT_STREAMK=0 keeps the one-
-    // workgroup-per-tile kernel below (diagnostics / A-B runs).
+    // Schedule (xv_gemm_nt_sk_kernel): either one workgroup per tile, dealt to the CUs by the hardware as slots free up ("dp"), or one
+    // co-resident round of XV_NT_WPC x 256 workgroups with equal runs of K-steps ("sk", tiles shared through slabs).  In K-steps on the
+    // busiest CU: dp = ceil(tiles / 256) * nk while the tiles fit the resident slots (beyond that the hardware's dealing evens out to
+    // about half a tile), sk = total / 256 + what the hand-overs cost - [measured, round 3] about 5.5 K-steps per workgroup and shared
+    // tile end (64 KB slab store + drain + ticket; the last arrival reads one or two slabs), three workgroups per CU.  A tile is never
+    // split into more than 8 shares: its LAST workgroup sums them alone (the few-tile, long-K problems of segment-level batches > 128).
+    // XV_NT_SCHED=dp|sk forces one; XV_NT_STREAMK=0 keeps the round-2 one-workgroup-per-tile kernel below (diagnostics / A-B runs).
     static const int use_sk = env_int("XV_NT_STREAMK", 1), wpc = std::min(std::max(env_int("XV_NT_WPC", 3), 1), XV_WGS_PER_CU);
+    static const char* sched_env = getenv("XV_NT_SCHED");
     if (use_sk) {
         NTSKArgs q;
         q.nk = ksteps;
         q.total = (long)tiles * ksteps;
-        q.P = (int)std::min<long>(256L * wpc, std::max<long>(1, q.total / 4));
+        const long p_sk = std::min<long>(std::min<long>(256L * wpc, std::max<long>(1, q.total / 4)), 8L * tiles);
+        const long t_sk = (q.total / p_sk) * xv_cdiv(p_sk, 256) + 17;
+        const long t_dp = tiles <= XV_RESIDENT_WGS ? (long)xv_cdiv(tiles, 256) * ksteps : q.total / 256 + ksteps / 2;
+        const bool sk = sched_env ? sched_env[0] == 's' : t_sk < t_dp;
+        q.P = sk ? (int)p_sk : tiles;
         const bool shared_tiles = q.total % q.P != 0 || (q.total / q.P) % ksteps != 0;
         if (!shared_tiles || ((size_t)q.P * 2 * BM * BN * sizeof(float) <= g.ws_bytes && g.ws && tiles <= XV_TN_MAX_TILES)) {
             p.C = g.C; p.ldc = g.ldc; p.c_split_stride = 0; p.k_chunk = ksteps * BK;
@@ -710,9 +830,21 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
             q.slab = (float*)g.ws;
             q.tickets = shared_tiles ? tn_tickets_for(s) : nullptr;
             XV_REQUIRE(!shared_tiles || (q.tickets && ((uintptr_t)q.slab % 16) == 0), "gemm_nt: hand-over buffers unavailable");
+            // context-window form: a spliced view (lda < K) of whole 16-channel chunks whose window fits the LDS slot for every tile
+            static const int use_conv = env_int("XV_NT_CONV", 1);
+            const int taps = (g.lda < g.K && g.K % g.lda == 0) ? (int)(g.K / g.lda) : 1;
+            const int boundaries = 127 / g.a_rps + 1;
+            const bool conv = use_conv && taps >= 2 && g.lda % BK == 0 && 127 + boundaries * (g.a_pitch - g.a_rps) + taps <= NT_WIN_ROWS;
+            q.g.taps = conv ? taps : 1;
+            q.g.a_rows = (long)xv_cdiv(g.M, g.a_rps) * g.a_pitch;
             XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
-            if (g.bn_part) hipLaunchKernelGGL(xv_gemm_nt_sk_kernel<true>, dim3(q.P), dim3(256), 0, s, q);
-            else hipLaunchKernelGGL(xv_gemm_nt_sk_kernel<false>, dim3(q.P), dim3(256), 0, s, q);
+            if (conv) {
+                if (g.bn_part) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, true>), dim3(q.P), dim3(256), 0, s, q);
+                else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<false, true>), dim3(q.P), dim3(256), 0, s, q);
+            } else {
+                if (g.bn_part) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, false>), dim3(q.P), dim3(256), 0, s, q);
+                else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<false, false>), dim3(q.P), dim3(256), 0, s, q);
+            }
             XV_LAUNCH_CHECK();
             return 0;
         }
@@ -771,16 +903,10 @@ struct TNArgs {
     const float* A; long lda; int a_pitch;
     const float* B; long ldb; int b_pitch;
     int rps; float inv_rps;
-    float* P;                 // split partials, [split][tile][16 registers][256 threads] float4 (what each lane holds, as it holds it)
+    float* P;
     int M, N, R, r_chunk;
     int tiles_m, tiles_n;
     const float* zero;
-    // epilogue: out[(j*C + c)][n] = sum over the splits of acc[j*c_pad + c][n] (+ l2 * w[(j*C + c)][n]); rows with c >= C are dropped
-    int splits;
-    unsigned* tickets;        // one per tile, zero between launches
-    float* out; long ldo;
-    int C, c_pad;
-    const float* w; long ldw; float l2;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -946,79 +1072,21 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     }
 #endif
 
-    // ---- epilogue: the split partials are summed by the workgroup that finishes its tile LAST (xv_handoff_* contract, xv_common.h) - in
-    // split order, so the result does not depend on which one that is - and the sum goes straight to the gradient tensor with the
-    // regulariser's l2 * w folded in.  (Round 2 wrote row-major slabs and summed them in a second kernel: 8 more launches per step and
-    // the slabs read back through HBM; here every lane stores and reloads exactly the registers it holds, 16 bytes per lane and 1 KB
-    // contiguous per wave instruction.)
-    // Slab of one (split, tile): [group g = register / 4][thread][register % 4] float4 - a lane's four float4 of one group are 64 contiguous
-    // bytes (one base address + immediate offsets), a wave instruction covers 4 KB with every 128-byte line half used and its neighbour
-    // instruction using the other half.
-    __shared__ int s_last;
-    if (p.splits > 1) {
-        float* mine = p.P + ((long)split * tiles + t) * (BM * BN) + tid * 16;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const f32x4 v = {acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]};
-            xv_handoff_store4(mine + (r >> 2) * (256 * 16) + (r & 3) * 4, v);
-        }
-        xv_handoff_drain();
-        __syncthreads();
-        if (tid == 0) s_last = xv_ticket_take(p.tickets + t, (unsigned)p.splits) ? 1 : 0;
-        __syncthreads();
-        if (!s_last) return;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-        const float* all = p.P + (long)t * (BM * BN) + tid * 16;
-        const long zstride = (long)tiles * (BM * BN);
-        for (int z = 0; z < p.splits; ++z) {
-            const float* src = all + z * zstride;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x4 v[8];
-                xv_handoff_load4x8(src + (2 * h) * (256 * 16), src + (2 * h + 1) * (256 * 16), v);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int r = 8 * h + u;
-                    acc[0][0][r] += v[u][0]; acc[0][1][r] += v[u][1]; acc[1][0][r] += v[u][2]; acc[1][1][r] += v[u][3];
-                }
-            }
-        }
-    }
-    // the tile's sum -> out (TF layout [k][C][n]: padded channel rows dropped), + l2 * w.  The regulariser's weights are fetched 16 rows
-    // at a time in front of the stores (a load inside each predicated store block would make every store wait for its own load:
-    // the serialised tail nt_store_tile describes); invalid positions read the zero page.
+    // [measured, round 3] summing the split partials inside this kernel - the workgroup that finishes a tile last adds the slabs of the
+    // others (ticket hand-over as in xv_gemm_nt_sk_kernel) - was built and dropped: ONE workgroup then reads splits x 64 KB at the ~65 GB/s
+    // a single workgroup gets, serially, at the very end of the launch: tdnn2 / tdnn4 / tdnn5 weight gradients 547 -> 630, 127 -> 279,
+    // 323 -> 413 us (12 / 64 / 21 splits).  The separate slab-sum launch spreads the same bytes over every CU.
+    float* P = p.P + (long)split * p.M * p.N;
     const int n = n0 + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {      // 8 registers at a time (register budget: 128)
-            int row[8];                    // output row, -1 = not stored
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = 8 * g + u;
-                const int m = m0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;
-                const int j = m / p.c_pad, c = m - j * p.c_pad;
-                row[u] = (m < p.M && n < p.N && c < p.C) ? j * p.C + c : -1;
+        for (int r = 0; r < 16; ++r) {
+            int m = m0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;
+            if (m < p.M && n < p.N) {
+                f32x2 v = {acc[a][0][r], acc[a][1][r]};
+                *(f32x2*)(P + (long)m * p.N + n) = v;
             }
-            if (p.w) {
-                f32x2 wv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) wv[u] = *(const f32x2*)(row[u] >= 0 ? p.w + (long)row[u] * p.ldw + n : p.zero);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { acc[a][0][8 * g + u] += p.l2 * wv[u].x; acc[a][1][8 * g + u] += p.l2 * wv[u].y; }
-                asm volatile("" : "+v"(acc[a][0]), "+v"(acc[a][1]));      // keeps hipcc from sinking the loads back into the store blocks
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (row[u] >= 0) {
-                    const f32x2 v = {acc[a][0][8 * g + u], acc[a][1][8 * g + u]};
-                    *(f32x2*)(p.out + (long)row[u] * p.ldo + n) = v;
-                }
         }
 }
 
@@ -1036,19 +1104,11 @@ int xv_tn_splits(int M, int N, int R) {
     return xv_cdiv(R, chunk);
 }
 
-size_t xv_tn_slab_bytes(int M, int N, int R) {
-    const int splits = xv_tn_splits(M, N, R);
-    return splits > 1 ? (size_t)splits * xv_cdiv(M, BM) * xv_cdiv(N, BN) * BM * BN * sizeof(float) : 0;
-}
-
 int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     XV_REQUIRE(g.M % 4 == 0 && g.N % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0,
                "gemm_tn: M/N/lda/ldb must be multiples of 4 (M=%d N=%d lda=%ld ldb=%ld)", g.M, g.N, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm_tn: operands must be 16-byte aligned");
     XV_REQUIRE(g.M > 0 && g.N > 0 && g.R > 0 && g.splits >= 1, "gemm_tn: empty problem");
-    XV_REQUIRE(g.out && g.c_pad > 0 && g.C > 0 && g.C <= g.c_pad && g.M % g.c_pad == 0 && g.ldo % 2 == 0 && ((uintptr_t)g.out % 8) == 0,
-               "gemm_tn: bad output description (M=%d C=%d c_pad=%d ldo=%ld)", g.M, g.C, g.c_pad, g.ldo);
-    XV_REQUIRE(!g.w || (g.ldw % 2 == 0 && ((uintptr_t)g.w % 8) == 0), "gemm_tn: the regulariser's weights must be 8-byte aligned rows");
     if (ensure_zero_page()) return 1;
     TNArgs p;
     p.zero = g_zero_page;
@@ -1063,15 +1123,7 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     p.r_chunk = xv_cdiv(ksteps, g.splits) * BK;
     int splits = xv_cdiv(g.R, p.r_chunk);
     XV_REQUIRE(splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", splits, g.splits);
-    const int tiles = p.tiles_m * p.tiles_n;
-    XV_REQUIRE(tiles <= XV_TN_MAX_TILES, "gemm_tn: %d output tiles (at most %d)", tiles, XV_TN_MAX_TILES);
-    XV_REQUIRE(splits == 1 || (g.P && ((uintptr_t)g.P % 16) == 0), "gemm_tn: the split partials need a 16-byte aligned scratch buffer");
-    p.splits = splits;
-    p.tickets = splits > 1 ? tn_tickets_for(s) : nullptr;
-    XV_REQUIRE(splits == 1 || p.tickets, "gemm_tn: could not allocate the hand-over tickets");
-    p.out = g.out; p.ldo = g.ldo; p.C = g.C; p.c_pad = g.c_pad;
-    p.w = g.l2 != 0.f ? g.w : nullptr; p.ldw = g.ldw; p.l2 = g.l2;
-    dim3 grid(tiles * splits, 1, 1);
+    dim3 grid(p.tiles_m * p.tiles_n * splits, 1, 1);
     {
         XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
         hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
@@ -1153,9 +1205,11 @@ extern "C" int xv_affine_wgrad(void* stream, const float* x, int segs, int t_in,
     g.B = dz + (long)dz_row0 * o; g.ldb = o; g.b_rps = t_out; g.b_pitch = dz_seg_pitch;
     g.M = k * c_pad; g.N = o; g.R = segs * t_out;
     g.splits = xv_tn_splits(g.M, g.N, g.R);
-    XV_REQUIRE(xv_tn_slab_bytes(g.M, g.N, g.R) <= ws_bytes, "affine_wgrad: workspace too small (%zu needed)", xv_tn_slab_bytes(g.M, g.N, g.R));
+    XV_REQUIRE((size_t)g.splits * g.M * g.N * sizeof(float) <= ws_bytes, "affine_wgrad: workspace too small (%zu needed)",
+               (size_t)g.splits * g.M * g.N * sizeof(float));
     g.P = (float*)ws;
-    g.out = dkernel; g.ldo = o; g.C = c; g.c_pad = c_pad;
-    g.w = kernel; g.ldw = o; g.l2 = l2_scale;
-    return xv_launch_gemm_tn((hipStream_t)stream, g);
+    int rc = xv_launch_gemm_tn((hipStream_t)stream, g);
+    if (rc) return rc;
+    return xv_launch_wgrad_reduce((hipStream_t)stream, g.P, g.splits, k, c, c_pad, o, o, l2_scale != 0.f ? kernel : nullptr, o,
+                                  l2_scale, dkernel, o);
 }
