@@ -452,6 +452,9 @@ __device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (i
 // chunk outer / tap inner, and the rows  xrow(m0) ... xrow(m0 + 127) + taps - 1  of ONE 16-channel chunk of x sit in LDS once for all
 // taps (rows of tap j = rows of tap 0 shifted by j), so x travels L2 -> LDS once instead of once per tap and only the weight tile is
 // staged per K-step.  [r02_pmc_traffic.json: the generic form moved 2.6-2.7 x the algorithmic bytes past L2 on tdnn2 / tdnn3]
+#ifndef XV_NT_WPC_DEFAULT
+#define XV_NT_WPC_DEFAULT 3                  // workgroups per CU of the even schedule
+#endif
 #define NT_WIN_ROWS 192                      // window rows per slot: 128 + (taps - 1) * (1 + chunk boundaries inside a tile), 3 DMA pieces per wave
 template <bool STATS, bool CONV>
 #ifndef XV_SK_VGPR_ATTR
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
 #endif
 
     constexpr int NT_RPI = 64 / NT_KQ;          // tile rows per wave-instruction (16 at BK=16)
-    static_assert(!CONV || (BK == 16 && NT_WIN_ROWS % (4 * NT_RPI) == 0), "the window is staged in whole 16-row pieces, equally by the 4 waves");
+    static_assert(!CONV || NT_WIN_ROWS % (4 * NT_RPI) == 0, "the window is staged in whole 1 KB pieces, equally by the 4 waves");
     constexpr int WIN_PIECES = NT_WIN_ROWS / (4 * NT_RPI);      // per wave
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int lrow = lane / NT_KQ, lpos = lane % NT_KQ;
@@ -807,20 +810,33 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     // Schedule (xv_gemm_nt_sk_kernel): either one workgroup per tile, dealt to the CUs by the hardware as slots free up ("dp"), or one
     // co-resident round of XV_NT_WPC x 256 workgroups with equal runs of K-steps ("sk", tiles shared through slabs).  In K-steps on the
     // busiest CU: dp = ceil(tiles / 256) * nk while the tiles fit the resident slots (beyond that the hardware's dealing evens out to
-    // about half a tile), sk = total / 256 + what the hand-overs cost - [measured, round 3] about 5.5 K-steps per workgroup and shared
-    // tile end (64 KB slab store + drain + ticket; the last arrival reads one or two slabs), three workgroups per CU.  A tile is never
-    // split into more than 8 shares: its LAST workgroup sums them alone (the few-tile, long-K problems of segment-level batches > 128).
-    // XV_NT_SCHED=dp|sk forces one; XV_NT_STREAMK=0 keeps the round-2 one-workgroup-per-tile kernel below (diagnostics / A-B runs).
-    static const int use_sk = env_int("XV_NT_STREAMK", 1), wpc = std::min(std::max(env_int("XV_NT_WPC", 3), 1), XV_WGS_PER_CU);
+    // about half a tile), sk = total / 256 + what the hand-overs cost: [measured, round 3, tools/gemm_probe on the S1 and 64 x 300 layer
+    // shapes] 15 K-steps of BK = 16 per workgroup (two shared tile ends each: 64 KB slab store + drain + ticket, the last arrival
+    // reads a slab and runs the tile's epilogue), which reproduces every measured time within 2 %: tdnn2's data gradient at S1 (784
+    // tiles) 641 -> 528 us, tdnn2 / tdnn3 forward of the 64 x 300 batch (584 / 572 tiles) 489 -> 413 / 677 -> 551 us, while the K = 512
+    // layers (32 K-steps per tile) lose 10-30 % to it and stay on dp.  A tile is never split into more than 8 shares: its LAST workgroup
+    // sums them alone (the few-tile, long-K problems of segment-level batches > 128).
+    // XV_NT_SCHED=dp|sk forces one; XV_NT_STREAMK=0 keeps the round-2 kernel for everything (diagnostics / A-B runs).
+    static const int use_sk = env_int("XV_NT_STREAMK", 1), wpc = std::min(std::max(env_int("XV_NT_WPC", XV_NT_WPC_DEFAULT), 1), XV_WGS_PER_CU);
     static const char* sched_env = getenv("XV_NT_SCHED");
+    static const int use_conv = env_int("XV_NT_CONV", 1);
+    // context-window form: a spliced view (lda < K) of whole K-step-wide channel chunks whose window fits the LDS slot for every tile
+    const int taps = (g.lda < g.K && g.K % g.lda == 0) ? (int)(g.K / g.lda) : 1;
+    const bool conv = use_conv && taps >= 2 && g.lda % BK == 0 && 127 + (127 / g.a_rps + 1) * (g.a_pitch - g.a_rps) + taps <= NT_WIN_ROWS;
+    bool sk = false;
+    long p_sk = 1;
     if (use_sk) {
+        const long total = (long)tiles * ksteps;
+        p_sk = std::min<long>(std::min<long>(256L * wpc, std::max<long>(1, total / 4)), 8L * tiles);
+        const long t_sk = (total / p_sk) * xv_cdiv(p_sk, 256) + (15 * 16 / BK) * std::min<long>(wpc, xv_cdiv(p_sk, 256));
+        const long t_dp = tiles <= XV_RESIDENT_WGS ? (long)xv_cdiv(tiles, 256) * ksteps : total / 256 + ksteps / 2;
+        sk = sched_env ? sched_env[0] == 's' : t_sk + t_sk / 32 < t_dp;
+    }
+    // dp without a context window is the round-2 kernel below (its per-tile prologue / epilogue is leaner: 3-6 % on the K = 512 layers)
+    if (use_sk && (sk || conv)) {
         NTSKArgs q;
         q.nk = ksteps;
         q.total = (long)tiles * ksteps;
-        const long p_sk = std::min<long>(std::min<long>(256L * wpc, std::max<long>(1, q.total / 4)), 8L * tiles);
-        const long t_sk = (q.total / p_sk) * xv_cdiv(p_sk, 256) + 17;
-        const long t_dp = tiles <= XV_RESIDENT_WGS ? (long)xv_cdiv(tiles, 256) * ksteps : q.total / 256 + ksteps / 2;
-        const bool sk = sched_env ? sched_env[0] == 's' : t_sk < t_dp;
         q.P = sk ? (int)p_sk : tiles;
         const bool shared_tiles = q.total % q.P != 0 || (q.total / q.P) % ksteps != 0;
         if (!shared_tiles || ((size_t)q.P * 2 * BM * BN * sizeof(float) <= g.ws_bytes && g.ws && tiles <= XV_TN_MAX_TILES)) {
@@ -830,11 +846,6 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
             q.slab = (float*)g.ws;
             q.tickets = shared_tiles ? tn_tickets_for(s) : nullptr;
             XV_REQUIRE(!shared_tiles || (q.tickets && ((uintptr_t)q.slab % 16) == 0), "gemm_nt: hand-over buffers unavailable");
-            // context-window form: a spliced view (lda < K) of whole 16-channel chunks whose window fits the LDS slot for every tile
-            static const int use_conv = env_int("XV_NT_CONV", 1);
-            const int taps = (g.lda < g.K && g.K % g.lda == 0) ? (int)(g.K / g.lda) : 1;
-            const int boundaries = 127 / g.a_rps + 1;
-            const bool conv = use_conv && taps >= 2 && g.lda % BK == 0 && 127 + boundaries * (g.a_pitch - g.a_rps) + taps <= NT_WIN_ROWS;
             q.g.taps = conv ? taps : 1;
             q.g.a_rows = (long)xv_cdiv(g.M, g.a_rps) * g.a_pitch;
             XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
