@@ -71,26 +71,20 @@ __device__ __forceinline__ void xv_handoff_drain() { asm volatile("s_waitcnt vmc
 __device__ __forceinline__ void xv_handoff_store4(float* p, f32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
-// four loads in flight: p + {0, 4, 8, 12} floats
-__device__ __forceinline__ void xv_handoff_load4x4(const float* p, f32x4 (&v)[4]) {
+// eight loads in flight: p + i * stride floats, i = 0..7 (a slab in [register][thread] order: every wave instruction moves 1 KB of
+// consecutive bytes - [measured, round 3] with a lane's four float4 side by side, i.e. 16-byte pieces at a 64-byte stride per
+// instruction, a shared tile end of the evenly scheduled GEMM cost ~19 us: every piece is a fabric transaction of its own)
+__device__ __forceinline__ void xv_handoff_load8(const float* p, int stride, f32x4 (&v)[8]) {
+    const float *p1 = p + stride, *p2 = p + 2 * stride, *p3 = p + 3 * stride, *p4 = p + 4 * stride, *p5 = p + 5 * stride, *p6 = p + 6 * stride,
+                *p7 = p + 7 * stride;
     asm volatile(
-        "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-        "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-        : "v"(p)
-        : "memory");
-}
-// eight loads in flight: p + {0, 4, 8, 12} floats and q + the same
-__device__ __forceinline__ void xv_handoff_load4x8(const float* p, const float* q, f32x4 (&v)[8]) {
-    asm volatile(
-        "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
-        "global_load_dwordx4 %2, %8, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
-        "global_load_dwordx4 %4, %9, off sc1\n\tglobal_load_dwordx4 %5, %9, off offset:16 sc1\n\t"
-        "global_load_dwordx4 %6, %9, off offset:32 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:48 sc1\n\t"
+        "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+        "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+        "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+        "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\t"
         "s_waitcnt vmcnt(0)"
         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-        : "v"(p), "v"(q)
+        : "v"(p), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
         : "memory");
 }
 // one lane per workgroup, after xv_handoff_drain + __syncthreads(): true for the workgroup that arrives last of `expected`; that
@@ -101,6 +95,15 @@ __device__ __forceinline__ bool xv_ticket_take(unsigned* ticket, unsigned expect
     if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return last;
 }
+
+// Fragment order of the NT GEMM's B operand: the float4 a lane (li = n % 32, lh) of a wave feeds to its MFMAs for K-step kt (16 columns),
+// half q, is element [(((n / 32) * nk + kt) * 2 + q) * 64 + lh * 32 + li] of a float4 array - a wave's four loads per K-step are 1 KB of
+// consecutive bytes each, and B never passes through LDS.  nk = K / 16; rows n padded to a multiple of 128 (zero).
+__host__ __device__ inline long xv_nt_sw_index(int n, int kk, int nk) {
+    const int nb = n >> 5, li = n & 31, kt = kk >> 4, kq = kk & 15, q = kq >> 3, lh = (kq >> 2) & 1, e = kq & 3;
+    return ((((long)nb * nk + kt) * 2 + q) * 64 + lh * 32 + li) * 4 + e;
+}
+inline size_t xv_nt_sw_floats(int n, int kk) { return (size_t)((n + 127) / 128 * 128) * kk; }
 
 // ---- GEMM geometry shared between launchers and the engine -------------------------
 #define XV_TILE_M 128
@@ -131,8 +134,18 @@ struct XvGemmNT {
     const float* bias;      // optional, [N]
     float* bn_part;         // optional, [4][tiles_m][N]: sum, centred squares, min, max (xv_epilogue.h)
     void* ws; size_t ws_bytes;
+    const float* a_scale; const float* a_shift;   // optional: A is read as relu(A * a_scale[channel] + a_shift[channel]) (a fused BatchNorm + ReLU of the producer)
+    const float* Bsw;       // optional: Bt in MFMA-fragment order (xv_nt_sw_index; K % 16 == 0, rows padded to 128): read straight into registers
+    int co_running;         // 1: another GEMM shares the chip (the backward pass: data gradient beside weight gradient) - see xv_launch_gemm_nt
 };
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g);
+// xv_affine_forward / xv_affine_dgrad (include/xvector_hip.h) with the weights also given in fragment order (nullptr: staged through LDS)
+// x_scale / x_shift (optional): x is the producing layer's PRE-BatchNorm tensor; the kernel reads it as relu(x * x_scale[c] + x_shift[c])
+int xv_affine_forward_ex(void* stream, const float* x, int segs, int t_in, int c_pad, int k, const float* wt, const float* wsw,
+                         const float* bias, float* z, int o, int ldz, float* bn_part, void* ws, size_t ws_bytes, const float* x_scale = nullptr,
+                         const float* x_shift = nullptr);
+int xv_affine_dgrad_ex(void* stream, const float* dz_pad, int segs, int t_out, int o, int k, const float* wf, const float* wfsw, float* dx,
+                       int c, void* ws, size_t ws_bytes);
 
 // P[z][m][n] = sum_{r in chunk z} A[amap(r)][m] * B[bmap(r)][n]   ("TN", reduction over rows)
 struct XvGemmTN {
@@ -177,7 +190,9 @@ int xv_launch_gemm16_tn(hipStream_t s, const XvGemm16TN& g);
 enum { XV_PREP_T32 = 0,     // wt[o][j*c_pad + c] = w[(j*C + c)*O + o]                (fp32, forward layout)
        XV_PREP_F32 = 1,     // wf[c][(k-1-j)*o_ld + o] = w[(j*C + c)*O + o]           (fp32, tap-flipped data-gradient layout)
        XV_PREP_T16 = 2,     // as T32, written as two fp16 planes scaled by pow2(*amax)
-       XV_PREP_F16 = 3 };   // as F32, planes
+       XV_PREP_F16 = 3,     // as F32, planes
+       XV_PREP_T32SW = 4,   // the values of T32 in MFMA-fragment order (xv_nt_sw_index): what a wave of the NT GEMM loads as its B operand
+       XV_PREP_F32SW = 5 }; // the values of F32 in MFMA-fragment order
 struct XvPrepJob {
     int type, k, C, O, c_pad, o_ld;
     int tiles_x, tile0;              // 32x32 tiles per row of tiles, first global tile index
@@ -186,7 +201,7 @@ struct XvPrepJob {
     long plane;                      // plane stride in elements (16-bit types)
     const unsigned* amax;
 };
-#define XV_PREP_MAX_JOBS 32      // two layouts x (XV_MAX_FRAME_LAYERS + 2 segment + 2 attention-key layers)
+#define XV_PREP_MAX_JOBS 48      // per launch (the job table travels as a kernel argument: 3 KB); prep_layers starts another launch when it is full
 struct XvPrepJobs { int n, total_tiles; XvPrepJob j[XV_PREP_MAX_JOBS]; };
 #define XV_AMAX_MAX_JOBS 16
 struct XvAmaxJobs { int n; const float* x[XV_AMAX_MAX_JOBS]; size_t count[XV_AMAX_MAX_JOBS]; unsigned* out[XV_AMAX_MAX_JOBS]; };
