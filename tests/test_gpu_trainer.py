@@ -412,7 +412,8 @@ def test_trainer_reads_and_writes_tensorflow_checkpoints(tmp_path, xv_precision)
     tr2 = Trainer(Params(str(cfg_path)), model)
     tr2.build("predict", dim=30)
     assert tr2.load() == 3
-    got = tr2.engine.get_variables()
-    for k, v in want.items():
-        assert np.array_equal(got[k], v), k
+    got = tr2.engine.get_variables()              # (the predict graph has no loss head: a subset of the training graph's variables)
+    assert len(got) >= 40 and set(got) <= set(want)
+    for k, v in got.items():
+        assert np.array_equal(want[k], v), k
     tr2.close()

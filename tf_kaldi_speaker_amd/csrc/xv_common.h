@@ -96,15 +96,6 @@ __device__ __forceinline__ bool xv_ticket_take(unsigned* ticket, unsigned expect
     return last;
 }
 
-// Fragment order of the NT GEMM's B operand: the float4 a lane (li = n % 32, lh) of a wave feeds to its MFMAs for K-step kt (16 columns),
-// half q, is element [(((n / 32) * nk + kt) * 2 + q) * 64 + lh * 32 + li] of a float4 array - a wave's four loads per K-step are 1 KB of
-// consecutive bytes each, and B never passes through LDS.  nk = K / 16; rows n padded to a multiple of 128 (zero).
-__host__ __device__ inline long xv_nt_sw_index(int n, int kk, int nk) {
-    const int nb = n >> 5, li = n & 31, kt = kk >> 4, kq = kk & 15, q = kq >> 3, lh = (kq >> 2) & 1, e = kq & 3;
-    return ((((long)nb * nk + kt) * 2 + q) * 64 + lh * 32 + li) * 4 + e;
-}
-inline size_t xv_nt_sw_floats(int n, int kk) { return (size_t)((n + 127) / 128 * 128) * kk; }
-
 // ---- GEMM geometry shared between launchers and the engine -------------------------
 #define XV_TILE_M 128
 #define XV_TILE_N 128
@@ -134,18 +125,9 @@ struct XvGemmNT {
     const float* bias;      // optional, [N]
     float* bn_part;         // optional, [4][tiles_m][N]: sum, centred squares, min, max (xv_epilogue.h)
     void* ws; size_t ws_bytes;
-    const float* a_scale; const float* a_shift;   // optional: A is read as relu(A * a_scale[channel] + a_shift[channel]) (a fused BatchNorm + ReLU of the producer)
-    const float* Bsw;       // optional: Bt in MFMA-fragment order (xv_nt_sw_index; K % 16 == 0, rows padded to 128): read straight into registers
     int co_running;         // 1: another GEMM shares the chip (the backward pass: data gradient beside weight gradient) - see xv_launch_gemm_nt
 };
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g);
-// xv_affine_forward / xv_affine_dgrad (include/xvector_hip.h) with the weights also given in fragment order (nullptr: staged through LDS)
-// x_scale / x_shift (optional): x is the producing layer's PRE-BatchNorm tensor; the kernel reads it as relu(x * x_scale[c] + x_shift[c])
-int xv_affine_forward_ex(void* stream, const float* x, int segs, int t_in, int c_pad, int k, const float* wt, const float* wsw,
-                         const float* bias, float* z, int o, int ldz, float* bn_part, void* ws, size_t ws_bytes, const float* x_scale = nullptr,
-                         const float* x_shift = nullptr);
-int xv_affine_dgrad_ex(void* stream, const float* dz_pad, int segs, int t_out, int o, int k, const float* wf, const float* wfsw, float* dx,
-                       int c, void* ws, size_t ws_bytes);
 
 // P[z][m][n] = sum_{r in chunk z} A[amap(r)][m] * B[bmap(r)][n]   ("TN", reduction over rows)
 struct XvGemmTN {
@@ -190,9 +172,7 @@ int xv_launch_gemm16_tn(hipStream_t s, const XvGemm16TN& g);
 enum { XV_PREP_T32 = 0,     // wt[o][j*c_pad + c] = w[(j*C + c)*O + o]                (fp32, forward layout)
        XV_PREP_F32 = 1,     // wf[c][(k-1-j)*o_ld + o] = w[(j*C + c)*O + o]           (fp32, tap-flipped data-gradient layout)
        XV_PREP_T16 = 2,     // as T32, written as two fp16 planes scaled by pow2(*amax)
-       XV_PREP_F16 = 3,     // as F32, planes
-       XV_PREP_T32SW = 4,   // the values of T32 in MFMA-fragment order (xv_nt_sw_index): what a wave of the NT GEMM loads as its B operand
-       XV_PREP_F32SW = 5 }; // the values of F32 in MFMA-fragment order
+       XV_PREP_F16 = 3 };   // as F32, planes
 struct XvPrepJob {
     int type, k, C, O, c_pad, o_ld;
     int tiles_x, tile0;              // 32x32 tiles per row of tiles, first global tile index
@@ -201,7 +181,7 @@ struct XvPrepJob {
     long plane;                      // plane stride in elements (16-bit types)
     const unsigned* amax;
 };
-#define XV_PREP_MAX_JOBS 48      // per launch (the job table travels as a kernel argument: 3 KB); prep_layers starts another launch when it is full
+#define XV_PREP_MAX_JOBS 32      // two layouts x (XV_MAX_FRAME_LAYERS + 2 segment + 2 attention-key layers)
 struct XvPrepJobs { int n, total_tiles; XvPrepJob j[XV_PREP_MAX_JOBS]; };
 #define XV_AMAX_MAX_JOBS 16
 struct XvAmaxJobs { int n; const float* x[XV_AMAX_MAX_JOBS]; size_t count[XV_AMAX_MAX_JOBS]; unsigned* out[XV_AMAX_MAX_JOBS]; };

@@ -185,10 +185,9 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(XvPrepJobs J) {
     const int lt = blockIdx.x - q.tile0;
     const int txt = lt % q.tiles_x, tyt = lt / q.tiles_x;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const bool planes = q.type == XV_PREP_T16 || q.type == XV_PREP_F16;
-    const bool sw = q.type >= XV_PREP_T32SW;
+    const bool planes = q.type >= XV_PREP_T16;
     const float sc = planes ? xv_pow2_scale(*q.amax) : 1.0f;
-    if (q.type == XV_PREP_T32 || q.type == XV_PREP_T16 || q.type == XV_PREP_T32SW) {
+    if (q.type == XV_PREP_T32 || q.type == XV_PREP_T16) {
         // transpose through LDS: reads run along o (contiguous in w), writes along the padded k axis
         const int kp = q.k * q.c_pad;
         const int kk0 = txt * 32, o0 = tyt * 32;
@@ -206,8 +205,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(XvPrepJobs J) {
             int o = o0 + r, kk = kk0 + tx;
             if (o < q.O && kk < kp) {
                 float v = tile[tx][r];
-                if (sw) ((float*)q.dst)[xv_nt_sw_index(o, kk, kp >> 4)] = v;
-                else if (!planes) ((float*)q.dst)[(long)o * kp + kk] = v;
+                if (!planes) ((float*)q.dst)[(long)o * kp + kk] = v;
                 else {
                     float xs = v * sc;
                     _Float16 h = (_Float16)xs, l = (_Float16)(xs - (float)h);
@@ -227,8 +225,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(XvPrepJobs J) {
                 int j = jc / q.C, c = jc - j * q.C;
                 float v = o < q.O ? q.w[(long)jc * q.O + o] : 0.f;
                 long di = (long)c * ldd + (long)(q.k - 1 - j) * q.o_ld + o;
-                if (sw) ((float*)q.dst)[xv_nt_sw_index(c, (q.k - 1 - j) * q.o_ld + o, (int)(ldd >> 4))] = v;
-                else if (!planes) ((float*)q.dst)[di] = v;
+                if (!planes) ((float*)q.dst)[di] = v;
                 else {
                     float xs = v * sc;
                     _Float16 h = (_Float16)xs, l = (_Float16)(xs - (float)h);
@@ -247,8 +244,7 @@ int xv_prep_add(XvPrepJobs& J, int type, const float* w, int k, int C, int O, in
     XvPrepJob& q = J.j[J.n++];
     q.type = type; q.k = k; q.C = C; q.O = O; q.c_pad = c_pad; q.o_ld = o_ld; q.w = w; q.dst = dst; q.plane = plane; q.amax = amax;
     int tiles_y;
-    XV_REQUIRE(type < XV_PREP_T32SW || ((type == XV_PREP_T32SW ? (long)k * c_pad : (long)k * o_ld) % 16 == 0), "weight_prep: fragment order needs K % 16 == 0");
-    if (type == XV_PREP_T32 || type == XV_PREP_T16 || type == XV_PREP_T32SW) { q.tiles_x = xv_cdiv((long)k * c_pad, 32); tiles_y = xv_cdiv(O, 32); }
+    if (type == XV_PREP_T32 || type == XV_PREP_T16) { q.tiles_x = xv_cdiv((long)k * c_pad, 32); tiles_y = xv_cdiv(O, 32); }
     else { q.tiles_x = xv_cdiv(o_ld, 32); tiles_y = xv_cdiv((long)k * C, 32); }
     q.tile0 = J.total_tiles;
     J.total_tiles += q.tiles_x * tiles_y;

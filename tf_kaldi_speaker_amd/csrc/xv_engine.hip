@@ -39,8 +39,6 @@ struct Affine {   // one conv/dense layer (+ optional BN, ReLU)
     bool has_bn, has_relu, fused_bn;
     int v_kernel, v_bias, v_gamma, v_beta, v_mmean, v_mvar;
     float *wt, *wf;                       // kernel-layout weights (wf only when k > 1)
-    bool a_valid = true;                  // false: `a` (the BN + activation output) was not written by the forward pass (its consumer GEMM reads z with the BN folded in); materialised on demand
-    float *wsw = nullptr, *wfsw = nullptr; // fp32 frame / key layers: the same two in MFMA-fragment order (xv_nt_sw_index), the B operand of the NT GEMM
     float *z, *a;                         // activations
     float *bn_part, *mean, *invstd, *scale, *shift;
     // split precision (f16x3): fp16 planes of the kernel-layout weights and of this layer's BN+ReLU output
@@ -158,9 +156,6 @@ enum { AMAX_X = 0, AMAX_SLOTS = 64 };
 
 // frame-level layers (rows = chunks x frames): tdnn1..F and the attention key layers; the two layers after pooling are segment level
 inline bool is_frame(const xv_engine* e, int i) { return i < e->F || i >= e->F + 2; }
-// XV_NT_BREG=1 (experiment, off by default): the frame layers' weights are also kept in MFMA-fragment order and the NT GEMM reads its B operand
-// straight into registers.  [measured, round 3] slower than staging it through LDS (tdnn2 forward 504 vs 497 us, the K = 512 layers 122 vs 109 us)
-inline bool breg_layouts() { static const bool on = getenv("XV_NT_BREG") && getenv("XV_NT_BREG")[0] == '1'; return on; }
 
 float* carve(xv_engine* e, size_t floats) {
     size_t bytes = xv_align(floats * sizeof(float), 256);
@@ -315,10 +310,6 @@ int alloc_buffers(xv_engine* e) {
         size_t r = lrows(i);
         want((size_t)a.c_out * a.k * a.c_pad);                 // wt
         if (a.k > 1) want((size_t)a.c_in * a.k * a.c_out);     // wf
-        if (breg_layouts() && !e->f16 && is_frame(e, i)) {     // wsw, wfsw (the arena is zeroed: padding rows stay zero)
-            if ((a.k * a.c_pad) % 16 == 0) want(xv_nt_sw_floats(a.c_out, a.k * a.c_pad));
-            if (i > 0 && (a.k * a.c_out) % 16 == 0) want(xv_nt_sw_floats(a.c_in, a.k * a.c_out));
-        }
         want(r * a.c_out); want(r * a.c_out);                  // z, a
         want(4 * (size_t)xv_cdiv(r, XV_TILE_M) * a.c_out);     // bn_part
         for (int j = 0; j < 4; ++j) want(a.c_out);
@@ -405,10 +396,6 @@ int alloc_buffers(xv_engine* e) {
         size_t r = lrows(i);
         a.wt = carve(e, (size_t)a.c_out * a.k * a.c_pad);
         a.wf = a.k > 1 ? carve(e, (size_t)a.c_in * a.k * a.c_out) : nullptr;
-        if (breg_layouts() && !e->f16 && is_frame(e, i)) {
-            if ((a.k * a.c_pad) % 16 == 0) a.wsw = carve(e, xv_nt_sw_floats(a.c_out, a.k * a.c_pad));
-            if (i > 0 && (a.k * a.c_out) % 16 == 0) a.wfsw = carve(e, xv_nt_sw_floats(a.c_in, a.k * a.c_out));
-        }
         a.z = carve(e, r * a.c_out);
         a.a = carve(e, r * a.c_out);
         a.bn_part = carve(e, 4 * (size_t)xv_cdiv(r, XV_TILE_M) * a.c_out);
@@ -525,11 +512,6 @@ int prep_layers(xv_engine* e, hipStream_t s, int first, int last) {
     for (int i = first; i < last; ++i) {
         Affine& a = e->L[i];
         const float* w = vptr(e, a.v_kernel);
-        if (J.n + 4 > XV_PREP_MAX_JOBS) {       // table full (only the 12-layer stacks get here): launch it and start another
-            int rc = xv_launch_weight_prep(s, J);
-            if (rc) return rc;
-            J = XvPrepJobs{};
-        }
         if (e->f16 && is_frame(e, i)) {
             // fp16 planes scaled by the tensor's own max |w|; the forward and dgrad layouts hold the same values, so one
             // max per layer, taken on the variable itself
@@ -547,14 +529,6 @@ int prep_layers(xv_engine* e, hipStream_t s, int first, int last) {
             if (rc) return rc;
             if (a.k > 1 && i > 0) {
                 rc = xv_prep_add(J, XV_PREP_F32, w, a.k, a.c_in, a.c_out, a.c_pad, a.c_out, a.wf, 0, nullptr);
-                if (rc) return rc;
-            }
-            if (a.wsw) {
-                rc = xv_prep_add(J, XV_PREP_T32SW, w, a.k, a.c_in, a.c_out, a.c_pad, a.c_out, a.wsw, 0, nullptr);
-                if (rc) return rc;
-            }
-            if (a.wfsw) {
-                rc = xv_prep_add(J, XV_PREP_F32SW, w, a.k, a.c_in, a.c_out, a.c_pad, a.c_out, a.wfsw, 0, nullptr);
                 if (rc) return rc;
             }
         }
@@ -634,26 +608,6 @@ int bn_forward(xv_engine* e, hipStream_t s, Affine& a, int rows, bool stats_from
     if (rc) return rc;
     if (!dst_a) return 0;       // the consumer applies scale/shift itself (tdnn5: statistics pooling)
     return xv_bn_apply(s, a.z, rows, a.c_out, a.c_out, a.scale, a.shift, a.has_relu ? 1 : 0, dst_a, a.c_out);
-}
-
-// Frame layer i's BN + ReLU output is not written in the forward pass when the next layer's GEMM can apply it to its own operand
-// fragments (fp32 operands, plain ReLU, whole K-steps of channels): the BN-apply pass leaves the critical path and the activation
-// tensor exists only for whoever else needs it - the layer's weight gradient reads it, so it is rebuilt on THAT stream in the backward
-// pass (beside the GEMMs), and xv_engine_endpoint rebuilds it on request.  XV_FUSE_ACT=0 switches the fusion off (A/B runs).
-bool fuse_act(const xv_engine* e, int i) {
-    static const bool on = !(getenv("XV_FUSE_ACT") && getenv("XV_FUSE_ACT")[0] == '0');
-    const Affine& a = e->L[i];
-    return on && !e->f16 && e->cfg.relu_type == XV_RELU_RELU && i < e->F - 1 && a.has_bn && a.has_relu && a.c_out % XV_TILE_K == 0 &&
-           a.c_out <= 1024;
-}
-// the materialised activation of layer i on stream s (no-op when the forward pass wrote it)
-int ensure_act(xv_engine* e, hipStream_t s, int i) {
-    Affine& a = e->L[i];
-    if (a.a_valid) return 0;
-    int rc = xv_bn_apply(s, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 1, a.a, a.c_out);
-    if (rc) return rc;
-    a.a_valid = true;
-    return 0;
 }
 
 }  // namespace
@@ -877,36 +831,30 @@ extern "C" int xv_engine_forward(xv_engine* e, void* stream, const float* featur
         rc = xv_pad_channels(s, features, b * t, e->cfg.feat_dim, e->xpad, e->c_pad0);
         if (rc) return rc;
         const float* cur = e->xpad;
-        const float *cur_scale = nullptr, *cur_shift = nullptr;      // non-null: `cur` is a pre-BatchNorm tensor, the BN + ReLU rides on the GEMM's operand
         for (int i = 0; i < F; ++i) {
             Affine& a = e->L[i];
             int t_out = cur_t - a.k + 1;
             int rows = b * t_out;
             if (i == 1) { rc = wait_prep(e, s); if (rc) return rc; }
-            rc = xv_affine_forward_ex(s, cur, b, cur_t, a.c_pad, a.k, a.wt, a.wsw, vptr(e, a.v_bias), a.z, a.c_out, a.c_out,
-                                      training ? a.bn_part : nullptr, e->ws, e->ws_bytes, cur_scale, cur_shift);
+            rc = xv_affine_forward(s, cur, b, cur_t, a.c_pad, a.k, a.wt, vptr(e, a.v_bias), a.z, a.c_out, a.c_out,
+                                   training ? a.bn_part : nullptr, e->ws, e->ws_bytes);
             if (rc) return rc;
-            const bool fused = fuse_act(e, i) && e->L[i + 1].c_pad == a.c_out;
-            rc = bn_forward(e, s, a, rows, true, (i < F - 1 && !fused) ? a.a : nullptr);
+            rc = bn_forward(e, s, a, rows, true, i < F - 1 ? a.a : nullptr);
             if (rc) return rc;
             a.rows = rows;
-            a.a_valid = !fused;
-            cur = fused ? a.z : a.a; cur_t = t_out;
-            cur_scale = fused ? a.scale : nullptr; cur_shift = fused ? a.shift : nullptr;
+            cur = a.a; cur_t = t_out;
             e->Tl[i + 1] = t_out;
         }
         if (e->att) {
             Affine &k0 = e->L[e->K0()], &k1 = e->L[e->K1()];
             const int rows = b * cur_t;
-            Affine& kin = e->L[F - 2];
-            rc = xv_affine_forward_ex(s, kin.a_valid ? kin.a : kin.z, rows, 1, k0.c_pad, 1, k0.wt, k0.wsw, vptr(e, k0.v_bias), k0.z, k0.c_out, k0.c_out,
-                                      training ? k0.bn_part : nullptr, e->ws, e->ws_bytes, kin.a_valid ? nullptr : kin.scale,
-                                      kin.a_valid ? nullptr : kin.shift);
+            rc = xv_affine_forward(s, e->L[F - 2].a, rows, 1, k0.c_pad, 1, k0.wt, vptr(e, k0.v_bias), k0.z, k0.c_out, k0.c_out,
+                                   training ? k0.bn_part : nullptr, e->ws, e->ws_bytes);
             if (rc) return rc;
             rc = bn_forward(e, s, k0, rows, true, k0.a);
             if (rc) return rc;
-            rc = xv_affine_forward_ex(s, k0.a, rows, 1, k1.c_pad, 1, k1.wt, k1.wsw, vptr(e, k1.v_bias), k1.z, k1.c_out, k1.c_out,
-                                      (k1.has_bn && training) ? k1.bn_part : nullptr, e->ws, e->ws_bytes);
+            rc = xv_affine_forward(s, k0.a, rows, 1, k1.c_pad, 1, k1.wt, vptr(e, k1.v_bias), k1.z, k1.c_out, k1.c_out,
+                                   (k1.has_bn && training) ? k1.bn_part : nullptr, e->ws, e->ws_bytes);
             if (rc) return rc;
             if (k1.has_bn) {
                 rc = bn_forward(e, s, k1, rows, true, k1.a);
@@ -1151,7 +1099,7 @@ int layer_dz(xv_engine* e, hipStream_t s, Affine& a, const float* da, int segs, 
 // enqueued on the side stream: its workgroups fill the CUs that the tail of the data-gradient GEMM (and the small BN kernels of
 // the next layer) leave idle.  ring: dz is the ring's current slot - it is handed to the side stream and the ring moves on; a slot
 // is rewritten only after the weight gradient that read it has finished (ZRing).
-int layer_wgrad(xv_engine* e, hipStream_t s, Affine& a, const float* x, const float* dz, int segs, int t_in, int pad, bool ring, int x_layer = -1) {
+int layer_wgrad(xv_engine* e, hipStream_t s, Affine& a, const float* x, const float* dz, int segs, int t_in, int pad, bool ring) {
     const xv_config& c = e->cfg;
     const int t_out = t_in - a.k + 1;
     const int seg_pitch = t_out + 2 * pad;
@@ -1163,10 +1111,6 @@ int layer_wgrad(xv_engine* e, hipStream_t s, Affine& a, const float* x, const fl
     int rc;
     if (concurrent) {
         rc = chain(s, e->side, e->ev_dz);
-        if (rc) return rc;
-    }
-    if (x_layer >= 0) {      // x = the activation of layer x_layer: rebuilt here, on the weight gradient's stream, if the forward pass skipped it
-        rc = ensure_act(e, ws_stream, x_layer);
         if (rc) return rc;
     }
     rc = xv_affine_wgrad(ws_stream, x, segs, t_in, a.c_pad, a.k, a.c_in, dz, seg_pitch, pad, a.c_out, vptr(e, a.v_kernel),
@@ -1185,7 +1129,7 @@ int layer_wgrad(xv_engine* e, hipStream_t s, Affine& a, const float* x, const fl
 }
 
 int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, const float* x, int segs, int t_in, float* dx,
-                   const float* act_out, int x_layer = -1) {
+                   const float* act_out) {
     const int t_out = t_in - a.k + 1;
     const int pad = (dx && a.k > 1) ? a.k - 1 : 0;
     const int lidx = (int)(&a - &e->L[0]);
@@ -1198,11 +1142,11 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     // busy with the layer above's weight gradient - its own (small) weight gradient finishes sooner in line on `s`, beside that one
     // (round-2 timeline: 166 us of MFMA-idle tail behind tdnn2's weight gradient: tdnn1's, two slab sums, the update)
     static const bool inline_first = !(getenv("XV_WGRAD1_INLINE") && getenv("XV_WGRAD1_INLINE")[0] == '0');      // A/B switch
-    rc = layer_wgrad(e, s, a, x, dz, segs, t_in, pad, ring && (dx != nullptr || !inline_first), x_layer);
+    rc = layer_wgrad(e, s, a, x, dz, segs, t_in, pad, ring && (dx != nullptr || !inline_first));
     if (rc) return rc;
     if (dx) {
         const float* wf = a.k > 1 ? a.wf : vptr(e, a.v_kernel);
-        rc = xv_affine_dgrad_ex(s, dz, segs, t_out, a.c_out, a.k, wf, a.wfsw, dx, a.c_in, e->ws, e->ws_bytes);
+        rc = xv_affine_dgrad(s, dz, segs, t_out, a.c_out, a.k, wf, dx, a.c_in, e->ws, e->ws_bytes);
         if (rc) return rc;
     }
     return 0;
@@ -1505,8 +1449,8 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
         Affine& a = e->L[i];
         const float* x = i > 0 ? e->L[i - 1].a : e->xpad;
         float* dx = i > 0 ? e->bufD : nullptr;
-        if (a.k > 1) return layer_backward(e, s, a, da, x, b, e->Tl[i], dx, nullptr, i - 1);
-        return layer_backward(e, s, a, da, x, b * e->Tl[i + 1], 1, dx, nullptr, i - 1);
+        if (a.k > 1) return layer_backward(e, s, a, da, x, b, e->Tl[i], dx, nullptr);
+        return layer_backward(e, s, a, da, x, b * e->Tl[i + 1], 1, dx, nullptr);
     };
     const int lo = F >= 4 ? 2 : 1;    // first layer of stage 2 (build_variables: stage ranges)
     if (stage == -1 || stage == 1) {
@@ -1516,8 +1460,6 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             Affine &k0 = e->L[e->K0()], &k1 = e->L[e->K1()];
             const int rows = b * Tp;
             const float scale = c.att_use_scale ? 1.0f / sqrtf((float)k1.c_out) : 1.0f;
-            rc = ensure_act(e, s, F - 2);      // tdnn(F-2)'s activation feeds two weight gradients (att_key0's and the last frame layer's): once, ahead of both
-            if (rc) return rc;
             {
                 ActScope actv(e, e->L[F - 1]);
                 rc = xv_att_pool_backward_weights(s, e->L[F - 1].z, b, Tp, e->P, e->L[F - 1].scale, e->L[F - 1].shift, 1, e->pool, e->d_small0, e->att_dw);
@@ -1633,7 +1575,7 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
         Affine& a = e->L[i];
         if (n == a.prefix + "_" + a.kind) return set(a.z, a.rows, a.c_out, a.c_out);
         if (n == a.prefix + "_relu" && a.has_relu) {
-            if ((e->f16 && (i < e->F - 1 || i == e->K0())) || i == e->F - 1 || !a.a_valid) {     // not materialised on the hot path (fp16 planes / fused into pooling / into the next GEMM): rebuild on demand
+            if ((e->f16 && (i < e->F - 1 || i == e->K0())) || i == e->F - 1) {     // not materialised on the hot path (fp16 planes / fused into pooling): rebuild on demand
                 ActScope act(e, a);
                 int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 1, a.a, a.c_out);
                 if (rc) return rc;

@@ -45,11 +45,7 @@ static_assert(BK == 16 || BK == 32, "K-step must be 16 or 32");
 #define NT_KQ (BK / 4)               // float4 per tile row
 #define NT_RPT (BM * NT_KQ / 256)    // tile rows staged per thread (2 or 4)
 #define NT_RSTRIDE (256 / NT_KQ)     // row distance between a thread's staged rows
-#ifndef XV_TN_TILE_K
-#define XV_TN_TILE_K 16                // the TN kernel's K-step: [measured, round 3] at 32 (2 workgroups per CU) its weight gradients run 10 % slower
-#endif
-#define TBK XV_TN_TILE_K
-#define TN_RPT (TBK / 8)             // reduction rows staged per thread (2 or 4)
+#define TN_RPT (BK / 8)              // reduction rows staged per thread (2 or 4)
 
 struct NTArgs {
     const float* A; long lda; int a_rps; int a_pitch;
@@ -62,8 +58,6 @@ struct NTArgs {
     const float* zero;
     int stamp_half;      // diagnostics (XV_NT_STAMP)
     int taps; long a_rows;      // context-window form: K = taps * channels, rows of the tensor behind A
-    const float* Bsw;           // BREG: the B operand in fragment order
-    const float* a_scale; const float* a_shift;      // ACT: A is read as relu(A * a_scale[channel] + a_shift[channel]), channel = column % (K / taps)
 };
 
 // Out-of-range rows / k read this 16-byte zero page instead of being masked after the load: the
@@ -185,9 +179,9 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
 #ifndef XV_NT_LDS_PAD_KB
 #define XV_NT_LDS_PAD_KB 0      // diagnostics: extra LDS per workgroup = fewer co-resident workgroups per CU
 #endif
-#ifndef XV_NT_STAGES
-#define XV_NT_STAGES 2          // LDS ring depth: 2 = the next K-step's DMA is in flight during this one, 3 = the next two
-#endif
+// [measured, round 3] a third LDS slot (DMA two K-steps ahead, with and without the fragment reads of the next step pipelined by hand) lowers
+// the MFMA-pipe occupancy from 0.867 to 0.83-0.85: the staging cost follows the bytes in flight, not their latency
+#define XV_NT_STAGES 2
     __shared__ __attribute__((aligned(16))) float smem[XV_NT_STAGES * 2 * BM * NT_PITCH + XV_NT_LDS_PAD_KB * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -246,12 +240,8 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         if (k0 + BK <= k_end) {        // full K-step (uniform): the address is base + k0, nothing else per step
 #pragma unroll
             for (int i = 0; i < NT_RPT; ++i) {
-#if !(XV_NT_ABLATE & 8)
                 __builtin_amdgcn_global_load_lds((gptr_t)(ap[i] + k0), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
-#endif
-#if !(XV_NT_ABLATE & 4)
                 __builtin_amdgcn_global_load_lds((gptr_t)(bp[i] + k0), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
-#endif
             }
         } else {                       // ragged last step: chunks at or beyond k_end come from the zero page
 #pragma unroll
@@ -322,63 +312,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     const int a_off = (wr * 64 + li) * NT_PITCH;
     const int b_off = (wc * 64 + li) * NT_PITCH;
     const int fsw = NT_SWZ(li);     // rows wr*64 + a*32 + li share f(li): the offsets are multiples of 16
-#if XV_NT_STAGES >= 3
-    // Ring of 3 slots with the software pipeline spelled out (BK = 16: two half-steps q = 0, 1 of 16 MFMAs each):
-    //   top of K-step kt:   DMA of K-step kt + 2 -> slot (kt + 2) % 3 (last read in K-step kt - 1: every wave has passed that step's barrier)
-    //                       fragments of half 1 of this step are read BEFORE the 16 MFMAs of half 0
-    //   middle of the step: wait for the own DMA of K-step kt + 1 (all but the youngest 2 * NT_RPT transfers) and for the LDS reads,
-    //                       barrier, then the fragments of half 0 of K-step kt + 1 are read BEFORE the 16 MFMAs of half 1
-    // so a transfer has a step and a half to land, no fragment read is waited for with an empty MFMA queue, and there is still one
-    // barrier per K-step.  (The first ring of this round kept the barrier at the END of the step: 0.83 instead of 0.87 MFMA-pipe
-    // occupancy - it had lost the overlap of the next step's fragment reads that hipcc's hoisting of __syncthreads() gives the 2-slot loop.)
-    static_assert(XV_GLDS && XV_NT_STAGES == 3 && BK == 16, "the pipelined ring is written for 3 slots of 16-column K-steps on LDS-DMA staging");
-    auto frag = [&](const float* sa, const float* sb, int q, f32x4 (&af)[2], f32x4 (&bf)[2]) {
-        const int pos = (((2 * q + lh) ^ fsw) << 2);
-        af[0] = *(const f32x4*)(sa + a_off + pos);
-        af[1] = *(const f32x4*)(sa + a_off + 32 * NT_PITCH + pos);
-        bf[0] = *(const f32x4*)(sb + b_off + pos);
-        bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
-    };
-    auto mma16 = [&](const f32x4 (&af)[2], const f32x4 (&bf)[2]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[0][e], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[1][e], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[0][e], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[1][e], acc[1][1], 0, 0, 0);
-        }
-    };
-    if (nk > 0) gstage(0, 0);
-    if (nk > 1) gstage(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NT_RPT) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    XV_STAMP(1);
-    f32x4 a0[2], b0[2], a1[2], b1[2];
-    if (nk > 0) frag(smem, smem + BM * NT_PITCH, 0, a0, b0);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int nbuf = buf == 2 ? 0 : buf + 1, nnbuf = buf == 0 ? 2 : buf - 1;      // (kt + 1) % 3, (kt + 2) % 3
-        if (kt + 2 < nk) gstage(kt + 2, nnbuf);
-        const float* sa = smem + buf * (2 * BM * NT_PITCH);
-        const float* sb = sa + BM * NT_PITCH;
-        frag(sa, sb, 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma16(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NT_RPT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const float* na = smem + nbuf * (2 * BM * NT_PITCH);
-            frag(na, na + BM * NT_PITCH, 0, a0, b0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mma16(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        buf = nbuf;
-    }
-    __syncthreads();      // the statistics epilogue reuses the ring as scratch
-#else
     if (nk > 0) NT_STAGE_FIRST();
     __syncthreads();
     XV_STAMP(1);
@@ -399,13 +332,8 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
 #else
             af[0] = *(const f32x4*)(sa + a_off + pos);
             af[1] = *(const f32x4*)(sa + a_off + 32 * NT_PITCH + pos);
-#if XV_NT_ABLATE & 16
-            bf[0] = bf[1] = f32x4{(float)pos, 1.f, 2.f, (float)kt};
-            asm volatile("" : "+v"(bf[0]), "+v"(bf[1]));
-#else
             bf[0] = *(const f32x4*)(sb + b_off + pos);
             bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
-#endif
 #endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -427,7 +355,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         __syncthreads();
 #endif
     }
-#endif
     XV_STAMP(2);
 
     // ---- epilogue
@@ -470,29 +397,22 @@ __device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (i
 // chunk outer / tap inner, and the rows  xrow(m0) ... xrow(m0 + 127) + taps - 1  of ONE 16-channel chunk of x sit in LDS once for all
 // taps (rows of tap j = rows of tap 0 shifted by j), so x travels L2 -> LDS once instead of once per tap and only the weight tile is
 // staged per K-step.  [r02_pmc_traffic.json: the generic form moved 2.6-2.7 x the algorithmic bytes past L2 on tdnn2 / tdnn3]
-#define XV_ACT_MAX_C 1024                    // channels of a fused input activation (scale / shift vectors in LDS)
 #ifndef XV_NT_WPC_DEFAULT
 #define XV_NT_WPC_DEFAULT 3                  // workgroups per CU of the even schedule
 #endif
 #define NT_WIN_ROWS 192                      // window rows per slot: 128 + (taps - 1) * (1 + chunk boundaries inside a tile), 3 DMA pieces per wave
-// BREG = the B operand (weights) comes straight from L2 into registers, in the fragment order the weight preparation wrote it
-// (xv_nt_sw_index, xv_common.h): no LDS slot, no DMA and no fragment read for B.  [measured, round 3, XV_NT_ABLATE on tdnn2 forward: MFMA-pipe
-// occupancy 0.867 with both operands staged, 0.906 / 0.908 with the DMA of B / of A left out, 0.951 with neither - the staging costs in
-// proportion to the bytes that pass through LDS, a deeper ring (more transfers in flight) made it worse.]
+template <bool STATS, bool CONV>
 #ifndef XV_SK_VGPR_ATTR
 #define XV_SK_VGPR_ATTR __attribute__((amdgpu_num_vgpr(128)))
 #endif
 #ifndef XV_SK_NOSHARE
 #define XV_SK_NOSHARE 0         // diagnostics: 1 compiles the shared-tile path out (only valid when no tile is shared)
 #endif
-template <bool STATS, bool CONV, bool BREG, bool ACT>
-__device__ __forceinline__ void nt_sk_body(const NTSKArgs& q) {
+__global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt_sk_kernel(NTSKArgs q) {
     const NTArgs& p = q.g;
     constexpr int A_SLOT = CONV ? NT_WIN_ROWS * NT_PITCH : BM * NT_PITCH;       // floats per A slot
     constexpr int B_SLOT = BM * NT_PITCH;
-    // ACT: the producing layer's BatchNorm scale / shift per channel, staged once (the A operand is that layer's PRE-BatchNorm tensor and the
-    // BN + ReLU is applied to the fragments on their way to the MFMAs: the separate BN-apply pass and the activation tensor disappear)
-    __shared__ __attribute__((aligned(16))) float smem[2 * A_SLOT + (BREG ? 0 : 2 * B_SLOT) + (ACT ? 2 * XV_ACT_MAX_C : 0)];   // [A slot 0 | A slot 1 | B slot 0 | B slot 1 | scale | shift]
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_SLOT + 2 * B_SLOT];   // [A slot 0 | A slot 1 | B slot 0 | B slot 1]
     int& s_last = *(int*)smem;      // (the staging buffers are idle when it is used; a variable of its own would be the 40 961st byte: 3 workgroups per CU)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -524,11 +444,6 @@ __device__ __forceinline__ void nt_sk_body(const NTSKArgs& q) {
     const int fsw = NT_SWZ(li);
     const int taps = CONV ? p.taps : 1;
     const int C = p.K / taps;                   // channels per tap (CONV: a multiple of 16)
-    float* s_act = smem + 2 * A_SLOT + (BREG ? 0 : 2 * B_SLOT);
-    if (ACT) {
-        for (int i = tid; i < C; i += 256) { s_act[i] = p.a_scale[i]; s_act[XV_ACT_MAX_C + i] = p.a_shift[i]; }
-        __syncthreads();
-    }
 
     while (u < u_end) {
         const int tile = (int)(u / q.nk);
@@ -547,18 +462,8 @@ __device__ __forceinline__ void nt_sk_body(const NTSKArgs& q) {
             const int row = NT_RPI * (NT_RPT * wave + i) + lrow;
             ksrc[i] = ((lpos ^ NT_SWZ(row)) << 2);
             const int n = n0 + row;
-            bp[i] = BREG ? zp : (n < p.N ? p.Bt + (long)n * p.ldb : zp) + ksrc[i];
+            bp[i] = (n < p.N ? p.Bt + (long)n * p.ldb : zp) + ksrc[i];
         }
-        // BREG: this wave's two 32-column blocks of the fragment-ordered weights; K-step kt, half q, block b = 1 KB at a time
-        const float* bw = BREG ? p.Bsw + (long)(tile_n * 4 + wc * 2) * q.nk * 512 + lane * 4 : nullptr;
-        const long bw_block = (long)q.nk * 512;
-        auto load_b = [&](int kt, f32x4 (&dst)[BK / 8][2]) {
-            const int kg = CONV ? (kt % taps) * (C / BK) + kt / taps : kt;
-#pragma unroll
-            for (int qq = 0; qq < BK / 8; ++qq)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb) dst[qq][bb] = *(const f32x4*)(bw + bb * bw_block + (long)kg * 512 + qq * 256);
-        };
         if (CONV) {
             const int seg0 = m0 / p.a_rps;
             const long xrow0 = (long)seg0 * p.a_pitch + (m0 - seg0 * p.a_rps);
@@ -588,7 +493,6 @@ __device__ __forceinline__ void nt_sk_body(const NTSKArgs& q) {
         }
         // K-step kt of a tile: generic = columns [kt*BK, +BK) of the spliced row; CONV = channel chunk kt / taps of tap kt % taps
         auto stage_b = [&](int kt, int slot) {
-            if (BREG) return;
             float* sb = smem + 2 * A_SLOT + slot * B_SLOT + NT_RPI * NT_RPT * uwave * NT_PITCH;
             const int k0 = CONV ? (kt % taps) * C + (kt / taps) * BK : kt * BK;
             if (CONV || k0 + BK <= p.K) {
@@ -631,10 +535,8 @@ __device__ __forceinline__ void nt_sk_body(const NTSKArgs& q) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-        f32x4 bcur[BK / 8][2], bnxt[BK / 8][2];
         stage_a(kt0, CONV ? (kt0 / taps) & 1 : 0);
         stage_b(kt0, 0);
-        if (BREG) load_b(kt0, bcur);
         __syncthreads();
 #if XV_NT_STAMP
         if (first_seg) { XV_STAMP(1); first_seg = false; }
@@ -654,12 +556,6 @@ __device__ __forceinline__ void nt_sk_body(const NTSKArgs& q) {
                 stage_a(kt + 1, buf ^ 1);
                 stage_b(kt + 1, buf ^ 1);
             }
-            if (BREG) {
-                // the next K-step's weights: issued BEHIND this step's DMA (the wait in front of the barrier leaves exactly these in flight)
-                __builtin_amdgcn_sched_barrier(0);
-                if (kt + 1 < kt1) load_b(kt + 1, bnxt);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             const float* sa = smem + aslot * A_SLOT;
             const float* sb = smem + 2 * A_SLOT + buf * B_SLOT;
 #pragma unroll
@@ -676,21 +572,8 @@ __device__ __forceinline__ void nt_sk_body(const NTSKArgs& q) {
                     af[0] = *(const f32x4*)(sa + a_row[0] + pos);
                     af[1] = *(const f32x4*)(sa + a_row[1] + pos);
                 }
-                if (ACT) {
-                    const int ch = (CONV ? (kt / taps) * BK : (kt * BK) % C) + (2 * qq + lh) * 4;
-                    const f32x4 sc = *(const f32x4*)(s_act + ch), sh = *(const f32x4*)(s_act + XV_ACT_MAX_C + ch);
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) af[a][e] = fmaxf(fmaf(af[a][e], sc[e], sh[e]), 0.f);
-                }
-                if (BREG) {
-                    bf[0] = bcur[qq][0];
-                    bf[1] = bcur[qq][1];
-                } else {
-                    bf[0] = *(const f32x4*)(sb + b_off + pos);
-                    bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
-                }
+                bf[0] = *(const f32x4*)(sb + b_off + pos);
+                bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[0][e], acc[0][0], 0, 0, 0);
@@ -699,16 +582,7 @@ __device__ __forceinline__ void nt_sk_body(const NTSKArgs& q) {
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[1][e], acc[1][1], 0, 0, 0);
                 }
             }
-            if (BREG) {
-                // all DMA of this wave landed (everything but the BK / 4 weight loads just issued), its fragment reads done: barrier
-                if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BK / 4) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-#pragma unroll
-                for (int qq = 0; qq < BK / 8; ++qq) { bcur[qq][0] = bnxt[qq][0]; bcur[qq][1] = bnxt[qq][1]; }
-            } else {
-                __syncthreads();
-            }
+            __syncthreads();
         }
         u += kt1 - kt0;
 #if XV_NT_STAMP
@@ -776,16 +650,6 @@ __device__ __forceinline__ void nt_sk_body(const NTSKArgs& q) {
     }
 #endif
 }
-
-// both operands staged: 128 registers, up to four workgroups per CU (a weight-gradient workgroup of the other stream fits beside three)
-template <bool STATS, bool CONV>
-__global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt_sk_kernel(NTSKArgs q) { nt_sk_body<STATS, CONV, false, false>(q); }
-// weights in registers (this and the next K-step's): 168 registers, three workgroups per CU
-template <bool STATS, bool CONV>
-__global__ __launch_bounds__(256, 3) void xv_gemm_nt_skb_kernel(NTSKArgs q) { nt_sk_body<STATS, CONV, true, false>(q); }
-// forward of a layer whose input is the previous layer's pre-BatchNorm tensor (BN + ReLU applied to the fragments): 168 registers
-template <bool STATS, bool CONV>
-__global__ __launch_bounds__(256, 3) void xv_gemm_nt_ska_kernel(NTSKArgs q) { nt_sk_body<STATS, CONV, false, true>(q); }
 
 // out[m][n] = sum_z slab[z][m][n] (+ bias[n])
 __global__ void xv_splitk_reduce_kernel(const float* __restrict__ slab, int splits, long split_stride, int M, int N,
@@ -920,14 +784,8 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
         // persistent round holds its three slots per CU to the end.
         sk = sched_env ? sched_env[0] == 's' : (!g.co_running && t_sk + t_sk / 32 < t_dp);
     }
-    static const int use_breg = env_int("XV_NT_BREG", 0);
-    const bool act = g.a_scale != nullptr;
-    const bool breg = !act && use_breg && g.Bsw && BK == 16 && g.K % 16 == 0 && ((uintptr_t)g.Bsw % 16) == 0;
-    XV_REQUIRE(!act || (use_sk && g.a_shift && (g.K / taps) % BK == 0 && g.K / taps <= XV_ACT_MAX_C),
-               "gemm_nt: a fused input activation needs whole K-steps of at most %d channels per tap (K=%d, taps=%d)", XV_ACT_MAX_C, g.K, taps);
-    // dp without a context window, register-fed weights or a fused input activation is the round-2 kernel below (its per-tile prologue /
-    // epilogue is leaner: 3-6 % on the K = 512 layers)
-    if (use_sk && (sk || conv || breg || act)) {
+    // dp without a context window is the round-2 kernel below (its per-tile prologue / epilogue is leaner: 3-6 % on the K = 512 layers)
+    if (use_sk && (sk || conv)) {
         NTSKArgs q;
         q.nk = ksteps;
         q.total = (long)tiles * ksteps;
@@ -943,24 +801,13 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
             q.g.taps = conv ? taps : 1;
             q.g.a_rows = (long)xv_cdiv(g.M, g.a_rps) * g.a_pitch;
             XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
-            q.g.Bsw = breg ? g.Bsw : nullptr;
-            q.g.a_scale = g.a_scale; q.g.a_shift = g.a_shift;
-            if (act) {
-                XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
-                if (conv) { if (g.bn_part) hipLaunchKernelGGL((xv_gemm_nt_ska_kernel<true, true>), dim3(q.P), dim3(256), 0, s, q); else hipLaunchKernelGGL((xv_gemm_nt_ska_kernel<false, true>), dim3(q.P), dim3(256), 0, s, q); }
-                else { if (g.bn_part) hipLaunchKernelGGL((xv_gemm_nt_ska_kernel<true, false>), dim3(q.P), dim3(256), 0, s, q); else hipLaunchKernelGGL((xv_gemm_nt_ska_kernel<false, false>), dim3(q.P), dim3(256), 0, s, q); }
-                XV_LAUNCH_CHECK();
-                return 0;
-            }
-#define XV_SK_LAUNCH(KERNEL, ST, CV) hipLaunchKernelGGL((KERNEL<ST, CV>), dim3(q.P), dim3(256), 0, s, q)
-            if (breg) {
-                if (conv) { if (g.bn_part) XV_SK_LAUNCH(xv_gemm_nt_skb_kernel, true, true); else XV_SK_LAUNCH(xv_gemm_nt_skb_kernel, false, true); }
-                else { if (g.bn_part) XV_SK_LAUNCH(xv_gemm_nt_skb_kernel, true, false); else XV_SK_LAUNCH(xv_gemm_nt_skb_kernel, false, false); }
+            if (conv) {
+                if (g.bn_part) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, true>), dim3(q.P), dim3(256), 0, s, q);
+                else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<false, true>), dim3(q.P), dim3(256), 0, s, q);
             } else {
-                if (conv) { if (g.bn_part) XV_SK_LAUNCH(xv_gemm_nt_sk_kernel, true, true); else XV_SK_LAUNCH(xv_gemm_nt_sk_kernel, false, true); }
-                else { if (g.bn_part) XV_SK_LAUNCH(xv_gemm_nt_sk_kernel, true, false); else XV_SK_LAUNCH(xv_gemm_nt_sk_kernel, false, false); }
+                if (g.bn_part) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, false>), dim3(q.P), dim3(256), 0, s, q);
+                else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<false, false>), dim3(q.P), dim3(256), 0, s, q);
             }
-#undef XV_SK_LAUNCH
             XV_LAUNCH_CHECK();
             return 0;
         }
@@ -1033,10 +880,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // direction (the MFMA only needs A and B to agree on r).  So accumulator (a,b) register reg of
 // lane l holds  m = m0 + wr*64 + 2*row(reg,l) + a,  n = n0 + wc*64 + 2*(l&31) + b.
 __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(128))) void xv_gemm_tn_kernel(TNArgs p) {
-#ifndef XV_TN_STAGES
-#define XV_TN_STAGES XV_NT_STAGES
-#endif
-    __shared__ __attribute__((aligned(16))) float smem[XV_TN_STAGES * 2 * TBK * BM];   // [slot][A|B][TBK][128]
+#define XV_TN_STAGES 2
+    __shared__ __attribute__((aligned(16))) float smem[XV_TN_STAGES * 2 * BK * BM];   // [slot][A|B][BK][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -1051,7 +896,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int r_begin = split * p.r_chunk;
     const int r_end = min(p.R, r_begin + p.r_chunk);
-    const int nk = (r_end - r_begin + TBK - 1) / TBK;
+    const int nk = (r_end - r_begin + BK - 1) / BK;
 
     // LDS-DMA staging: one wave-instruction = 1 KiB = two whole [r][128] rows of the image; lane l lands on
     // row 2*(RPT*wave+i) + l/32, columns 4*(l%32)..+3.  The reduction-row -> address map (spliced view)
@@ -1065,11 +910,11 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     auto gstage = [&](int kt, int buf) {
-        float* sa = smem + buf * (2 * TBK * BM) + 2 * TN_RPT * uwave * BM;
-        float* sb = sa + TBK * BM;
+        float* sa = smem + buf * (2 * BK * BM) + 2 * TN_RPT * uwave * BM;
+        float* sb = sa + BK * BM;
 #pragma unroll
         for (int i = 0; i < TN_RPT; ++i) {
-            int r = r_begin + kt * TBK + 2 * (TN_RPT * wave + i) + (lane >> 5);
+            int r = r_begin + kt * BK + 2 * (TN_RPT * wave + i) + (lane >> 5);
             bool rv = r < r_end;
             int seg = (int)((float)r * p.inv_rps);
             int tt = r - seg * p.rps;
@@ -1092,93 +937,38 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
 
     const int a_off = lh * BM + wr * 64 + 2 * li;
     const int b_off = lh * BN + wc * 64 + 2 * li;
-#if XV_TN_STAGES >= 3
-    // the LDS ring of the NT kernel (see there): transfers get XV_TN_STAGES - 1 K-steps to land, one barrier per K-step
-    static_assert(XV_TN_STAGES <= 4, "s_waitcnt immediates are spelled out for at most 4 slots");
-    auto wait_younger = [&](int younger) {
-        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN_RPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TN_RPT) : "memory");
-    };
-    for (int j = 0; j < XV_TN_STAGES - 1; ++j)
-        if (j < nk) gstage(j, j);
-    wait_younger(min(nk, XV_TN_STAGES - 1) - 1);
-    __builtin_amdgcn_s_barrier();
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int nbuf = buf == 0 ? XV_TN_STAGES - 1 : buf - 1;
-        if (kt + XV_TN_STAGES - 1 < nk) gstage(kt + XV_TN_STAGES - 1, nbuf);
-        const float* sa = smem + buf * (2 * TBK * BM) + a_off;
-        const float* sb = smem + buf * (2 * TBK * BM) + TBK * BM + b_off;
-        // Software pipeline over the two halves of the K-step: the second half's 16 fragment reads
-        // are issued BEFORE the first half's 32 MFMAs.  sched_barrier pins that order - hipcc's
-        // scheduler otherwise sinks every ds_read to just in front of its use and exposes the LDS
-        // latency once per 8 MFMAs.
-        f32x2 af[TBK / 4], bf[TBK / 4], an[TBK / 4], bn[TBK / 4];
-#pragma unroll
-        for (int j = 0; j < TBK / 4; ++j) {
-            af[j] = *(const f32x2*)(sa + 2 * j * BM);
-            bf[j] = *(const f32x2*)(sb + 2 * j * BN);
-        }
-#pragma unroll
-        for (int j = 0; j < TBK / 4; ++j) {
-            an[j] = *(const f32x2*)(sa + 2 * (TBK / 4 + j) * BM);
-            bn[j] = *(const f32x2*)(sb + 2 * (TBK / 4 + j) * BN);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < TBK / 4; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[1][1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < TBK / 4; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].y, acc[1][1], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            wait_younger(min(nk - 1, kt + XV_TN_STAGES - 1) - (kt + 1));
-            __builtin_amdgcn_s_barrier();
-        }
-        buf = buf == XV_TN_STAGES - 1 ? 0 : buf + 1;
-    }
-#else
     if (nk > 0) gstage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
-        const float* sa = smem + buf * (2 * TBK * BM) + a_off;
-        const float* sb = smem + buf * (2 * TBK * BM) + TBK * BM + b_off;
+        const float* sa = smem + buf * (2 * BK * BM) + a_off;
+        const float* sb = smem + buf * (2 * BK * BM) + BK * BM + b_off;
         // Software pipeline over the two halves of the K-step: the second half's 16 fragment reads
         // are issued BEFORE the first half's 32 MFMAs.  sched_barrier pins that order - hipcc's
         // scheduler otherwise sinks every ds_read to just in front of its use and exposes the LDS
         // latency once per 8 MFMAs.
-        f32x2 af[TBK / 4], bf[TBK / 4], an[TBK / 4], bn[TBK / 4];
+        f32x2 af[BK / 4], bf[BK / 4], an[BK / 4], bn[BK / 4];
 #pragma unroll
-        for (int j = 0; j < TBK / 4; ++j) {
+        for (int j = 0; j < BK / 4; ++j) {
             af[j] = *(const f32x2*)(sa + 2 * j * BM);
             bf[j] = *(const f32x2*)(sb + 2 * j * BN);
         }
 #pragma unroll
-        for (int j = 0; j < TBK / 4; ++j) {
-            an[j] = *(const f32x2*)(sa + 2 * (TBK / 4 + j) * BM);
-            bn[j] = *(const f32x2*)(sb + 2 * (TBK / 4 + j) * BN);
+        for (int j = 0; j < BK / 4; ++j) {
+            an[j] = *(const f32x2*)(sa + 2 * (BK / 4 + j) * BM);
+            bn[j] = *(const f32x2*)(sb + 2 * (BK / 4 + j) * BN);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < TBK / 4; ++j) {
+        for (int j = 0; j < BK / 4; ++j) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].y, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[1][1], 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < TBK / 4; ++j) {
+        for (int j = 0; j < BK / 4; ++j) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].x, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].y, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].x, acc[1][0], 0, 0, 0);
@@ -1186,7 +976,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         }
         __syncthreads();
     }
-#endif
 
     // [measured, round 3] summing the split partials inside this kernel - the workgroup that finishes a tile last adds the slabs of the
     // others (ticket hand-over as in xv_gemm_nt_sk_kernel) - was built and dropped: ONE workgroup then reads splits x 64 KB at the ~65 GB/s
@@ -1206,95 +995,18 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         }
 }
 
-// TN without LDS: every wave loads its MFMA operands straight from global memory into registers.  The reduction index r is the ROW of
-// both operands, so for one r the 32 lanes of a lane-half read 32 consecutive float2 = 256 contiguous bytes (the same "two output rows
-// per lane" fragment the LDS kernel reads with ds_read_b64): no staging, no barrier, no LDS slot - a wave only waits for its own loads,
-// one K-step ahead in registers.  Cost: the two waves that share an operand fetch it twice (L1 / L2 hits).  Why try: [measured, round 3]
-// the staged kernels lose MFMA-pipe occupancy in proportion to the bytes that pass through LDS (0.867 with both operands, 0.951 with none).
-__global__ __launch_bounds__(256, 3) void xv_gemm_tn_direct_kernel(TNArgs p) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    const int v = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tiles = p.tiles_m * p.tiles_n;
-    const int split = v / tiles, t = v - split * tiles;
-    const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int r_begin = split * p.r_chunk;
-    const int r_end = min(p.R, r_begin + p.r_chunk);
-    const int nk = (r_end - r_begin + TBK - 1) / TBK;
-    const int a_col = m0 + wr * 64 + 2 * li, b_col = n0 + wc * 64 + 2 * li;
-    const float* __restrict__ zp = p.zero;
-    const float* abase = a_col < p.M ? p.A + a_col : nullptr;      // nullptr: this lane's two columns lie beyond the matrix -> zero page
-    const float* bbase = b_col < p.N ? p.B + b_col : nullptr;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    // (segment, frame) of reduction row r_begin, advanced row by row (wave-uniform: scalar registers)
-    int seg = r_begin / p.rps, tt = r_begin - seg * p.rps;
-    auto load_step = [&](int kt, f32x2 (&af)[TBK / 2], f32x2 (&bf)[TBK / 2]) {
-        int r = r_begin + kt * TBK;
-#pragma unroll
-        for (int j = 0; j < TBK / 2; ++j) {
-            // rows r (lane-half 0) and r + 1 (lane-half 1)
-            const long ra0 = (long)seg * p.a_pitch + tt, rb0 = (long)seg * p.b_pitch + tt;
-            const bool v0 = r < r_end;
-            if (++tt == p.rps) { tt = 0; ++seg; }
-            const long ra1 = (long)seg * p.a_pitch + tt, rb1 = (long)seg * p.b_pitch + tt;
-            const bool v1 = r + 1 < r_end;
-            if (++tt == p.rps) { tt = 0; ++seg; }
-            r += 2;
-            const long ra = lh ? ra1 : ra0, rb = lh ? rb1 : rb0;
-            const bool rv = lh ? v1 : v0;
-            af[j] = *(const f32x2*)((rv && abase) ? abase + ra * p.lda : zp);
-            bf[j] = *(const f32x2*)((rv && bbase) ? bbase + rb * p.ldb : zp);
-        }
-    };
-    f32x2 af[TBK / 2], bf[TBK / 2], an[TBK / 2], bn[TBK / 2];
-    if (nk > 0) load_step(0, af, bf);
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_step(kt + 1, an, bn);
-#pragma unroll
-        for (int j = 0; j < TBK / 2; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[1][1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < TBK / 2; ++j) { af[j] = an[j]; bf[j] = bn[j]; }
-    }
-    float* P = p.P + (long)split * p.M * p.N;
-    const int n = n0 + wc * 64 + 2 * li;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int m = m0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;
-            if (m < p.M && n < p.N) {
-                f32x2 v2 = {acc[a][0][r], acc[a][1][r]};
-                *(f32x2*)(P + (long)m * p.N + n) = v2;
-            }
-        }
-}
-
 int xv_tn_splits(int M, int N, int R) {
     int tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
-    int ksteps = xv_cdiv(R, TBK);
+    int ksteps = xv_cdiv(R, BK);
     // XV_WGS_PER_CU (4) workgroups are resident per CU (LDS 32 KB each): keep tiles*splits <= XV_RESIDENT_WGS (1 024) so the
     // whole grid is ONE co-resident round.  (On the first build - 2 per CU - 560 workgroups = 512 + a 48-workgroup second
     // round cost 2x: 61 TF on tdnn2/3, 24 TF on tdnn5.)
     // [measured, round 2] fewer co-resident workgroups (smaller slabs, cheaper slab sum) lose: 768 -> +0.06 ms/step, 512 -> +0.19 ms
-    int splits = XV_RESIDENT_WGS / tiles;
+    static const int target = env_int("XV_TN_WGS", XV_RESIDENT_WGS);      // (A/B switch of the co-resident workgroup target)
+    int splits = target / tiles;
     if (splits > ksteps / 2) splits = ksteps / 2;
     if (splits < 1) splits = 1;
-    int chunk = xv_cdiv(ksteps, splits) * TBK;
+    int chunk = xv_cdiv(ksteps, splits) * BK;
     return xv_cdiv(R, chunk);
 }
 
@@ -1313,16 +1025,14 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     p.rps = g.a_rps; p.inv_rps = 1.0f / (float)g.a_rps;
     p.P = g.P; p.M = g.M; p.N = g.N; p.R = g.R;
     p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
-    int ksteps = xv_cdiv(g.R, TBK);
-    p.r_chunk = xv_cdiv(ksteps, g.splits) * TBK;
+    int ksteps = xv_cdiv(g.R, BK);
+    p.r_chunk = xv_cdiv(ksteps, g.splits) * BK;
     int splits = xv_cdiv(g.R, p.r_chunk);
     XV_REQUIRE(splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", splits, g.splits);
     dim3 grid(p.tiles_m * p.tiles_n * splits, 1, 1);
     {
         XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
-        static const int direct = env_int("XV_TN_DIRECT", 0);
-        if (direct) hipLaunchKernelGGL(xv_gemm_tn_direct_kernel, grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
     }
     XV_LAUNCH_CHECK();
     return 0;
@@ -1331,44 +1041,6 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
 // -------------------------------------------------------------------------------------
 // Public op-level wrappers around the two GEMMs
 // -------------------------------------------------------------------------------------
-// Bt [N][ldb] (K used columns, K % 16 == 0) -> fragment order (xv_nt_sw_index): diagnostics path of the op-level entry points
-// (XV_NT_BREG_OPLEVEL); the engine gets the order straight from the weight preparation (XV_PREP_T32SW / F32SW).
-__global__ void xv_swizzle_bt_kernel(const float* __restrict__ Bt, int N, int K, long ldb, float* __restrict__ dst, long total4) {
-    for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < total4; f += (long)gridDim.x * blockDim.x) {
-        const int lane = (int)(f & 63);
-        long r = f >> 6;
-        const int q = (int)(r & 1); r >>= 1;
-        const int nk = K >> 4;
-        const int kt = (int)(r % nk), nb = (int)(r / nk);
-        const int n = nb * 32 + (lane & 31), kk = kt * 16 + (2 * q + (lane >> 5)) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < N) v = *(const f32x4*)(Bt + (long)n * ldb + kk);
-        *(f32x4*)(dst + f * 4) = v;
-    }
-}
-// XV_NT_BREG_OPLEVEL=1: swizzle once per (pointer, shape) and keep it (tools/gemm_probe: constant weights); =2: on every call (tests)
-static const float* oplevel_swizzled(hipStream_t s, const float* Bt, int N, int K, long ldb) {
-    static const int mode = env_int("XV_NT_BREG_OPLEVEL", 0);
-    if (!mode || K % 16 != 0 || ldb % 4 != 0) return nullptr;
-    struct Key { const float* p; int n, k; bool operator<(const Key& o) const { return p != o.p ? p < o.p : n != o.n ? n < o.n : k < o.k; } };
-    static std::map<Key, float*> cache;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    const Key key = {Bt, N, K};
-    auto it = cache.find(key);
-    float* dst = it != cache.end() ? it->second : nullptr;
-    const bool fresh = dst == nullptr;
-    if (fresh) {
-        if (hipMalloc((void**)&dst, xv_nt_sw_floats(N, K) * sizeof(float)) != hipSuccess) return nullptr;
-        cache[key] = dst;
-    }
-    if (fresh || mode == 2) {
-        const long total4 = (long)xv_nt_sw_floats(N, K) / 4;
-        hipLaunchKernelGGL(xv_swizzle_bt_kernel, dim3((unsigned)std::min<long>((total4 + 255) / 256, 4096)), dim3(256), 0, s, Bt, N, K, ldb, dst, total4);
-    }
-    return dst;
-}
-
 extern "C" size_t xv_op_workspace_bytes(int rows, int cols_in, int cols_out) {
     // split slabs: at most XV_RESIDENT_WGS (+ one ragged round) workgroup tiles of 128x128 floats, plus column partials
     size_t slabs = (size_t)(2 * XV_RESIDENT_WGS + 256) * BM * BN * sizeof(float);      // NT: two shared tiles per workgroup
@@ -1380,17 +1052,8 @@ extern "C" size_t xv_op_workspace_bytes(int rows, int cols_in, int cols_out) {
 
 extern "C" int xv_affine_forward(void* stream, const float* x, int segs, int t_in, int c_pad, int k, const float* wt,
                                  const float* bias, float* z, int o, int ldz, float* bn_part, void* ws, size_t ws_bytes) {
-    return xv_affine_forward_ex(stream, x, segs, t_in, c_pad, k, wt, oplevel_swizzled((hipStream_t)stream, wt, o, k * c_pad, (long)k * c_pad), bias, z, o,
-                                ldz, bn_part, ws, ws_bytes, nullptr, nullptr);
-}
-
-int xv_affine_forward_ex(void* stream, const float* x, int segs, int t_in, int c_pad, int k, const float* wt, const float* wsw,
-                         const float* bias, float* z, int o, int ldz, float* bn_part, void* ws, size_t ws_bytes, const float* x_scale,
-                         const float* x_shift) {
     XV_REQUIRE(segs > 0 && k >= 1 && t_in >= k && c_pad > 0 && o > 0 && ldz >= o, "affine_forward: bad shape (t_in=%d k=%d)", t_in, k);
     XvGemmNT g = {};
-    g.Bsw = wsw;
-    g.a_scale = x_scale; g.a_shift = x_shift;
     g.A = x; g.lda = c_pad; g.a_rps = t_in - k + 1; g.a_pitch = t_in;
     g.Bt = wt; g.ldb = (long)k * c_pad;
     g.C = z; g.ldc = ldz;
@@ -1401,14 +1064,8 @@ int xv_affine_forward_ex(void* stream, const float* x, int segs, int t_in, int c
 
 extern "C" int xv_affine_dgrad(void* stream, const float* dz_pad, int segs, int t_out, int o, int k, const float* wf, float* dx,
                                int c, void* ws, size_t ws_bytes) {
-    return xv_affine_dgrad_ex(stream, dz_pad, segs, t_out, o, k, wf, oplevel_swizzled((hipStream_t)stream, wf, c, k * o, (long)k * o), dx, c, ws, ws_bytes);
-}
-
-int xv_affine_dgrad_ex(void* stream, const float* dz_pad, int segs, int t_out, int o, int k, const float* wf, const float* wfsw, float* dx,
-                       int c, void* ws, size_t ws_bytes) {
     XV_REQUIRE(segs > 0 && k >= 1 && t_out >= 1 && o > 0 && c > 0, "affine_dgrad: bad shape");
     XvGemmNT g = {};
-    g.Bsw = wfsw;
     g.A = dz_pad; g.lda = o; g.a_rps = t_out + k - 1; g.a_pitch = t_out + 2 * (k - 1);
     g.Bt = wf; g.ldb = (long)k * o;
     g.C = dx; g.ldc = c;
