@@ -42,8 +42,8 @@ int xv_device_count(void);
 
 /* Live kernel timing for bench.py's roofline leg: while enabled, every launch of the three MFMA
  * GEMM kernels is bracketed by hipEvents on the stream it is launched on.
- *   kind 0 = xv_gemm_nt_kernel<true>  (forward conv/dense + BN-statistics epilogue)
- *   kind 1 = xv_gemm_nt_kernel<false> (data gradients, logits, split launches)
+ *   kind 0 = xv_gemm_nt_kernel<true> / xv_gemm_nt_sk_kernel<true, *>   (forward conv/dense + BN-statistics epilogue)
+ *   kind 1 = xv_gemm_nt_kernel<false> / xv_gemm_nt_sk_kernel<false, *> (data gradients, logits)
  *   kind 2 = xv_gemm_tn_kernel        (weight gradients)
  *   kind 3 = xv_gemm16_nt_kernel<true>, kind 4 = xv_gemm16_nt_kernel<false>, kind 5 = xv_gemm16_tn_kernel
  *            (the same three roles on fp16 hi/lo planes, XV_PRECISION_F16X3)

@@ -1003,8 +1003,9 @@ int xv_tn_splits(int M, int N, int R) {
     // round cost 2x: 61 TF on tdnn2/3, 24 TF on tdnn5.)
     // [measured, round 2] fewer co-resident workgroups (smaller slabs, cheaper slab sum) lose: 768 -> +0.06 ms/step, 512 -> +0.19 ms
     static const int target = env_int("XV_TN_WGS", XV_RESIDENT_WGS);      // (A/B switch of the co-resident workgroup target)
+    static const int min_ksteps = std::max(1, env_int("XV_TN_MIN_KSTEPS", 2));      // (A/B switch: fewest K-steps a workgroup is given)
     int splits = target / tiles;
-    if (splits > ksteps / 2) splits = ksteps / 2;
+    if (splits > ksteps / min_ksteps) splits = ksteps / min_ksteps;
     if (splits < 1) splits = 1;
     int chunk = xv_cdiv(ksteps, splits) * BK;
     return xv_cdiv(R, chunk);

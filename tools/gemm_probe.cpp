@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
     if (!fwd || !dgrad || !wgrad || !wsb) { fprintf(stderr, "missing symbols\n"); return 1; }
 
     struct L { const char* name; int t_in, c, k, o; };
-    const L layers[] = {{"tdnn2", T - 4, 512, 5, 512}, {"tdnn3", T - 8, 512, 7, 512}, {"tdnn4", T - 14, 512, 1, 512}, {"tdnn5", T - 14, 512, 1, 1500}};
+    const L layers[] = {{"tdnn1", T, 32, 5, 512}, {"tdnn2", T - 4, 512, 5, 512}, {"tdnn3", T - 8, 512, 7, 512}, {"tdnn4", T - 14, 512, 1, 512}, {"tdnn5", T - 14, 512, 1, 1500}};
     double sum_us = 0, sum_fl = 0;
     for (const L& l : layers) {
         if (only && !strstr(only, l.name)) continue;
