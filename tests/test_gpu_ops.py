@@ -277,6 +277,57 @@ def test_pooled_bn_backward_closed_form(ops, b, t, n):
     assert np.abs(host(dbias)).max() <= 1e-4 * max(np.abs(dz_ref).sum(axis=0).max(), 1e-30)
 
 
+@pytest.mark.parametrize("kind,weighted,b,t,n", [("prelu", False, 5, 37, 1500), ("lrelu", False, 3, 186, 512), ("relu", True, 4, 70, 512),
+                                                  ("prelu", True, 3, 129, 96), ("none", False, 2, 64, 512)])
+def test_pooled_bn_backward_direct_pass(ops, kind, weighted, b, t, n):
+    """The pass over z that serves the cases without a closed form (bn_bwd_reduce_pooled_kernel: prelu / lrelu slopes, attention frame
+    weights, no activation; common.py:27-42, pooling.py:148-155): T below, at and above the 64-row block, T not a multiple of 4."""
+    rs = np.random.RandomState(b * 1000 + t)
+    z = (rs.randn(b * t, n) * 2 + 0.3).astype(np.float32)
+    gamma, beta = (rs.rand(n) + 0.5).astype(np.float32), (0.3 * rs.randn(n)).astype(np.float32)
+    dout = rs.randn(b, 2 * n).astype(np.float32)
+    alpha = {"prelu": (0.01 + 0.3 * rs.rand(n)).astype(np.float32), "lrelu": np.full(n, O.LRELU_ALPHA, np.float32)}.get(kind)
+    w = None
+    if weighted:
+        w = rs.rand(b, t) + 0.05
+        w = (w / w.sum(axis=1, keepdims=True)).astype(np.float32)
+    z64, g64, b64 = z.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64)
+    y, cache = O.batchnorm_train_fwd(z64, g64, b64)
+    a = {"relu": np.maximum(y, 0), "none": y}.get(kind)
+    if a is None:
+        a = O.act_fwd(y, kind, alpha.astype(np.float64))
+    a3 = a.reshape(b, t, n)
+    w64 = np.full((b, t), 1.0 / t) if w is None else w.astype(np.float64)
+    mean = (w64[:, :, None] * a3).sum(axis=1)
+    var = (w64[:, :, None] * (a3 - mean[:, None]) ** 2).sum(axis=1)
+    std = np.sqrt(np.maximum(var, 1e-12))
+    pool = np.concatenate([mean, std], axis=1)
+    d64 = dout.astype(np.float64)
+    da = (d64[:, None, :n] * w64[:, :, None] + (d64[:, None, n:] / std[:, None]) * w64[:, :, None] * (a3 - mean[:, None])).reshape(b * t, n)
+    if kind == "relu":
+        dy, dalpha_ref = da * (y > 0), None
+    elif kind == "none":
+        dy, dalpha_ref = da, None
+    else:
+        dy, dalpha_ref = O.act_bwd(y, a, da, kind, alpha.astype(np.float64))
+    dz_ref, dg_ref, db_ref = O.batchnorm_train_bwd(dy, cache, g64)
+    part = ops.col_stats(dev(z))
+    mean_d, invstd, scale, shift = ops.bn_finalize(part, b * t, dev(gamma), dev(beta), 1e-3, 0.99, False, None, None)
+    d_dalpha = dev(np.zeros(n, np.float32)) if kind == "prelu" else None
+    args = (dev(pool.astype(np.float32)), dev(dout), b, t, dev(z), dev(gamma), mean_d, invstd, scale, shift, kind != "none")
+    kw = dict(weights=dev(w.reshape(-1)) if weighted else None)
+    if alpha is not None:
+        with ops.activation(dev(alpha), d_dalpha):
+            dz, dg, db, _ = ops.bn_relu_backward_pooled(*args, **kw)
+    else:
+        dz, dg, db, _ = ops.bn_relu_backward_pooled(*args, **kw)
+    assert_close(host(dz), dz_ref, 2e-5, 2e-4, "pooled dz (%s)" % kind)
+    assert_close(host(dg), dg_ref, 2e-5, 1e-4, "pooled dgamma (%s)" % kind)
+    assert_close(host(db), db_ref, 2e-5, 1e-4, "pooled dbeta (%s)" % kind)
+    if kind == "prelu":
+        assert_close(host(d_dalpha), dalpha_ref, 2e-5, 1e-4, "pooled dalpha")
+
+
 def test_l2_scaling(ops):
     rs = np.random.RandomState(3)
     x = rs.randn(100, 512).astype(np.float32)

@@ -139,6 +139,9 @@ struct XvGemmTN {
 };
 int xv_tn_splits(int M, int N, int R);
 int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g);
+int xv_affine_wgrad_two_streams(hipStream_t gemm_stream, hipStream_t sum_stream, hipEvent_t ev, const float* x, int segs, int t_in, int c_pad,
+                                int k, int c, const float* dz, int dz_seg_pitch, int dz_row0, int o, const float* kernel, float l2_scale,
+                                float* dkernel, void* ws, size_t ws_bytes);
 int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int C, int c_pad, int n_in, int n_out, const float* w,
                            long ldw, float l2, float* out, long ldo);
 

@@ -405,16 +405,17 @@ __global__ __launch_bounds__(256) void col_stats4_kernel(const float* __restrict
     const bool cv = col < n;
     f32x4 v[XV_TILE_M / 8];
     f32x4 s = {0, 0, 0, 0}, mn = {INFINITY, INFINITY, INFINITY, INFINITY}, mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    // unconditional loads (row / column clamped), all sixteen in flight: a predicated load compiles to a branch + s_waitcnt vmcnt(0)
+    const float* __restrict__ zc = z + (cv ? col : 0);
+#pragma unroll
+    for (int i = 0; i < XV_TILE_M / 8; ++i) v[i] = *(const f32x4*)(zc + (long)min(r0 + rl + 8 * i, r1 - 1) * ldz);
 #pragma unroll
     for (int i = 0; i < XV_TILE_M / 8; ++i) {
-        const int r = r0 + rl + 8 * i;
-        const bool ok = cv && r < r1;
-        v[i] = ok ? *(const f32x4*)(z + (long)r * ldz + col) : f32x4{0, 0, 0, 0};
-        if (ok) {
-            s += v[i];
-            mn.x = fminf(mn.x, v[i].x); mn.y = fminf(mn.y, v[i].y); mn.z = fminf(mn.z, v[i].z); mn.w = fminf(mn.w, v[i].w);
-            mx.x = fmaxf(mx.x, v[i].x); mx.y = fmaxf(mx.y, v[i].y); mx.z = fmaxf(mx.z, v[i].z); mx.w = fmaxf(mx.w, v[i].w);
-        }
+        const bool ok = cv && r0 + rl + 8 * i < r1;
+        const f32x4 x = v[i];
+        s += ok ? x : f32x4{0, 0, 0, 0};
+        mn.x = ok ? fminf(mn.x, x.x) : mn.x; mn.y = ok ? fminf(mn.y, x.y) : mn.y; mn.z = ok ? fminf(mn.z, x.z) : mn.z; mn.w = ok ? fminf(mn.w, x.w) : mn.w;
+        mx.x = ok ? fmaxf(mx.x, x.x) : mx.x; mx.y = ok ? fmaxf(mx.y, x.y) : mx.y; mx.z = ok ? fmaxf(mx.z, x.z) : mx.z; mx.w = ok ? fmaxf(mx.w, x.w) : mx.w;
     }
     red[rl][cq] = s; rmin[rl][cq] = mn; rmax[rl][cq] = mx;
     __syncthreads();
@@ -656,28 +657,34 @@ extern "C" int xv_bn_inference_scale(void* stream, int n, const float* gamma, co
     return 0;
 }
 
-// a = relu?(z*scale+shift), 16 B per lane along channels
-__global__ void bn_apply_kernel(const float* __restrict__ z, long rows, int nq, long ldz, const float* __restrict__ scale,
-                                const float* __restrict__ shift, int relu, float* __restrict__ a, long lda, const float* __restrict__ slope) {
-    const unsigned total = (unsigned)(rows * nq);      // < 2^31 (checked by the wrapper)
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const long r = i / (unsigned)nq;
-        int q = (int)(i - (unsigned)r * nq);
-        f32x4 v = *(const f32x4*)(z + r * ldz + 4 * q);
-        f32x4 sc = *(const f32x4*)(scale + 4 * q);
-        f32x4 sh = *(const f32x4*)(shift + 4 * q);
-        v = v * sc + sh;
-        if (relu) v = slope ? act4(v, *(const f32x4*)(slope + 4 * q)) : relu4(v);
-        *(f32x4*)(a + r * lda + 4 * q) = v;
+// a = relu?(z*scale+shift).  Thread = one channel quad (16 B) x a strip of rows, block = 64 quads x 4 row lanes over BA_ROWS rows: scale,
+// shift and slope are loaded once per thread and the strip's eight loads are in flight together (the element-per-thread grid-stride form
+// divided by the row length and reloaded the three vectors for every 16 bytes: 34 us for 97.5 MB alone, r02_elementwise.json).
+#define BA_ROWS 32
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, int rows, int nq, long ldz, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int relu, float* __restrict__ a, long lda,
+                                                       const float* __restrict__ slope) {
+    const int q = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    if (q >= nq) return;
+    const f32x4 sc = *(const f32x4*)(scale + 4 * q), sh = *(const f32x4*)(shift + 4 * q);
+    f32x4 sl = {0, 0, 0, 0};
+    if (slope) sl = *(const f32x4*)(slope + 4 * q);
+    const int r0 = blockIdx.x * BA_ROWS + rl;
+    f32x4 v[BA_ROWS / 4];
+#pragma unroll
+    for (int j = 0; j < BA_ROWS / 4; ++j) v[j] = *(const f32x4*)(z + (long)min(r0 + 4 * j, rows - 1) * ldz + 4 * q);
+#pragma unroll
+    for (int j = 0; j < BA_ROWS / 4; ++j) {
+        f32x4 y = v[j] * sc + sh;
+        if (relu) y = slope ? act4(y, sl) : relu4(y);
+        if (r0 + 4 * j < rows) *(f32x4*)(a + (long)(r0 + 4 * j) * lda + 4 * q) = y;
     }
 }
 
 extern "C" int xv_bn_apply(void* stream, const float* z, int rows, int n, int ldz, const float* scale, const float* shift,
                            int relu, float* a, int lda) {
     XV_REQUIRE(rows > 0 && n > 0 && n % 4 == 0 && ldz % 4 == 0 && lda % 4 == 0, "bn_apply: n/ld must be multiples of 4 (n=%d)", n);
-    long total = (long)rows * (n / 4);
-    XV_REQUIRE(total < (1L << 31), "bn_apply: tensor too large for 32-bit indexing");
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, z, (long)rows, n / 4,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(xv_cdiv(rows, BA_ROWS), xv_cdiv(n / 4, 64)), dim3(256), 0, (hipStream_t)stream, z, rows, n / 4,
                        (long)ldz, scale, shift, relu, a, (long)lda, g_act.slope);
     XV_LAUNCH_CHECK();
     return 0;
@@ -742,11 +749,11 @@ __device__ __forceinline__ f32x4 upstream_grad(const float* __restrict__ da, con
     return dd;
 }
 
-// Backward pass 1: per (64-row chunk, 256-column block) partial sums of dy and dy*xhat.
+// Backward pass 1: per (64-row chunk, 256-column block) partial sums of dy and dy*xhat (upstream gradient d a in memory; the pooled
+// form is bn_bwd_reduce_pooled_kernel below).
 // block = 256 threads = 64 column-quads x 4 row lanes.
 #define BB_ROWS 64
-template <bool POOLED>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, PoolGrad pg, const float* __restrict__ z, int rows,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ z, int rows,
                                                             int n, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu,
@@ -763,37 +770,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
         f32x4 sl = {0, 0, 0, 0};
         if (hs) sl = *(const f32x4*)(slope + col);
-        PoolCoef pc = {};
-        int pb = -1, b_end = 0;           // chunk whose statistics are in pc; its first row beyond
-        float invT = 0.f;
-        auto row = [&](int r, f32x4 zz) {
-            if (POOLED) {
-                if (r >= b_end) { pb = r / pg.t; b_end = (pb + 1) * pg.t; pc = pool_coef(pg, pb, n, col); }
-                invT = pool_frame_weight(pg, r);
-            }
+        const PoolCoef pc = {};
+        // one row per trip: [measured] four rows' loads issued together make this form slower inside the step (42 -> 46 us; its 50 MB
+        // tensors sit in the Infinity Cache)
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const f32x4 zz = *(const f32x4*)(z + (long)r * n + col);
             f32x4 dn = {0, 0, 0, 0};
-            f32x4 dd = upstream_grad<POOLED>(da, pc, invT, (long)r, n, col, zz, sc, sh, relu, sl, hs, want4 ? &dn : nullptr);
+            f32x4 dd = upstream_grad<false>(da, pc, 0.f, (long)r, n, col, zz, sc, sh, relu, sl, hs, want4 ? &dn : nullptr);
             f32x4 xh = (zz - mu) * is;
             s1 += dd;
             s2 += dd * xh;
             s4 += dn;
             s3.x = fmaxf(s3.x, fabsf(dd.x)); s3.y = fmaxf(s3.y, fabsf(dd.y));
             s3.z = fmaxf(s3.z, fabsf(dd.z)); s3.w = fmaxf(s3.w, fabsf(dd.w));
-        };
-        if (POOLED) {
-            // four rows per trip with their z loads issued together: tdnn5's 143 MB z comes from HBM (the 50 MB tensors of the
-            // other layers sit in the Infinity Cache) and one 16-byte load in flight per lane is latency-bound: 37 -> 33 us.
-            // [measured] the same batching makes the non-pooled form slower inside the step (42 -> 46 us)
-            for (int rb = r0 + rl; rb < r1; rb += 16) {
-                f32x4 zq[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) zq[j] = *(const f32x4*)(z + (long)min(rb + 4 * j, rows - 1) * n + col);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (rb + 4 * j < r1) row(rb + 4 * j, zq[j]);
-            }
-        } else {
-            for (int r = r0 + rl; r < r1; r += 4) row(r, *(const f32x4*)(z + (long)r * n + col));
         }
     }
     red[0][rl][qx] = s1;
@@ -815,6 +804,101 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         if (want4) *(f32x4*)(part + ((long)blockIdx.y * nstat + 3) * n + col) = (red[3][0][qx] + red[3][1][qx]) + (red[3][2][qx] + red[3][3][qx]);
     }
 }
+
+// The POOLED reductions as a kernel of their own (prelu / lrelu / attention pooling: the cases without a closed form).  A workgroup stays
+// inside ONE chunk of the batch (grid.y = chunk x row block), so the pooled statistics, their four divisions and 1/T are loaded once per
+// thread, the row loop has no chunk-crossing branch and keeps eight 16-byte loads of z in flight per lane; rows beyond the block carry a
+// frame weight of zero (every summand of theirs is 0) instead of a predicate.  [measured, round 2, 143 MB of z at S1] the generic kernel above
+// needed 52.7 us (86 branches, a vmcnt(0) per row) where the pooling forward reads the same bytes in 27.5 us.
+#define BBP_ROWS 64
+#define BBP_FLIGHT 8
+template <bool RELU, bool HS, bool ATT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(PoolGrad pg, const float* __restrict__ z, int n, int nsub, int rows_per,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   float* __restrict__ part /* [chunks * nsub][nstat][n] */,
+                                                                   const float* __restrict__ slope, int nstat) {
+    __shared__ f32x4 red[4][4][64];
+    const int qx = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + qx) * 4;
+    const int b = blockIdx.y / nsub, jb = blockIdx.y - b * nsub;
+    const int r0 = b * pg.t + jb * rows_per, r1 = min((b + 1) * pg.t, r0 + rows_per);
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0}, s4 = {0, 0, 0, 0};
+    if (col < n && r0 < r1) {
+        const f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
+        const f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
+        f32x4 sl = {0, 0, 0, 0};
+        if (HS) sl = *(const f32x4*)(slope + col);
+        const PoolCoef pc = pool_coef(pg, b, n, col);
+        const float w_uniform = 1.f / (float)pg.t;
+        const float* __restrict__ zc = z + col;
+        for (int rb = r0 + rl; rb < r1; rb += 4 * BBP_FLIGHT) {
+            f32x4 zq[BBP_FLIGHT];
+            float wq[BBP_FLIGHT];
+#pragma unroll
+            for (int j = 0; j < BBP_FLIGHT; ++j) {
+                const int r = min(rb + 4 * j, r1 - 1);
+                zq[j] = *(const f32x4*)(zc + (long)r * n);
+                wq[j] = ATT ? pg.w[r] : w_uniform;
+            }
+#pragma unroll
+            for (int j = 0; j < BBP_FLIGHT; ++j) {
+                const float w = rb + 4 * j < r1 ? wq[j] : 0.f;
+                const f32x4 y = zq[j] * sc + sh;
+                f32x4 a = y;
+                if (RELU) a = HS ? act4(a, sl) : relu4(a);
+                f32x4 dd = pool_grad(pc, w, a);
+                if (RELU) {
+                    if (HS) {
+                        s4 += dd * neg4(y);
+                        dd.x = y.x > 0.f ? dd.x : dd.x * sl.x; dd.y = y.y > 0.f ? dd.y : dd.y * sl.y;
+                        dd.z = y.z > 0.f ? dd.z : dd.z * sl.z; dd.w = y.w > 0.f ? dd.w : dd.w * sl.w;
+                    } else {
+                        dd.x = y.x > 0.f ? dd.x : 0.f; dd.y = y.y > 0.f ? dd.y : 0.f;
+                        dd.z = y.z > 0.f ? dd.z : 0.f; dd.w = y.w > 0.f ? dd.w : 0.f;
+                    }
+                }
+                const f32x4 xh = (zq[j] - mu) * is;
+                s1 += dd;
+                s2 += dd * xh;
+                s3.x = fmaxf(s3.x, fabsf(dd.x)); s3.y = fmaxf(s3.y, fabsf(dd.y));
+                s3.z = fmaxf(s3.z, fabsf(dd.z)); s3.w = fmaxf(s3.w, fabsf(dd.w));
+            }
+        }
+    }
+    red[0][rl][qx] = s1;
+    red[1][rl][qx] = s2;
+    red[2][rl][qx] = s3;
+    red[3][rl][qx] = s4;
+    __syncthreads();
+    if (rl == 0 && col < n) {
+        f32x4 t3;
+        t3.x = fmaxf(fmaxf(red[2][0][qx].x, red[2][1][qx].x), fmaxf(red[2][2][qx].x, red[2][3][qx].x));
+        t3.y = fmaxf(fmaxf(red[2][0][qx].y, red[2][1][qx].y), fmaxf(red[2][2][qx].y, red[2][3][qx].y));
+        t3.z = fmaxf(fmaxf(red[2][0][qx].z, red[2][1][qx].z), fmaxf(red[2][2][qx].z, red[2][3][qx].z));
+        t3.w = fmaxf(fmaxf(red[2][0][qx].w, red[2][1][qx].w), fmaxf(red[2][2][qx].w, red[2][3][qx].w));
+        float* o = part + (long)blockIdx.y * nstat * n + col;
+        *(f32x4*)(o) = (red[0][0][qx] + red[0][1][qx]) + (red[0][2][qx] + red[0][3][qx]);
+        *(f32x4*)(o + n) = (red[1][0][qx] + red[1][1][qx]) + (red[1][2][qx] + red[1][3][qx]);
+        *(f32x4*)(o + 2 * n) = t3;
+        if (nstat == 4) *(f32x4*)(o + 3 * n) = (red[3][0][qx] + red[3][1][qx]) + (red[3][2][qx] + red[3][3][qx]);
+    }
+}
+
+// the POOLED reductions of (z, pooled statistics) into part [*chunks][nstat][n]; *chunks = the number of partials written
+static void launch_bn_bwd_reduce_pooled(hipStream_t s, const PoolGrad& pg, const float* z, int rows, int n, const float* mean, const float* invstd,
+                                        const float* scale, const float* shift, int relu, float* part, const float* slope, int nstat, int* chunks) {
+    const int nb = rows / pg.t, nsub = xv_cdiv(pg.t, BBP_ROWS), rows_per = xv_cdiv(pg.t, nsub);
+    *chunks = nb * nsub;
+    const dim3 grid(xv_cdiv(n / 4, 64), nb * nsub), block(256);
+#define XV_BBP(R, H, A) hipLaunchKernelGGL((bn_bwd_reduce_pooled_kernel<R, H, A>), grid, block, 0, s, pg, z, n, nsub, rows_per, mean, invstd, scale, shift, part, slope, nstat)
+    const bool hs = relu && slope, att = pg.w != nullptr;
+    if (!relu) { if (att) XV_BBP(false, false, true); else XV_BBP(false, false, false); }
+    else if (hs) { if (att) XV_BBP(true, true, true); else XV_BBP(true, true, false); }
+    else { if (att) XV_BBP(true, false, true); else XV_BBP(true, false, false); }
+#undef XV_BBP
+}
+static int bn_bwd_pooled_chunks(int rows, int t) { return (rows / t) * xv_cdiv(t, BBP_ROWS); }
 
 // block = 256 threads = 8 channels x 32 chunk lanes, fixed-order combine
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int n, int rows,
@@ -1087,22 +1171,26 @@ static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, co
     XV_REQUIRE(segs > 0 && t > 0 && n > 0 && n % 4 == 0 && pad >= 0, "bn_relu_backward: bad shape (n=%d must be a multiple of 4)", n);
     XV_REQUIRE((long)segs * (t + 2 * pad) * (n / 4) < (1L << 31), "bn_relu_backward: tensor too large for 32-bit indexing");
     const int rows = segs * t;
-    const int chunks = xv_cdiv(rows, BB_ROWS);
+    const bool pooled = pg.out != nullptr;
+    XV_REQUIRE(!pooled || (pg.t > 0 && rows % pg.t == 0), "bn_relu_backward: %d rows are not whole chunks of %d pooled frames", rows, pg.t);
+    int chunks = pooled ? bn_bwd_pooled_chunks(rows, pg.t) : xv_cdiv(rows, BB_ROWS);
     const XvActContext act = g_act;
     const int nstat = (relu && act.slope && act.dalpha) ? 4 : 3;      // prelu: one more reduction, sum d act * min(y, 0)
     size_t need = ((size_t)chunks * nstat * n + 2 * n) * sizeof(float);
     XV_REQUIRE(need <= ws_bytes, "bn_relu_backward: workspace too small (%zu > %zu)", need, ws_bytes);
     float* part = (float*)ws;
     float* coef = part + (size_t)chunks * nstat * n;
-    const bool pooled = pg.out != nullptr;
     if (pooled && pg.wpos && !(relu && act.slope)) {
         // closed form from the pooled statistics: no pass over z, no finalize launch
         hipLaunchKernelGGL(bn_bwd_pooled_stats_kernel, dim3(xv_cdiv(n / 4, PS_QUADS)), dim3(256), 0, s, pg, rows / pg.t, n, rows, gamma, shift, mean,
                            invstd, scale, dgamma, dbeta, coef, dbias, (const float*)nullptr, (const float*)nullptr, (unsigned*)nullptr);
         XV_LAUNCH_CHECK();
     } else {
-        hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
-                           da, pg, z, rows, n, mean, invstd, scale, shift, relu, part, relu ? act.slope : nullptr, nstat);
+        if (pooled)
+            launch_bn_bwd_reduce_pooled(s, pg, z, rows, n, mean, invstd, scale, shift, relu, part, relu ? act.slope : nullptr, nstat, &chunks);
+        else
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
+                               da, z, rows, n, mean, invstd, scale, shift, relu, part, relu ? act.slope : nullptr, nstat);
         XV_LAUNCH_CHECK();
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, s, (const float*)part, chunks, n, rows,
                            dgamma, dbeta, coef, gamma, invstd, dbias, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
@@ -1127,7 +1215,9 @@ static int bn_relu_backward_split_impl(hipStream_t s, const float* da, PoolGrad 
     const int rows = segs * t;
     // the reduction partials either come from the data-gradient GEMM's epilogue (ext_part, one chunk per 128-row tile) or
     // are computed here from (da, z)
-    const int chunks = ext_part ? ext_chunks : xv_cdiv(rows, BB_ROWS);
+    const bool pooled = pg.out != nullptr;
+    XV_REQUIRE(!pooled || (pg.t > 0 && rows % pg.t == 0), "bn_relu_backward_split: %d rows are not whole chunks of %d pooled frames", rows, pg.t);
+    int chunks = ext_part ? ext_chunks : pooled ? bn_bwd_pooled_chunks(rows, pg.t) : xv_cdiv(rows, BB_ROWS);
     const XvActContext act = g_act;
     XV_REQUIRE(!(ext_part && relu && act.slope), "bn_relu_backward_split: GEMM-epilogue partials only exist for a plain ReLU");
     const int nstat = (relu && act.slope && act.dalpha) ? 4 : 3;
@@ -1135,7 +1225,6 @@ static int bn_relu_backward_split_impl(hipStream_t s, const float* da, PoolGrad 
     XV_REQUIRE(need <= ws_bytes, "bn_relu_backward_split: workspace too small (%zu > %zu)", need, ws_bytes);
     float* part = ext_part ? const_cast<float*>(ext_part) : (float*)ws;
     float* coef = ext_part ? (float*)ws : part + (size_t)chunks * nstat * n;
-    const bool pooled = pg.out != nullptr;
     if (zero_amax) XV_CHECK_HIP(hipMemsetAsync(dz_amax, 0, sizeof(uint32_t), s));
     if (pooled && pg.wpos && pg.amax && !pg.w && !ext_part && !(relu && act.slope)) {
         // statistics pooling, plain ReLU: reductions, finalize and the |dz| bound in closed form from the pooled statistics (no pass over z)
@@ -1144,8 +1233,11 @@ static int bn_relu_backward_split_impl(hipStream_t s, const float* da, PoolGrad 
         XV_LAUNCH_CHECK();
     } else {
         if (!ext_part) {
-            hipLaunchKernelGGL(pooled ? bn_bwd_reduce_kernel<true> : bn_bwd_reduce_kernel<false>, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
-                               da, pg, z, rows, n, mean, invstd, scale, shift, relu, part, relu ? act.slope : nullptr, nstat);
+            if (pooled)
+                launch_bn_bwd_reduce_pooled(s, pg, z, rows, n, mean, invstd, scale, shift, relu, part, relu ? act.slope : nullptr, nstat, &chunks);
+            else
+                hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(xv_cdiv(n / 4, 64), chunks), dim3(256), 0, s,
+                                   da, z, rows, n, mean, invstd, scale, shift, relu, part, relu ? act.slope : nullptr, nstat);
             XV_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(xv_cdiv(n, FIN_CH)), dim3(256), 0, s, (const float*)part, chunks, n, rows,

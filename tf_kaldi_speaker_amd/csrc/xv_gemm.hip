@@ -174,6 +174,29 @@ extern "C" int xv_debug_read_stamps_prev(void* dst, size_t bytes) { return read_
 #else
 #define XV_STAMP(slot) ((void)0)
 #endif
+#ifndef XV_NT_ROTPRIO
+// The evenly scheduled kernel rotates the issue priority of its waves every XV_NT_ROTPRIO K-steps (0 = off): priority = (K-step + the
+// wave's slot in its SIMD) mod 4, so the co-resident workgroups take turns at the top.  [measured, round 3, stamps of tdnn2 forward at S1]
+// the arbiter serves the oldest wave first and the three workgroups of a CU finish at 384 / 444 / 481 us, the CU running two, then one
+// workgroup at the end; with the rotation 471 / 471 / 476 us.  tdnn2 / tdnn3 forward 497 -> 484 / 687 -> 669 us (rotation every step),
+// 398 -> 388 / 531 -> 521 us at 64 x 300.  NOT in the one-workgroup-per-tile kernel: a launch of several rounds (tdnn5: 2 232 tiles)
+// wants its oldest workgroups to finish first and free their slots - the rotation cost it 3-8 % (256 -> 278 us at 64 x 300).
+#define XV_NT_ROTPRIO 1
+#endif
+#if XV_NT_ROTPRIO
+__device__ __forceinline__ int xv_wave_slot() { return __builtin_amdgcn_s_getreg(4 | (3 << 11)) & 15; }      // HW_ID.WAVE_ID: differs between the waves of one SIMD
+__device__ __forceinline__ void xv_rot_prio(int x) {
+    switch (x & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+#define XV_ROT_PRIO(kt, slot) do { if (((kt) % XV_NT_ROTPRIO) == 0) xv_rot_prio((kt) / XV_NT_ROTPRIO + (slot)); } while (0)
+#else
+#define XV_ROT_PRIO(kt, slot) ((void)0)
+#endif
 template <bool STATS>
 __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(128))) void xv_gemm_nt_kernel(NTArgs p) {
 #ifndef XV_NT_LDS_PAD_KB
@@ -442,6 +465,9 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int b_off = (wc * 64 + li) * NT_PITCH;
     const int fsw = NT_SWZ(li);
+#if XV_NT_ROTPRIO
+    const int wslot = xv_wave_slot();
+#endif
     const int taps = CONV ? p.taps : 1;
     const int C = p.K / taps;                   // channels per tap (CONV: a multiple of 16)
 
@@ -543,6 +569,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
 #endif
         for (int kt = kt0; kt < kt1; ++kt) {
             const int buf = (kt - kt0) & 1;
+            XV_ROT_PRIO(kt, wslot);
             int tap = 0, aslot = buf;
             if (CONV) {
                 const int cc = kt / taps;
@@ -585,6 +612,9 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
             __syncthreads();
         }
         u += kt1 - kt0;
+#if XV_NT_ROTPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #if XV_NT_STAMP
         XV_STAMP(2);
 #endif
@@ -1120,4 +1150,26 @@ extern "C" int xv_affine_wgrad(void* stream, const float* x, int segs, int t_in,
     if (rc) return rc;
     return xv_launch_wgrad_reduce((hipStream_t)stream, g.P, g.splits, k, c, c_pad, o, o, l2_scale != 0.f ? kernel : nullptr, o,
                                   l2_scale, dkernel, o);
+}
+
+// xv_affine_wgrad with the slab sum on a stream of its own (engine): the GEMM on `gemm_stream`, `ev` recorded behind it, the sum
+// (+ lambda W) on `sum_stream` behind the event - the GEMM stream is free for the next layer's weight gradient while the slabs are summed.
+int xv_affine_wgrad_two_streams(hipStream_t gemm_stream, hipStream_t sum_stream, hipEvent_t ev, const float* x, int segs, int t_in, int c_pad,
+                                int k, int c, const float* dz, int dz_seg_pitch, int dz_row0, int o, const float* kernel, float l2_scale,
+                                float* dkernel, void* ws, size_t ws_bytes) {
+    XV_REQUIRE(segs > 0 && k >= 1 && t_in >= k && c_pad >= c && o > 0 && o % 4 == 0, "affine_wgrad: bad shape (o=%d must be a multiple of 4)", o);
+    const int t_out = t_in - k + 1;
+    XvGemmTN g = {};
+    g.A = x; g.lda = c_pad; g.a_rps = t_out; g.a_pitch = t_in;
+    g.B = dz + (long)dz_row0 * o; g.ldb = o; g.b_rps = t_out; g.b_pitch = dz_seg_pitch;
+    g.M = k * c_pad; g.N = o; g.R = segs * t_out;
+    g.splits = xv_tn_splits(g.M, g.N, g.R);
+    XV_REQUIRE((size_t)g.splits * g.M * g.N * sizeof(float) <= ws_bytes, "affine_wgrad: workspace too small (%zu needed)",
+               (size_t)g.splits * g.M * g.N * sizeof(float));
+    g.P = (float*)ws;
+    int rc = xv_launch_gemm_tn(gemm_stream, g);
+    if (rc) return rc;
+    XV_CHECK_HIP(hipEventRecord(ev, gemm_stream));
+    XV_CHECK_HIP(hipStreamWaitEvent(sum_stream, ev, 0));
+    return xv_launch_wgrad_reduce(sum_stream, g.P, g.splits, k, c, c_pad, o, o, l2_scale != 0.f ? kernel : nullptr, o, l2_scale, dkernel, o);
 }

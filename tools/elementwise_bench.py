@@ -48,6 +48,10 @@ for n in (512, 1500):
         run(lambda: ops.stat_pool_forward_bn(z, B, T, scale, shift, True))
         run(lambda: ops.bn_relu_backward_pooled(pool, dpool, B, T, z, gamma, mean, invstd, scale, shift, True))
         run(lambda: ops.bn_relu_backward_pooled_split(pool, dpool, B, T, z, gamma, mean, invstd, scale, shift, zmin, zmax, True))
+        # prelu (a per-channel slope + its gradient): the reduction pass has no closed form - bn_bwd_reduce_pooled_kernel<true, true, false>
+        slope, dalpha = rnd(n).abs() * 0.2 + 0.01, torch.zeros(n).cuda()
+        with ops.activation(slope, dalpha):
+            run(lambda: ops.bn_relu_backward_pooled(pool, dpool, B, T, z, gamma, mean, invstd, scale, shift, True))
 p, g = rnd(9_830_000), rnd(9_830_000)
 run(lambda: ops.sgd_update(p, g, 0.01))
 print("done")

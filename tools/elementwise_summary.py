@@ -8,7 +8,7 @@ T = (int(sys.argv[2]) if len(sys.argv) > 2 else 200) - 14
 R = 128 * T
 agg = collections.defaultdict(list)
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
     key = (name, r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", ""), r.get("Grid_Size_Y", ""))
     agg[key].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
 
@@ -19,8 +19,8 @@ def nbytes(name, n):
     if name.startswith("bn_apply_split"): return t + t            # fp32 in, two fp16 planes out
     if name.startswith("bn_apply_kernel"): return 2 * t
     if "stat_pool_fwd" in name: return t
-    if "bn_bwd_reduce_kernel<true>" in name: return t
-    if "bn_bwd_reduce_kernel<false>" in name: return 2 * t
+    if "bn_bwd_reduce_pooled_kernel" in name: return t
+    if name.startswith("bn_bwd_reduce_kernel") or "bn_bwd_reduce_kernel<false>" in name: return 2 * t
     if "bn_bwd_apply_kernel<true>" in name or "bn_bwd_apply_split_kernel<true>" in name: return 2 * t
     if "bn_bwd_apply_kernel<false>" in name or "bn_bwd_apply_split_kernel<false>" in name: return 3 * t * (1 + 8.0 / T / 3)
     if name.startswith("sgd_kernel"): return 9.83e6 * 12
@@ -43,7 +43,7 @@ for name, gx, gy, n, us, b in sorted(out, key=lambda v: v[0]):
     # two candidate widths per (name, grid): keep 1500 for the larger grid of a name, 512 for the smaller
     grids = sorted({(int(a[1] or 0) * max(int(a[2] or 1), 1)) for a in out if a[0] == name})
     g = int(gx or 0) * max(int(gy or 1), 1)
-    width = 1500 if (len(grids) > 1 and g == grids[-1]) or ("true>" in name or "stat_pool" in name) else 512
+    width = 1500 if (len(grids) > 1 and g == grids[-1]) or ("true>" in name or "stat_pool" in name or "reduce_pooled" in name) else 512
     if name.startswith("sgd_kernel"):
         width = 0
     if n != (width or 512) or (name, gx, gy) in seen:

@@ -35,7 +35,7 @@ for d in sorted(glob.glob(os.path.join(root, "*/"))):
         us = sum(dur.get(i, 0.0) for i in ids[k]) / n if dur else None
         gui = c.get("GRBM_GUI_ACTIVE", 0.0) / n
         cyc = gui / 8.0
-        ks[k.split("(")[0][:80]] = {
+        ks[k.replace("(anonymous namespace)::", "").split("(")[0][:80]] = {
             "dispatches": n, "avg_us": None if us is None else round(us, 1),
             "clock_ghz": None if not us else round(cyc / us / 1e3, 3),
             "mfma_util": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / n / (1024.0 * cyc), 4) if cyc else None,

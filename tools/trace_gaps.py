@@ -29,7 +29,7 @@ union += cur_e - cur_s
 print("GPU busy (union) %.3f ms/step, idle %.3f ms/step" % (union / steps / 1e6, (t1 - t0 - union) / steps / 1e6))
 tot = collections.Counter(); cnt = collections.Counter()
 for r in sel:
-    k = r["Kernel_Name"].split("(")[0]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
     tot[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); cnt[k] += 1
 for k, v in tot.most_common(40):
     print("  %-46s %5.1f/step  avg %7.1f us  %7.1f us/step" % (k[:46], cnt[k] / steps, v / cnt[k] / 1e3, v / steps / 1e3))
@@ -41,7 +41,8 @@ gaps = collections.defaultdict(lambda: [0, 0])
 for (s0, e0, k0), (s1, e1, k1) in zip(iv, iv[1:]):
     g = s1 - e0
     if g > 0:
-        key = (k0.split("(")[0][:34], k1.split("(")[0][:34])
+        cl = lambda k: k.replace("(anonymous namespace)::", "").split("(")[0][:34]
+        key = (cl(k0), cl(k1))
         gaps[key][0] += g; gaps[key][1] += 1
 print("idle gaps on queue %s (us/step):" % mainq)
 for key, (g, n) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:22]:

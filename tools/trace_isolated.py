@@ -9,7 +9,7 @@ con = rows[sgd[-6 - 1 - 20] + 1:sgd[-6 - 1] + 1]    # 20 timed steps before the 
 def avg(sel):
     t, c = collections.Counter(), collections.Counter()
     for r in sel:
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         t[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); c[k] += 1
     return {k: (t[k] / c[k] / 1e3, c[k]) for k in t}
 a, b = avg(con), avg(iso)

@@ -10,4 +10,4 @@ qs = sorted(set(r["Queue_Id"] for r in rows[lo:hi]))
 for r in rows[lo:hi]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
     q = qs.index(r["Queue_Id"])
-    print("%9.1f %s%-2d %8.1f  %s" % (s / 1e3, "          " * q, q, (e - s) / 1e3, r["Kernel_Name"].split("(")[0][:60]))
+    print("%9.1f %s%-2d %8.1f  %s" % (s / 1e3, "          " * q, q, (e - s) / 1e3, r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:60]))
