@@ -87,6 +87,21 @@ __device__ __forceinline__ void xv_handoff_load8(const float* p, int stride, f32
         : "v"(p), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
         : "memory");
 }
+
+// LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4) in the address form that costs the issuing wave least: a wave-uniform 64-bit
+// base in SGPRs + ONE 32-bit byte offset per lane, M0 = the LDS byte address the wave's 1 KB lands at.  [measured, round 3, tdnn2 forward at
+// S1, stamps] with per-lane 64-bit addresses (a v_lshl_add_u64 + a two-VGPR address read per instruction, which is what hipcc makes of the
+// builtin inside a loop - it folds a scalar base back into the vector address) the MFMA pipe was 0.867 occupied; the same loads fed from one
+// hot KiB 0.883 (so it is not the memory side); this form 0.939: 488 -> 449 us, 132 -> 143 TF.  The compiler does not see the loads:
+// callers wait with xv_dma_wait_all() before the barrier that publishes a stage, and every operand row must lie within 4 GB of the base.
+__device__ __forceinline__ void xv_dma16(const float* sbase, unsigned voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void xv_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// the LDS byte address of a wave-uniform shared-memory pointer, as a scalar
+__device__ __forceinline__ unsigned xv_lds_addr(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const void*)p);
+}
 // one lane per workgroup, after xv_handoff_drain + __syncthreads(): true for the workgroup that arrives last of `expected`; that
 // lane also re-arms the ticket for the next launch (every other arrival has already been counted)
 __device__ __forceinline__ bool xv_ticket_take(unsigned* ticket, unsigned expected) {
@@ -139,9 +154,6 @@ struct XvGemmTN {
 };
 int xv_tn_splits(int M, int N, int R);
 int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g);
-int xv_affine_wgrad_two_streams(hipStream_t gemm_stream, hipStream_t sum_stream, hipEvent_t ev, const float* x, int segs, int t_in, int c_pad,
-                                int k, int c, const float* dz, int dz_seg_pitch, int dz_row0, int o, const float* kernel, float l2_scale,
-                                float* dkernel, void* ws, size_t ws_bytes);
 int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int C, int c_pad, int n_in, int n_out, const float* w,
                            long ldw, float l2, float* out, long ldo);
 

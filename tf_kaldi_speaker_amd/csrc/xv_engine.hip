@@ -97,14 +97,6 @@ struct xv_engine {
     // front of the segment layers' weight gradients on `side` (whose dz slots the main chain is waiting for)
     hipStream_t side2 = nullptr;
     void* ws_side2 = nullptr;
-    // the slab sums of the frame layers' fp32 weight gradients, on a stream of their own: behind the GEMM on `side` they kept the next
-    // layer's weight-gradient GEMM waiting while the data-gradient GEMM had the chip alone (r03 timelines: tdnn2's started 338 us late
-    // at S1).  Two slab buffers alternate; a buffer is rewritten only after the sum that read it has finished (ev_sum).
-    hipStream_t sum = nullptr;
-    void* ws_sum[2] = {nullptr, nullptr};
-    hipEvent_t ev_tn[2] = {}, ev_sum[2] = {}, ev_sum_join = nullptr;
-    bool sum_pending[2] = {false, false};
-    int sum_cur = 0;
     bool stage_lw = false;        // deferred stage 0: its slice also needs ev_lw
     hipEvent_t ev_dz = nullptr, ev_lw = nullptr;
     hipEvent_t ev_prep = nullptr, ev_lossprep = nullptr;     // side-stream halves of ensure_weights
@@ -392,7 +384,7 @@ int alloc_buffers(xv_engine* e) {
         if (s > ws) ws = s;
     }
     ws = xv_align(ws, 256);
-    need += 5 * ws + 8192;
+    need += 3 * ws + 8192;
     XV_CHECK_HIP(hipMalloc((void**)&e->arena, need));
     XV_CHECK_HIP(hipMemset(e->arena, 0, need));
     e->arena_bytes = need;
@@ -479,8 +471,6 @@ int alloc_buffers(xv_engine* e) {
     e->ws = carve(e, ws / sizeof(float));
     e->ws_side = carve(e, ws / sizeof(float));
     e->ws_side2 = carve(e, ws / sizeof(float));
-    e->ws_sum[0] = carve(e, ws / sizeof(float));
-    e->ws_sum[1] = carve(e, ws / sizeof(float));
     e->ws_bytes = ws;
     XV_REQUIRE(e->ws != nullptr && e->ws_side != nullptr && e->scalars != nullptr, "engine: internal arena accounting error");
     {   // lowest priority: the weight-gradient GEMMs are filler work; the small kernels of the critical
@@ -489,14 +479,7 @@ int alloc_buffers(xv_engine* e) {
         XV_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         XV_CHECK_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
         XV_CHECK_HIP(hipStreamCreateWithPriority(&e->side2, hipStreamNonBlocking, least));
-        const char* v = getenv("XV_SUM_STREAM");      // A/B switch: 0 = slab sums behind their GEMM on `side`
-        if (!(v && v[0] == '0')) XV_CHECK_HIP(hipStreamCreateWithPriority(&e->sum, hipStreamNonBlocking, least));
     }
-    for (int i = 0; i < 2; ++i) {
-        XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_tn[i], hipEventDisableTiming));
-        XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_sum[i], hipEventDisableTiming));
-    }
-    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_sum_join, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_dz, hipEventDisableTiming));
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < 2; ++i) XV_CHECK_HIP(hipEventCreateWithFlags(&e->zr[r].ev[i], hipEventDisableTiming));
@@ -685,12 +668,6 @@ extern "C" void xv_engine_destroy(xv_engine* e) {
     if (!e) return;
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
     if (e->side2) { (void)hipStreamSynchronize(e->side2); (void)hipStreamDestroy(e->side2); }
-    if (e->sum) { (void)hipStreamSynchronize(e->sum); (void)hipStreamDestroy(e->sum); }
-    for (int i = 0; i < 2; ++i) {
-        if (e->ev_tn[i]) (void)hipEventDestroy(e->ev_tn[i]);
-        if (e->ev_sum[i]) (void)hipEventDestroy(e->ev_sum[i]);
-    }
-    if (e->ev_sum_join) (void)hipEventDestroy(e->ev_sum_join);
     if (e->ev_dz) (void)hipEventDestroy(e->ev_dz);
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < 2; ++i) if (e->zr[r].ev[i]) (void)hipEventDestroy(e->zr[r].ev[i]);
@@ -1060,11 +1037,6 @@ int join_side(xv_engine* e, hipStream_t s) {
         XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_lw, 0));
         e->lw_pending = false;
     }
-    for (int i = 0; i < 2; ++i)
-        if (e->sum_pending[i]) {
-            XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_sum[i], 0));
-            e->sum_pending[i] = false;
-        }
     return 0;
 }
 
@@ -1141,23 +1113,8 @@ int layer_wgrad(xv_engine* e, hipStream_t s, Affine& a, const float* x, const fl
         rc = chain(s, e->side, e->ev_dz);
         if (rc) return rc;
     }
-    const int lidx = (int)(&a - &e->L[0]);
-    if (concurrent && e->sum && is_frame(e, lidx)) {
-        const int sb = e->sum_cur;
-        if (e->sum_pending[sb]) {                     // WAR on the slab buffer: the sum that read it two layers up
-            XV_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_sum[sb], 0));
-            e->sum_pending[sb] = false;
-        }
-        rc = xv_affine_wgrad_two_streams(e->side, e->sum, e->ev_tn[sb], x, segs, t_in, a.c_pad, a.k, a.c_in, dz, seg_pitch, pad, a.c_out,
-                                         vptr(e, a.v_kernel), c.weight_l2_regularizer, gptr(e, a.v_kernel), e->ws_sum[sb], e->ws_bytes);
-        if (rc) return rc;
-        XV_CHECK_HIP(hipEventRecord(e->ev_sum[sb], e->sum));
-        e->sum_pending[sb] = true;
-        e->sum_cur ^= 1;
-    } else {
-        rc = xv_affine_wgrad(ws_stream, x, segs, t_in, a.c_pad, a.k, a.c_in, dz, seg_pitch, pad, a.c_out, vptr(e, a.v_kernel),
-                             c.weight_l2_regularizer, gptr(e, a.v_kernel), wws, e->ws_bytes);
-    }
+    rc = xv_affine_wgrad(ws_stream, x, segs, t_in, a.c_pad, a.k, a.c_in, dz, seg_pitch, pad, a.c_out, vptr(e, a.v_kernel),
+                         c.weight_l2_regularizer, gptr(e, a.v_kernel), wws, e->ws_bytes);
     if (rc) return rc;
     if (!a.has_bn) {      // a bias in front of a BN gets its (zero + rounding noise) gradient from the BN backward
         rc = xv_colsum(ws_stream, dz, segs * seg_pitch, a.c_out, a.c_out, gptr(e, a.v_bias), wws, e->ws_bytes);
@@ -1302,17 +1259,7 @@ int end_stage(xv_engine* e, hipStream_t s, int stage, bool defer) {
     XV_CHECK_HIP(hipEventRecord(e->ev_stage[stage][0], s));
     if (stage == 0) e->stage_lw = e->lw_pending;      // the loss head's weight gradient (third stream) belongs to this slice
     e->stage_side[stage] = !last && e->concurrent && e->side;
-    if (e->stage_side[stage]) {
-        if (e->sum && (e->sum_pending[0] || e->sum_pending[1])) {
-            // the slice is complete when the side stream AND the slab sums enqueued so far are: the event goes on the sum stream, behind
-            // a wait for the side stream's position (the sums that follow depend on later side-stream work anyway)
-            XV_CHECK_HIP(hipEventRecord(e->ev_sum_join, e->side));
-            XV_CHECK_HIP(hipStreamWaitEvent(e->sum, e->ev_sum_join, 0));
-            XV_CHECK_HIP(hipEventRecord(e->ev_stage[stage][1], e->sum));
-        } else {
-            XV_CHECK_HIP(hipEventRecord(e->ev_stage[stage][1], e->side));
-        }
-    }
+    if (e->stage_side[stage]) XV_CHECK_HIP(hipEventRecord(e->ev_stage[stage][1], e->side));
     return 0;
 }
 int engine_backward(xv_engine* e, void* stream, int stage, bool defer);

@@ -238,10 +238,11 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     constexpr int NT_RPI = 64 / NT_KQ;          // tile rows per wave-instruction (16 at BK=16)
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int lrow = lane / NT_KQ, lpos = lane % NT_KQ;
-    // per-lane source pointers, the swizzled chunk offset folded in; out-of-range rows point into the zero page for good
+    // per-lane byte offsets from p.A / p.Bt with the swizzled chunk folded in (xv_dma16: scalar base + 32-bit offset).  Rows outside the
+    // matrix read row 0 - their products land in accumulator rows / columns that are neither stored nor counted; only k beyond k_end must
+    // read zeros (it is summed into valid outputs): the ragged last K-step takes the zero page through the builtin's 64-bit form.
     const float* __restrict__ zp = p.zero;
-    const float* ap[NT_RPT];
-    const float* bp[NT_RPT];
+    unsigned aoff[NT_RPT], boff[NT_RPT];
     int ksrc[NT_RPT];
 #pragma unroll
     for (int i = 0; i < NT_RPT; ++i) {
@@ -250,28 +251,42 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         int m = m0 + row;
         int mm = m < p.M ? m : 0;
         int seg = mm / p.a_rps, tt = mm - seg * p.a_rps;
-        ap[i] = (m < p.M ? p.A + ((long)seg * p.a_pitch + tt) * p.lda : zp) + ksrc[i];
+        aoff[i] = (unsigned)((((long)seg * p.a_pitch + tt) * p.lda + ksrc[i]) * 4);
         int n = n0 + row;
-        bp[i] = (n < p.N ? p.Bt + (long)n * p.ldb : zp) + ksrc[i];
+        boff[i] = (unsigned)(((long)(n < p.N ? n : 0) * p.ldb + ksrc[i]) * 4);
     }
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned lds0 = xv_lds_addr(smem + NT_RPI * NT_RPT * uwave * NT_PITCH);
     auto gstage = [&](int kt, int buf) {
-        float* sa = smem + buf * (2 * BM * NT_PITCH) + NT_RPI * NT_RPT * uwave * NT_PITCH;
-        float* sb = sa + BM * NT_PITCH;
         const int k0 = k_begin + kt * BK;
-        if (k0 + BK <= k_end) {        // full K-step (uniform): the address is base + k0, nothing else per step
+        if (k0 + BK <= k_end) {        // full K-step (uniform): scalar bases + k0, the lane offsets never change
+#if XV_NT_ABLATE & 32
+            // diagnostics: the same DMA instructions fed from one hot KiB (no traffic past the L1)
 #pragma unroll
             for (int i = 0; i < NT_RPT; ++i) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(ap[i] + k0), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(bp[i] + k0), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                xv_dma16(zp, lane * 16, lds0 + (buf * (2 * BM * NT_PITCH) + NT_RPI * i * NT_PITCH) * 4);
+                xv_dma16(zp, lane * 16, lds0 + (buf * (2 * BM * NT_PITCH) + BM * NT_PITCH + NT_RPI * i * NT_PITCH) * 4);
             }
+#else
+            const float* abase = p.A + k0;
+            const float* bbase = p.Bt + k0;
+#pragma unroll
+            for (int i = 0; i < NT_RPT; ++i) {
+                xv_dma16(abase, aoff[i], lds0 + (buf * (2 * BM * NT_PITCH) + NT_RPI * i * NT_PITCH) * 4);
+                xv_dma16(bbase, boff[i], lds0 + (buf * (2 * BM * NT_PITCH) + BM * NT_PITCH + NT_RPI * i * NT_PITCH) * 4);
+            }
+#endif
         } else {                       // ragged last step: chunks at or beyond k_end come from the zero page
+            float* sa = smem + buf * (2 * BM * NT_PITCH) + NT_RPI * NT_RPT * uwave * NT_PITCH;
+            float* sb = sa + BM * NT_PITCH;
 #pragma unroll
             for (int i = 0; i < NT_RPT; ++i) {
                 const bool kv = k0 + ksrc[i] < k_end;
-                __builtin_amdgcn_global_load_lds((gptr_t)(kv ? ap[i] + k0 : zp), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(kv ? bp[i] + k0 : zp), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                const float* pa = (const float*)((const char*)(p.A + k0) + aoff[i]);
+                const float* pb = (const float*)((const char*)(p.Bt + k0) + boff[i]);
+                __builtin_amdgcn_global_load_lds((gptr_t)(kv ? pa : zp), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(kv ? pb : zp), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
             }
         }
     };
@@ -336,6 +351,9 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     const int b_off = (wc * 64 + li) * NT_PITCH;
     const int fsw = NT_SWZ(li);     // rows wr*64 + a*32 + li share f(li): the offsets are multiples of 16
     if (nk > 0) NT_STAGE_FIRST();
+#if XV_GLDS
+    xv_dma_wait_all();
+#endif
     __syncthreads();
     XV_STAMP(1);
     for (int kt = 0; kt < nk; ++kt) {
@@ -367,6 +385,9 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             }
         }
         if (kt + 1 < nk) NT_COMMIT(buf);
+#if XV_GLDS
+        xv_dma_wait_all();      // the compiler does not see xv_dma16's loads
+#endif
 #if XV_NT_BARRIER_END
         __builtin_amdgcn_sched_barrier(0);      // keeps hipcc from hoisting the barrier above the second MFMA group
 #endif
@@ -468,6 +489,10 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
 #if XV_NT_ROTPRIO
     const int wslot = xv_wave_slot();
 #endif
+    // LDS byte addresses this wave's DMA pieces land at (slot 0; xv_dma16)
+    const unsigned lds_a = xv_lds_addr(smem + NT_RPI * NT_RPT * uwave * NT_PITCH);
+    const unsigned lds_aw = xv_lds_addr(smem + NT_RPI * (CONV ? WIN_PIECES : NT_RPT) * uwave * NT_PITCH);
+    const unsigned lds_b = xv_lds_addr(smem + 2 * A_SLOT + NT_RPI * NT_RPT * uwave * NT_PITCH);
     const int taps = CONV ? p.taps : 1;
     const int C = p.K / taps;                   // channels per tap (CONV: a multiple of 16)
 
@@ -478,9 +503,10 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
         const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-        // per-lane source pointers of this tile (swizzled chunk folded in; out-of-range rows -> zero page)
-        const float* ap[CONV ? WIN_PIECES : NT_RPT];
-        const float* bp[NT_RPT];
+        // per-lane byte offsets of this tile from p.A / p.Bt (swizzled chunk folded in; xv_dma16).  Rows outside the operand read row 0:
+        // their products only reach accumulator rows / columns that are never stored, counted or - in a shared tile - used after the sum
+        unsigned aoff[CONV ? WIN_PIECES : NT_RPT];
+        unsigned boff[NT_RPT];
         int ksrc[NT_RPT];
         int a_row[2];                           // CONV: window row of this lane's two fragment rows at tap 0; else their LDS offset
 #pragma unroll
@@ -488,7 +514,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
             const int row = NT_RPI * (NT_RPT * wave + i) + lrow;
             ksrc[i] = ((lpos ^ NT_SWZ(row)) << 2);
             const int n = n0 + row;
-            bp[i] = (n < p.N ? p.Bt + (long)n * p.ldb : zp) + ksrc[i];
+            boff[i] = (unsigned)(((long)(n < p.N ? n : 0) * p.ldb + ksrc[i]) * 4);
         }
         if (CONV) {
             const int seg0 = m0 / p.a_rps;
@@ -497,7 +523,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
             for (int i = 0; i < WIN_PIECES; ++i) {
                 const int wrow = NT_RPI * (WIN_PIECES * wave + i) + lrow;
                 const long xr = xrow0 + wrow;
-                ap[i] = xr < p.a_rows ? p.A + xr * p.lda + ((lpos ^ NT_SWZ(wrow)) << 2) : zp;
+                aoff[i] = (unsigned)(((xr < p.a_rows ? xr : 0) * p.lda + ((lpos ^ NT_SWZ(wrow)) << 2)) * 4);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
@@ -512,43 +538,45 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
                 const int m = m0 + row;
                 const int mm = m < p.M ? m : 0;
                 const int seg = mm / p.a_rps, tt = mm - seg * p.a_rps;
-                ap[i] = (m < p.M ? p.A + ((long)seg * p.a_pitch + tt) * p.lda : zp) + ksrc[i];
+                aoff[i] = (unsigned)((((long)seg * p.a_pitch + tt) * p.lda + ksrc[i]) * 4);
             }
             a_row[0] = (wr * 64 + li) * NT_PITCH;
             a_row[1] = a_row[0] + 32 * NT_PITCH;
         }
         // K-step kt of a tile: generic = columns [kt*BK, +BK) of the spliced row; CONV = channel chunk kt / taps of tap kt % taps
         auto stage_b = [&](int kt, int slot) {
-            float* sb = smem + 2 * A_SLOT + slot * B_SLOT + NT_RPI * NT_RPT * uwave * NT_PITCH;
             const int k0 = CONV ? (kt % taps) * C + (kt / taps) * BK : kt * BK;
             if (CONV || k0 + BK <= p.K) {
+                const float* bbase = p.Bt + k0;
 #pragma unroll
-                for (int i = 0; i < NT_RPT; ++i)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(bp[i] + k0), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                for (int i = 0; i < NT_RPT; ++i) xv_dma16(bbase, boff[i], lds_b + (slot * B_SLOT + NT_RPI * i * NT_PITCH) * 4);
             } else {                       // ragged last step of a row: chunks at or beyond K come from the zero page
+                float* sb = smem + 2 * A_SLOT + slot * B_SLOT + NT_RPI * NT_RPT * uwave * NT_PITCH;
 #pragma unroll
-                for (int i = 0; i < NT_RPT; ++i)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(k0 + ksrc[i] < p.K ? bp[i] + k0 : zp), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                for (int i = 0; i < NT_RPT; ++i) {
+                    const float* pb = (const float*)((const char*)(p.Bt + k0) + boff[i]);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(k0 + ksrc[i] < p.K ? pb : zp), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                }
             }
         };
         auto stage_a = [&](int kt, int slot) {      // generic: the tile's rows of K-step kt; CONV: the window of channel chunk kt / taps
             if (CONV) {
-                float* sa = smem + slot * A_SLOT + NT_RPI * WIN_PIECES * uwave * NT_PITCH;
-                const int c0 = (kt / taps) * BK;
+                const float* abase = p.A + (kt / taps) * BK;
 #pragma unroll
-                for (int i = 0; i < WIN_PIECES; ++i)      // (a row beyond the tensor points at the zero page, which is at least K floats long: + c0 stays inside)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(ap[i] + c0), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                for (int i = 0; i < WIN_PIECES; ++i) xv_dma16(abase, aoff[i], lds_aw + (slot * A_SLOT + NT_RPI * i * NT_PITCH) * 4);
             } else {
-                float* sa = smem + slot * A_SLOT + NT_RPI * NT_RPT * uwave * NT_PITCH;
                 const int k0 = kt * BK;
-                if (k0 + BK <= p.K) {          // full K-step (uniform): the address is base + k0, nothing else per step
+                if (k0 + BK <= p.K) {          // full K-step (uniform): scalar base + k0, the lane offsets never change
+                    const float* abase = p.A + k0;
 #pragma unroll
-                    for (int i = 0; i < NT_RPT; ++i)
-                        __builtin_amdgcn_global_load_lds((gptr_t)(ap[i] + k0), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                    for (int i = 0; i < NT_RPT; ++i) xv_dma16(abase, aoff[i], lds_a + (slot * A_SLOT + NT_RPI * i * NT_PITCH) * 4);
                 } else {
+                    float* sa = smem + slot * A_SLOT + NT_RPI * NT_RPT * uwave * NT_PITCH;
 #pragma unroll
-                    for (int i = 0; i < NT_RPT; ++i)
-                        __builtin_amdgcn_global_load_lds((gptr_t)(k0 + ksrc[i] < p.K ? ap[i] + k0 : zp), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                    for (int i = 0; i < NT_RPT; ++i) {
+                        const float* pa = (const float*)((const char*)(p.A + k0) + aoff[i]);
+                        __builtin_amdgcn_global_load_lds((gptr_t)(k0 + ksrc[i] < p.K ? pa : zp), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                    }
                 }
             }
         };
@@ -563,6 +591,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
 
         stage_a(kt0, CONV ? (kt0 / taps) & 1 : 0);
         stage_b(kt0, 0);
+        xv_dma_wait_all();      // (the compiler does not see xv_dma16's loads)
         __syncthreads();
 #if XV_NT_STAMP
         if (first_seg) { XV_STAMP(1); first_seg = false; }
@@ -609,6 +638,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[1][e], acc[1][1], 0, 0, 0);
                 }
             }
+            xv_dma_wait_all();
             __syncthreads();
         }
         u += kt1 - kt0;
@@ -814,8 +844,14 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
         // persistent round holds its three slots per CU to the end.
         sk = sched_env ? sched_env[0] == 's' : (!g.co_running && t_sk + t_sk / 32 < t_dp);
     }
+    // Few tiles and no BatchNorm statistics to emit (one utterance at a time in extraction, the segment-level layers of batches > 128 chunks):
+    // split-K over the whole chip + the slab-sum launch below.  [measured, round 3, tools/extract_bench.py / segment_bench.py] the
+    // persistent kernel - a tile shared by at most 8 workgroups, its last arrival summing alone - was slower there: 0.214 -> 0.288 ms
+    // per 300-frame utterance (12 tiles), 0.30 -> 0.35 ms at 1 000 frames, 30 -> 80 us for d out (4 tiles, K = 7 352); at 10 000 frames
+    // (316 tiles) it wins, 1.45 -> 1.41 ms.
+    const bool few = !g.bn_part && tiles < 192 && ksteps >= 8 && !sched_env;
     // dp without a context window is the round-2 kernel below (its per-tile prologue / epilogue is leaner: 3-6 % on the K = 512 layers)
-    if (use_sk && (sk || conv)) {
+    if (use_sk && !few && (sk || conv)) {
         NTSKArgs q;
         q.nk = ksteps;
         q.total = (long)tiles * ksteps;
@@ -939,7 +975,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     const float* bbase = p.B + (b_cv ? n0 + lc : 0);
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    auto gstage = [&](int kt, int buf) {
+    auto gstage_ragged = [&](int kt, int buf) {      // a K-step with rows at or beyond r_end: those read the zero page (they are summed)
         float* sa = smem + buf * (2 * BK * BM) + 2 * TN_RPT * uwave * BM;
         float* sb = sa + BK * BM;
 #pragma unroll
@@ -956,6 +992,41 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(sb + 2 * i * BN), 16, 0, 0);
         }
     };
+    // Full K-steps (every row below r_end): scalar bases + 32-bit lane offsets (xv_dma16) that ADVANCE by BK rows per step - a row of the
+    // spliced view is (segment, frame): frame += BK, and on crossing the segment's last frame the offset also skips the rows between two
+    // segments.  (The first build resolved row -> (segment, frame) -> 64-bit address from scratch for every K-step: ~40 VALU instructions
+    // per wave and step beside the MFMAs.)  Columns outside the matrix read column 0: their products are never stored.
+    const bool steady = p.rps >= BK;      // at most one segment boundary per step
+    int tt_i[TN_RPT];
+    unsigned aoff[TN_RPT], boff[TN_RPT];
+#pragma unroll
+    for (int i = 0; i < TN_RPT; ++i) {
+        const int r = min(r_begin + 2 * (TN_RPT * wave + i) + (lane >> 5), p.R - 1);
+        const int seg = r / p.rps;
+        tt_i[i] = r - seg * p.rps;
+        aoff[i] = (unsigned)((((long)seg * p.a_pitch + tt_i[i]) * p.lda + (a_cv ? m0 + lc : 0)) * 4);
+        boff[i] = (unsigned)((((long)seg * p.b_pitch + tt_i[i]) * p.ldb + (b_cv ? n0 + lc : 0)) * 4);
+    }
+    const unsigned a_step = (unsigned)(BK * p.lda * 4), b_step = (unsigned)(BK * p.ldb * 4);
+    const unsigned a_skip = (unsigned)((long)(p.a_pitch - p.rps) * p.lda * 4), b_skip = (unsigned)((long)(p.b_pitch - p.rps) * p.ldb * 4);
+    const unsigned lds0 = xv_lds_addr(smem + 2 * TN_RPT * uwave * BM);
+    auto gstage = [&](int kt, int buf) {
+        if (!steady || r_begin + (kt + 1) * BK > r_end) {
+            gstage_ragged(kt, buf);
+            return;
+        }
+        // (kt counts up by one per call, so the offsets are at step kt here)
+#pragma unroll
+        for (int i = 0; i < TN_RPT; ++i) {
+            xv_dma16(p.A, aoff[i], lds0 + (buf * (2 * BK * BM) + 2 * i * BM) * 4);
+            xv_dma16(p.B, boff[i], lds0 + (buf * (2 * BK * BM) + BK * BM + 2 * i * BN) * 4);
+            tt_i[i] += BK;
+            const bool wrap = tt_i[i] >= p.rps;
+            tt_i[i] -= wrap ? p.rps : 0;
+            aoff[i] += a_step + (wrap ? a_skip : 0u);
+            boff[i] += b_step + (wrap ? b_skip : 0u);
+        }
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -967,17 +1038,27 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
 
     const int a_off = lh * BM + wr * 64 + 2 * li;
     const int b_off = lh * BN + wc * 64 + 2 * li;
+#ifndef XV_TN_PIPE
+#define XV_TN_PIPE 1
+#endif
+    // Schedule of a K-step: all sixteen fragment reads of stage kt, the first sixteen MFMAs, then - in mid-step - the wait for the DMA of
+    // stage kt + 1, the workgroup barrier (every wave has read stage kt: its slot is free; stage kt + 1 is visible), the DMA of stage
+    // kt + 2 into the slot just freed, and the other sixteen MFMAs.  A stage's loads so have a whole K-step to land.  sched_barrier pins
+    // the order: left alone, hipcc moves the wait and the barrier to right behind the fragment reads (they are the last MEMORY operations
+    // of the step; MFMAs do not count), i.e. in front of all 32 MFMAs, where the loads of the next stage have only just been issued.
     if (nk > 0) gstage(0, 0);
+    xv_dma_wait_all();      // (the compiler does not see xv_dma16's loads)
     __syncthreads();
+#if XV_TN_PIPE
+    if (nk > 1) gstage(1, 1);
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+#if !XV_TN_PIPE
         if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
+#endif
         const float* sa = smem + buf * (2 * BK * BM) + a_off;
         const float* sb = smem + buf * (2 * BK * BM) + BK * BM + b_off;
-        // Software pipeline over the two halves of the K-step: the second half's 16 fragment reads
-        // are issued BEFORE the first half's 32 MFMAs.  sched_barrier pins that order - hipcc's
-        // scheduler otherwise sinks every ds_read to just in front of its use and exposes the LDS
-        // latency once per 8 MFMAs.
         f32x2 af[BK / 4], bf[BK / 4], an[BK / 4], bn[BK / 4];
 #pragma unroll
         for (int j = 0; j < BK / 4; ++j) {
@@ -997,6 +1078,13 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[1][1], 0, 0, 0);
         }
+#if XV_TN_PIPE
+        __builtin_amdgcn_sched_barrier(0);
+        xv_dma_wait_all();
+        __syncthreads();
+        if (kt + 2 < nk) gstage(kt + 2, buf);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int j = 0; j < BK / 4; ++j) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].x, acc[0][0], 0, 0, 0);
@@ -1004,7 +1092,10 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].y, acc[1][1], 0, 0, 0);
         }
+#if !XV_TN_PIPE
+        xv_dma_wait_all();
         __syncthreads();
+#endif
     }
 
     // [measured, round 3] summing the split partials inside this kernel - the workgroup that finishes a tile last adds the slabs of the
@@ -1150,26 +1241,4 @@ extern "C" int xv_affine_wgrad(void* stream, const float* x, int segs, int t_in,
     if (rc) return rc;
     return xv_launch_wgrad_reduce((hipStream_t)stream, g.P, g.splits, k, c, c_pad, o, o, l2_scale != 0.f ? kernel : nullptr, o,
                                   l2_scale, dkernel, o);
-}
-
-// xv_affine_wgrad with the slab sum on a stream of its own (engine): the GEMM on `gemm_stream`, `ev` recorded behind it, the sum
-// (+ lambda W) on `sum_stream` behind the event - the GEMM stream is free for the next layer's weight gradient while the slabs are summed.
-int xv_affine_wgrad_two_streams(hipStream_t gemm_stream, hipStream_t sum_stream, hipEvent_t ev, const float* x, int segs, int t_in, int c_pad,
-                                int k, int c, const float* dz, int dz_seg_pitch, int dz_row0, int o, const float* kernel, float l2_scale,
-                                float* dkernel, void* ws, size_t ws_bytes) {
-    XV_REQUIRE(segs > 0 && k >= 1 && t_in >= k && c_pad >= c && o > 0 && o % 4 == 0, "affine_wgrad: bad shape (o=%d must be a multiple of 4)", o);
-    const int t_out = t_in - k + 1;
-    XvGemmTN g = {};
-    g.A = x; g.lda = c_pad; g.a_rps = t_out; g.a_pitch = t_in;
-    g.B = dz + (long)dz_row0 * o; g.ldb = o; g.b_rps = t_out; g.b_pitch = dz_seg_pitch;
-    g.M = k * c_pad; g.N = o; g.R = segs * t_out;
-    g.splits = xv_tn_splits(g.M, g.N, g.R);
-    XV_REQUIRE((size_t)g.splits * g.M * g.N * sizeof(float) <= ws_bytes, "affine_wgrad: workspace too small (%zu needed)",
-               (size_t)g.splits * g.M * g.N * sizeof(float));
-    g.P = (float*)ws;
-    int rc = xv_launch_gemm_tn(gemm_stream, g);
-    if (rc) return rc;
-    XV_CHECK_HIP(hipEventRecord(ev, gemm_stream));
-    XV_CHECK_HIP(hipStreamWaitEvent(sum_stream, ev, 0));
-    return xv_launch_wgrad_reduce(sum_stream, g.P, g.splits, k, c, c_pad, o, o, l2_scale != 0.f ? kernel : nullptr, o, l2_scale, dkernel, o);
 }

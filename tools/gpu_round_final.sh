@@ -17,4 +17,12 @@ python3 tools/bench_summary.py $O/bench_extended.json | grep -E "^f32|^f16x3"
 python3 tools/shape_sweep.py --precision f32 2>/dev/null > $O/shapes_f32.json
 python3 tools/shape_sweep.py --precision f16x3 2>/dev/null > $O/shapes_f16x3.json
 python3 tools/loader_scale.py --batches 400 --need 22800 2>/dev/null | tail -1 > $O/loader_scale.json
+python3 tools/trainer_bench.py 400 2>&1 | grep -v amdgpu.ids | tail -3 > $O/trainer_bench.txt
+tools/step_timeline.sh $O/s3_64x300 -- --chunks 64 --frames 300; rm -f $O/s3_64x300.log $O/s3_64x300.json
+tools/pmc_mfma.sh gpurun_out/profiles_$tag/pmc_mfma_run > /dev/null 2>&1; cp $O/pmc_mfma_run/pmc_mfma.json $O/pmc_mfma.json; rm -rf $O/pmc_mfma_run
+for shape in "128 200" "64 300"; do set -- $shape
+  for sched in dp sk auto; do
+    echo "=== XV_NT_SCHED=$sched"; if [ $sched == auto ]; then tools/gemm_probe tf_kaldi_speaker_amd/libxvector_hip.so $1 $2 5; else XV_NT_SCHED=$sched tools/gemm_probe tf_kaldi_speaker_amd/libxvector_hip.so $1 $2 5; fi
+  done > $O/gemm_probe_schedules_$1x$2.txt 2>&1
+done
 ls -la $O
