@@ -23,6 +23,7 @@
 // The contraction is order-insensitive in k as long as A and B agree, so the NT kernel lets
 // lane-half h own 4 CONSECUTIVE k of every 8 (one ds_read_b128 feeds 4 MFMAs).
 #include "xv_common.h"
+#include <type_traits>
 #include "xv_epilogue.h"
 #include <algorithm>
 #include <cstdlib>
@@ -850,8 +851,12 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     // per 300-frame utterance (12 tiles), 0.30 -> 0.35 ms at 1 000 frames, 30 -> 80 us for d out (4 tiles, K = 7 352); at 10 000 frames
     // (316 tiles) it wins, 1.45 -> 1.41 ms.
     const bool few = !g.bn_part && tiles < 192 && ksteps >= 8 && !sched_env;
-    // dp without a context window is the round-2 kernel below (its per-tile prologue / epilogue is leaner: 3-6 % on the K = 512 layers)
-    if (use_sk && !few && (sk || conv)) {
+    // One workgroup per tile ("dp") is the kernel below, context window or not.  [measured, round 3, after the LDS-DMA moved to scalar
+    // bases] staging is cheap now (MFMA-pipe occupancy 0.939 against 0.951 without any), so what the window saves - 39 % of the staged bytes
+    // at 5 taps - no longer pays for its per-step row arithmetic in a dp launch: tdnn2 / tdnn3 forward at S1 478 / 660 us with the window,
+    // 447 / 621 us (144 / 140 TF) without, the S1 step 5.39 -> 5.28 ms.  The evenly scheduled launches keep it (64 x 300: 381 / 514 us
+    // against 388 / 519 us).
+    if (use_sk && !few && sk) {
         NTSKArgs q;
         q.nk = ksteps;
         q.total = (long)tiles * ksteps;
@@ -936,6 +941,7 @@ struct TNArgs {
     int M, N, R, r_chunk;
     int tiles_m, tiles_n;
     const float* zero;
+    int ahead;      // K-step schedule (see the kernel)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1038,65 +1044,66 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
 
     const int a_off = lh * BM + wr * 64 + 2 * li;
     const int b_off = lh * BN + wc * 64 + 2 * li;
-#ifndef XV_TN_PIPE
-#define XV_TN_PIPE 1
-#endif
-    // Schedule of a K-step: all sixteen fragment reads of stage kt, the first sixteen MFMAs, then - in mid-step - the wait for the DMA of
-    // stage kt + 1, the workgroup barrier (every wave has read stage kt: its slot is free; stage kt + 1 is visible), the DMA of stage
-    // kt + 2 into the slot just freed, and the other sixteen MFMAs.  A stage's loads so have a whole K-step to land.  sched_barrier pins
-    // the order: left alone, hipcc moves the wait and the barrier to right behind the fragment reads (they are the last MEMORY operations
-    // of the step; MFMAs do not count), i.e. in front of all 32 MFMAs, where the loads of the next stage have only just been issued.
+    // Schedule of a K-step, two forms.  AHEAD: all sixteen fragment reads of stage kt, the first sixteen MFMAs, then - in mid-step - the
+    // wait for the DMA of stage kt + 1, the workgroup barrier (every wave has read stage kt: its slot is free; stage kt + 1 is visible),
+    // the DMA of stage kt + 2 into the slot just freed, and the other sixteen MFMAs: a stage's loads have a whole K-step to land.
+    // sched_barrier pins the order.  Plain: the DMA of stage kt + 1 at the top of step kt, wait + barrier where hipcc puts them (right
+    // behind the fragment reads - the last MEMORY operations of the step - i.e. in front of all 32 MFMAs).
+    // [measured, round 3, weight gradients incl. slab sum at S1] AHEAD wins on long runs of K-steps per workgroup and loses on short ones:
+    // tdnn2 / tdnn3 (128 / 166 K-steps) 514 -> 505 / 661 -> 648 us, tdnn5 / tdnn4 (71 / 24) 322 -> 341 / 129 -> 138 us - the launcher
+    // chooses per problem (TNArgs::ahead).
     if (nk > 0) gstage(0, 0);
     xv_dma_wait_all();      // (the compiler does not see xv_dma16's loads)
     __syncthreads();
-#if XV_TN_PIPE
-    if (nk > 1) gstage(1, 1);
-#endif
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-#if !XV_TN_PIPE
-        if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
-#endif
-        const float* sa = smem + buf * (2 * BK * BM) + a_off;
-        const float* sb = smem + buf * (2 * BK * BM) + BK * BM + b_off;
-        f32x2 af[BK / 4], bf[BK / 4], an[BK / 4], bn[BK / 4];
+    auto k_loop = [&](auto ahead_c) {
+        constexpr bool AHEAD = decltype(ahead_c)::value;
+        if (AHEAD && nk > 1) gstage(1, 1);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (!AHEAD && kt + 1 < nk) gstage(kt + 1, buf ^ 1);
+            const float* sa = smem + buf * (2 * BK * BM) + a_off;
+            const float* sb = smem + buf * (2 * BK * BM) + BK * BM + b_off;
+            f32x2 af[BK / 4], bf[BK / 4], an[BK / 4], bn[BK / 4];
 #pragma unroll
-        for (int j = 0; j < BK / 4; ++j) {
-            af[j] = *(const f32x2*)(sa + 2 * j * BM);
-            bf[j] = *(const f32x2*)(sb + 2 * j * BN);
-        }
+            for (int j = 0; j < BK / 4; ++j) {
+                af[j] = *(const f32x2*)(sa + 2 * j * BM);
+                bf[j] = *(const f32x2*)(sb + 2 * j * BN);
+            }
 #pragma unroll
-        for (int j = 0; j < BK / 4; ++j) {
-            an[j] = *(const f32x2*)(sa + 2 * (BK / 4 + j) * BM);
-            bn[j] = *(const f32x2*)(sb + 2 * (BK / 4 + j) * BN);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < BK / 4; ++j) {
+                an[j] = *(const f32x2*)(sa + 2 * (BK / 4 + j) * BM);
+                bn[j] = *(const f32x2*)(sb + 2 * (BK / 4 + j) * BN);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < BK / 4; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[1][1], 0, 0, 0);
-        }
-#if XV_TN_PIPE
-        __builtin_amdgcn_sched_barrier(0);
-        xv_dma_wait_all();
-        __syncthreads();
-        if (kt + 2 < nk) gstage(kt + 2, buf);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+            for (int j = 0; j < BK / 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[1][1], 0, 0, 0);
+            }
+            if (AHEAD) {
+                __builtin_amdgcn_sched_barrier(0);
+                xv_dma_wait_all();
+                __syncthreads();
+                if (kt + 2 < nk) gstage(kt + 2, buf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-        for (int j = 0; j < BK / 4; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].y, acc[1][1], 0, 0, 0);
+            for (int j = 0; j < BK / 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].y, acc[1][1], 0, 0, 0);
+            }
+            if (!AHEAD) {
+                xv_dma_wait_all();
+                __syncthreads();
+            }
         }
-#if !XV_TN_PIPE
-        xv_dma_wait_all();
-        __syncthreads();
-#endif
-    }
+    };
+    if (p.ahead) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 
     // [measured, round 3] summing the split partials inside this kernel - the workgroup that finishes a tile last adds the slabs of the
     // others (ticket hand-over as in xv_gemm_nt_sk_kernel) - was built and dropped: ONE workgroup then reads splits x 64 KB at the ~65 GB/s
@@ -1149,6 +1156,8 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
     int ksteps = xv_cdiv(g.R, BK);
     p.r_chunk = xv_cdiv(ksteps, g.splits) * BK;
+    static const int ahead_min = env_int("XV_TN_AHEAD_MIN", 96);      // (A/B switch: fewest K-steps per workgroup that stage two steps ahead)
+    p.ahead = p.r_chunk / BK >= ahead_min;
     int splits = xv_cdiv(g.R, p.r_chunk);
     XV_REQUIRE(splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", splits, g.splits);
     dim3 grid(p.tiles_m * p.tiles_n * splits, 1, 1);

@@ -228,6 +228,12 @@ struct NT16Args {
 #define PLANE_HALFS (128 * BK16)
 #define BUF_HALFS (4 * PLANE_HALFS)
 
+// the workgroup barrier of the staging pipelines: xv_dma16's loads are inline assembly the compiler does not count
+__device__ __forceinline__ void xv16_sync() {
+    xv_dma_wait_all();
+    __syncthreads();
+}
+
 template <int EPI>      // 0: plain, 1: + forward BN statistics of the tile, 2: + BN backward reductions (data gradient)
 __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel(NT16Args p) {
     constexpr int RPI = 64 / CQ16;                 // tile rows per LDS-DMA wave-instruction (16)
@@ -244,33 +250,46 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
     const int nk = (p.K + BK16 - 1) / BK16;
 
     const int lrow = lane / CQ16, lpos = lane % CQ16;
-    long aoff[IPW], boff[IPW];
-    bool av[IPW], bv[IPW];
+    // per-lane byte offsets from the plane bases, swizzled chunk folded in (xv_dma16: scalar base + 32-bit offset, xv_common.h; both planes
+    // share them).  Rows outside the matrix read row 0 - their products are never stored or counted; k beyond K must read zeros and
+    // takes the zero page through the builtin's 64-bit form (a ragged last K-step only).
+    unsigned aoff[IPW], boff[IPW];
     int ksrc[IPW];
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
         const int row = RPI * (IPW * wave + i) + lrow;
         ksrc[i] = ((lpos ^ SWZ16(row)) << 3);
         int m = m0 + row;
-        av[i] = m < p.M;
-        int mm = av[i] ? m : 0;
+        int mm = m < p.M ? m : 0;
         int seg = mm / p.a_rps, tt = mm - seg * p.a_rps;
-        aoff[i] = ((long)seg * p.a_pitch + tt) * p.lda;
+        aoff[i] = (unsigned)((((long)seg * p.a_pitch + tt) * p.lda + ksrc[i]) * 2);
         int n = n0 + row;
-        bv[i] = n < p.N;
-        boff[i] = (long)(bv[i] ? n : 0) * p.ldb;
+        boff[i] = (unsigned)(((long)(n < p.N ? n : 0) * p.ldb + ksrc[i]) * 2);
     }
+    const unsigned lds0 = xv_lds_addr(smem + RPI * IPW * uwave * BK16);
     auto gstage = [&](int kt, int buf) {
-        u16* base = smem + buf * BUF_HALFS + RPI * IPW * uwave * BK16;
         const int k0 = kt * BK16;
-#pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-            const int k = k0 + ksrc[i];
-            const bool kv = k < p.K;
+        if (k0 + BK16 <= p.K) {
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                const u16* pa = (kv && av[i]) ? p.A + pl * p.a_plane + aoff[i] + k : p.zero;
-                const u16* pb = (kv && bv[i]) ? p.Bt + pl * p.b_plane + boff[i] + k : p.zero;
+                const float* abase = (const float*)(p.A + pl * p.a_plane + k0);
+                const float* bbase = (const float*)(p.Bt + pl * p.b_plane + k0);
+#pragma unroll
+                for (int i = 0; i < IPW; ++i) {
+                    xv_dma16(abase, aoff[i], lds0 + (buf * BUF_HALFS + pl * PLANE_HALFS + RPI * i * BK16) * 2);
+                    xv_dma16(bbase, boff[i], lds0 + (buf * BUF_HALFS + (2 + pl) * PLANE_HALFS + RPI * i * BK16) * 2);
+                }
+            }
+            return;
+        }
+        u16* base = smem + buf * BUF_HALFS + RPI * IPW * uwave * BK16;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const bool kv = k0 + ksrc[i] < p.K;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const u16* pa = kv ? (const u16*)((const char*)(p.A + pl * p.a_plane + k0) + aoff[i]) : p.zero;
+                const u16* pb = kv ? (const u16*)((const char*)(p.Bt + pl * p.b_plane + k0) + boff[i]) : p.zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(base + pl * PLANE_HALFS + RPI * i * BK16), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + (2 + pl) * PLANE_HALFS + RPI * i * BK16), 16, 0, 0);
             }
@@ -292,7 +311,7 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
         b_off[q] = rb * BK16 + ((lg ^ SWZ16(rb)) << 3);
     }
     if (nk > 0) gstage(0, 0);
-    __syncthreads();
+    xv16_sync();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
                 MM(0, 1); MM(1, 0); MM(0, 0);
 #undef MM
             }
-        __syncthreads();
+        xv16_sync();
     }
     const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
     // scale + bias in a pass of their own, THEN the stores: with both in one predicated block per element hipcc put the
@@ -357,7 +376,7 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
     const int fsw = SWZ16(li);
     const int a_row = (wr * 64 + li) * BK16, b_row = (wc * 32 * NB16 + li) * BK16;
     if (nk > 0) gstage(0, 0);
-    __syncthreads();
+    xv16_sync();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
 #if !(XV16_ABL & 1)
@@ -395,7 +414,7 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
 #undef MM
                 }
         }
-        __syncthreads();
+        xv16_sync();
     }
 
     const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
@@ -511,39 +530,34 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
 
     // DMA lane geometry: one wave-instruction = 16 image rows x 64 B; lane -> row l>>2, 16-byte chunk l&3 (source chunk swizzled)
     const int drow = lane >> 2, dchunk = lane & 3;
-    // B: rows 16*(BG*wave + i) + drow of the weight tile
-    long boff[G::BG];
-    bool bv[G::BG];
-    int bsrc[G::BG];
+    // B: rows 16*(BG*wave + i) + drow of the weight tile.  Byte offsets from the plane bases (xv_dma16: scalar base + 32-bit lane offset,
+    // both planes share them); rows outside the operands read row 0 - their products are never stored or counted.
+    unsigned boff[G::BG];
 #pragma unroll
     for (int i = 0; i < G::BG; ++i) {
         const int row = 16 * (G::BG * wave + i) + drow;
-        bsrc[i] = (dchunk ^ CONV_SWZ(row)) << 3;
-        int n = n0 + row;
-        bv[i] = n < p.N;
-        boff[i] = (long)(bv[i] ? n : 0) * p.ldb;
+        const int n = n0 + row;
+        boff[i] = (unsigned)(((long)(n < p.N ? n : 0) * p.ldb + ((dchunk ^ CONV_SWZ(row)) << 3)) * 2);
     }
+    const unsigned lds_b = xv_lds_addr(sB + 16 * G::BG * uwave * 32), lds_a = xv_lds_addr(sA);
     auto stage_b = [&](int cc, int j, int buf) {
-        u16* base = sB + buf * CONV_BBUF + 16 * G::BG * uwave * 32;
         const long k0 = (long)j * C + cc * 32;
 #pragma unroll
-        for (int i = 0; i < G::BG; ++i)
+        for (int pl = 0; pl < 2; ++pl) {
+            const float* bbase = (const float*)(p.Bt + pl * p.b_plane + k0);
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                const u16* pb = bv[i] ? p.Bt + pl * p.b_plane + boff[i] + k0 + bsrc[i] : p.zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + pl * CONV_BPLANE + 16 * i * 32), 16, 0, 0);
-            }
+            for (int i = 0; i < G::BG; ++i) xv_dma16(bbase, boff[i], lds_b + (buf * CONV_BBUF + pl * CONV_BPLANE + 16 * i * 32) * 2);
+        }
     };
     // A: NG row groups x 2 planes wave-instructions per chunk, id = plane*NG + group; slice `part` of `nparts`
     // hands ids part*NW + wave + s*NW*nparts to this wave.
+    const int asrc = (dchunk ^ CONV_SWZ(drow)) << 3;      // (CONV_SWZ looks at bit 2 of the row: 16 * group does not touch it)
     auto stage_a = [&](int cc, int buf, int part, int nparts) {
         for (int id = part * G::NW + uwave; id < 2 * G::NG; id += G::NW * nparts) {
             const int pl = id >= G::NG ? 1 : 0, grp = id - G::NG * pl;
-            const int row = 16 * grp + drow;
-            const long xr = xr0 + row;
-            const int src = (dchunk ^ CONV_SWZ(row)) << 3;
-            const u16* pa = xr < q.a_rows ? p.A + pl * p.a_plane + xr * C + cc * 32 + src : p.zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(sA + buf * G::ABUF + pl * G::APLANE + 16 * grp * 32), 16, 0, 0);
+            const long xr = xr0 + 16 * grp + drow;
+            const unsigned aoff = (unsigned)(((xr < q.a_rows ? xr : 0) * C + asrc) * 2);
+            xv_dma16((const float*)(p.A + pl * p.a_plane + cc * 32), aoff, lds_a + (buf * G::ABUF + pl * G::APLANE + 16 * grp * 32) * 2);
         }
     };
 
@@ -564,7 +578,7 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
     }
     stage_a(0, 0, 0, 1);
     stage_b(0, 0, 0);
-    __syncthreads();
+    xv16_sync();
     int st = 0;
     for (int cc = 0; cc < nc; ++cc) {
         const u16* abase = sA + (cc & 1) * G::ABUF;
@@ -592,7 +606,7 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
                     MM(0, 1); MM(1, 0); MM(0, 0);
 #undef MM
                 }
-            __syncthreads();
+            xv16_sync();
         }
     }
     const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
@@ -644,7 +658,7 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
     const int bsw = (li >> 2) & 3;
     stage_a(0, 0, 0, 1);
     stage_b(0, 0, 0);
-    __syncthreads();
+    xv16_sync();
     int st = 0;
     for (int cc = 0; cc < nc; ++cc) {
         const u16* abase = sA + (cc & 1) * G::ABUF;
@@ -680,7 +694,7 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
 #undef MM
                     }
             }
-            __syncthreads();
+            xv16_sync();
         }
     }
 
@@ -857,7 +871,10 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
     const int scol = (((((dpos >> 1) ^ (2 * drow)) << 1) | (dpos & 1))) * 8;    // source column (16-bit elements)
 #endif
     const bool a_cv = (m0 + scol) < p.M, b_cv = (n0 + scol) < p.N;
-    auto gstage = [&](int kt, int buf) {
+#ifndef XV16_TN_ABLATE
+#define XV16_TN_ABLATE 0      // diagnostics only (tools/variant_libs.sh; wrong results): 1 = the A (x) planes are staged for the first stage only, 2 = the B (dz) planes
+#endif
+    auto gstage_ragged = [&](int kt, int buf) {      // a stage with rows at or beyond r_end: those read the zero page (they are summed)
         u16* base = smem + buf * BH;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -870,16 +887,50 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
             tt = r - seg * p.rps;
             const long ao = ((long)seg * p.a_pitch + tt) * p.lda + m0 + scol;
             const long bo = ((long)seg * p.b_pitch + tt) * p.ldb + n0 + scol;
-#ifndef XV16_TN_ABLATE
-#define XV16_TN_ABLATE 0      // diagnostics only (tools/variant_libs.sh; wrong results): 1 = the A (x) planes are staged for the first stage only, 2 = the B (dz) planes
-#endif
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
                 const u16* pa = (rv && a_cv) ? p.A + pl * p.a_plane + ao : p.zero;
                 const u16* pb = (rv && b_cv) ? p.B + pl * p.b_plane + bo : p.zero;
-                if (!(XV16_TN_ABLATE & 1) || kt < 2) __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(base + pl * PH + 4 * rg * 128), 16, 0, 0);
-                if (!(XV16_TN_ABLATE & 2) || kt < 2) __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + (2 + pl) * PH + 4 * rg * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(base + pl * PH + 4 * rg * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + (2 + pl) * PH + 4 * rg * 128), 16, 0, 0);
             }
+        }
+    };
+    // Full stages: scalar plane bases + 32-bit lane offsets that advance by BR rows per stage (xv_dma16; the fp32 weight-gradient kernel's
+    // scheme, xv_gemm.hip): a row of the spliced view is (segment, frame), frame += BR, and on crossing a segment's last frame the offset
+    // skips the rows between two segments.  Columns outside the matrix read column 0: their products are never stored.
+    const bool steady = p.rps >= BR;
+    int tt_i[2];
+    unsigned aoff[2], boff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = min(r_begin + 4 * (2 * wave + i) + drow, p.R - 1);
+        const int seg = r / p.rps;
+        tt_i[i] = r - seg * p.rps;
+        aoff[i] = (unsigned)((((long)seg * p.a_pitch + tt_i[i]) * p.lda + (a_cv ? m0 + scol : 0)) * 2);
+        boff[i] = (unsigned)((((long)seg * p.b_pitch + tt_i[i]) * p.ldb + (b_cv ? n0 + scol : 0)) * 2);
+    }
+    const unsigned a_step = (unsigned)(BR * p.lda * 2), b_step = (unsigned)(BR * p.ldb * 2);
+    const unsigned a_skip = (unsigned)((long)(p.a_pitch - p.rps) * p.lda * 2), b_skip = (unsigned)((long)(p.b_pitch - p.rps) * p.ldb * 2);
+    const unsigned lds0 = xv_lds_addr(smem + 4 * 2 * uwave * 128);
+    auto gstage = [&](int kt, int buf) {
+        if (!steady || r_begin + (kt + 1) * BR > r_end) {
+            gstage_ragged(kt, buf);
+            return;
+        }
+        // (kt counts up by one per call, so the offsets are at stage kt here)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                if (!(XV16_TN_ABLATE & 1) || kt < 2) xv_dma16((const float*)(p.A + pl * p.a_plane), aoff[i], lds0 + (buf * BH + pl * PH + 4 * i * 128) * 2);
+                if (!(XV16_TN_ABLATE & 2) || kt < 2) xv_dma16((const float*)(p.B + pl * p.b_plane), boff[i], lds0 + (buf * BH + (2 + pl) * PH + 4 * i * 128) * 2);
+            }
+            tt_i[i] += BR;
+            const bool wrap = tt_i[i] >= p.rps;
+            tt_i[i] -= wrap ? p.rps : 0;
+            aoff[i] += a_step + (wrap ? a_skip : 0u);
+            boff[i] += b_step + (wrap ? b_skip : 0u);
         }
     };
 
@@ -899,7 +950,7 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
     };
     typedef __attribute__((address_space(3))) s16x4* ltr_t;
     if (nk > 0) gstage(0, 0);
-    __syncthreads();
+    xv16_sync();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
@@ -926,7 +977,7 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
                 MM(0, 1); MM(1, 0); MM(0, 0);
 #undef MM
             }
-        __syncthreads();
+        xv16_sync();
     }
     const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
     float* P = p.P + (long)split * p.M * p.N;
@@ -961,7 +1012,7 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
     };
     typedef __attribute__((address_space(3))) s16x4* ltr_t;
     if (nk > 0) gstage(0, 0);
-    __syncthreads();
+    xv16_sync();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
@@ -992,7 +1043,7 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
 #undef MM
                 }
         }
-        __syncthreads();
+        xv16_sync();
     }
 
     const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
