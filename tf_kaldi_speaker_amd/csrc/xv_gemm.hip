@@ -801,6 +801,9 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     XV_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm_nt: K/lda/ldb must be multiples of 4 (K=%d lda=%ld ldb=%ld)", g.K, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0, "gemm_nt: operands must be 16-byte aligned");
     XV_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.a_rps > 0, "gemm_nt: empty problem");
+    // xv_dma16 addresses every operand row as a 32-bit byte offset from the operand's base
+    XV_REQUIRE(((long)xv_cdiv(g.M, g.a_rps) * g.a_pitch + 1) * g.lda * 4 < (1L << 32) && ((long)g.N + 1) * g.ldb * 4 < (1L << 32),
+               "gemm_nt: an operand spans 4 GB or more (M=%d a_pitch=%d lda=%ld N=%d ldb=%ld): split the batch", g.M, g.a_pitch, g.lda, g.N, g.ldb);
     if (ensure_zero_page((size_t)g.K)) return 1;
     NTArgs p;
     p.zero = g_zero_page;
@@ -1149,6 +1152,12 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     p.zero = g_zero_page;
     XV_REQUIRE(g.a_rps == g.b_rps && g.a_rps > 0, "gemm_tn: both operands must share the rows-per-segment");
     XV_REQUIRE(g.R < (1 << 24), "gemm_tn: at most 2^24 reduction rows");
+    {   // xv_dma16 addresses every operand row as a 32-bit byte offset from the operand's base
+        const long segs = xv_cdiv(g.R, g.a_rps);
+        XV_REQUIRE((segs * g.a_pitch + 1) * g.lda * 4 < (1L << 32) && (segs * g.b_pitch + 1) * g.ldb * 4 < (1L << 32),
+                   "gemm_tn: an operand spans 4 GB or more (%ld segments of %d / %d rows, lda=%ld ldb=%ld): split the batch", segs, g.a_pitch,
+                   g.b_pitch, g.lda, g.ldb);
+    }
     p.A = g.A; p.lda = g.lda; p.a_pitch = g.a_pitch;
     p.B = g.B; p.ldb = g.ldb; p.b_pitch = g.b_pitch;
     p.rps = g.a_rps; p.inv_rps = 1.0f / (float)g.a_rps;

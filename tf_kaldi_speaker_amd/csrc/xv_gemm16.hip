@@ -789,6 +789,9 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0 && g.a_plane % 8 == 0 && g.b_plane % 8 == 0,
                "gemm16_nt: planes must be 16-byte aligned");
     XV_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.a_rps > 0, "gemm16_nt: empty problem");
+    // xv_dma16 addresses every row of a plane as a 32-bit byte offset from the plane's base
+    XV_REQUIRE(((long)xv_cdiv(g.M, g.a_rps) * g.a_pitch + 1) * g.lda * 2 < (1L << 32) && ((long)g.N + 1) * g.ldb * 2 < (1L << 32),
+               "gemm16_nt: a plane spans 4 GB or more (M=%d a_pitch=%d lda=%ld N=%d ldb=%ld): split the batch", g.M, g.a_pitch, g.lda, g.N, g.ldb);
     if (ensure_zero16()) return 1;
     NT16Args p;
     p.A = (const u16*)g.A; p.lda = g.lda; p.a_plane = g.a_plane; p.a_rps = g.a_rps; p.a_pitch = g.a_pitch;
@@ -1075,6 +1078,11 @@ int xv_tn16_splits(int M, int N, int R) {
 int xv_launch_gemm16_tn(hipStream_t s, const XvGemm16TN& g) {
     XV_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && g.M % 8 == 0 && g.N % 8 == 0, "gemm16_tn: lda/ldb/M/N must be multiples of 8 (M=%d N=%d)", g.M, g.N);
     XV_REQUIRE(g.R > 0 && g.R < (1 << 24) && g.rps > 0 && g.splits >= 1, "gemm16_tn: bad reduction shape");
+    {   // xv_dma16 addresses every row of a plane as a 32-bit byte offset from the plane's base
+        const long segs = xv_cdiv(g.R, g.rps);
+        XV_REQUIRE((segs * g.a_pitch + 1) * g.lda * 2 < (1L << 32) && (segs * g.b_pitch + 1) * g.ldb * 2 < (1L << 32),
+                   "gemm16_tn: a plane spans 4 GB or more (%ld segments, lda=%ld ldb=%ld): split the batch", segs, g.lda, g.ldb);
+    }
     if (ensure_zero16()) return 1;
     TN16Args p;
     p.A = (const u16*)g.A; p.lda = g.lda; p.a_plane = g.a_plane; p.a_pitch = g.a_pitch;
