@@ -1300,6 +1300,7 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
         // last frame layer's BN backward waited ~80 us for the dz slot tdnn7's weight gradient still had to read; on its own stream but
         // launched at the END of this stage (it has 3 ms of slack, and d out runs 23 instead of 49 us without it alongside) it again
         // costs fp32 0.24 ms: its many-workgroup TN kernel then competes with the first big data-gradient GEMMs
+        // [measured, round 3] started right BEHIND the d-out launch instead of in front of it: no difference (5.36 / 4.42 / 12.70 ms at S1 / 64 x 300 / S5 either way)
         auto loss_head_wgrad = [&]() -> int {
             int rc = 0;
             hipStream_t ss = e->concurrent ? e->side2 : s;

@@ -18,29 +18,32 @@ for k in sorted(f, key=lambda k: -f[k][0] * f[k][1]):
                   "bytes_per_launch_corrected": int((2.0 * fk + wk) * 1024)}
 
 
-def s1_algorithmic_mb():
+def s1_algorithmic_mb(names):
     """Algorithmic MB per launch (operands read once + the result written once, fp32) of every GEMM launch of one S1 step (128 x 200 x 30,
-    tdnn.py:35-127, 7351 speakers), grouped by the kernel that runs it under the launcher's policy at that shape."""
+    tdnn.py:35-127, 7351 speakers), grouped by the kernel that runs it: the layers with taps go to the context-window kernel when the
+    trace has one (round-3 first half), else to the plain kernel with the others."""
     B, T, spk = 128, 200, 7351
     layers = [(5, 32, 512), (5, 512, 512), (7, 512, 512), (1, 512, 512), (1, 512, 1500)]      # (taps, padded input channels, outputs)
     mb = lambda *els: sum(els) * 4 / 1e6
-    groups = {"xv_gemm_nt_sk_kernel<true, true>": [], "xv_gemm_nt_kernel<true>": [], "xv_gemm_nt_sk_kernel<false, true>": [],
-              "xv_gemm_nt_kernel<false>": [], "xv_gemm_tn_kernel": []}
+    fwd_w, fwd_p, bwd_w, bwd_p = ("xv_gemm_nt_sk_kernel<true, true>", "xv_gemm_nt_kernel<true>", "xv_gemm_nt_sk_kernel<false, true>",
+                                  "xv_gemm_nt_kernel<false>")
+    has = lambda g: any(g in n for n in names)
+    groups = {fwd_w: [], fwd_p: [], bwd_w: [], bwd_p: [], "xv_gemm_tn_kernel": []}
     t_in = T
     for i, (k, c, o) in enumerate(layers):
         t_out = t_in - k + 1
         x, w, y = B * t_in * c, k * c * o, B * t_out * o
-        groups["xv_gemm_nt_sk_kernel<true, true>" if k > 1 else "xv_gemm_nt_kernel<true>"].append(mb(x, w, y))       # forward
+        groups[fwd_w if k > 1 and has(fwd_w) else fwd_p].append(mb(x, w, y))              # forward
         if i > 0:
-            groups["xv_gemm_nt_sk_kernel<false, true>" if k > 1 else "xv_gemm_nt_kernel<false>"].append(mb(y, w, x))  # data gradient
-        groups["xv_gemm_tn_kernel"].append(mb(x, y, w))                                                               # weight gradient
+            groups[bwd_w if k > 1 and has(bwd_w) else bwd_p].append(mb(y, w, x))          # data gradient
+        groups["xv_gemm_tn_kernel"].append(mb(x, y, w))                                   # weight gradient
         t_in = t_out
     for m, n in ((3000, 512), (512, 512), (512, spk + 1)):            # tdnn6, tdnn7, the loss head: weight gradients of [B][m]^T . [B][n]
         groups["xv_gemm_tn_kernel"].append(mb(B * m, B * n, m * n))
-    return groups
+    return {g: v for g, v in groups.items() if v}
 
 
-alg = s1_algorithmic_mb()
+alg = s1_algorithmic_mb(list(kernels))
 for name, v in kernels.items():
     for g, mbs in alg.items():
         if g in name:
