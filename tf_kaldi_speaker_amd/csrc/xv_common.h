@@ -94,6 +94,8 @@ __device__ __forceinline__ void xv_handoff_load8(const float* p, int stride, f32
 // builtin inside a loop - it folds a scalar base back into the vector address) the MFMA pipe was 0.867 occupied; the same loads fed from one
 // hot KiB 0.883 (so it is not the memory side); this form 0.939: 488 -> 449 us, 132 -> 143 TF.  The compiler does not see the loads:
 // callers wait with xv_dma_wait_all() before the barrier that publishes a stage, and every operand row must lie within 4 GB of the base.
+// (M0 is a reserved register: hipcc sets it immediately in front of each of its own uses - the LDS-DMA builtin of the ragged paths -
+// and keeps nothing in it across statements, so writing it here needs no clobber; naming it in the clobber list is rejected as reserved.)
 __device__ __forceinline__ void xv_dma16(const float* sbase, unsigned voff, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory");
 }

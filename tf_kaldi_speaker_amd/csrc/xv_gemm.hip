@@ -1216,28 +1216,69 @@ extern "C" int xv_affine_dgrad(void* stream, const float* dz_pad, int segs, int 
 }
 
 // out[(j*C + c)][n] = sum_z P[z][j*c_pad + c][n] (+ l2 * w[(j*C + c)][n])
-__global__ void xv_wgrad_reduce_kernel(const float* __restrict__ P, int splits, long slab, int k, int C, int c_pad, int n_in,
-                                       int n_out, const float* __restrict__ w, long ldw, float l2, float* __restrict__ out, long ldo) {
-    long total = (long)k * C * n_out;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long row = i / n_out;
-        int n = (int)(i - row * n_out);
-        int j = (int)(row / C), c = (int)(row - (long)j * C);
-        long m = (long)j * c_pad + c;
-        float v = 0.f;
-        for (int z = 0; z < splits; ++z) v += P[z * slab + m * n_in + n];
-        if (w) v += l2 * w[row * ldw + n];
-        out[row * ldo + n] = v;
+// Block = 64 column quads (16 B per lane) x 4; splits are added in split order with eight loads in flight.  ZSPLIT (many splits, few
+// output rows - tdnn1: 150 rows x 128 splits): the 4 thread groups of a block take contiguous runs of the splits of ONE row and their sums
+// are added in group order (a fixed association: bit-reproducible).  Otherwise the 4 groups are 4 rows and a thread adds all splits of
+// its quad.  Row blocks are grid-strided (at most ~2 048 workgroups: a launch of many short workgroups crawls beside a GEMM).
+// (The first build read 4 bytes per lane with two 64-bit divisions per element: 45 us for tdnn2's 63 MB of slabs alone on the chip -
+// and the last of these launches sits between the last GEMM of a step and the update.)
+#define WR_FLIGHT 8
+template <bool ZSPLIT>
+__global__ __launch_bounds__(256) void xv_wgrad_reduce_kernel(const float* __restrict__ P, int splits, long slab, int rows, int C, int c_pad,
+                                                              int n_in, int nq_out, const float* __restrict__ w, long ldw, float l2,
+                                                              float* __restrict__ out, long ldo) {
+    __shared__ f32x4 part[ZSPLIT ? 4 : 1][64];
+    const int qx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + qx;
+    const bool qv = q < nq_out;
+    const int per = ZSPLIT ? (splits + 3) / 4 : splits;
+    const int z0 = ZSPLIT ? g * per : 0, z1 = min(splits, z0 + per);
+    for (int rb = blockIdx.y; rb * (ZSPLIT ? 1 : 4) < rows; rb += gridDim.y) {
+        const int row = ZSPLIT ? rb : 4 * rb + g;
+        const bool rv = row < rows;
+        const int rr = rv ? row : 0;
+        const int j = rr / C, c = rr - j * C;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (qv && rv) {
+            const float* src = P + ((long)j * c_pad + c) * n_in + 4 * q;
+            for (int z = z0; z < z1; z += WR_FLIGHT) {
+                f32x4 t[WR_FLIGHT];
+#pragma unroll
+                for (int u = 0; u < WR_FLIGHT; ++u) t[u] = *(const f32x4*)(src + (long)min(z + u, z1 - 1) * slab);
+#pragma unroll
+                for (int u = 0; u < WR_FLIGHT; ++u)
+                    if (z + u < z1) v += t[u];
+            }
+        }
+        if (ZSPLIT) {
+            __syncthreads();      // (the previous row's sums have been read)
+            part[g][qx] = v;
+            __syncthreads();
+            if (g != 0) continue;
+            v = ((part[0][qx] + part[1][qx]) + part[2][qx]) + part[3][qx];
+        }
+        if (qv && rv) {
+            if (w) v += l2 * *(const f32x4*)(w + (long)row * ldw + 4 * q);
+            *(f32x4*)(out + (long)row * ldo + 4 * q) = v;
+        }
     }
 }
 
 int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int C, int c_pad, int n_in, int n_out, const float* w,
                            long ldw, float l2, float* out, long ldo) {
-    long total = (long)k * C * n_out;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(xv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, P, splits, (long)k * c_pad * n_in, k, C, c_pad, n_in,
-                       n_out, w, ldw, l2, out, ldo);
+    XV_REQUIRE(n_out % 4 == 0 && n_in % 4 == 0 && ldo % 4 == 0 && (!w || ldw % 4 == 0) && ((uintptr_t)P % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+                   (!w || ((uintptr_t)w % 16) == 0),
+               "wgrad_reduce: widths and leading dimensions must be multiples of 4 floats, buffers 16-byte aligned (n_out=%d)", n_out);
+    const int rows = k * C, gx = xv_cdiv(n_out / 4, 64);
+    const bool zsplit = splits >= 32 && (long)rows * gx < 1024;
+    const int row_blocks = zsplit ? rows : xv_cdiv(rows, 4);
+    const dim3 grid(gx, std::min(row_blocks, std::max(1, 2048 / gx)));
+    if (zsplit)
+        hipLaunchKernelGGL(xv_wgrad_reduce_kernel<true>, grid, dim3(256), 0, s, P, splits, (long)k * c_pad * n_in, rows, C, c_pad, n_in, n_out / 4, w,
+                           ldw, l2, out, ldo);
+    else
+        hipLaunchKernelGGL(xv_wgrad_reduce_kernel<false>, grid, dim3(256), 0, s, P, splits, (long)k * c_pad * n_in, rows, C, c_pad, n_in, n_out / 4, w,
+                           ldw, l2, out, ldo);
     XV_LAUNCH_CHECK();
     return 0;
 }
