@@ -15,8 +15,9 @@
 //
 // Both kernels: 128x128 output tile, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile
 // as 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 acc VGPRs), K-step XV_TILE_K = 16, operand tiles
-// staged by LDS-DMA (global_load_lds_dwordx4) into a double-buffered 32 KB LDS image, one barrier per
-// K-step, XV_WGS_PER_CU = 4 workgroups per CU (xv_common.h).
+// staged by LDS-DMA (global_load_lds_dwordx4, scalar base + 32-bit lane offsets: xv_dma16 in xv_common.h - the address
+// form decides what a stage costs the MFMA pipe) into a double-buffered 32 KB LDS image, one barrier per K-step,
+// XV_WGS_PER_CU = 4 workgroups per CU (xv_common.h).
 //
 // MFMA operand maps (cdna_hip_programming.md section 3): lane l supplies A[i=l&31][k=l>>5] and
 // B[k=l>>5][j=l&31]; D register r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), column l&31.
@@ -45,7 +46,6 @@
 static_assert(BK == 16 || BK == 32, "K-step must be 16 or 32");
 #define NT_KQ (BK / 4)               // float4 per tile row
 #define NT_RPT (BM * NT_KQ / 256)    // tile rows staged per thread (2 or 4)
-#define NT_RSTRIDE (256 / NT_KQ)     // row distance between a thread's staged rows
 #define TN_RPT (BK / 8)              // reduction rows staged per thread (2 or 4)
 
 struct NTArgs {
@@ -227,10 +227,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     const int k_end = min(p.K, k_begin + p.k_chunk);
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
-#ifndef XV_GLDS
-#define XV_GLDS 1
-#endif
-#if XV_GLDS
     // ---- global -> LDS staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write.
     // One wave-instruction writes 1 KiB linearly (wave-uniform base + lane*16 B) = NT_RPI whole tile rows,
     // so lane l lands on row RPI*(RPT*wave+i) + l/KQ at chunk POSITION l%KQ; the XOR swizzle therefore
@@ -291,54 +287,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             }
         }
     };
-#define NT_STAGE_FIRST() gstage(0, 0)
-#define NT_STAGE_NEXT(kt, buf) gstage((kt) + 1, (buf) ^ 1)
-#define NT_COMMIT(buf) ((void)0)
-#else
-    // ---- global -> register staging: thread owns rows lrow+32i, 4 consecutive k at lk
-    const int lrow = tid / NT_KQ, lk = (tid % NT_KQ) * 4;
-    const float* ap[NT_RPT];
-    const float* bp[NT_RPT];
-    bool av[NT_RPT], bv[NT_RPT];
-#pragma unroll
-    for (int i = 0; i < NT_RPT; ++i) {
-        int m = m0 + lrow + NT_RSTRIDE * i;
-        av[i] = m < p.M;
-        int mm = av[i] ? m : 0;
-        int seg = mm / p.a_rps, tt = mm - seg * p.a_rps;
-        ap[i] = p.A + ((long)seg * p.a_pitch + tt) * p.lda;
-        int n = n0 + lrow + NT_RSTRIDE * i;
-        bv[i] = n < p.N;
-        bp[i] = p.Bt + (long)(bv[i] ? n : 0) * p.ldb;
-    }
-    f32x4 ra[NT_RPT], rb[NT_RPT];
-    const float* __restrict__ zp = p.zero;
-    auto gload = [&](int kt) {
-        int k = k_begin + kt * BK + lk;
-        bool kv = k < k_end;
-#pragma unroll
-        for (int i = 0; i < NT_RPT; ++i) {
-            const float* pa = (kv && av[i]) ? ap[i] + k : zp;
-            const float* pb = (kv && bv[i]) ? bp[i] + k : zp;
-            ra[i] = *(const f32x4*)pa;
-            rb[i] = *(const f32x4*)pb;
-        }
-    };
-    auto lstore = [&](int buf) {
-        float* sa = smem + buf * (2 * BM * NT_PITCH);
-        float* sb = sa + BM * NT_PITCH;
-#pragma unroll
-        for (int i = 0; i < NT_RPT; ++i) {
-            const int row = lrow + NT_RSTRIDE * i;
-            const int pos = (((lk >> 2) ^ NT_SWZ(row)) << 2);
-            *(f32x4*)(sa + row * NT_PITCH + pos) = ra[i];
-            *(f32x4*)(sb + row * NT_PITCH + pos) = rb[i];
-        }
-    };
-#define NT_STAGE_FIRST() do { gload(0); lstore(0); } while (0)
-#define NT_STAGE_NEXT(kt, buf) gload((kt) + 1)
-#define NT_COMMIT(buf) lstore((buf) ^ 1)
-#endif
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -351,16 +299,14 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     const int a_off = (wr * 64 + li) * NT_PITCH;
     const int b_off = (wc * 64 + li) * NT_PITCH;
     const int fsw = NT_SWZ(li);     // rows wr*64 + a*32 + li share f(li): the offsets are multiples of 16
-    if (nk > 0) NT_STAGE_FIRST();
-#if XV_GLDS
+    if (nk > 0) gstage(0, 0);
     xv_dma_wait_all();
-#endif
     __syncthreads();
     XV_STAMP(1);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
 #if !(XV_NT_ABLATE & 2)
-        if (kt + 1 < nk) NT_STAGE_NEXT(kt, buf);
+        if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
 #endif
         const float* sa = smem + buf * (2 * BM * NT_PITCH);
         const float* sb = sa + BM * NT_PITCH;
@@ -385,10 +331,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][e], bf[1][e], acc[1][1], 0, 0, 0);
             }
         }
-        if (kt + 1 < nk) NT_COMMIT(buf);
-#if XV_GLDS
         xv_dma_wait_all();      // the compiler does not see xv_dma16's loads
-#endif
 #if XV_NT_BARRIER_END
         __builtin_amdgcn_sched_barrier(0);      // keeps hipcc from hoisting the barrier above the second MFMA group
 #endif
@@ -846,7 +789,8 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
         // other kernel's workgroups take the slots its short CUs free (tdnn2's data and weight gradient together: 1 076 us with the
         // one-tile-per-workgroup launch that takes 647 us alone, 1 113 us with the balanced one that takes 527 us alone) - while the
         // persistent round holds its three slots per CU to the end.
-        sk = sched_env ? sched_env[0] == 's' : (!g.co_running && t_sk + t_sk / 32 < t_dp);
+        static const int corun_sk = env_int("XV_NT_CORUN_SK", 0);      // (A/B switch: let launches beside the weight-gradient stream take the even schedule too)
+        sk = sched_env ? sched_env[0] == 's' : ((!g.co_running || corun_sk) && t_sk + t_sk / 32 < t_dp);
     }
     // Few tiles and no BatchNorm statistics to emit (one utterance at a time in extraction, the segment-level layers of batches > 128 chunks):
     // split-K over the whole chip + the slab-sum launch below.  [measured, round 3, tools/extract_bench.py / segment_bench.py] the
