@@ -90,7 +90,9 @@ int xv_prep_weight_dgrad(void* stream, const float* kernel, int k, int c, int o,
  * If bn_part != NULL it receives per-128-row-tile column statistics of z (sum and centred
  * sum of squares, min, max: layout [4][tiles_m][o]) for xv_bn_finalize - the batch statistics of
  * tf.layers.batch_normalization(training=True), tdnn.py:46.  `ws` is scratch
- * (xv_op_workspace_bytes) used when the launcher splits the reduction. */
+ * (xv_op_workspace_bytes) used when the launcher splits the reduction.
+ * Every GEMM operand (x, wt, dz - in split precision: each fp16 plane) must span less than 4 GB: the kernels address operand rows as
+ * 32-bit byte offsets from the operand's base (an error is returned otherwise: split the batch). */
 int xv_affine_forward(void* stream, const float* x, int segs, int t_in, int c_pad, int k,
                       const float* wt, const float* bias, float* z, int o, int ldz,
                       float* bn_part, void* ws, size_t ws_bytes);
