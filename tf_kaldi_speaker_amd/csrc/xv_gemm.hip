@@ -1079,9 +1079,11 @@ int xv_tn_splits(int M, int N, int R) {
     // [measured, round 2] fewer co-resident workgroups (smaller slabs, cheaper slab sum) lose: 768 -> +0.06 ms/step, 512 -> +0.19 ms
     // [measured, round 3, after the DMA / slab-sum work; medians of 4 alternated runs, S1 | 64 x U{200..400} | 64 x 300 | S5]
     //   960: -0.7 | -0.5 | -1.2 | -0.5 %     896: -0.4 | -1.2 | -2.4 | -0.1 %     832: +0.4 | -0.6 | -1.5 | -0.4 %     768: -0.8 | -0.5 | . | -0.4 %
-    // against 1 024: a slot left free on half the CUs lets the BatchNorm kernels of the data-gradient chain in beside the weight gradient
-    // (they took 200-360 us instead of 20-50 while it held every slot).  7/8 of the slots: best on the shipped batch shape.
-    static const int target = env_int("XV_TN_WGS", XV_RESIDENT_WGS * 7 / 8);      // (A/B switch of the co-resident workgroup target)
+    // against 1 024: a free slot per CU lets the BatchNorm kernels of the data-gradient chain in beside the weight gradient (they took
+    // 200-360 us instead of 20-50 while it held every slot).  896 is best inside the step on the shipped batch shape, but 3.5 workgroups
+    // per CU is an unbalanced launch when the kernel runs alone (its isolated rate 123 -> 112 TF, MFMA busy 0.83 -> 0.74); 768 = 3 per CU
+    // keeps the launch balanced and most of the gain.
+    static const int target = env_int("XV_TN_WGS", XV_RESIDENT_WGS * 3 / 4);      // (A/B switch of the co-resident workgroup target)
     static const int min_ksteps = std::max(1, env_int("XV_TN_MIN_KSTEPS", 2));      // (A/B switch: fewest K-steps a workgroup is given)
     int splits = target / tiles;
     if (splits > ksteps / min_ksteps) splits = ksteps / min_ksteps;
