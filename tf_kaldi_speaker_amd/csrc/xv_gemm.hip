@@ -1077,13 +1077,13 @@ int xv_tn_splits(int M, int N, int R) {
     // whole grid is ONE co-resident round.  (On the first build - 2 per CU - 560 workgroups = 512 + a 48-workgroup second
     // round cost 2x: 61 TF on tdnn2/3, 24 TF on tdnn5.)
     // [measured, round 2] fewer co-resident workgroups (smaller slabs, cheaper slab sum) lose: 768 -> +0.06 ms/step, 512 -> +0.19 ms
-    // [measured, round 3, after the DMA / slab-sum work; medians of 4 alternated runs, S1 | 64 x U{200..400} | 64 x 300 | S5]
-    //   960: -0.7 | -0.5 | -1.2 | -0.5 %     896: -0.4 | -1.2 | -2.4 | -0.1 %     832: +0.4 | -0.6 | -1.5 | -0.4 %     768: -0.8 | -0.5 | . | -0.4 %
-    // against 1 024: a free slot per CU lets the BatchNorm kernels of the data-gradient chain in beside the weight gradient (they took
-    // 200-360 us instead of 20-50 while it held every slot).  896 is best inside the step on the shipped batch shape, but 3.5 workgroups
-    // per CU is an unbalanced launch when the kernel runs alone (its isolated rate 123 -> 112 TF, MFMA busy 0.83 -> 0.74); 768 = 3 per CU
-    // keeps the launch balanced and most of the gain.
-    static const int target = env_int("XV_TN_WGS", XV_RESIDENT_WGS * 3 / 4);      // (A/B switch of the co-resident workgroup target)
+    // [measured, round 3, after the DMA / slab-sum work; medians of 3-4 alternated runs against 1 024, S1 | 64 x U{200..400} | S5]
+    //   896: -0.1 ... -0.4 | -1.1 | -0.2 %     768: -0.6 ... -0.8 | -0.2 ... -0.5 | -0.1 ... -0.4 %
+    // (a free slot per CU lets the BatchNorm kernels of the data-gradient chain in beside the weight gradient) - but the kernel itself
+    // is slower with fewer workgroups: alone 1 655 -> 1 724 (768) / 1 837 us (896: 3.5 per CU is an unbalanced launch) over the five
+    // frame layers, its isolated roofline fraction 0.78 -> 0.75 / 0.71.  Kept at one full round: the step gains are at the noise level
+    // of a box change, the kernel's loss is not.
+    static const int target = env_int("XV_TN_WGS", XV_RESIDENT_WGS);      // (A/B switch of the co-resident workgroup target)
     static const int min_ksteps = std::max(1, env_int("XV_TN_MIN_KSTEPS", 2));      // (A/B switch: fewest K-steps a workgroup is given)
     int splits = target / tiles;
     if (splits > ksteps / min_ksteps) splits = ksteps / min_ksteps;
