@@ -789,7 +789,11 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
         // other kernel's workgroups take the slots its short CUs free (tdnn2's data and weight gradient together: 1 076 us with the
         // one-tile-per-workgroup launch that takes 647 us alone, 1 113 us with the balanced one that takes 527 us alone) - while the
         // persistent round holds its three slots per CU to the end.
-        static const int corun_sk = env_int("XV_NT_CORUN_SK", 0);      // (A/B switch: let launches beside the weight-gradient stream take the even schedule too)
+        // [measured again after the DMA / slab-sum work, medians of 4 alternated runs] with the even schedule ALSO for the launches beside
+        // the weight-gradient stream (tdnn2's data gradient at S1: 784 tiles): S1 -0.7 %, S2 -0.5 %, 64 x U{200..400} -0.3 %, S4 -0.4 %,
+        // S5 +0.1 % - the data-gradient launches now spend a good part of their time alone on the chip (the weight-gradient stream sums
+        // slabs or waits for the next dz meanwhile).  On by default; XV_NT_CORUN_SK=0 restores "launches that own the chip only".
+        static const int corun_sk = env_int("XV_NT_CORUN_SK", 1);
         sk = sched_env ? sched_env[0] == 's' : ((!g.co_running || corun_sk) && t_sk + t_sk / 32 < t_dp);
     }
     // Few tiles and no BatchNorm statistics to emit (one utterance at a time in extraction, the segment-level layers of batches > 128 chunks):
