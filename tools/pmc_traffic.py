@@ -50,7 +50,48 @@ for name, v in kernels.items():
             v["s1_algorithmic_mb_per_launch"] = round(sum(mbs) / len(mbs), 1)
             v["s1_launches_per_step"] = len(mbs)
             v["ratio_to_algorithmic"] = round(v["bytes_per_launch_corrected"] / 1e6 / (sum(mbs) / len(mbs)), 2)
-json.dump({"algorithmic_note": "s1_algorithmic_mb_per_launch = operands once + result once, averaged over the launches of one S1 step that the "
+
+
+def direction_ratios():
+    """Per direction (all kernels that serve it together, dispatch-weighted): bytes past L2 per step / algorithmic bytes per step at S1 -
+    independent of which kernel the launcher's schedule picked for which layer."""
+    B, T, spk = 128, 200, 7351
+    layers = [(5, 32, 512), (5, 512, 512), (7, 512, 512), (1, 512, 512), (1, 512, 1500)]
+    mb = lambda *els: sum(els) * 4 / 1e6
+    alg = {"forward": 0.0, "data_gradient": 0.0, "weight_gradient": 0.0}
+    n = {"forward": 0, "data_gradient": 0, "weight_gradient": 0}
+    t_in = T
+    for i, (k, c, o) in enumerate(layers):
+        t_out = t_in - k + 1
+        x, w, y = B * t_in * c, k * c * o, B * t_out * o
+        alg["forward"] += mb(x, w, y); n["forward"] += 1
+        if i > 0:
+            alg["data_gradient"] += mb(y, w, x); n["data_gradient"] += 1
+        alg["weight_gradient"] += mb(x, y, w); n["weight_gradient"] += 1
+        t_in = t_out
+    for m, nn in ((3000, 512), (512, 512), (512, spk + 1)):
+        alg["weight_gradient"] += mb(B * m, B * nn, m * nn); n["weight_gradient"] += 1
+    pick = {"forward": lambda k: "gemm_nt" in k and "16" not in k and "<true" in k,
+            "data_gradient": lambda k: "gemm_nt" in k and "16" not in k and "<false" in k,
+            "weight_gradient": lambda k: "xv_gemm_tn_kernel" in k}
+    out = {}
+    for d, f in pick.items():
+        ks = [k for k in kernels if f(k)]
+        disp = sum(kernels[k]["dispatches"] for k in ks)
+        if not disp:
+            continue
+        steps = disp / float(n[d])
+        per_step = sum(kernels[k]["bytes_per_launch_corrected"] * kernels[k]["dispatches"] for k in ks) / steps / 1e6
+        out[d] = {"mb_per_step": round(per_step, 1), "s1_algorithmic_mb_per_step": round(alg[d], 1), "ratio_to_algorithmic": round(per_step / alg[d], 2)}
+    return out
+
+
+for name, v in kernels.items():
+    if "nt_sk_kernel" in name:
+        v["note"] = ("evenly scheduled launch: the figure includes the shared-tile hand-over (write-through 16-byte stores, L2-bypassing 16-byte loads, "
+                     "xv_handoff_* in xv_common.h), which the TCC counters book per lane access, not per coalesced line - the launch could not move this "
+                     "many bytes through HBM in its duration; the same kernel without shared tiles: r03_pmc_traffic_context_window.json")
+json.dump({"s1_direction_totals_fp32": direction_ratios(), "algorithmic_note": "s1_algorithmic_mb_per_launch = operands once + result once, averaged over the launches of one S1 step that the "
                                "launcher gives to this kernel (valid for the default S1 bench command only)",
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `%s`; values are KiB per dispatch averaged "
                      "over all dispatches of the kernel; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports 1/2 of a wide "
