@@ -447,7 +447,8 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
     // first.  Every workgroup then walks K upwards from (about) 0 in step with the others, so the K-slices of the weight matrix in flight on
     // an XCD at any moment are the same few for all its workgroups, as in a one-workgroup-per-tile launch.  In run order the workgroups of
     // an XCD sit at all K offsets at once, their weight slices do not fit the L2 together and are re-fetched from the Infinity Cache
-    // ([measured, r03_pmc_traffic] 1.45 GB past the L2 for tdnn2's data gradient at S1 against 0.18 GB in tile order).
+    // [measured, FETCH_SIZE, tdnn2's data gradient at S1: 784 tiles on 768 workgroups] 1.45 GB fetched past the L2 per launch in run order,
+    // 0.16 GB with this order (0.18 GB for one workgroup per tile); the time is the same - the Infinity Cache absorbed it.
     const long u_begin = u;
     const long u_mid = (u / q.nk + 1) * q.nk;                  // end of the first tile of the run
     const bool wrap_first = XV_SK_WRAP_FIRST && u % q.nk != 0 && u_mid < u_end && u_end - u_mid <= q.nk;

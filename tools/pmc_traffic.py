@@ -86,11 +86,6 @@ def direction_ratios():
     return out
 
 
-for name, v in kernels.items():
-    if "nt_sk_kernel" in name:
-        v["note"] = ("evenly scheduled launch: the figure includes the shared-tile hand-over (write-through 16-byte stores, L2-bypassing 16-byte loads, "
-                     "xv_handoff_* in xv_common.h), which the TCC counters book per lane access, not per coalesced line - the launch could not move this "
-                     "many bytes through HBM in its duration; the same kernel without shared tiles: r03_pmc_traffic_context_window.json")
 json.dump({"s1_direction_totals_fp32": direction_ratios(), "algorithmic_note": "s1_algorithmic_mb_per_launch = operands once + result once, averaged over the launches of one S1 step that the "
                                "launcher gives to this kernel (valid for the default S1 bench command only)",
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `%s`; values are KiB per dispatch averaged "
