@@ -67,3 +67,43 @@ def test_every_unit_once_and_consistent_sharing(rows, cols, K, wpc):
     # a workgroup has at most two shared tiles
     for w in range(P):
         assert sum(1 for (ww, tile, kt0, kt1, slot) in shares if ww == w and (kt0 != 0 or kt1 != nk)) <= 2
+
+
+def run_order(tiles, nk, P, w):
+    """The order in which workgroup w walks its run (xv_gemm_nt_sk_kernel, XV_SK_WRAP_FIRST): a run that ends one tile and begins the next
+    takes the beginning of the next tile first, so that every workgroup starts near K = 0."""
+    total = tiles * nk
+    u0, u_end = w * total // P, (w + 1) * total // P
+    u_mid = (u0 // nk + 1) * nk
+    wrap_first = u0 % nk != 0 and u_mid < u_end and u_end - u_mid <= nk
+    passes = [(u_mid, u_end), (u0, u_mid)] if wrap_first else [(u0, u_end)]
+    segs = []
+    for u, u_stop in passes:
+        while u < u_stop:
+            tile = u // nk
+            kt0 = u - tile * nk
+            kt1 = min(nk, kt0 + (u_stop - u))
+            segs.append((tile, kt0, kt1))
+            u += kt1 - kt0
+    return segs, wrap_first
+
+
+@pytest.mark.parametrize("rows,cols,K", SHAPES)
+def test_wrap_first_order_covers_the_same_units(rows, cols, K):
+    tiles = -(-rows // 128) * -(-cols // 128)
+    nk = -(-K // 16)
+    total = tiles * nk
+    P = min(768, max(1, total // 4), 8 * tiles)
+    _, begin, _, shares = schedule(tiles, nk, P)
+    wrapped = 0
+    for w in range(P):
+        segs, wrap = run_order(tiles, nk, P, w)
+        wrapped += wrap
+        natural = sorted((tile, kt0, kt1) for ww, tile, kt0, kt1, slot in shares if ww == w)
+        assert sorted(segs) == natural                                    # the same shares, another order
+        if wrap:
+            assert len(segs) == 2 and segs[0][1] == 0 and segs[0][0] == segs[1][0] + 1 and segs[1][2] == nk
+            # in step with the others: the walk starts at K = 0 and its second leg starts no more than one run length further on
+            assert segs[1][1] >= segs[0][2] - (begin[w + 1] - begin[w])
+    if rows == 25088 and K == 2560:                                       # tdnn2's data gradient at S1: 784 tiles on 768 workgroups
+        assert wrapped >= 700
