@@ -75,6 +75,10 @@ int xv_pad_channels(void* stream, const float* src, int rows, int c_src, float* 
  *   [min f32][range f32][d x (p0, p25, p75, p100) u16][d x t u8, column after column]
  * -> out [b][t][d] float32, bit-identical to the host decoder and the reference reader.  d <= 128. */
 int xv_cm_decode(void* stream, const uint8_t* packed, int b, int t, int d, size_t chunk_stride, float* out);
+/* Ragged form for whole utterances of different lengths (batched extraction, extract.py:64-93 / kaldi_io.py:768-812 read_mat_ark): chunk i
+ * is the packed image above of a matrix with rows[i] <= t frames (its bytes are [d][rows[i]]) at byte offsets[i] of `packed`; it is decoded
+ * into out[i][0 .. rows[i]) of the [b][t][d] tensor and the padding rows behind it are zeroed.  offsets / rows: device arrays [b]. */
+int xv_cm_decode_ragged(void* stream, const uint8_t* packed, const int64_t* offsets, const int32_t* rows, int b, int t, int d, float* out);
 
 /* Kernel-layout weights for xv_affine_forward: wt[o][j*c_pad + c] = kernel[j][c][o]
  * (TF layout [k][C][O] of tdnn/tdnnX_{conv,dense}/kernel, tdnn.py:39,57,75,96,115,147,166);
@@ -391,6 +395,9 @@ typedef struct xv_config {
     int32_t frame_context[12];
     int32_t frame_width[12];
     int32_t relu_type;                /* XV_RELU_*: network_relu_type, tdnn.py:24-30 (no shipped config sets it) */
+    /* capacity in rows = chunks x frames of one forward; 0 = max_batch * max_frames.  Batched extraction sets it (with a large
+     * max_frames): a batch is many short utterances or a few long ones, never max_batch chunks of max_frames frames */
+    int32_t max_rows;
 } xv_config;
 #define XV_MAX_FRAME_LAYERS 12
 /* the non-linearity behind every BatchNorm: relu | prelu = relu(x) + alpha (x - |x|) / 2 with a trainable per-channel alpha
@@ -427,6 +434,13 @@ int xv_engine_bind(xv_engine* e, float* variables, float* grads, float* opt_stat
 /* tdnn(features) (+ entire_network's l2_scaling).  features: [b][t][feat_dim].
  * training != 0: batch statistics + moving-average update (is_training=True). */
 int xv_engine_forward(xv_engine* e, void* stream, const float* features, int b, int t, int training);
+/* Inference forward (is_training=False, trainer.py:708-726) over a batch of utterances of DIFFERENT lengths, the batched form of the loop
+ * extract.py:64-93 runs one utterance at a time: chunk i of features [b][t][feat_dim] holds frames[i] valid frames (receptive field <=
+ * frames[i] <= t) followed by padding (finite values, e.g. zeros).  The frame layers are valid convolutions, so the first
+ * frames[i] - (receptive field - 1) output frames of chunk i do not see the padding; pooling (and the attention softmax) use exactly
+ * those.  Segment-level endpoints ("pooling", "tdnn6_dense", ...) are per chunk as usual; frame-level endpoints keep their padded rows.
+ * frames: device array [b]. */
+int xv_engine_forward_lengths(xv_engine* e, void* stream, const float* features, int b, int t, const int32_t* frames);
 /* loss_network(features, labels) + gradients of loss + regulariser w.r.t. every trainable
  * variable into the bound gradient buffer.  global_step feeds the lambda schedule
  * (trainer.py:505-508).  stage: -1 = everything; 0..XV_BWD_STAGES-1 = that slice only (lets the

@@ -378,3 +378,72 @@ def test_sample_validset_spk2utt_rules(tmp_path):
     with redirect_stdout(buf2):
         main(["2", "3", str(p), "--seed", "7"])
     assert buf2.getvalue() == buf.getvalue()
+
+
+def test_length_batch_planner_and_batched_utterance_embeddings():
+    """Batched extraction, host side: utterances sorted into padded batches within the chunk / row / fill limits, every index once;
+    the windowed driver gives the embeddings of the one-at-a-time driver (extract.py:64-93) in archive order."""
+    rs = np.random.RandomState(0)
+    lengths = [int(v) for v in rs.randint(25, 2001, 300)] + [10000, 9000, 26]
+    plan = U.plan_length_batches(lengths, 49152, 128)
+    seen = sorted(i for idx, _ in plan for i in idx)
+    assert seen == list(range(len(lengths)))
+    for idx, t in plan:
+        assert t == max(lengths[i] for i in idx) and len(idx) <= 128 and (len(idx) == 1 or len(idx) * t <= 49152)
+        short = [k for k, i in enumerate(idx) if lengths[i] < 0.9 * t]      # members in sorted order: padding beyond 10 % only while the batch is small
+        assert all(k * t < 8192 for k in short), (t, short)
+    padded = sum(len(idx) * t for idx, t in plan)
+    assert padded <= 1.08 * sum(lengths), "more than 8 %% padding on a uniform length mix: %d vs %d" % (padded, sum(lengths))
+    assert U.plan_length_batches([], 100, 4) == [] and U.plan_length_batches([7], 3, 4) == [([0], 7)]      # an utterance longer than the row budget goes alone
+
+    def predict(x):       # "embedding" = (first value, frames) per matrix
+        x = np.asarray(x)
+        return np.array([x[0, 0], x.shape[0]], np.float32) if x.ndim == 2 else np.stack([[c[0, 0], c.shape[0]] for c in x]).astype(np.float32)
+
+    calls = []
+
+    def predict_batch(items):
+        calls.append([it.shape[0] for it in items])
+        return np.stack([predict(it.decode() if hasattr(it, "decode") else it) for it in items])
+
+    feats = [np.arange(n, dtype=np.float32)[:, None] * np.ones((1, 3), np.float32) + k for k, n in enumerate((60, 130, 40, 61))]
+    for normalize in (False, True):
+        del calls[:]
+        got = U.batched_utterance_embeddings(predict_batch, feats, 60, normalize)
+        assert len(calls) == 1 and calls[0] == [60, 60, 60, 60, 40, 40, 60, 31]      # 1 + 4 + 1 + 2 pieces in one call
+        for f, (emb, pieces) in zip(feats, got):
+            ref, ref_pieces = U.utterance_embedding(predict, f, 60, normalize)
+            assert pieces == ref_pieces and np.allclose(emb, ref, rtol=1e-6, atol=0)
+    assert U.batched_utterance_embeddings(predict_batch, [], 60, False) == []
+
+
+def test_packed_matrix_reader(tmp_path):
+    """read_mat_ark_packed: 'CM ' matrices undecoded (the image the GPU decodes), other formats decoded; PackedMatrix.decode /
+    row_range agree bit for bit with the (reference-pinned) host reader."""
+    rs = np.random.RandomState(1)
+    mats = {"a": rs.randn(77, 30).astype(np.float32) * 3, "b": rs.randn(5, 30).astype(np.float32), "c": rs.randn(300, 23).astype(np.float32),
+            "d": rs.randn(40, 30).astype(np.float32)}
+    ark = str(tmp_path / "mixed.ark")
+    with open(ark, "wb") as f:
+        kaldi_io.write_compressed_mat(f, mats["a"], key="a")
+        kaldi_io.write_mat(f, mats["b"], key="b")                       # 'FM '
+        kaldi_io.write_compressed_mat(f, mats["c"], key="c")
+        kaldi_io.write_compressed_mat(f, mats["d"], key="d")
+    ref = dict(kaldi_io.read_mat_ark(ark))
+    got = list(kaldi_io.read_mat_ark_packed(ark))
+    assert [k for k, _ in got] == ["a", "b", "c", "d"]
+    for k, m in got:
+        if k == "b":
+            assert isinstance(m, np.ndarray) and np.array_equal(m, ref[k])
+            continue
+        assert isinstance(m, kaldi_io.PackedMatrix) and m.shape == ref[k].shape
+        assert np.array_equal(m.decode(), ref[k])
+        s, n = 3, min(17, m.rows - 3)
+        part = m.row_range(s, n)
+        assert part.shape == (n, m.cols) and np.array_equal(part.decode(), ref[k][s:s + n])
+    with open(ark, "rb") as f:      # a truncated archive is an error, not a short matrix
+        data = f.read()
+    bad = str(tmp_path / "cut.ark")
+    open(bad, "wb").write(data[:200])
+    with pytest.raises(Exception):
+        list(kaldi_io.read_mat_ark_packed(bad))

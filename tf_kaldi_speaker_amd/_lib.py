@@ -61,6 +61,7 @@ class XvConfig(C.Structure):
         ("frame_context", C.c_int32 * 12),
         ("frame_width", C.c_int32 * 12),
         ("relu_type", C.c_int32),
+        ("max_rows", C.c_int32),
     ]
 
 
@@ -141,6 +142,7 @@ SIGNATURES = {
     "xv_loss_prep_weight": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP]),
     "xv_margin_softmax_rows": (_I, [_VP, _I, _VP, _I, _I, _I, _VP, _I, _VP, _F, _F, _VP, _VP, _VP, _VP]),
     "xv_cm_decode": (_I, [_VP, _VP, _I, _I, _I, _SZ, _VP]),
+    "xv_cm_decode_ragged": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "xv_add_norm_grad": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
     "xv_segment_gemm": (_I, [_VP, _VP, C.c_long, _VP, C.c_long, _I, _I, _I, _VP, _VP, _VP, _VP, C.c_long, _VP, C.c_long, _VP, _SZ, _VP]),
     "xv_segment_affine_bn_forward": (_I, [_VP, _VP, C.c_long, _VP, C.c_long, _I, _I, _I, _VP, _VP, _VP, _F, _F, _I, _VP, _VP, _VP, _VP, _VP,
@@ -162,6 +164,7 @@ SIGNATURES = {
     "xv_engine_optimizer_state_count": (_SZ, [_VP]),
     "xv_engine_bind": (_I, [_VP, _VP, _VP, _VP]),
     "xv_engine_forward": (_I, [_VP, _VP, _VP, _I, _I, _I]),
+    "xv_engine_forward_lengths": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
     "xv_engine_loss_forward": (_I, [_VP, _VP, _VP, _I, _I]),
     "xv_engine_backward": (_I, [_VP, _VP, _I]),
     "xv_engine_backward_async": (_I, [_VP, _VP, _I]),

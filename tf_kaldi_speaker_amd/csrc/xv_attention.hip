@@ -38,10 +38,17 @@ __global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict_
 }
 
 // w[b][t] = softmax_t(score[b][t]); one workgroup per chunk
-__global__ __launch_bounds__(256) void softmax_segments_kernel(const float* __restrict__ score, int t, float* __restrict__ w) {
+// flen (batched extraction): chunk b has flen[b] - shrink valid frames; the padding behind them gets weight 0
+__global__ __launch_bounds__(256) void softmax_segments_kernel(const float* __restrict__ score, int t, float* __restrict__ w,
+                                                               const int* __restrict__ flen, int shrink) {
     __shared__ float red[4];
     const float* s = score + (long)blockIdx.x * t;
     float* o = w + (long)blockIdx.x * t;
+    if (flen) {
+        const int tv = max(1, min(t, flen[blockIdx.x] - shrink));
+        for (int i = tv + threadIdx.x; i < t; i += 256) o[i] = 0.f;
+        t = tv;
+    }
     float m = -INFINITY;
     for (int i = threadIdx.x; i < t; i += 256) m = fmaxf(m, s[i]);
     m = wave_max(m);
@@ -166,11 +173,14 @@ extern "C" int xv_att_score(void* stream, const float* zk, int rows, int n, int 
     return 0;
 }
 
-extern "C" int xv_softmax_segments(void* stream, const float* score, int b, int t, float* weights) {
+int xv_softmax_segments_ex(hipStream_t s, const float* score, int b, int t, float* weights, const int32_t* frames, int shrink) {
     XV_REQUIRE(score && weights && b > 0 && t > 0, "softmax_segments: bad arguments");
-    hipLaunchKernelGGL(softmax_segments_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, score, t, weights);
+    hipLaunchKernelGGL(softmax_segments_kernel, dim3(b), dim3(256), 0, s, score, t, weights, (const int*)frames, shrink);
     XV_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int xv_softmax_segments(void* stream, const float* score, int b, int t, float* weights) {
+    return xv_softmax_segments_ex((hipStream_t)stream, score, b, t, weights, nullptr, 0);
 }
 
 extern "C" int xv_softmax_segments_backward(void* stream, const float* weights, const float* dweights, int b, int t, float* dscore) {

@@ -254,8 +254,12 @@ size_t xv_skinny_tickets(int max_n);
 // wpos [b][c] = the share of each chunk's frame weights on frames with an active ReLU; given that, the BatchNorm backward gets its
 // two reductions in closed form from the pooled statistics instead of a pass over z (plain ReLU / no activation); amax [b][c] = each
 // chunk's largest activation, which bounds |d a| for the split-precision dz scale (XvBnBwdSplit.wpos / .pamax, unit frame weights)
+// frames (optional, device [b]) / shrink: chunk i pools only its first frames[i] - shrink rows (batched extraction: utterances of different
+// lengths padded to t rows; shrink = the frames the frame layers consumed)
 int xv_stat_pool_forward_bn_ex(hipStream_t s, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
-                               const float* weights, float* out, float* wpos, float* amax);
+                               const float* weights, float* out, float* wpos, float* amax, const int32_t* frames = nullptr, int shrink = 0);
+// softmax over the first frames[i] - shrink scores of chunk i (weights beyond are 0); frames == nullptr: all t (xv_attention.hip)
+int xv_softmax_segments_ex(hipStream_t s, const float* score, int b, int t, float* weights, const int32_t* frames, int shrink);
 int xv_bn_relu_backward_pooled_ex(hipStream_t s, const float* pool_out, const float* dpool, const float* weights, const float* wpos, int b, int t,
                                   const float* z, int n, const float* gamma, const float* mean, const float* invstd, const float* scale,
                                   const float* shift, int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes);

@@ -70,12 +70,21 @@ extern "C" int xv_pad_channels(void* stream, const float* src, int rows, int c_s
 // ------------------------------------------------------------------------------------
 #define CMD_MAX_D 128
 #define CMD_TT 128
-__global__ __launch_bounds__(256) void cm_decode_kernel(const uint8_t* __restrict__ packed, long stride, int T, int D, float* __restrict__ out) {
+// Ragged form (batched extraction: whole utterances of different lengths): chunk i starts at byte offs[i], holds rows[i] frames (its bytes
+// are [D][rows[i]]) and is written to out[i][0 .. rows[i]) of a [b][T][D] tensor whose remaining rows are zeroed.
+__global__ __launch_bounds__(256) void cm_decode_kernel(const uint8_t* __restrict__ packed, long stride, int T, int D, float* __restrict__ out,
+                                                        const long* __restrict__ offs, const int* __restrict__ rows) {
 #pragma clang fp contract(off)
     __shared__ float prm[6][CMD_MAX_D];                  // p0, p25, p75, s_lo, s_mid, s_hi per column
     __shared__ uint8_t tile[CMD_MAX_D][CMD_TT + 4];
-    const uint8_t* chunk = packed + (long)blockIdx.x * stride;
+    const uint8_t* chunk = packed + (offs ? offs[blockIdx.x] : (long)blockIdx.x * stride);
     const int tid = threadIdx.x;
+    const int Tout = T;
+    if (rows) {
+        T = min(T, rows[blockIdx.x]);
+        float* pad = out + ((long)blockIdx.x * Tout + T) * D;
+        for (long i = tid; i < (long)(Tout - T) * D; i += 256) pad[i] = 0.f;
+    }
     float minv, range;
     memcpy(&minv, chunk, 4);
     memcpy(&range, chunk + 4, 4);
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(256) void cm_decode_kernel(const uint8_t* __restric
         prm[5][tid] = (p100 - p75) / 63.0f;
     }
     const uint8_t* bytes = chunk + 8 + 8 * (long)D;
-    float* o = out + (long)blockIdx.x * T * D;
+    float* o = out + (long)blockIdx.x * Tout * D;
     for (int t0 = 0; t0 < T; t0 += CMD_TT) {
         const int tt_n = min(CMD_TT, T - t0);
         __syncthreads();
@@ -119,7 +128,17 @@ extern "C" int xv_cm_decode(void* stream, const uint8_t* packed, int b, int t, i
     XV_REQUIRE(packed && out && b > 0 && t > 0 && d > 0, "cm_decode: bad arguments");
     XV_REQUIRE(d <= CMD_MAX_D, "cm_decode: at most %d feature dimensions (got %d)", CMD_MAX_D, d);
     XV_REQUIRE(chunk_stride >= (size_t)8 + 8 * (size_t)d + (size_t)d * t, "cm_decode: chunk stride %zu is smaller than a chunk", chunk_stride);
-    hipLaunchKernelGGL(cm_decode_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, packed, (long)chunk_stride, t, d, out);
+    hipLaunchKernelGGL(cm_decode_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, packed, (long)chunk_stride, t, d, out, (const long*)nullptr,
+                       (const int*)nullptr);
+    XV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xv_cm_decode_ragged(void* stream, const uint8_t* packed, const int64_t* offsets, const int32_t* rows, int b, int t, int d, float* out) {
+    XV_REQUIRE(packed && offsets && rows && out && b > 0 && t > 0 && d > 0, "cm_decode_ragged: bad arguments");
+    XV_REQUIRE(d <= CMD_MAX_D, "cm_decode_ragged: at most %d feature dimensions (got %d)", CMD_MAX_D, d);
+    static_assert(sizeof(long) == sizeof(int64_t), "offsets are passed as long");
+    hipLaunchKernelGGL(cm_decode_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, packed, 0L, t, d, out, (const long*)offsets, (const int*)rows);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -1527,7 +1546,8 @@ template <bool BN>
 __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restrict__ x, int T, int C, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu, const float* __restrict__ wts,
                                                             float* __restrict__ out, const float* __restrict__ slope,
-                                                            float* __restrict__ wpos, float* __restrict__ amax_o) {
+                                                            float* __restrict__ wpos, float* __restrict__ amax_o,
+                                                            const int* __restrict__ flen, int shrink) {
     __shared__ f32x4 s_mean[4][64], s_m2[4][64], s_wp[4][64], s_mx[4][64];
     __shared__ float s_n[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1535,6 +1555,9 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
     const int b = blockIdx.y;
     const bool cv = col < C;
     const float* xp = x + (long)b * T * C + (cv ? col : 0);
+    // flen (batched extraction): chunk b holds flen[b] - shrink valid frames, the rest of its T rows is padding that is not pooled
+    const int Tstride = T;
+    if (flen) T = max(1, min(T, flen[b] - shrink));
     f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0}, sl = {0, 0, 0, 0};
     const bool hs = BN && slope != nullptr;
     if (BN && cv) { sc = *(const f32x4*)(scale + col); sh = *(const f32x4*)(shift + col); if (hs) sl = *(const f32x4*)(slope + col); }
@@ -1545,7 +1568,7 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
         }
         return v;
     };
-    const float* wp = wts ? wts + (long)b * T : nullptr;
+    const float* wp = wts ? wts + (long)b * Tstride : nullptr;
     f32x4 mean0 = {0, 0, 0, 0}, m20 = {0, 0, 0, 0}, mean1 = {0, 0, 0, 0}, m21 = {0, 0, 0, 0};
     f32x4 wpp = {0, 0, 0, 0};       // sum of the frame weights where the activation is on (all frames without a ReLU)
     const bool cnt_all = !(BN && relu);
@@ -1618,17 +1641,18 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
 extern "C" int xv_stat_pool_forward(void* stream, const float* x, int b, int t, int c, float* out) {
     XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0, "stat_pool_forward: bad shape (c=%d must be a multiple of 4)", c);
     hipLaunchKernelGGL(stat_pool_fwd_kernel<false>, dim3(xv_cdiv(c / 4, 64), b), dim3(256), 0, (hipStream_t)stream, x, t, c,
-                       (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, out, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                       (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, out, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       (const int*)nullptr, 0);
     XV_LAUNCH_CHECK();
     return 0;
 }
 
 // wpos, amax (optional, [b][c]): see PoolGrad
 int xv_stat_pool_forward_bn_ex(hipStream_t s, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
-                               const float* weights, float* out, float* wpos, float* amax) {
+                               const float* weights, float* out, float* wpos, float* amax, const int32_t* frames, int shrink) {
     XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0 && scale && shift, "stat_pool_forward_bn: bad shape (c=%d must be a multiple of 4)", c);
     hipLaunchKernelGGL(stat_pool_fwd_kernel<true>, dim3(xv_cdiv(c / 4, 64), b), dim3(256), 0, s, z, t, c, scale, shift,
-                       relu, weights, out, relu ? g_act.slope : nullptr, wpos, wpos ? amax : nullptr);
+                       relu, weights, out, relu ? g_act.slope : nullptr, wpos, wpos ? amax : nullptr, (const int*)frames, shrink);
     XV_LAUNCH_CHECK();
     return 0;
 }

@@ -625,7 +625,9 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
             const int w_first = ntsk_owner(t_first, q.P, q.total), w_last = ntsk_owner(t_first + q.nk - 1, q.P, q.total);
             if (tid == 0) s_last = xv_ticket_take(q.tickets + tile, (unsigned)(w_last - w_first + 1)) ? 1 : 0;
             __syncthreads();
-            if (!s_last) continue;                       // (uniform; the next share starts behind the barrier above)
+            const int last = s_last;                     // s_last aliases the staging buffers: every wave has read it before the barrier
+            __syncthreads();                             // below lets anyone stage the next share or use the statistics scratch
+            if (!last) continue;                         // (uniform)
             // The tile's value is ((s0 + s1) + s2) + ... in K order whoever arrives last.  The first two shares commute, so a workgroup that
             // holds share 0 or 1 keeps it in its registers and reads only the others (one slab for the usual two-share tile); a later
             // share is re-read from its slab at its place in the order.

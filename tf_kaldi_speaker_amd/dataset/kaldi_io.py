@@ -327,6 +327,83 @@ def read_mat_ark(file_or_fd):
             fd.close()
 
 
+class PackedMatrix(object):
+    """A Kaldi 'CM ' matrix kept as it sits in the archive - [min f32][range f32][cols x (p0, p25, p75, p100) u16][cols x rows u8,
+    column after column] - which is the image xv_cm_decode_ragged (include/xvector_hip.h) decodes on the GPU: the extraction driver
+    ships a quarter of the fp32 bytes and the host never runs the codec."""
+    __slots__ = ("rows", "cols", "payload")
+
+    def __init__(self, rows, cols, payload):
+        self.rows, self.cols, self.payload = int(rows), int(cols), payload
+        assert len(payload) == 8 + 8 * self.cols + self.cols * self.rows
+
+    @property
+    def shape(self):
+        return (self.rows, self.cols)
+
+    def decode(self):
+        """float32 [rows, cols] through the host codec (the reference's arithmetic, _decode_cm)."""
+        buf = np.frombuffer(self.payload, np.uint8)
+        gmin, grange = np.frombuffer(buf[:8].tobytes(), "<f4")
+        hdr = np.frombuffer(buf[8:8 + 8 * self.cols].tobytes(), dtype=_COL_HDR, count=self.cols)
+        data = buf[8 + 8 * self.cols:].reshape(self.cols, self.rows)
+        return _decode_cm(data, _col_percentiles(hdr, float(gmin), float(grange)))
+
+    def row_range(self, start, length):
+        """Rows [start, start + length) as a PackedMatrix of their own (same header: the codec is per element)."""
+        assert 0 <= start and start + length <= self.rows
+        buf = np.frombuffer(self.payload, np.uint8)
+        head = 8 + 8 * self.cols
+        data = buf[head:].reshape(self.cols, self.rows)[:, start:start + length]
+        return PackedMatrix(length, self.cols, buf[:head].tobytes() + np.ascontiguousarray(data).tobytes())
+
+
+def read_mat_ark_packed(file_or_fd):
+    """read_mat_ark for the batched extraction driver: 'CM ' matrices come back undecoded as PackedMatrix (one read of the payload, no
+    arithmetic on the host), every other format as the float32 matrix read_mat gives."""
+    fd = open_or_fd(file_or_fd)
+    try:
+        key = read_key(fd)
+        while key:
+            binary = fd.read(2)
+            if binary == b"\0B":
+                fmt = fd.read(3)
+                if fmt == b"CM ":
+                    g = fd.read(16)
+                    rows, cols = struct.unpack("<ii", g[8:16])
+                    body = fd.read(8 * cols + cols * rows)
+                    if len(body) != 8 * cols + cols * rows:
+                        raise BadInputFormat
+                    yield key, PackedMatrix(rows, cols, g[:8] + body)
+                else:
+                    yield key, _read_mat_binary(_Pushback(fd, fmt))
+            else:
+                assert binary == b" ["
+                yield key, _read_mat_ascii(fd)
+            key = read_key(fd)
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+class _Pushback(object):
+    """A stream with a few bytes put back in front of it (pipes cannot seek)."""
+
+    def __init__(self, fd, head):
+        self.fd, self.head = fd, head
+
+    def read(self, n=-1):
+        if not self.head:
+            return self.fd.read(n)
+        if n < 0:
+            out, self.head = self.head + self.fd.read(), b""
+            return out
+        out, self.head = self.head[:n], self.head[n:]
+        if len(out) < n:
+            out += self.fd.read(n - len(out))
+        return out
+
+
 def read_mat_scp(file_or_fd):
     fd = open_or_fd(file_or_fd)
     try:

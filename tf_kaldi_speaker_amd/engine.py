@@ -46,7 +46,7 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
                 bn_epsilon=1e-3, fused_bn_unbiased_moving_var=True, optimizer="sgd", momentum=0.9, use_nesterov=False,
                 clip_gradient_norm=0.0, max_batch=128, max_frames=400, precision=None, pooling_type="statistics_pooling",
                 att_key_num_nodes=(1500, 1500), att_key_network_type=3, att_use_scale=True, aux_loss_func=(), ring_loss_init=20.0,
-                ring_loss_lambda=0.01, mhe_lambda=0.01, frame_layers=None, network_relu_type="relu"):
+                ring_loss_lambda=0.01, mhe_lambda=0.01, frame_layers=None, network_relu_type="relu", max_rows=0):
     if pooling_type not in POOLINGS:
         raise NotImplementedError("Not implement %s pooling" % pooling_type)
     if loss_func not in LOSS_KINDS:
@@ -77,6 +77,7 @@ def make_config(feat_dim, num_speakers=0, loss_func="softmax", margin_m=0.0, lam
     c.clip_gradient_norm = float(clip_gradient_norm)
     c.max_batch = int(max_batch)
     c.max_frames = int(max_frames)
+    c.max_rows = int(max_rows or 0)
     if precision is None:
         precision = os.environ.get("XV_PRECISION", DEFAULT_PRECISION)
     if precision not in PRECISIONS:
@@ -236,6 +237,34 @@ class Engine(object):
         self._keep = [x]
         _lib.check(self.lib.xv_engine_forward(self.h, _stream(), _ptr(x), int(b), int(t), int(bool(training))),
                    "xv_engine_forward")
+
+    def forward_lengths(self, features, frames):
+        """Inference forward over utterances of different lengths (xv_engine_forward_lengths): features [b, t, d] with chunk i
+        holding frames[i] valid frames followed by padding; pooling uses the valid part only."""
+        x = self._dev(features, torch.float32)
+        n = self._dev(frames, torch.int32)
+        b, t, d = x.shape
+        if d != self.config.feat_dim:
+            raise ValueError("feature dim %d != %d" % (d, self.config.feat_dim))
+        if n.numel() != b:
+            raise ValueError("%d frame counts for %d chunks" % (n.numel(), b))
+        self._keep = [x, n]
+        _lib.check(self.lib.xv_engine_forward_lengths(self.h, _stream(), _ptr(x), int(b), int(t), _ptr(n)), "xv_engine_forward_lengths")
+
+    def decode_packed(self, payload, offsets, rows, t):
+        """'CM ' matrices of different lengths, packed back to back in `payload` (uint8; kaldi_io.PackedMatrix images at byte
+        `offsets`, `rows[i]` frames each) -> device tensor [b, t, feat_dim] with zero padding (xv_cm_decode_ragged)."""
+        dev = self.device
+        pk = payload if isinstance(payload, torch.Tensor) else torch.from_numpy(payload)
+        pk = pk.to(dev, non_blocking=True)
+        off = torch.as_tensor(offsets, dtype=torch.int64).to(dev, non_blocking=True)
+        rw = torch.as_tensor(rows, dtype=torch.int32).to(dev, non_blocking=True)
+        b = int(rw.numel())
+        out = torch.empty((b, int(t), self.config.feat_dim), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.xv_cm_decode_ragged(_stream(), _ptr(pk), _ptr(off), _ptr(rw), b, int(t), int(self.config.feat_dim), _ptr(out)),
+                   "xv_cm_decode_ragged")
+        self._keep_decode = [pk, off]
+        return out, rw
 
     def loss(self, labels, global_step, with_margin=True):
         y = self._dev(labels, torch.int32)

@@ -394,6 +394,55 @@ def utterance_embedding(predict, feature, chunk_size, normalize):
     return np.asarray(embedding, np.float32), len(chunks)
 
 
+def plan_length_batches(lengths, max_rows, max_chunks, min_fill=0.9, min_rows=8192):
+    """Utterances of different lengths -> padded batches for one forward each: [(indices, t)] with t = the longest utterance of the
+    batch.  Sorted by length (longest first), a batch takes utterances while it stays within max_chunks utterances and max_rows =
+    chunks x t padded rows, and - once it holds min_rows rows - only members that fill at least min_fill of their padded length: a
+    forward of fewer than ~min_rows rows leaves most of the chip idle, so padding is cheaper than a small batch below that size and
+    dearer above it.  With a window of a few hundred utterances neighbours in the sorted order differ by a few frames."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    batches, i = [], 0
+    while i < len(order):
+        t = int(lengths[order[i]])
+        cap = max(1, min(int(max_chunks), int(max_rows) // max(t, 1)))
+        j = i + 1
+        while j < len(order) and j - i < cap and ((j - i) * t < min_rows or lengths[order[j]] >= min_fill * t):
+            j += 1
+        batches.append((order[i:j], t))
+        i = j
+    return batches
+
+
+def batched_utterance_embeddings(predict_batch, features, chunk_size, normalize):
+    """utterance_embedding() for a window of utterances at once: every utterance's pieces (itself, or its half-overlapping chunks
+    when longer than chunk_size, extract.py:69-79) go through ONE predict_batch call; long utterances are then averaged by piece length
+    (extract.py:81-93).  features: matrices or kaldi_io.PackedMatrix.  Returns [(embedding, number of pieces)] in input order."""
+    pieces, owner = [], []
+    for u, f in enumerate(features):
+        chunks = split_into_chunks(f.shape[0], chunk_size)
+        for s, n in chunks:
+            if len(chunks) == 1:
+                pieces.append(f)
+            else:
+                pieces.append(f.row_range(s, n) if hasattr(f, "row_range") else f[s:s + n])
+            owner.append((u, n))
+    emb = predict_batch(pieces) if pieces else np.zeros((0, 0), np.float32)
+    out, k = [], 0
+    for u, f in enumerate(features):
+        m = k
+        while m < len(owner) and owner[m][0] == u:
+            m += 1
+        if m - k == 1:
+            e = emb[k]
+        else:
+            e = average_chunk_embeddings(emb[k:m], [owner[j][1] for j in range(k, m)], normalize)
+        if normalize:
+            e = e / np.sqrt(np.sum(np.square(e)))
+        out.append((np.asarray(e, np.float32), m - k))
+        k = m
+    return out
+
+
 def prefetch_iter(iterable, depth=8):
     """The items of `iterable`, produced by a background thread up to `depth` ahead of the consumer (extract.py: reading and decoding
     utterance i+1.. from the ark while the GPU runs utterance i - the host side was half of the 0.63 ms per utterance).  Exceptions of

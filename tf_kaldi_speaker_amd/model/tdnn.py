@@ -102,7 +102,7 @@ def check_params(params):
         params.last_layer_linear = False
 
 
-def engine_config(params, dim, num_speakers=0, loss_type="softmax", max_batch=128, max_frames=400):
+def engine_config(params, dim, num_speakers=0, loss_type="softmax", max_batch=128, max_frames=400, max_rows=0):
     check_params(params)
     d = params.dict
     kw = dict(num_nodes_pooling_layer=d["num_nodes_pooling_layer"], num_nodes_last_layer=d["num_nodes_last_layer"],
@@ -113,7 +113,7 @@ def engine_config(params, dim, num_speakers=0, loss_type="softmax", max_batch=12
               batchnorm_momentum=float(d["batchnorm_momentum"]), optimizer=d.get("optimizer", "sgd"),
               momentum=float(d.get("momentum", 0.0) or 0.0), use_nesterov=bool(d.get("use_nesterov", False)),
               clip_gradient_norm=float(d["clip_gradient_norm"]) if d.get("clip_gradient", False) else 0.0,
-              max_batch=max_batch, max_frames=max_frames,
+              max_batch=max_batch, max_frames=max_frames, max_rows=max_rows,
               frame_layers=frame_layer_table(params), network_relu_type=d.get("network_relu_type", "relu"),
               precision=d.get("precision", None),      # engine extension: "f32" (default) | "f16x3" (opt-in fast mode); absent from reference configs
               pooling_type=d["pooling_type"])

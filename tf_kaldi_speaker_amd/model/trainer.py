@@ -28,7 +28,8 @@ try:
     from .. import _lib
     from ..parallel import GradAllReduce, average_bn_statistics, broadcast_variables
     from ..dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, PlannedRandomQueue, DataOutOfRange
-    from ..misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state
+    from ..misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state, plan_length_batches
+    from ..dataset.kaldi_io import PackedMatrix
     from ..misc import tf_checkpoint
     from .tdnn import tdnn, extended_tdnn, engine_config, collect_endpoints, check_params
     from . import loss as _loss
@@ -37,7 +38,8 @@ except (ImportError, ValueError):      # drop-in layout: PYTHONPATH=$TF_KALDI_RO
     import _lib
     from parallel import GradAllReduce, average_bn_statistics, broadcast_variables
     from dataset.data_loader import KaldiDataRandomQueue, KaldiDataSeqQueue, PlannedRandomQueue, DataOutOfRange
-    from misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state
+    from misc.utils import substring_in_list, read_checkpoint_state, write_checkpoint_state, plan_length_batches
+    from dataset.kaldi_io import PackedMatrix
     from misc import tf_checkpoint
     from model.tdnn import tdnn, extended_tdnn, engine_config, collect_endpoints, check_params
     from model import loss as _loss
@@ -124,8 +126,8 @@ class Trainer(object):
         t = int(p.get("max_segment_len", 400))
         return max(b, 1), max(t, 15)
 
-    def _make_engine(self, num_speakers, loss_type, max_batch, max_frames, keep=None):
-        cfg = engine_config(self.params, self.dim, num_speakers or 0, loss_type or "softmax", max_batch, max_frames)
+    def _make_engine(self, num_speakers, loss_type, max_batch, max_frames, keep=None, max_rows=0):
+        cfg = engine_config(self.params, self.dim, num_speakers or 0, loss_type or "softmax", max_batch, max_frames, max_rows)
         eng = E.Engine(cfg, device=self.device)
         seed = int(self.params.dict.get("seed", 0))
         eng.init_variables(seed=seed)
@@ -133,17 +135,24 @@ class Trainer(object):
             eng.set_variables({k: v for k, v in keep.items() if k in eng.table})
         return eng
 
-    def _ensure_capacity(self, b, t):
+    def _ensure_capacity(self, b, t, rows=0):
+        """Grow the engine to hold b chunks of t frames.  rows > 0 (batched extraction): a capacity in rows = chunks x frames instead
+        of the full b x t rectangle - many short utterances or a few long ones per batch."""
         eng = self.engine
-        if b <= eng.config.max_batch and t <= eng.config.max_frames:
+        cfg = eng.config
+        have_rows = cfg.max_rows if cfg.max_rows > 0 else cfg.max_batch * cfg.max_frames
+        if b <= cfg.max_batch and t <= cfg.max_frames and b * t <= have_rows:
             return
         values = eng.get_variables()
         opt, cnt = eng.opt_state.clone(), eng.update_count
-        nb, nt = max(b, eng.config.max_batch), max(t, eng.config.max_frames)
-        if t > eng.config.max_frames:
-            nt = max(t, min(2 * eng.config.max_frames, 20000))
+        nb, nt = max(b, cfg.max_batch), max(t, cfg.max_frames)
+        if t > cfg.max_frames:
+            nt = max(t, min(2 * cfg.max_frames, 20000))
+        nrows = 0
+        if rows > 0 or cfg.max_rows > 0:
+            nrows = max(rows, b * t, cfg.max_rows)
         self._close_engine()
-        self.engine = self._make_engine(self.num_speakers, self.loss_type, nb, nt, keep=values)
+        self.engine = self._make_engine(self.num_speakers, self.loss_type, nb, nt, keep=values, max_rows=nrows)
         if self.engine.opt_state.numel() == opt.numel():
             self.engine.opt_state.copy_(opt)
         self._apply_update_filter()
@@ -429,6 +438,63 @@ class Trainer(object):
         self.endpoints = OrderedDict([(node, emb)])
         if rank == 2:
             emb = np.squeeze(emb, axis=0)
+        return emb
+
+    # rows (chunks x frames) of one batched-extraction forward: about two S1 training batches - large enough for the GEMMs to run at
+    # their training-pass rate, small enough that the activation arena stays at a few GB
+    PREDICT_ROWS = 49152
+    PREDICT_CHUNKS = 128
+
+    def predict_batch(self, items, return_device=False):
+        """Embeddings of MANY utterances of different lengths, [n, E] in the order given - the batched form of the loop
+        extract.py:64-93 runs one predict() at a time.  items: float32 matrices [T_i, D] and / or kaldi_io.PackedMatrix ('CM '
+        matrices as read from the archive, decoded on the GPU).  Utterances are sorted by length, padded to the longest of their
+        batch (misc.utils.plan_length_batches) and run through xv_engine_forward_lengths, whose pooling sees only each utterance's
+        own frames; the embedding node must be a segment-level one (tdnn6_dense, tdnn7_*, output)."""
+        if not self.is_loaded:
+            if os.path.isfile(os.path.join(self.model, "checkpoint")):
+                self.load()
+            else:
+                sys.exit("Cannot find model in %s" % self.model)
+        n = len(items)
+        if n == 0:
+            return np.zeros((0, 0), np.float32)
+        lengths = [int(it.shape[0]) for it in items]
+        node = self.params.embedding_node
+        plan = plan_length_batches(lengths, self.PREDICT_ROWS, self.PREDICT_CHUNKS)
+        self._ensure_capacity(max(len(idx) for idx, _ in plan), max(t for _, t in plan), rows=max(self.PREDICT_ROWS, max(len(idx) * t for idx, t in plan)))
+        eng = self.engine
+        dim = self.dim
+        outs = []
+        for idx, t in plan:
+            b = len(idx)
+            if all(isinstance(items[i], PackedMatrix) for i in idx):
+                # one packed host buffer -> one H2D copy (a quarter of the fp32 bytes) -> on-GPU decode into the padded batch
+                sizes = [len(items[i].payload) for i in idx]
+                offsets = np.zeros(b, np.int64)
+                offsets[1:] = np.cumsum(sizes[:-1])
+                payload = np.frombuffer(b"".join(items[i].payload for i in idx), np.uint8)
+                x, rows = eng.decode_packed(payload, offsets, [lengths[i] for i in idx], t)
+            else:
+                host = np.zeros((b, t, dim), np.float32)
+                for j, i in enumerate(idx):
+                    m = items[i].decode() if isinstance(items[i], PackedMatrix) else np.asarray(items[i], np.float32)
+                    host[j, :lengths[i]] = m
+                x, rows = host, np.asarray([lengths[i] for i in idx], np.int32)
+            eng.forward_lengths(x, rows)
+            emb = eng.endpoint(node)
+            if emb.shape[0] != b:
+                raise ValueError("predict_batch: embedding node %s is a frame-level endpoint (%d rows for %d utterances)" % (node, emb.shape[0], b))
+            outs.append((idx, emb))
+        dev = torch.cat([e for _, e in outs], dim=0)
+        order = np.concatenate([np.asarray(idx) for idx, _ in outs])
+        inv = np.empty(n, np.int64)
+        inv[order] = np.arange(n)
+        dev = dev[torch.as_tensor(inv, device=dev.device)]
+        if return_device:
+            return dev
+        emb = dev.cpu().numpy()
+        self.endpoints = OrderedDict([(node, emb)])
         return emb
 
     # ------------------------------------------------------------------ fine-tuning / diagnostics (trainer.py:522-590, 728-920)

@@ -13,8 +13,14 @@ import sys
 
 import _cli
 from model.trainer import Trainer
-from misc.utils import Params, utterance_embedding, prefetch_iter
-from dataset.kaldi_io import open_or_fd, read_mat_ark, write_vec_flt
+from misc.utils import Params, batched_utterance_embeddings, prefetch_iter
+from dataset.kaldi_io import open_or_fd, read_mat_ark_packed, write_vec_flt
+
+# utterances gathered before they go to the GPU together (sorted by length into padded batches, Trainer.predict_batch); results are
+# written in archive order.  One utterance per forward, as the reference runs (extract.py:64-93), left the chip at 9-20 % of its
+# training-pass rate at real utterance lengths (profiles/r03_extract_bench.txt).
+WINDOW_UTTERANCES = 512
+WINDOW_FRAMES = 400000
 
 
 def main():
@@ -42,14 +48,29 @@ def main():
     if "." in args.rspecifier and args.rspecifier.rsplit(".", 1)[1] == "scp":
         sys.exit("The rspecifier must be ark or input pipe")
     fp_out = open_or_fd(args.wspecifier, "wb")
-    for key, feature in prefetch_iter(read_mat_ark(args.rspecifier)):       # the reader runs ahead of the GPU in its own thread
-        frames = feature.shape[0]
-        if frames < args.min_chunk_size:
-            log.info("[INFO] Key %s length too short, %d < %d, skip." % (key, frames, args.min_chunk_size))
-            continue
-        embedding, pieces = utterance_embedding(trainer.predict, feature, args.chunk_size, args.normalize)
-        log.info("[INFO] Key %s length %d%s." % (key, frames, "" if pieces == 1 else " > %d, split to %d segments" % (args.chunk_size, pieces)))
-        write_vec_flt(fp_out, embedding, key=key)
+    window, window_frames = [], 0
+
+    def flush():
+        keep = [(key, feature) for key, feature in window if feature.shape[0] >= args.min_chunk_size]
+        results = iter(batched_utterance_embeddings(trainer.predict_batch, [f for _, f in keep], args.chunk_size, args.normalize))
+        for key, feature in window:          # log lines and output vectors in archive order, as the one-at-a-time loop gives them
+            frames = feature.shape[0]
+            if frames < args.min_chunk_size:
+                log.info("[INFO] Key %s length too short, %d < %d, skip." % (key, frames, args.min_chunk_size))
+                continue
+            embedding, pieces = next(results)
+            log.info("[INFO] Key %s length %d%s." % (key, frames, "" if pieces == 1 else " > %d, split to %d segments" % (args.chunk_size, pieces)))
+            write_vec_flt(fp_out, embedding, key=key)
+        del window[:]
+
+    # the reader runs ahead of the GPU in its own thread; 'CM ' matrices arrive undecoded (kaldi_io.PackedMatrix) and are decoded on the GPU
+    for key, feature in prefetch_iter(read_mat_ark_packed(args.rspecifier), depth=2 * WINDOW_UTTERANCES):
+        window.append((key, feature))
+        window_frames += feature.shape[0]
+        if len(window) >= WINDOW_UTTERANCES or window_frames >= WINDOW_FRAMES:
+            flush()
+            window_frames = 0
+    flush()
     fp_out.close()
     trainer.close()
 

@@ -44,6 +44,41 @@ def main():
         one(x)
     dt = time.perf_counter() - t0
     print("mixed 400..2000 frames: %d utterances in %.3f s = %.0f utterances/s, %.2f M frames/s" % (n_utts, dt, n_utts / dt, lens.sum() / dt / 1e6))
+    eng.close()
+    batched(rs)
+
+
+def batched(rs, n_utts=2048):
+    """The same mix through Trainer.predict_batch (length-sorted padded batches, xv_engine_forward_lengths), host float32 matrices and
+    'CM ' matrices decoded on the GPU, in windows of 512 utterances as nnet/lib/extract.py feeds it."""
+    import io
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tf_kaldi_speaker_amd"))
+    from extract_driver_bench import make_model
+    from model.trainer import Trainer
+    from misc.utils import Params
+    from dataset import kaldi_io
+    tmp = tempfile.mkdtemp(prefix="xv_extract_b_")
+    model = os.path.join(tmp, "exp")
+    make_model(model)
+    tr = Trainer(Params(os.path.join(model, "nnet", "config.json")), model, single_cpu=True)
+    tr.build("predict", dim=30)
+    lens = rs.randint(400, 2001, n_utts)
+    utts = [rs.randn(int(t), 30).astype(np.float32) for t in lens]
+    buf = io.BytesIO()
+    for i, u in enumerate(utts):
+        kaldi_io.write_compressed_mat(buf, u, key="u%d" % i)
+    buf.seek(0)
+    packed = [m for _, m in kaldi_io.read_mat_ark_packed(buf)]
+    for name, items in (("host fp32 matrices", utts), ("'CM ' matrices, GPU decode", packed)):
+        tr.predict_batch(items[:512])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for w in range(0, n_utts, 512):
+            tr.predict_batch(items[w:w + 512])
+        dt = time.perf_counter() - t0
+        print("batched, %s: %d utterances in %.3f s = %.0f utterances/s, %.2f M frames/s" % (name, n_utts, dt, n_utts / dt, lens.sum() / dt / 1e6))
+    tr.close()
 
 
 if __name__ == "__main__":
