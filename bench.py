@@ -333,26 +333,81 @@ def summarize(res, args, world, chunks):
     return out
 
 
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT initialising HIP (the parent of the ranks must never hold the GPU): the *_VISIBLE_DEVICES
+    lists when set, else the KFD topology (nodes with SIMDs).  None when neither source says anything."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        return n
+    except (OSError, ValueError):
+        return None
+
+
+def failure_line(n, error, **extra):
+    """One JSON line for a run that produced no measurement, so that a broken multi-GPU launch still leaves a diagnosable record."""
+    out = {"metric": "utterance-chunks/sec (%d-frame x %d-dim)" % (T, D), "value": None, "unit": "chunks/s", "n_gpus": n, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "data": "synthetic", "error": error}
+    out.update(extra)
+    return json.dumps(out)
+
+
 def self_launch(n):
-    """`python bench.py --gpus N` with no launcher around it: start one rank per GPU as CHILD processes (torch.distributed.run) and
-    relay their output.  Nothing in this process has touched the GPU yet (`import torch` and `device_count()` do not initialise
-    HIP on this image), and the children are spawned, never exec'd over this process."""
-    import socket
+    """`python bench.py --gpus N` with no launcher around it: start one rank per GPU as CHILD processes (torch.distributed.run,
+    spawned - never exec'd over this process) and relay their output.  This process never initialises HIP: the device count comes
+    from the environment / the KFD topology (visible_gpu_count), the rendezvous port is chosen by the launcher itself
+    (--standalone).  If the ranks die or print no result, ONE JSON line with "error", the return code and the tail of their stderr
+    is printed instead of the bench line."""
+    import collections
     import subprocess
-    have = torch.cuda.device_count()
-    if have < n and os.environ.get("XV_SHARE_GPU") != "1":
-        print("bench.py --gpus %d: only %d device(s) visible (XV_SHARE_GPU=1 runs the ranks on shared devices over gloo - a wiring "
-              "check, not a measurement)" % (n, have), file=sys.stderr)
+    import threading
+    have = visible_gpu_count()
+    if have is not None and have < n and os.environ.get("XV_SHARE_GPU") != "1":
+        msg = ("bench.py --gpus %d: only %d device(s) visible (XV_SHARE_GPU=1 runs the ranks on shared devices over gloo - a wiring "
+               "check, not a measurement)" % (n, have))
+        print(msg, file=sys.stderr)
+        print(failure_line(n, msg, visible_devices=have))
         return 2
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(n),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, bufsize=1)
+    tail = collections.deque(maxlen=25)
+    head = []
+    got_line = []
+
+    def relay(src, dst, keep):
+        for line in src:
+            dst.write(line)
+            dst.flush()
+            if keep is not None:
+                keep.append(line.rstrip("\n"))
+                if len(head) < 15:
+                    head.append(line.rstrip("\n"))
+            elif line.startswith("{") and '"metric"' in line:
+                got_line.append(True)
+
+    threads = [threading.Thread(target=relay, args=(proc.stdout, sys.stdout, None)), threading.Thread(target=relay, args=(proc.stderr, sys.stderr, tail))]
+    for th in threads:
+        th.start()
+    rc = proc.wait()
+    for th in threads:
+        th.join()
+    if rc != 0 or not got_line:
+        print(failure_line(n, "the %d ranks exited with status %d%s" % (n, rc, "" if got_line else " without printing a result"), returncode=rc,
+                           stderr_head=head, stderr_tail=[ln for ln in tail if ln not in head]))
+        return rc or 1
+    return 0
 
 
 def main():
@@ -481,4 +536,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as exc:      # a rank that dies still leaves one diagnosable JSON line (rank 0 only; the launcher reports the rest)
+        if int(os.environ.get("RANK", "0")) == 0:
+            import traceback
+            print(failure_line(int(os.environ.get("WORLD_SIZE", "1")), "%s: %s" % (type(exc).__name__, exc), traceback=traceback.format_exc().splitlines()[-8:]))
+        raise

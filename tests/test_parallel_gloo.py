@@ -60,20 +60,46 @@ def test_gradient_allreduce_world(world):
         assert np.allclose(v[1003:], v0[1003:] + 0.5 * (world - 1), atol=1e-5)    # BN statistics: mean over ranks
 
 
-def test_bench_gpus_n_launches_itself_before_touching_the_gpu():
-    """`python bench.py --gpus N` with no launcher around it (the form the driver uses for N = 1) must start the N ranks itself.  No GPU
-    here, so (i) without XV_SHARE_GPU it refuses by name before spawning anything, (ii) with it the ranks are spawned through
-    torch.distributed.run and each of them stops at the product's "needs an MI355X" check - which proves the parent got that far
-    without initialising HIP itself and that the children received the rendezvous environment."""
+def test_bench_gpus_n_launches_itself_and_reports_failures_as_json():
+    """`python bench.py --gpus N` with no launcher around it (the form the driver uses for N = 1) starts the N ranks itself, as child
+    processes, and never leaves a run without a record: here there is no GPU, so (i) without XV_SHARE_GPU it refuses by name before
+    spawning anything - the device count comes from the environment / the KFD topology, not from a HIP call - and (ii) with it the
+    ranks are spawned through torch.distributed.run and stop at the product's "needs an MI355X" check.  Either way stdout carries ONE
+    JSON line with "error", n_gpus and a null value.  (That the parent never initialises HIP is a property of the code - it makes no
+    torch.cuda call - which a box without a GPU cannot demonstrate.)"""
+    import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "XV_SHARE_GPU")}
+    env["HIP_VISIBLE_DEVICES"] = ""                 # "no device", whatever box runs this
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 2 and "device(s) visible" in out.stderr, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and line["n_gpus"] == 2 and "device(s) visible" in line["error"] and line["visible_devices"] == 0
     env["XV_SHARE_GPU"] = "1"
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode != 0
     assert "needs an MI355X" in out.stderr and "must be launched with" not in out.stderr, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and line["n_gpus"] == 2 and line["returncode"] != 0 and "ranks exited" in line["error"]
+    assert any("needs an MI355X" in ln for ln in line["stderr_head"] + line["stderr_tail"])
+
+
+def test_visible_gpu_count_reads_the_environment_first(monkeypatch):
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    n = bench.visible_gpu_count()
+    assert n is None or n >= 0

@@ -130,6 +130,17 @@ def open_or_fd(file, mode="rb"):
 def read_key(fd):
     """Utterance key up to the first space; '' / None at EOF (reference read_key, kaldi_io.py:413-425)."""
     key = b""
+    peek = getattr(fd, "peek", None)
+    if peek is not None:          # buffered files: one look ahead instead of one read() per character
+        buf = peek(256)
+        pos = buf.find(b" ")
+        if pos >= 0:
+            key = fd.read(pos + 1)[:-1]
+            key = key.decode("latin1").strip()
+            if key == "":
+                return None
+            assert re.match(r"^\S+$", key) is not None
+            return key
     while True:
         ch = fd.read(1)
         if ch == b"":

@@ -150,7 +150,10 @@ class Trainer(object):
             nt = max(t, min(2 * cfg.max_frames, 20000))
         nrows = 0
         if rows > 0 or cfg.max_rows > 0:
+            # row-bounded capacity: chunks and frames per chunk cost nothing beyond the rows, so take them generously once instead of
+            # rebuilding the engine whenever a later window holds a slightly longer utterance or a slightly larger batch
             nrows = max(rows, b * t, cfg.max_rows)
+            nb, nt = max(nb, self.PREDICT_CHUNKS), max(nt, 20000)
         self._close_engine()
         self.engine = self._make_engine(self.num_speakers, self.loss_type, nb, nt, keep=values, max_rows=nrows)
         if self.engine.opt_state.numel() == opt.numel():
@@ -473,7 +476,7 @@ class Trainer(object):
                 sizes = [len(items[i].payload) for i in idx]
                 offsets = np.zeros(b, np.int64)
                 offsets[1:] = np.cumsum(sizes[:-1])
-                payload = np.frombuffer(b"".join(items[i].payload for i in idx), np.uint8)
+                payload = np.frombuffer(bytearray().join(items[i].payload for i in idx), np.uint8)      # (bytearray: a writable buffer for torch)
                 x, rows = eng.decode_packed(payload, offsets, [lengths[i] for i in idx], t)
             else:
                 host = np.zeros((b, t, dim), np.float32)
