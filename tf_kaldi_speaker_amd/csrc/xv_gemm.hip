@@ -903,15 +903,25 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
 // -------------------------------------------------------------------------------------
 // TN: weight gradients
 // -------------------------------------------------------------------------------------
+// Schedule.  The reduction runs over the ~25 k (chunk, frame) rows and the output has few tiles (16 ... 112), so every tile is shared by
+// many workgroups.  The (tile, K-step) pairs are numbered tile-major, u = tile * nk + kt, and each of P workgroups (one co-resident
+// round, XV_RESIDENT_WGS) owns the equal run [w * total / P, (w + 1) * total / P): a run may end one tile and begin the next (two
+// segments), each segment's partial tile goes to a slab of its own, and xv_tn_reduce_kernel adds a tile's slabs in K order.
+// [measured, round 3, one rectangle of whole splits per workgroup] tiles x splits rarely fills the round: tdnn2 80 x 12 = 960 of 1 024
+// slots (its weight gradient ran at 127.8 TF against 134.9 TF for tdnn3 with 1 008), tdnn5 48 x 21 = 1 008.
 struct TNArgs {
     const float* A; long lda; int a_pitch;
     const float* B; long ldb; int b_pitch;
     int rps; float inv_rps;
-    float* P;
-    int M, N, R, r_chunk;
+    int M, N, R;
     int tiles_m, tiles_n;
     const float* zero;
-    int ahead;      // K-step schedule (see the kernel)
+    int P;              // workgroups
+    int nk;             // K-steps per tile
+    long total;         // tiles * nk
+    int max_segs;       // slabs reserved per workgroup
+    float* slab;        // [P][max_segs][16][256] float4, see the epilogue
+    int ahead_min;      // fewest K-steps of a segment that run the two-steps-ahead schedule
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -927,30 +937,37 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
+    const int w = xcd_swizzle(blockIdx.x, gridDim.x);
+    long u = (long)w * p.total / p.P;
+    const long u_end = (long)(w + 1) * p.total / p.P;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int lc = (lane & 31) * 4;
+    const float* __restrict__ zp = p.zero;
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned lds0 = xv_lds_addr(smem + 2 * TN_RPT * uwave * BM);
+    const unsigned a_step = (unsigned)(BK * p.lda * 4), b_step = (unsigned)(BK * p.ldb * 4);
+    const unsigned a_skip = (unsigned)((long)(p.a_pitch - p.rps) * p.lda * 4), b_skip = (unsigned)((long)(p.b_pitch - p.rps) * p.ldb * 4);
+    const bool steady = p.rps >= BK;      // at most one segment boundary per step
+    const int a_off = lh * BM + wr * 64 + 2 * li;
+    const int b_off = lh * BN + wc * 64 + 2 * li;
 
-    // 1-D grid over (split, tile): after the XCD swizzle every XCD owns a contiguous run, i.e. whole
-    // reduction chunks, so the rows of A and B that one chunk touches are fetched into ONE L2
-    // (the (tiles, splits) grid of the first build spread every chunk over all 8 XCDs: 51 % hits).
-    const int v = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tiles = p.tiles_m * p.tiles_n;
-    const int split = v / tiles, t = v - split * tiles;
+    for (int seg = 0; u < u_end; ++seg) {
+    const int t = (int)(u / p.nk);
+    const int kt0 = (int)(u - (long)t * p.nk);
+    const int nk = (int)min((long)(p.nk - kt0), u_end - u);
+    u += nk;
     const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int r_begin = split * p.r_chunk;
-    const int r_end = min(p.R, r_begin + p.r_chunk);
-    const int nk = (r_end - r_begin + BK - 1) / BK;
+    const int r_begin = kt0 * BK;
+    const int r_end = min(p.R, r_begin + nk * BK);
 
     // LDS-DMA staging: one wave-instruction = 1 KiB = two whole [r][128] rows of the image; lane l lands on
     // row 2*(RPT*wave+i) + l/32, columns 4*(l%32)..+3.  The reduction-row -> address map (spliced view)
     // is evaluated per lane without an integer divide (r < 2^24, float quotient off by <= 1).
-    const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    const int lc = (lane & 31) * 4;
     const bool a_cv = (m0 + lc) < p.M, b_cv = (n0 + lc) < p.N;
-    const float* __restrict__ zp = p.zero;
     const float* abase = p.A + (a_cv ? m0 + lc : 0);
     const float* bbase = p.B + (b_cv ? n0 + lc : 0);
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
     auto gstage_ragged = [&](int kt, int buf) {      // a K-step with rows at or beyond r_end: those read the zero page (they are summed)
         float* sa = smem + buf * (2 * BK * BM) + 2 * TN_RPT * uwave * BM;
         float* sb = sa + BK * BM;
@@ -958,12 +975,12 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         for (int i = 0; i < TN_RPT; ++i) {
             int r = r_begin + kt * BK + 2 * (TN_RPT * wave + i) + (lane >> 5);
             bool rv = r < r_end;
-            int seg = (int)((float)r * p.inv_rps);
-            int tt = r - seg * p.rps;
-            seg += (tt >= p.rps) - (tt < 0);
-            tt = r - seg * p.rps;
-            const float* pa = (rv && a_cv) ? abase + ((long)seg * p.a_pitch + tt) * p.lda : zp;
-            const float* pb = (rv && b_cv) ? bbase + ((long)seg * p.b_pitch + tt) * p.ldb : zp;
+            int sg = (int)((float)r * p.inv_rps);
+            int tt = r - sg * p.rps;
+            sg += (tt >= p.rps) - (tt < 0);
+            tt = r - sg * p.rps;
+            const float* pa = (rv && a_cv) ? abase + ((long)sg * p.a_pitch + tt) * p.lda : zp;
+            const float* pb = (rv && b_cv) ? bbase + ((long)sg * p.b_pitch + tt) * p.ldb : zp;
             __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(sa + 2 * i * BM), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(sb + 2 * i * BN), 16, 0, 0);
         }
@@ -972,20 +989,16 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     // spliced view is (segment, frame): frame += BK, and on crossing the segment's last frame the offset also skips the rows between two
     // segments.  (The first build resolved row -> (segment, frame) -> 64-bit address from scratch for every K-step: ~40 VALU instructions
     // per wave and step beside the MFMAs.)  Columns outside the matrix read column 0: their products are never stored.
-    const bool steady = p.rps >= BK;      // at most one segment boundary per step
     int tt_i[TN_RPT];
     unsigned aoff[TN_RPT], boff[TN_RPT];
 #pragma unroll
     for (int i = 0; i < TN_RPT; ++i) {
         const int r = min(r_begin + 2 * (TN_RPT * wave + i) + (lane >> 5), p.R - 1);
-        const int seg = r / p.rps;
-        tt_i[i] = r - seg * p.rps;
-        aoff[i] = (unsigned)((((long)seg * p.a_pitch + tt_i[i]) * p.lda + (a_cv ? m0 + lc : 0)) * 4);
-        boff[i] = (unsigned)((((long)seg * p.b_pitch + tt_i[i]) * p.ldb + (b_cv ? n0 + lc : 0)) * 4);
+        const int sg = r / p.rps;
+        tt_i[i] = r - sg * p.rps;
+        aoff[i] = (unsigned)((((long)sg * p.a_pitch + tt_i[i]) * p.lda + (a_cv ? m0 + lc : 0)) * 4);
+        boff[i] = (unsigned)((((long)sg * p.b_pitch + tt_i[i]) * p.ldb + (b_cv ? n0 + lc : 0)) * 4);
     }
-    const unsigned a_step = (unsigned)(BK * p.lda * 4), b_step = (unsigned)(BK * p.ldb * 4);
-    const unsigned a_skip = (unsigned)((long)(p.a_pitch - p.rps) * p.lda * 4), b_skip = (unsigned)((long)(p.b_pitch - p.rps) * p.ldb * 4);
-    const unsigned lds0 = xv_lds_addr(smem + 2 * TN_RPT * uwave * BM);
     auto gstage = [&](int kt, int buf) {
         if (!steady || r_begin + (kt + 1) * BK > r_end) {
             gstage_ragged(kt, buf);
@@ -1012,17 +1025,16 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int a_off = lh * BM + wr * 64 + 2 * li;
-    const int b_off = lh * BN + wc * 64 + 2 * li;
     // Schedule of a K-step, two forms.  AHEAD: all sixteen fragment reads of stage kt, the first sixteen MFMAs, then - in mid-step - the
     // wait for the DMA of stage kt + 1, the workgroup barrier (every wave has read stage kt: its slot is free; stage kt + 1 is visible),
     // the DMA of stage kt + 2 into the slot just freed, and the other sixteen MFMAs: a stage's loads have a whole K-step to land.
     // sched_barrier pins the order.  Plain: the DMA of stage kt + 1 at the top of step kt, wait + barrier where hipcc puts them (right
     // behind the fragment reads - the last MEMORY operations of the step - i.e. in front of all 32 MFMAs).
     // [measured, round 3, weight gradients incl. slab sum at S1] AHEAD wins on long runs of K-steps per workgroup and loses on short ones:
-    // tdnn2 / tdnn3 (128 / 166 K-steps) 514 -> 505 / 661 -> 648 us, tdnn5 / tdnn4 (71 / 24) 322 -> 341 / 129 -> 138 us - the launcher
-    // chooses per problem (TNArgs::ahead).
-    if (nk > 0) gstage(0, 0);
+    // tdnn2 / tdnn3 (128 / 166 K-steps) 514 -> 505 / 661 -> 648 us, tdnn5 / tdnn4 (71 / 24) 322 -> 341 / 129 -> 138 us - chosen per
+    // segment (TNArgs::ahead_min).
+    // (every wave left the previous segment's last K-step through a barrier behind its fragment reads: the slots are free)
+    gstage(0, 0);
     xv_dma_wait_all();      // (the compiler does not see xv_dma16's loads)
     __syncthreads();
     auto k_loop = [&](auto ahead_c) {
@@ -1072,54 +1084,105 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             }
         }
     };
-    if (p.ahead) k_loop(std::true_type{});
+    if (nk >= p.ahead_min) k_loop(std::true_type{});
     else k_loop(std::false_type{});
 
     // [measured, round 3] summing the split partials inside this kernel - the workgroup that finishes a tile last adds the slabs of the
     // others (ticket hand-over as in xv_gemm_nt_sk_kernel) - was built and dropped: ONE workgroup then reads splits x 64 KB at the ~65 GB/s
     // a single workgroup gets, serially, at the very end of the launch: tdnn2 / tdnn4 / tdnn5 weight gradients 547 -> 630, 127 -> 279,
     // 323 -> 413 us (12 / 64 / 21 splits).  The separate slab-sum launch spreads the same bytes over every CU.
-    float* P = p.P + (long)split * p.M * p.N;
-    const int n = n0 + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
+    // Slab of a segment: [register r][thread] float4 = (acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]) - the 2 x 2 block of outputs
+    // (m, n), (m, n+1), (m+1, n), (m+1, n+1) the lane holds - so a wave instruction stores 1 KB of consecutive bytes (sixteen 16-byte
+    // stores per lane; the row-major slab of the first build took thirty-two 8-byte ones); xv_tn_reduce_kernel undoes the permutation.
+    float* mine = p.slab + ((long)w * p.max_segs + seg) * (BM * BN) + tid * 4;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int m = m0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;
-            if (m < p.M && n < p.N) {
-                f32x2 v = {acc[a][0][r], acc[a][1][r]};
-                *(f32x2*)(P + (long)m * p.N + n) = v;
-            }
-        }
+    for (int r = 0; r < 16; ++r) {
+        const f32x4 v = {acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]};
+        *(f32x4*)(mine + r * (256 * 4)) = v;
+    }
+    }
 }
 
-int xv_tn_splits(int M, int N, int R) {
-    int tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
-    int ksteps = xv_cdiv(R, BK);
-    // XV_WGS_PER_CU (4) workgroups are resident per CU (LDS 32 KB each): keep tiles*splits <= XV_RESIDENT_WGS (1 024) so the
-    // whole grid is ONE co-resident round.  (On the first build - 2 per CU - 560 workgroups = 512 + a 48-workgroup second
-    // round cost 2x: 61 TF on tdnn2/3, 24 TF on tdnn5.)
+__host__ __device__ __forceinline__ int tn_owner(long u, int P, long total) { return (int)((((u + 1) * P) - 1) / total); }
+
+// out[(j*C + c)][n] = sum over the slabs of tile (m = j*c_pad + c, n) in K order (+ l2 * w[(j*C + c)][n]).  Block = (tile, one accumulator
+// register index r): thread tid adds the float4 it finds at [r][tid] of every slab of the tile - 1 KB of consecutive bytes per wave
+// instruction, eight loads in flight - and writes the 2 x 2 outputs those four values are (the TN kernel's epilogue comment).
+// The association is fixed by K order, whatever the launch timing: bit-reproducible.
+#define WR_FLIGHT 8
+__global__ __launch_bounds__(256) void xv_tn_reduce_kernel(const float* __restrict__ slab, int P, int nk, long total, int max_segs, int tiles_n,
+                                                           int M, int N, int C, int c_pad, const float* __restrict__ w, long ldw, float l2,
+                                                           float* __restrict__ out, long ldo) {
+    const int tile = blockIdx.y, r = blockIdx.x, tid = threadIdx.x;
+    const long u0 = (long)tile * nk;
+    const int w_first = tn_owner(u0, P, total), w_last = tn_owner(u0 + nk - 1, P, total);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const float* base = slab + r * (256 * 4) + tid * 4;
+    for (int w0 = w_first; w0 <= w_last; w0 += WR_FLIGHT) {
+        f32x4 t[WR_FLIGHT];
+#pragma unroll
+        for (int q = 0; q < WR_FLIGHT; ++q) {
+            const int ww = min(w0 + q, w_last);
+            const int first_tile = (int)(((long)ww * total / P) / nk);
+            t[q] = *(const f32x4*)(base + ((long)ww * max_segs + (tile - first_tile)) * (BM * BN));
+        }
+#pragma unroll
+        for (int q = 0; q < WR_FLIGHT; ++q)
+            if (w0 + q <= w_last) v += t[q];
+    }
+    const int wave = tid >> 6, lane = tid & 63, wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const int m = tile_m * BM + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh);
+    const int n = tile_n * BN + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
+    if (n >= N) return;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int mm = m + a;
+        if (mm >= M) continue;
+        const int j = mm / c_pad, c = mm - j * c_pad;
+        if (c >= C) continue;                               // padded input channels (the feature layer: 30 -> 32)
+        const long row = (long)j * C + c;
+        f32x2 o = a == 0 ? f32x2{v.x, v.y} : f32x2{v.z, v.w};
+        if (w) o += l2 * *(const f32x2*)(w + row * ldw + n);
+        *(f32x2*)(out + row * ldo + n) = o;
+    }
+}
+
+// Schedule of one weight-gradient problem: workgroups, K-steps per tile, slabs per workgroup
+struct TNPlan { int tiles, nk, P, max_segs; long total; };
+static TNPlan tn_plan(int M, int N, int R) {
+    TNPlan q;
+    q.tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
+    q.nk = xv_cdiv(R, BK);
+    q.total = (long)q.tiles * q.nk;
+    // XV_WGS_PER_CU (4) workgroups are resident per CU (LDS 32 KB each): P <= XV_RESIDENT_WGS (1 024) makes the whole grid ONE co-resident
+    // round.  (On the first build - 2 per CU - 560 workgroups = 512 + a 48-workgroup second round cost 2x: 61 TF on tdnn2/3, 24 TF on tdnn5.)
     // [measured, round 2] fewer co-resident workgroups (smaller slabs, cheaper slab sum) lose: 768 -> +0.06 ms/step, 512 -> +0.19 ms
     // [measured, round 3, after the DMA / slab-sum work; medians of 3-4 alternated runs against 1 024, S1 | 64 x U{200..400} | S5]
     //   896: -0.1 ... -0.4 | -1.1 | -0.2 %     768: -0.6 ... -0.8 | -0.2 ... -0.5 | -0.1 ... -0.4 %
     // (a free slot per CU lets the BatchNorm kernels of the data-gradient chain in beside the weight gradient) - but the kernel itself
     // is slower with fewer workgroups: alone 1 655 -> 1 724 (768) / 1 837 us (896: 3.5 per CU is an unbalanced launch) over the five
-    // frame layers, its isolated roofline fraction 0.78 -> 0.75 / 0.71.  Kept at one full round: the step gains are at the noise level
-    // of a box change, the kernel's loss is not.
+    // frame layers, its isolated roofline fraction 0.78 -> 0.75 / 0.71.  Kept at one full round.
     static const int target = env_int("XV_TN_WGS", XV_RESIDENT_WGS);      // (A/B switch of the co-resident workgroup target)
     static const int min_ksteps = std::max(1, env_int("XV_TN_MIN_KSTEPS", 2));      // (A/B switch: fewest K-steps a workgroup is given)
-    int splits = target / tiles;
-    if (splits > ksteps / min_ksteps) splits = ksteps / min_ksteps;
-    if (splits < 1) splits = 1;
-    int chunk = xv_cdiv(ksteps, splits) * BK;
-    return xv_cdiv(R, chunk);
+    q.P = (int)std::max<long>(1, std::min<long>(target, q.total / min_ksteps));
+    const long run = (q.total + q.P - 1) / q.P;            // longest run of K-steps
+    q.max_segs = (int)(run / q.nk) + 2;                     // a run of L steps touches at most L / nk + 2 tiles
+    return q;
 }
 
-int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
+size_t xv_tn_ws_bytes(int M, int N, int R) {
+    const TNPlan q = tn_plan(M, N, R);
+    return (size_t)q.P * q.max_segs * BM * BN * sizeof(float);
+}
+
+int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g, int k, int C, int c_pad, const float* w, long ldw, float l2, float* out, long ldo) {
     XV_REQUIRE(g.M % 4 == 0 && g.N % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0,
                "gemm_tn: M/N/lda/ldb must be multiples of 4 (M=%d N=%d lda=%ld ldb=%ld)", g.M, g.N, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm_tn: operands must be 16-byte aligned");
-    XV_REQUIRE(g.M > 0 && g.N > 0 && g.R > 0 && g.splits >= 1, "gemm_tn: empty problem");
+    XV_REQUIRE(g.M > 0 && g.N > 0 && g.R > 0, "gemm_tn: empty problem");
+    XV_REQUIRE(k >= 1 && c_pad >= C && k * c_pad == g.M && ldo % 2 == 0 && (!w || ldw % 2 == 0) && ((uintptr_t)out % 8) == 0 && (!w || ((uintptr_t)w % 8) == 0),
+               "gemm_tn: output rows are k x c_pad = M (k=%d c_pad=%d M=%d), leading dimensions even", k, c_pad, g.M);
     if (ensure_zero_page()) return 1;
     TNArgs p;
     p.zero = g_zero_page;
@@ -1131,22 +1194,25 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
                    "gemm_tn: an operand spans 4 GB or more (%ld segments of %d / %d rows, lda=%ld ldb=%ld): split the batch", segs, g.a_pitch,
                    g.b_pitch, g.lda, g.ldb);
     }
+    const TNPlan q = tn_plan(g.M, g.N, g.R);
+    XV_REQUIRE(g.ws && ((uintptr_t)g.ws % 16) == 0 && (size_t)q.P * q.max_segs * BM * BN * sizeof(float) <= g.ws_bytes,
+               "gemm_tn: workspace too small (%zu bytes needed, %zu given)", (size_t)q.P * q.max_segs * BM * BN * sizeof(float), g.ws_bytes);
     p.A = g.A; p.lda = g.lda; p.a_pitch = g.a_pitch;
     p.B = g.B; p.ldb = g.ldb; p.b_pitch = g.b_pitch;
     p.rps = g.a_rps; p.inv_rps = 1.0f / (float)g.a_rps;
-    p.P = g.P; p.M = g.M; p.N = g.N; p.R = g.R;
+    p.M = g.M; p.N = g.N; p.R = g.R;
     p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
-    int ksteps = xv_cdiv(g.R, BK);
-    p.r_chunk = xv_cdiv(ksteps, g.splits) * BK;
-    static const int ahead_min = env_int("XV_TN_AHEAD_MIN", 96);      // (A/B switch: fewest K-steps per workgroup that stage two steps ahead)
-    p.ahead = p.r_chunk / BK >= ahead_min;
-    int splits = xv_cdiv(g.R, p.r_chunk);
-    XV_REQUIRE(splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", splits, g.splits);
-    dim3 grid(p.tiles_m * p.tiles_n * splits, 1, 1);
+    p.P = q.P; p.nk = q.nk; p.total = q.total; p.max_segs = q.max_segs;
+    p.slab = (float*)g.ws;
+    static const int ahead_min = env_int("XV_TN_AHEAD_MIN", 96);      // (A/B switch: fewest K-steps per segment that stage two steps ahead)
+    p.ahead_min = ahead_min;
     {
         XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
-        hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(xv_gemm_tn_kernel, dim3(q.P), dim3(256), 0, s, p);
     }
+    XV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(xv_tn_reduce_kernel, dim3(16, q.tiles), dim3(256), 0, s, (const float*)p.slab, q.P, q.nk, q.total, q.max_segs, p.tiles_n, g.M,
+                       g.N, C, c_pad, w, ldw, l2, out, ldo);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -1156,7 +1222,7 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
 // -------------------------------------------------------------------------------------
 extern "C" size_t xv_op_workspace_bytes(int rows, int cols_in, int cols_out) {
     // split slabs: at most XV_RESIDENT_WGS (+ one ragged round) workgroup tiles of 128x128 floats, plus column partials
-    size_t slabs = (size_t)(2 * XV_RESIDENT_WGS + 256) * BM * BN * sizeof(float);      // NT: two shared tiles per workgroup
+    size_t slabs = (size_t)(2 * XV_RESIDENT_WGS + 256) * BM * BN * sizeof(float);      // NT: two shared tiles per workgroup; TN: two segments
     size_t wg = (size_t)xv_align(cols_in, BM) * xv_align(cols_out, BN) * sizeof(float) * 8;
     size_t part = ((size_t)xv_cdiv(rows > 0 ? rows : 1, 64) * 2 + 2) * (size_t)(cols_out > cols_in ? cols_out : cols_in) * sizeof(float);
     size_t m = slabs > wg ? slabs : wg;
@@ -1195,7 +1261,6 @@ extern "C" int xv_affine_dgrad(void* stream, const float* dz_pad, int segs, int 
 // its quad.  Row blocks are grid-strided (at most ~2 048 workgroups: a launch of many short workgroups crawls beside a GEMM).
 // (The first build read 4 bytes per lane with two 64-bit divisions per element: 45 us for tdnn2's 63 MB of slabs alone on the chip -
 // and the last of these launches sits between the last GEMM of a step and the update.)
-#define WR_FLIGHT 8
 template <bool ZSPLIT>
 __global__ __launch_bounds__(256) void xv_wgrad_reduce_kernel(const float* __restrict__ P, int splits, long slab, int rows, int C, int c_pad,
                                                               int n_in, int nq_out, const float* __restrict__ w, long ldw, float l2,
@@ -1265,12 +1330,6 @@ extern "C" int xv_affine_wgrad(void* stream, const float* x, int segs, int t_in,
     g.A = x; g.lda = c_pad; g.a_rps = t_out; g.a_pitch = t_in;
     g.B = dz + (long)dz_row0 * o; g.ldb = o; g.b_rps = t_out; g.b_pitch = dz_seg_pitch;
     g.M = k * c_pad; g.N = o; g.R = segs * t_out;
-    g.splits = xv_tn_splits(g.M, g.N, g.R);
-    XV_REQUIRE((size_t)g.splits * g.M * g.N * sizeof(float) <= ws_bytes, "affine_wgrad: workspace too small (%zu needed)",
-               (size_t)g.splits * g.M * g.N * sizeof(float));
-    g.P = (float*)ws;
-    int rc = xv_launch_gemm_tn((hipStream_t)stream, g);
-    if (rc) return rc;
-    return xv_launch_wgrad_reduce((hipStream_t)stream, g.P, g.splits, k, c, c_pad, o, o, l2_scale != 0.f ? kernel : nullptr, o,
-                                  l2_scale, dkernel, o);
+    g.ws = ws; g.ws_bytes = ws_bytes;
+    return xv_launch_gemm_tn((hipStream_t)stream, g, k, c, c_pad, l2_scale != 0.f ? kernel : nullptr, o, l2_scale, dkernel, o);
 }

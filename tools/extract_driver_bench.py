@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """nnet/lib/extract.py itself, end to end: a 'CM '-compressed ark of VoxCeleb-like utterances (400..2000 frames, 30-dim) in, a float-vector
 ark of embeddings out - process start, checkpoint load, ark reading / decoding, forward, writing.  Prints utterances/s of the whole run
-and of its steady part (the reading + forward + writing loop, from the driver's own log timestamps is not needed: a second, 3x longer
+and of its steady part (the reading + forward + writing loop, from the driver's own log timestamps is not needed: a second, 5x longer
 ark separates the fixed start-up cost from the per-utterance cost)."""
 import json
 import os
@@ -53,7 +53,7 @@ def main():
     make_model(model)
     env = dict(os.environ, TF_KALDI_ROOT=PKG, PYTHONPATH=PKG)
     times = {}
-    for n in (300, 900):
+    for n in (1000, 5000):
         ark = os.path.join(tmp, "in%d.ark" % n)
         frames = make_ark(ark, n, n)
         t0 = time.perf_counter()
@@ -62,8 +62,8 @@ def main():
         assert r.returncode == 0, r.stderr[-2000:]
         times[n] = (time.perf_counter() - t0, frames)
         print("%4d utterances (%.2f M frames): %.2f s wall = %.0f utterances/s incl. start-up" % (n, frames / 1e6, times[n][0], n / times[n][0]))
-    per = (times[900][0] - times[300][0]) / 600
-    print("steady state: %.3f ms per utterance = %.0f utterances/s, %.2f M frames/s" % (per * 1e3, 1 / per, (times[900][1] - times[300][1]) / 600 / per / 1e6))
+    per = (times[5000][0] - times[1000][0]) / 4000
+    print("steady state: %.3f ms per utterance = %.0f utterances/s, %.2f M frames/s" % (per * 1e3, 1 / per, (times[5000][1] - times[1000][1]) / 4000 / per / 1e6))
 
 
 if __name__ == "__main__":
