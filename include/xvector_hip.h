@@ -455,6 +455,16 @@ int xv_engine_backward(xv_engine* e, void* stream, int stage);
  * still has to call xv_engine_stage_wait for it. */
 int xv_engine_backward_async(xv_engine* e, void* stream, int stage);
 int xv_engine_stage_wait(xv_engine* e, void* waiter_stream, int stage);
+/* Data parallelism for hosts without torch.distributed (the reference has no multi-GPU path: model/trainer.py:349 withholds its
+ * tower design): sum-all-reduce, in place, of the gradient slice that backward stage `stage` completed - after
+ * xv_engine_backward_async(e, compute_stream, stage) - over the RCCL communicator the host created (ncclComm_t passed as void*; one
+ * rank per GPU), enqueued on `comm_stream` behind the stage's completion events, so the collective of stage k overlaps the backward
+ * of stages k+1...  Call it for stages 0..XV_BWD_STAGES-1 in order (largest slice - the speaker matrix - first), then
+ * xv_engine_allreduce_wait(e, compute_stream) and xv_engine_apply(..., grad_scale = 1 / world size, ...).  BatchNorm statistics stay
+ * local to each rank.  RCCL is looked up in the process at first use (no link-time dependency). */
+int xv_engine_allreduce(xv_engine* e, void* comm_stream, int stage, void* rccl_comm);
+/* `stream` waits for every all-reduce enqueued so far through xv_engine_allreduce. */
+int xv_engine_allreduce_wait(xv_engine* e, void* stream);
 /* [begin,end) float range of the gradient buffer completed by backward stage `stage`. */
 int xv_engine_stage_grad_range(const xv_engine* e, int stage, size_t* begin, size_t* end);
 /* optimiser step on the bound buffers (after the gradient all-reduce). t = 1-based update count. */

@@ -3,7 +3,11 @@
  * by tests/test_gpu_c_abi.py, runs one full optimiser step (forward, loss, backward, apply) on caller-owned hipMalloc
  * buffers and writes raw loss, regularisation loss, the tdnn6_dense embedding and the updated variables back to a file.
  *
- *   engine_step <in.bin> <out.bin> feat_dim num_speakers loss_kind margin_m batch frames precision lr global_step
+ *   engine_step <in.bin> <out.bin> feat_dim num_speakers loss_kind margin_m batch frames precision lr global_step [allreduce]
+ *
+ * With the optional last argument the backward pass runs in its four stages and every finished gradient slice goes through
+ * xv_engine_allreduce on a communication stream of the host's, over an RCCL communicator the host creates (one rank: the one GPU of the
+ * test box; the call sequence is the one a multi-GPU host runs, and a sum over one rank must leave every bit where it was).
  *
  * in.bin : float32 variables[variables_count] | float32 features[b*t*d] | int32 labels[b]
  * out.bin: float32 raw_loss | float32 reg_loss | int32 rows | int32 cols | float32 embedding[rows*cols] | float32 variables[...]
@@ -12,16 +16,18 @@
 #include <stdlib.h>
 #include <string.h>
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 #include "xvector_hip.h"
 
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e_)); return 2; } } while (0)
 #define XV_OK(call) do { if ((call) != 0) { fprintf(stderr, "%s: %s\n", #call, xv_last_error()); return 3; } } while (0)
 
 int main(int argc, char** argv) {
-    if (argc != 12) {
-        fprintf(stderr, "usage: %s in.bin out.bin feat_dim num_speakers loss_kind margin_m batch frames precision lr global_step\n", argv[0]);
+    if (argc != 12 && !(argc == 13 && strcmp(argv[12], "allreduce") == 0)) {
+        fprintf(stderr, "usage: %s in.bin out.bin feat_dim num_speakers loss_kind margin_m batch frames precision lr global_step [allreduce]\n", argv[0]);
         return 1;
     }
+    const int dp = argc == 13;
     xv_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.feat_dim = atoi(argv[3]);
@@ -74,7 +80,20 @@ int main(int argc, char** argv) {
     HIP_OK(hipStreamCreate(&s));
     XV_OK(xv_engine_forward(e, s, d_x, b, t, 1));
     XV_OK(xv_engine_loss_forward(e, s, d_y, global_step, 1));
-    XV_OK(xv_engine_backward(e, s, -1));
+    ncclComm_t comm = NULL;
+    hipStream_t cs = NULL;
+    if (dp) {
+        const int dev0 = 0;
+        if (ncclCommInitAll(&comm, 1, &dev0) != ncclSuccess) { fprintf(stderr, "ncclCommInitAll failed\n"); return 7; }
+        HIP_OK(hipStreamCreate(&cs));
+        for (int stage = 0; stage < XV_BWD_STAGES; ++stage) {
+            XV_OK(xv_engine_backward_async(e, s, stage));
+            XV_OK(xv_engine_allreduce(e, cs, stage, comm));
+        }
+        XV_OK(xv_engine_allreduce_wait(e, s));
+    } else {
+        XV_OK(xv_engine_backward(e, s, -1));
+    }
     float *d_raw, *d_reg, *d_emb;
     int32_t rows, cols, ld;
     XV_OK(xv_engine_loss_ptrs(e, &d_raw, &d_reg));
@@ -102,6 +121,7 @@ int main(int argc, char** argv) {
     printf("engine_step: %d variables (%zu floats), loss %.6f reg %.6f, embedding %d x %d\n", xv_engine_num_variables(e), nv, raw, reg, rows, cols);
 
     xv_engine_destroy(e);
+    if (dp) { (void)hipStreamDestroy(cs); (void)ncclCommDestroy(comm); }
     (void)hipStreamDestroy(s);
     (void)hipFree(d_vars); (void)hipFree(d_grads); (void)hipFree(d_opt); (void)hipFree(d_x); (void)hipFree(d_y);
     free(h_vars); free(h_x); free(h_y); free(h_emb);

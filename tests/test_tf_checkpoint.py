@@ -136,3 +136,25 @@ def test_reads_a_checkpoint_written_by_tensorflow():
     assert set(want.files) <= set(got)
     for k in want.files:
         assert got[k].shape == want[k].shape and np.array_equal(got[k], want[k]), k
+
+
+def test_non_numeric_entries_are_skipped_and_writes_are_atomic(tmp_path):
+    """An object-based saver adds the DT_STRING entry `_CHECKPOINTABLE_OBJECT_GRAPH` to the index: it is no model variable, and a
+    checkpoint that holds it must still load.  write_checkpoint leaves no temporary file and never a lone index."""
+    prefix = str(tmp_path / "model-7")
+    want = {"tdnn/tdnn1_conv/bias": np.arange(5, dtype=np.float32), "global_step": np.array(7, np.int64)}
+    T.write_checkpoint(prefix, want)
+    assert sorted(os.listdir(tmp_path)) == ["model-7.data-00000-of-00001", "model-7.index"]
+    items = [(k, v) for k, v in T.read_table(prefix + ".index")]
+    size = os.path.getsize(prefix + ".data-00000-of-00001")
+    blob = b"\x08\x01graph"                                             # what a string tensor's bytes might look like
+    with open(prefix + ".data-00000-of-00001", "ab") as f:
+        f.write(blob)
+    string_entry = T._field(1, 0, 7) + T._field(2, 2, T._encode_shape(())) + T._field(3, 0, 0) + T._field(4, 0, size) + T._field(5, 0, len(blob)) + \
+        T._field(6, 5, struct.pack("<I", T.mask_crc(T.crc32c(blob))))       # dtype 7 = DT_STRING
+    items.append((b"_CHECKPOINTABLE_OBJECT_GRAPH", string_entry))
+    T.write_table(prefix + ".index", sorted(items))
+    entries, _ = T.list_variables(prefix)
+    assert sorted(entries) == sorted(want) and T.list_variables.skipped == [("_CHECKPOINTABLE_OBJECT_GRAPH", 7)]
+    got = T.read_checkpoint(prefix, verify=True)
+    assert sorted(got) == sorted(want) and all(np.array_equal(got[k], want[k]) for k in want)

@@ -169,6 +169,8 @@ SIGNATURES = {
     "xv_engine_backward": (_I, [_VP, _VP, _I]),
     "xv_engine_backward_async": (_I, [_VP, _VP, _I]),
     "xv_engine_stage_wait": (_I, [_VP, _VP, _I]),
+    "xv_engine_allreduce": (_I, [_VP, _VP, _I, _VP]),
+    "xv_engine_allreduce_wait": (_I, [_VP, _VP]),
     "xv_engine_stage_grad_range": (_I, [_VP, _I, C.POINTER(_SZ), C.POINTER(_SZ)]),
     "xv_engine_apply": (_I, [_VP, _VP, _F, _F, _I]),
     "xv_engine_loss_ptrs": (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),

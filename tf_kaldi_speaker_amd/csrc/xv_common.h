@@ -94,10 +94,18 @@ __device__ __forceinline__ void xv_handoff_load8(const float* p, int stride, f32
 // builtin inside a loop - it folds a scalar base back into the vector address) the MFMA pipe was 0.867 occupied; the same loads fed from one
 // hot KiB 0.883 (so it is not the memory side); this form 0.939: 488 -> 449 us, 132 -> 143 TF.  The compiler does not see the loads:
 // callers wait with xv_dma_wait_all() before the barrier that publishes a stage, and every operand row must lie within 4 GB of the base.
-// (M0 is a reserved register: hipcc sets it immediately in front of each of its own uses - the LDS-DMA builtin of the ragged paths -
-// and keeps nothing in it across statements, so writing it here needs no clobber; naming it in the clobber list is rejected as reserved.)
+// (M0 is a reserved register: naming it in the clobber list is rejected.  hipcc sets it immediately in front of each of its own uses and
+// keeps nothing in it across statements; the kernels that use this form issue ALL their LDS-DMA through it or xv_dma16_ptr.)
 __device__ __forceinline__ void xv_dma16(const float* sbase, unsigned voff, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory");
+}
+// the same instruction with a 64-bit address per lane (the ragged K-steps, whose out-of-range pieces read a zero page that may lie more
+// than 4 GB from the operand).  Every LDS-DMA of these kernels goes through one of the two forms, so hipcc never materialises M0 for a
+// DMA of its own in them and cannot hoist or merge an M0 initialisation across these statements.  `lds` = a wave-uniform
+// shared-memory pointer.
+__device__ __forceinline__ void xv_dma16_ptr(const void* gaddr, const void* lds) {
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(la), "v"(gaddr) : "memory");
 }
 __device__ __forceinline__ void xv_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // the LDS byte address of a wave-uniform shared-memory pointer, as a scalar

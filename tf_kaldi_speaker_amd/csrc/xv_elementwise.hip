@@ -1026,6 +1026,77 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// The same pass for a layer without zero frames around its chunks (pad == 0: the dense layers, among them the last frame layer whose
+// upstream gradient is the pooling backward - 286 MB at S1, on the critical chain between the loss and the first data-gradient GEMM).
+// The loop above loads, computes and stores one row per trip behind two branches, so every trip waits for its own load; here a thread's
+// BAF_ROWS / 4 rows are loaded together (addresses clamped instead of predicated) and, POOLED, the statistics of the at most two chunks
+// a strip touches are loaded up front and selected per row.  [measured, round 3, r03_elementwise.json] generic form, 1 500 channels:
+// 0.62 of 8 TB/s alone, 0.49 in the step (72.6 us for 285.7 MB).
+template <bool POOLED>
+__global__ __launch_bounds__(256) void bn_bwd_apply_dense_kernel(const float* __restrict__ da, PoolGrad pg, const float* __restrict__ z, int rows,
+                                                                 int n, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const float* __restrict__ coef, int relu,
+                                                                 float* __restrict__ dz, const float* __restrict__ slope) {
+    constexpr int NR = BAF_ROWS / 4;
+    const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int rl = threadIdx.x >> 6;
+    if (col >= n) return;
+    const int r0 = blockIdx.y * BAF_ROWS + rl;
+    f32x4 zz[NR], dd[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) zz[j] = *(const f32x4*)(z + (long)min(r0 + 4 * j, rows - 1) * n + col);
+    if (!POOLED) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) dd[j] = *(const f32x4*)(da + (long)min(r0 + 4 * j, rows - 1) * n + col);
+    }
+    const f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
+    const f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
+    const f32x4 c1 = *(const f32x4*)(coef + col), c2 = *(const f32x4*)(coef + n + col);
+    const f32x4 g_is = *(const f32x4*)(gamma + col) * is;
+    const bool hs = slope != nullptr;
+    f32x4 sl = {0, 0, 0, 0};
+    if (hs) sl = *(const f32x4*)(slope + col);
+    PoolCoef pc0 = {}, pc1 = {};
+    int b_end = 0;                                  // first row of the strip's second chunk
+    float w[NR];
+    if (POOLED) {
+        const int nb = rows / pg.t;
+        const int b0 = min(blockIdx.y * BAF_ROWS / pg.t, nb - 1);
+        b_end = (b0 + 1) * pg.t;
+        pc0 = pool_coef(pg, b0, n, col);
+        pc1 = pool_coef(pg, min(b0 + 1, nb - 1), n, col);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) w[j] = pg.w ? pg.w[min(r0 + 4 * j, rows - 1)] : 1.f / (float)pg.t;
+        // (a strip of BAF_ROWS rows crosses at most one chunk boundary when pg.t >= BAF_ROWS; shorter chunks take the generic kernel)
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = r0 + 4 * j;
+        f32x4 d;
+        if (POOLED) {
+            const bool second = r >= b_end;
+            PoolCoef pc;
+            pc.mean = second ? pc1.mean : pc0.mean; pc.dm = second ? pc1.dm : pc0.dm; pc.q = second ? pc1.q : pc0.q;
+            d = upstream_grad<true>(nullptr, pc, w[j], (long)r, n, col, zz[j], sc, sh, relu, sl, hs);
+        } else {
+            const f32x4 y = zz[j] * sc + sh;
+            d = dd[j];
+            if (relu) {
+                if (hs) {
+                    d.x = y.x > 0.f ? d.x : d.x * sl.x; d.y = y.y > 0.f ? d.y : d.y * sl.y;
+                    d.z = y.z > 0.f ? d.z : d.z * sl.z; d.w = y.w > 0.f ? d.w : d.w * sl.w;
+                } else {
+                    d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f;
+                    d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;
+                }
+            }
+        }
+        const f32x4 xh = (zz[j] - mu) * is;
+        if (r < rows) *(f32x4*)(dz + (long)r * n + col) = g_is * (d - c1 - xh * c2);
+    }
+}
+
 // Same as bn_bwd_apply_kernel but dz is written as two fp16 planes [2][segs*(t+2pad)][ldd] scaled by the power of two
 // derived from *amax (xv_gemm16.hip); pad rows / columns are zero.
 // Thread = one 8-channel chunk (16 B per plane) x a strip of rows: the 7 per-channel parameter vectors are loaded
@@ -1217,8 +1288,12 @@ static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, co
         XV_LAUNCH_CHECK();
     }
     dim3 agrid(xv_cdiv(n / 4, 64), xv_cdiv(segs * (t + 2 * pad), BAF_ROWS));
-    hipLaunchKernelGGL(pooled ? bn_bwd_apply_kernel<true> : bn_bwd_apply_kernel<false>, agrid, dim3(256), 0, s, da,
-                       pg, z, segs, t, n, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad, dz_pad, relu ? act.slope : nullptr);
+    if (pad == 0 && (!pooled || pg.t >= BAF_ROWS))
+        hipLaunchKernelGGL(pooled ? bn_bwd_apply_dense_kernel<true> : bn_bwd_apply_dense_kernel<false>, agrid, dim3(256), 0, s, da, pg, z, rows, n, gamma,
+                           mean, invstd, scale, shift, (const float*)coef, relu, dz_pad, relu ? act.slope : nullptr);
+    else
+        hipLaunchKernelGGL(pooled ? bn_bwd_apply_kernel<true> : bn_bwd_apply_kernel<false>, agrid, dim3(256), 0, s, da,
+                           pg, z, segs, t, n, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad, dz_pad, relu ? act.slope : nullptr);
     XV_LAUNCH_CHECK();
     return 0;
 }

@@ -14,6 +14,8 @@
 //                GEMM as the forward pass (xv_gemm.hip).
 //   weights    : kernel-layout copies (transposed / tap-flipped / channel-padded) rebuilt once
 //                per optimiser step.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <string>
@@ -101,6 +103,8 @@ struct xv_engine {
     hipEvent_t ev_dz = nullptr, ev_lw = nullptr;
     hipEvent_t ev_prep = nullptr, ev_lossprep = nullptr;     // side-stream halves of ensure_weights
     bool prep_pending = false, lossprep_pending = false;
+    hipEvent_t ev_comm = nullptr;                 // behind the most recent xv_engine_allreduce on the caller's communication stream
+    bool comm_pending = false;
     hipEvent_t ev_stage[XV_BWD_STAGES][2] = {};   // [stage][0 main, 1 side]: that stage's gradients are complete (backward_async)
     bool stage_side[XV_BWD_STAGES] = {};          // the side-stream event of the stage was recorded
     // dz ping-pong state.  ring 0: the frame-level layers' dz (fp16 planes `dzh` in split precision) and, in fp32, every
@@ -488,6 +492,7 @@ int alloc_buffers(xv_engine* e) {
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < 2; ++i) XV_CHECK_HIP(hipEventCreateWithFlags(&e->zr[r].ev[i], hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lw, hipEventDisableTiming));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_comm, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_prep, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lossprep, hipEventDisableTiming));
     for (int k = 0; k < XV_BWD_STAGES; ++k)
@@ -676,6 +681,7 @@ extern "C" void xv_engine_destroy(xv_engine* e) {
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < 2; ++i) if (e->zr[r].ev[i]) (void)hipEventDestroy(e->zr[r].ev[i]);
     if (e->ev_lw) (void)hipEventDestroy(e->ev_lw);
+    if (e->ev_comm) (void)hipEventDestroy(e->ev_comm);
     if (e->ev_prep) (void)hipEventDestroy(e->ev_prep);
     if (e->ev_lossprep) (void)hipEventDestroy(e->ev_lossprep);
     for (int k = 0; k < XV_BWD_STAGES; ++k)
@@ -1527,6 +1533,59 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
     return 0;
 }
 }  // namespace
+
+// ---- gradient exchange for hosts without torch.distributed (the Python host runs the same collective through
+// torch.distributed in parallel.py).  RCCL is resolved at first use from the process - the host that created the communicator has it
+// loaded, and the communicator must be used with the library that made it - and only then from the default library path: this library
+// has no link-time dependency on RCCL and loads on a box without it.
+namespace {
+typedef int (*rccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*rccl_errstr_fn)(int);
+struct Rccl { rccl_allreduce_fn allreduce = nullptr; rccl_errstr_fn errstr = nullptr; bool tried = false; };
+Rccl& rccl() {
+    static Rccl r;
+    if (!r.tried) {
+        r.tried = true;
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        void* h = nullptr;
+        if (!sym) {
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (h) break;
+            }
+            if (h) sym = dlsym(h, "ncclAllReduce");
+        }
+        r.allreduce = (rccl_allreduce_fn)sym;
+        r.errstr = (rccl_errstr_fn)(h ? dlsym(h, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+    }
+    return r;
+}
+}  // namespace
+
+extern "C" int xv_engine_allreduce(xv_engine* e, void* comm_stream, int stage, void* rccl_comm) {
+    XV_REQUIRE(e && e->G && rccl_comm && stage >= 0 && stage < XV_BWD_STAGES, "engine_allreduce: bad arguments (stage %d)", stage);
+    Rccl& r = rccl();
+    XV_REQUIRE(r.allreduce, "engine_allreduce: ncclAllReduce is not available in this process (load RCCL - it made the communicator - first)");
+    int rc = xv_engine_stage_wait(e, comm_stream, stage);
+    if (rc) return rc;
+    const size_t begin = e->stage_begin[stage], count = e->stage_end[stage] - begin;
+    if (count > 0) {
+        const int nr = r.allreduce(e->G + begin, e->G + begin, count, 7 /* ncclFloat32 */, 0 /* ncclSum */, rccl_comm, (hipStream_t)comm_stream);
+        XV_REQUIRE(nr == 0, "engine_allreduce: ncclAllReduce of stage %d (%zu floats) failed: %s", stage, count, r.errstr ? r.errstr(nr) : "?");
+    }
+    XV_CHECK_HIP(hipEventRecord(e->ev_comm, (hipStream_t)comm_stream));
+    e->comm_pending = true;
+    return 0;
+}
+
+extern "C" int xv_engine_allreduce_wait(xv_engine* e, void* stream) {
+    XV_REQUIRE(e, "engine_allreduce_wait: null engine");
+    if (e->comm_pending) {
+        XV_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, e->ev_comm, 0));
+        e->comm_pending = false;
+    }
+    return 0;
+}
 
 extern "C" int xv_engine_stage_grad_range(const xv_engine* e, int stage, size_t* begin, size_t* end) {
     XV_REQUIRE(e && stage >= 0 && stage < XV_BWD_STAGES && begin && end, "stage_grad_range: bad arguments");

@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 #define BM XV_TILE_M
@@ -252,8 +253,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         int n = n0 + row;
         boff[i] = (unsigned)(((long)(n < p.N ? n : 0) * p.ldb + ksrc[i]) * 4);
     }
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
     const unsigned lds0 = xv_lds_addr(smem + NT_RPI * NT_RPT * uwave * NT_PITCH);
     auto gstage = [&](int kt, int buf) {
         const int k0 = k_begin + kt * BK;
@@ -282,8 +281,8 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
                 const bool kv = k0 + ksrc[i] < k_end;
                 const float* pa = (const float*)((const char*)(p.A + k0) + aoff[i]);
                 const float* pb = (const float*)((const char*)(p.Bt + k0) + boff[i]);
-                __builtin_amdgcn_global_load_lds((gptr_t)(kv ? pa : zp), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(kv ? pb : zp), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                xv_dma16_ptr((kv ? pa : zp), sa + NT_RPI * i * NT_PITCH);
+                xv_dma16_ptr((kv ? pb : zp), sb + NT_RPI * i * NT_PITCH);
             }
         }
     };
@@ -426,8 +425,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int lrow = lane / NT_KQ, lpos = lane % NT_KQ;
     const float* __restrict__ zp = p.zero;
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
     const int b_off = (wc * 64 + li) * NT_PITCH;
     const int fsw = NT_SWZ(li);
 #if XV_NT_ROTPRIO
@@ -515,7 +512,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
 #pragma unroll
                 for (int i = 0; i < NT_RPT; ++i) {
                     const float* pb = (const float*)((const char*)(p.Bt + k0) + boff[i]);
-                    __builtin_amdgcn_global_load_lds((gptr_t)(k0 + ksrc[i] < p.K ? pb : zp), (lptr_t)(sb + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                    xv_dma16_ptr((k0 + ksrc[i] < p.K ? pb : zp), sb + NT_RPI * i * NT_PITCH);
                 }
             }
         };
@@ -535,7 +532,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
 #pragma unroll
                     for (int i = 0; i < NT_RPT; ++i) {
                         const float* pa = (const float*)((const char*)(p.A + k0) + aoff[i]);
-                        __builtin_amdgcn_global_load_lds((gptr_t)(k0 + ksrc[i] < p.K ? pa : zp), (lptr_t)(sa + NT_RPI * i * NT_PITCH), 16, 0, 0);
+                        xv_dma16_ptr((k0 + ksrc[i] < p.K ? pa : zp), sa + NT_RPI * i * NT_PITCH);
                     }
                 }
             }
@@ -922,6 +919,7 @@ struct TNArgs {
     int max_segs;       // slabs reserved per workgroup
     float* slab;        // [P][max_segs][16][256] float4, see the epilogue
     int ahead_min;      // fewest K-steps of a segment that run the two-steps-ahead schedule
+    const unsigned short* order;      // [P] launch slot -> run (tn_order), or null
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -937,14 +935,17 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int w = xcd_swizzle(blockIdx.x, gridDim.x);
+    // Which run a workgroup takes: launch slots that share an XCD (contiguous after the swizzle) get the runs that start at the SAME reduction
+    // rows of their tiles (tn_order sorts the runs by their first K-step), so the rows of x and dz they stream are fetched into that XCD's
+    // L2 once for all the tiles that need them.  In run order an XCD would hold all K offsets of a few tiles: nothing shared, every
+    // operand byte from the Infinity Cache (4 x the traffic past L2 on the K = 512 layers, whose 16 tiles all read the same rows).
+    const int slot = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int w = p.order ? (int)p.order[slot] : slot;
     long u = (long)w * p.total / p.P;
     const long u_end = (long)(w + 1) * p.total / p.P;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int lc = (lane & 31) * 4;
     const float* __restrict__ zp = p.zero;
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
     const unsigned lds0 = xv_lds_addr(smem + 2 * TN_RPT * uwave * BM);
     const unsigned a_step = (unsigned)(BK * p.lda * 4), b_step = (unsigned)(BK * p.ldb * 4);
     const unsigned a_skip = (unsigned)((long)(p.a_pitch - p.rps) * p.lda * 4), b_skip = (unsigned)((long)(p.b_pitch - p.rps) * p.ldb * 4);
@@ -981,8 +982,8 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             tt = r - sg * p.rps;
             const float* pa = (rv && a_cv) ? abase + ((long)sg * p.a_pitch + tt) * p.lda : zp;
             const float* pb = (rv && b_cv) ? bbase + ((long)sg * p.b_pitch + tt) * p.ldb : zp;
-            __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(sa + 2 * i * BM), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(sb + 2 * i * BN), 16, 0, 0);
+            xv_dma16_ptr(pa, sa + 2 * i * BM);
+            xv_dma16_ptr(pb, sb + 2 * i * BN);
         }
     };
     // Full K-steps (every row below r_end): scalar bases + 32-bit lane offsets (xv_dma16) that ADVANCE by BK rows per step - a row of the
@@ -1105,32 +1106,50 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
 
 __host__ __device__ __forceinline__ int tn_owner(long u, int P, long total) { return (int)((((u + 1) * P) - 1) / total); }
 
-// out[(j*C + c)][n] = sum over the slabs of tile (m = j*c_pad + c, n) in K order (+ l2 * w[(j*C + c)][n]).  Block = (tile, one accumulator
-// register index r): thread tid adds the float4 it finds at [r][tid] of every slab of the tile - 1 KB of consecutive bytes per wave
-// instruction, eight loads in flight - and writes the 2 x 2 outputs those four values are (the TN kernel's epilogue comment).
-// The association is fixed by K order, whatever the launch timing: bit-reproducible.
+// out[(j*C + c)][n] = sum over the slabs of tile (m = j*c_pad + c, n) in K order (+ l2 * w[(j*C + c)][n]).  A slab is [register r][thread]
+// float4 (the TN kernel's epilogue); block = 4 groups of 64 lanes on (tile, register r, quarter q of its 256 float4).  Few shares per tile
+// (GROUPS = false): the 4 groups are the 4 quarters and a lane adds all shares of its float4 in K order.  Many shares (tdnn1: 128, the
+// K = 512 layers: 64): the 4 groups take contiguous quarters of the shares of ONE quarter row and their sums are added in group order -
+// a fixed association either way, whatever the launch timing: bit-reproducible.  Eight 16-byte loads in flight per lane, 1 KB of
+// consecutive bytes per wave instruction.
 #define WR_FLIGHT 8
+template <bool GROUPS>
 __global__ __launch_bounds__(256) void xv_tn_reduce_kernel(const float* __restrict__ slab, int P, int nk, long total, int max_segs, int tiles_n,
                                                            int M, int N, int C, int c_pad, const float* __restrict__ w, long ldw, float l2,
                                                            float* __restrict__ out, long ldo) {
-    const int tile = blockIdx.y, r = blockIdx.x, tid = threadIdx.x;
+    __shared__ f32x4 part[GROUPS ? 4 : 1][64];
+    const int tile = blockIdx.y, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int r = GROUPS ? blockIdx.x >> 2 : blockIdx.x, quarter = GROUPS ? blockIdx.x & 3 : g;
+    const int tid = quarter * 64 + lane;               // the thread of the TN kernel whose float4 this lane adds
     const long u0 = (long)tile * nk;
     const int w_first = tn_owner(u0, P, total), w_last = tn_owner(u0 + nk - 1, P, total);
+    int wa = w_first, wb = w_last;
+    if (GROUPS) {
+        const int per = (w_last - w_first + 4) / 4;
+        wa = w_first + g * per;
+        wb = min(w_last, wa + per - 1);
+    }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const float* base = slab + r * (256 * 4) + tid * 4;
-    for (int w0 = w_first; w0 <= w_last; w0 += WR_FLIGHT) {
+    for (int w0 = wa; w0 <= wb; w0 += WR_FLIGHT) {
         f32x4 t[WR_FLIGHT];
 #pragma unroll
         for (int q = 0; q < WR_FLIGHT; ++q) {
-            const int ww = min(w0 + q, w_last);
+            const int ww = min(w0 + q, wb);
             const int first_tile = (int)(((long)ww * total / P) / nk);
             t[q] = *(const f32x4*)(base + ((long)ww * max_segs + (tile - first_tile)) * (BM * BN));
         }
 #pragma unroll
         for (int q = 0; q < WR_FLIGHT; ++q)
-            if (w0 + q <= w_last) v += t[q];
+            if (w0 + q <= wb) v += t[q];
     }
-    const int wave = tid >> 6, lane = tid & 63, wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+    if (GROUPS) {
+        part[g][lane] = v;
+        __syncthreads();
+        if (g != 0) return;
+        v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    }
+    const int wave = tid >> 6, wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const int m = tile_m * BM + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh);
     const int n = tile_n * BN + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
@@ -1146,6 +1165,28 @@ __global__ __launch_bounds__(256) void xv_tn_reduce_kernel(const float* __restri
         if (w) o += l2 * *(const f32x2*)(w + row * ldw + n);
         *(f32x2*)(out + row * ldo + n) = o;
     }
+}
+
+// Launch slot -> run, sorted by the K-step a run starts at within its tile (ties in run order): see the kernel.  One small device table per
+// (tiles, nk, P), built on first use and kept (a training step repeats the same eight problems).
+static const unsigned short* tn_order(int tiles, int nk, int P) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int>, unsigned short*> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_tuple(tiles, nk, P);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    const long total = (long)tiles * nk;
+    std::vector<std::pair<int, int>> ks(P);
+    for (int w = 0; w < P; ++w) ks[w] = {(int)(((long)w * total / P) % nk), w};
+    std::sort(ks.begin(), ks.end());
+    std::vector<unsigned short> h(P);
+    for (int i = 0; i < P; ++i) h[i] = (unsigned short)ks[i].second;
+    unsigned short* d = nullptr;
+    if (hipMalloc((void**)&d, P * sizeof(unsigned short)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), P * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) return nullptr;      // (synchronous, once per shape)
+    cache[key] = d;
+    return d;
 }
 
 // Schedule of one weight-gradient problem: workgroups, K-steps per tile, slabs per workgroup
@@ -1206,13 +1247,20 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g, int k, int C, int c_pad,
     p.slab = (float*)g.ws;
     static const int ahead_min = env_int("XV_TN_AHEAD_MIN", 96);      // (A/B switch: fewest K-steps per segment that stage two steps ahead)
     p.ahead_min = ahead_min;
+    static const int use_order = env_int("XV_TN_ORDER", 1);      // (A/B switch)
+    p.order = (use_order && q.P <= 65535) ? tn_order(q.tiles, q.nk, q.P) : nullptr;
     {
         XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
         hipLaunchKernelGGL(xv_gemm_tn_kernel, dim3(q.P), dim3(256), 0, s, p);
     }
     XV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(xv_tn_reduce_kernel, dim3(16, q.tiles), dim3(256), 0, s, (const float*)p.slab, q.P, q.nk, q.total, q.max_segs, p.tiles_n, g.M,
-                       g.N, C, c_pad, w, ldw, l2, out, ldo);
+    const int shares = xv_cdiv(q.P, q.tiles) + 1;
+    if (shares >= 32)
+        hipLaunchKernelGGL(xv_tn_reduce_kernel<true>, dim3(64, q.tiles), dim3(256), 0, s, (const float*)p.slab, q.P, q.nk, q.total, q.max_segs,
+                           p.tiles_n, g.M, g.N, C, c_pad, w, ldw, l2, out, ldo);
+    else
+        hipLaunchKernelGGL(xv_tn_reduce_kernel<false>, dim3(16, q.tiles), dim3(256), 0, s, (const float*)p.slab, q.P, q.nk, q.total, q.max_segs,
+                           p.tiles_n, g.M, g.N, C, c_pad, w, ldw, l2, out, ldo);
     XV_LAUNCH_CHECK();
     return 0;
 }

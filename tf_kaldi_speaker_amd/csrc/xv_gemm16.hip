@@ -23,8 +23,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 static u16* g_zero16 = nullptr;
 static int ensure_zero16() {
@@ -290,8 +288,8 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
             for (int pl = 0; pl < 2; ++pl) {
                 const u16* pa = kv ? (const u16*)((const char*)(p.A + pl * p.a_plane + k0) + aoff[i]) : p.zero;
                 const u16* pb = kv ? (const u16*)((const char*)(p.Bt + pl * p.b_plane + k0) + boff[i]) : p.zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(base + pl * PLANE_HALFS + RPI * i * BK16), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + (2 + pl) * PLANE_HALFS + RPI * i * BK16), 16, 0, 0);
+                xv_dma16_ptr(pa, base + pl * PLANE_HALFS + RPI * i * BK16);
+                xv_dma16_ptr(pb, base + (2 + pl) * PLANE_HALFS + RPI * i * BK16);
             }
         }
     };
@@ -894,8 +892,8 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
             for (int pl = 0; pl < 2; ++pl) {
                 const u16* pa = (rv && a_cv) ? p.A + pl * p.a_plane + ao : p.zero;
                 const u16* pb = (rv && b_cv) ? p.B + pl * p.b_plane + bo : p.zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(base + pl * PH + 4 * rg * 128), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(base + (2 + pl) * PH + 4 * rg * 128), 16, 0, 0);
+                xv_dma16_ptr(pa, base + pl * PH + 4 * rg * 128);
+                xv_dma16_ptr(pb, base + (2 + pl) * PH + 4 * rg * 128);
             }
         }
     };

@@ -262,7 +262,7 @@ def _shard_name(prefix, shard, num_shards):
 
 def list_variables(prefix, verify=True):
     """-> {name: (dtype, shape, shard, offset, size, masked crc)} of the checkpoint `<prefix>.index`, and the shard count."""
-    entries, num_shards = {}, 1
+    entries, num_shards, skipped = {}, 1, []
     for key, value in read_table(prefix + ".index", verify):
         fields = _parse_proto(value)
         if key == b"":
@@ -291,8 +291,12 @@ def list_variables(prefix, verify=True):
         if sliced:
             raise ValueError("%s: partitioned variables are not supported" % key.decode())
         if dtype not in _DTYPES:
-            raise ValueError("%s: unsupported dtype code %d" % (key.decode(), dtype))
+            # not a numeric tensor - e.g. the DT_STRING entry `_CHECKPOINTABLE_OBJECT_GRAPH` an object-based saver adds: no model
+            # variable can be one, so it is skipped here and only a REQUESTED name that is missing is an error
+            skipped.append((key.decode("utf-8", "replace"), dtype))
+            continue
         entries[key.decode("utf-8")] = (np.dtype(_DTYPES[dtype]), shape, shard, offset, size, crc)
+    list_variables.skipped = skipped
     return entries, num_shards
 
 
@@ -326,7 +330,10 @@ def write_checkpoint(prefix, variables, with_crc=True):
     names = sorted(variables, key=lambda s: s.encode("utf-8"))
     items = [(b"", _field(1, 0, 1) + _field(2, 0, 0) + _field(3, 2, _field(1, 0, 1)))]       # 1 shard, little endian, producer 1
     offset = 0
-    with open(_shard_name(prefix, 0, 1), "wb") as f:
+    # both files are written under temporary names and moved into place (data first, the index last): a reader never sees a
+    # half-written checkpoint, as with the .npz payload written beside it
+    data_path, index_path = _shard_name(prefix, 0, 1), prefix + ".index"
+    with open(data_path + ".tmp", "wb") as f:
         for name in names:
             a = np.asarray(variables[name], order="C")      # (ascontiguousarray would turn a scalar into shape (1,))
             if a.dtype not in _DTYPE_CODES:
@@ -337,7 +344,9 @@ def write_checkpoint(prefix, variables, with_crc=True):
                 _field(5, 0, len(raw)) + _field(6, 5, struct.pack("<I", mask_crc(crc32c(raw)) if with_crc else 0))
             items.append((name.encode("utf-8"), entry))
             offset += len(raw)
-    write_table(prefix + ".index", items)
+    write_table(index_path + ".tmp", items)
+    os.replace(data_path + ".tmp", data_path)
+    os.replace(index_path + ".tmp", index_path)
 
 
 # optimiser slots and bookkeeping a Saver stores beside the model variables (trainer.py:332-346: GradientDescent / Momentum / Adam

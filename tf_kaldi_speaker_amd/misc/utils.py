@@ -413,34 +413,48 @@ def plan_length_batches(lengths, max_rows, max_chunks, min_fill=0.9, min_rows=81
     return batches
 
 
-def batched_utterance_embeddings(predict_batch, features, chunk_size, normalize):
-    """utterance_embedding() for a window of utterances at once: every utterance's pieces (itself, or its half-overlapping chunks
-    when longer than chunk_size, extract.py:69-79) go through ONE predict_batch call; long utterances are then averaged by piece length
-    (extract.py:81-93).  features: matrices or kaldi_io.PackedMatrix.  Returns [(embedding, number of pieces)] in input order."""
-    pieces, owner = [], []
-    for u, f in enumerate(features):
-        chunks = split_into_chunks(f.shape[0], chunk_size)
-        for s, n in chunks:
-            if len(chunks) == 1:
-                pieces.append(f)
+class EmbeddingWindow(object):
+    """utterance_embedding() for a window of utterances at once, in two steps so that the caller can put the next window on the GPU
+    before it post-processes this one: the constructor sends every utterance's pieces (itself, or its half-overlapping chunks when
+    longer than chunk_size, extract.py:69-79) through ONE predict_batch call - which may return a device tensor, nothing is read back
+    yet; results() fetches the embeddings and averages long utterances by piece length (extract.py:81-93).
+    features: matrices or kaldi_io.PackedMatrix.  results() -> [(embedding, number of pieces)] in input order."""
+
+    def __init__(self, predict_batch, features, chunk_size, normalize):
+        self.normalize = normalize
+        self.n = len(features)
+        pieces, self.owner = [], []
+        for u, f in enumerate(features):
+            chunks = split_into_chunks(f.shape[0], chunk_size)
+            for s, n in chunks:
+                if len(chunks) == 1:
+                    pieces.append(f)
+                else:
+                    pieces.append(f.row_range(s, n) if hasattr(f, "row_range") else f[s:s + n])
+                self.owner.append((u, n))
+        self.emb = predict_batch(pieces) if pieces else np.zeros((0, 0), np.float32)
+
+    def results(self):
+        emb = self.emb if isinstance(self.emb, np.ndarray) else self.emb.cpu().numpy()      # (a torch tensor: the read-back waits for the GPU here)
+        owner, normalize = self.owner, self.normalize
+        out, k = [], 0
+        for u in range(self.n):
+            m = k
+            while m < len(owner) and owner[m][0] == u:
+                m += 1
+            if m - k == 1:
+                e = emb[k]
             else:
-                pieces.append(f.row_range(s, n) if hasattr(f, "row_range") else f[s:s + n])
-            owner.append((u, n))
-    emb = predict_batch(pieces) if pieces else np.zeros((0, 0), np.float32)
-    out, k = [], 0
-    for u, f in enumerate(features):
-        m = k
-        while m < len(owner) and owner[m][0] == u:
-            m += 1
-        if m - k == 1:
-            e = emb[k]
-        else:
-            e = average_chunk_embeddings(emb[k:m], [owner[j][1] for j in range(k, m)], normalize)
-        if normalize:
-            e = e / np.sqrt(np.sum(np.square(e)))
-        out.append((np.asarray(e, np.float32), m - k))
-        k = m
-    return out
+                e = average_chunk_embeddings(emb[k:m], [owner[j][1] for j in range(k, m)], normalize)
+            if normalize:
+                e = e / np.sqrt(np.sum(np.square(e)))
+            out.append((np.asarray(e, np.float32), m - k))
+            k = m
+        return out
+
+
+def batched_utterance_embeddings(predict_batch, features, chunk_size, normalize):
+    return EmbeddingWindow(predict_batch, features, chunk_size, normalize).results()
 
 
 def prefetch_iter(iterable, depth=8):

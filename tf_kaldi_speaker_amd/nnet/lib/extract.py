@@ -13,7 +13,7 @@ import sys
 
 import _cli
 from model.trainer import Trainer
-from misc.utils import Params, batched_utterance_embeddings, prefetch_iter
+from misc.utils import Params, EmbeddingWindow, prefetch_iter
 from dataset.kaldi_io import open_or_fd, read_mat_ark_packed, write_vec_flt
 
 # utterances gathered before they go to the GPU together (sorted by length into padded batches, Trainer.predict_batch); results are
@@ -49,11 +49,22 @@ def main():
         sys.exit("The rspecifier must be ark or input pipe")
     fp_out = open_or_fd(args.wspecifier, "wb")
     window, window_frames = [], 0
+    pending = []           # the window whose forward passes are on the GPU while the next one is read, planned and enqueued
 
-    def flush():
-        keep = [(key, feature) for key, feature in window if feature.shape[0] >= args.min_chunk_size]
-        results = iter(batched_utterance_embeddings(trainer.predict_batch, [f for _, f in keep], args.chunk_size, args.normalize))
-        for key, feature in window:          # log lines and output vectors in archive order, as the one-at-a-time loop gives them
+    def submit():
+        entries = list(window)
+        del window[:]
+        keep = [feature for _, feature in entries if feature.shape[0] >= args.min_chunk_size]
+        job = EmbeddingWindow(lambda pieces: trainer.predict_batch(pieces, return_device=True), keep, args.chunk_size, args.normalize)
+        finish()           # the previous window: read back, log, write - while this one runs
+        pending.append((entries, job))
+
+    def finish():
+        if not pending:
+            return
+        entries, job = pending.pop()
+        results = iter(job.results())
+        for key, feature in entries:         # log lines and output vectors in archive order, as the one-at-a-time loop gives them
             frames = feature.shape[0]
             if frames < args.min_chunk_size:
                 log.info("[INFO] Key %s length too short, %d < %d, skip." % (key, frames, args.min_chunk_size))
@@ -61,16 +72,16 @@ def main():
             embedding, pieces = next(results)
             log.info("[INFO] Key %s length %d%s." % (key, frames, "" if pieces == 1 else " > %d, split to %d segments" % (args.chunk_size, pieces)))
             write_vec_flt(fp_out, embedding, key=key)
-        del window[:]
 
     # the reader runs ahead of the GPU in its own thread; 'CM ' matrices arrive undecoded (kaldi_io.PackedMatrix) and are decoded on the GPU
     for key, feature in prefetch_iter(read_mat_ark_packed(args.rspecifier), depth=2 * WINDOW_UTTERANCES):
         window.append((key, feature))
         window_frames += feature.shape[0]
         if len(window) >= WINDOW_UTTERANCES or window_frames >= WINDOW_FRAMES:
-            flush()
+            submit()
             window_frames = 0
-    flush()
+    submit()
+    finish()
     fp_out.close()
     trainer.close()
 
