@@ -277,6 +277,9 @@ def run_mode(precision, args, dev, rank, world, dist, chunks, t_lo, t_hi, h2d=Fa
     if not np.isfinite(raw):
         sys.exit("bench.py: loss is not finite (%r)" % raw)
     res["loss"] = raw
+    # replicas must stay bit-identical (same initial variables, summed gradients, same update): an order-free integer checksum of the
+    # trainable variables' bit patterns, compared across ranks by whoever reads the `comm` report (BN moving statistics are local)
+    res["trainable_checksum"] = int(eng.variables[:eng.n_train].view(torch.int32).to(torch.int64).sum().item())
     eng.close()
     del eng
     torch.cuda.empty_cache()
@@ -472,7 +475,8 @@ def main():
     if dist is not None:       # per-rank communication report, gathered on every rank (collective), printed by rank 0
         try:
             mine = {"rank": rank, "backend": dist.get_backend(), "world_size": dist.get_world_size(), "device": torch.cuda.get_device_name(dev),
-                    "device_index": dev_index, "data_seed": 1000 + rank, "report": head["comm"]}
+                    "device_index": dev_index, "data_seed": 1000 + rank, "loss": head["loss"], "trainable_checksum": head["trainable_checksum"],
+                    "report": head["comm"]}
             comm_all = [None] * world
             dist.all_gather_object(comm_all, mine)
         except Exception as exc:       # the report must never cost the bench line

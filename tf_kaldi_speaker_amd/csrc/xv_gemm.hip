@@ -1107,63 +1107,73 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
 __host__ __device__ __forceinline__ int tn_owner(long u, int P, long total) { return (int)((((u + 1) * P) - 1) / total); }
 
 // out[(j*C + c)][n] = sum over the slabs of tile (m = j*c_pad + c, n) in K order (+ l2 * w[(j*C + c)][n]).  A slab is [register r][thread]
-// float4 (the TN kernel's epilogue); block = 4 groups of 64 lanes on (tile, register r, quarter q of its 256 float4).  Few shares per tile
-// (GROUPS = false): the 4 groups are the 4 quarters and a lane adds all shares of its float4 in K order.  Many shares (tdnn1: 128, the
-// K = 512 layers: 64): the 4 groups take contiguous quarters of the shares of ONE quarter row and their sums are added in group order -
-// a fixed association either way, whatever the launch timing: bit-reproducible.  Eight 16-byte loads in flight per lane, 1 KB of
-// consecutive bytes per wave instruction.
+// float4 (the TN kernel's epilogue).  Unit of work = (tile, register r) = the 256 float4 one wave instruction of each of the 4 waves
+// stored; a block = 4 groups of 64 lanes.  Few shares per tile (GROUPS = false): the groups are the unit's 4 quarters and a lane adds all
+// shares of its float4 in K order.  Many shares (tdnn1: 128, the K = 512 layers: 64): a unit is (tile, r, quarter), the groups take
+// contiguous quarters of its shares and their sums are added in group order - a fixed association either way, whatever the launch
+// timing: bit-reproducible.  Eight 16-byte loads in flight per lane, 1 KB of consecutive bytes per wave instruction.
+// The grid is at most TN_REDUCE_WGS blocks that stride over the units.  [measured, round 4, rocprofv3 timeline of the S1 step] this launch
+// runs beside two GEMM kernels whose waves hold every register of the SIMDs, so each of its blocks waits for a GEMM workgroup to exit: as
+// 1 024 short blocks the sum of tdnn4's slabs took 545 us there (12 us for 256 blocks) and held up the next weight-gradient GEMM queued
+// behind it.
 #define WR_FLIGHT 8
+#define TN_REDUCE_WGS 256
 template <bool GROUPS>
-__global__ __launch_bounds__(256) void xv_tn_reduce_kernel(const float* __restrict__ slab, int P, int nk, long total, int max_segs, int tiles_n,
-                                                           int M, int N, int C, int c_pad, const float* __restrict__ w, long ldw, float l2,
-                                                           float* __restrict__ out, long ldo) {
+__global__ __launch_bounds__(256) void xv_tn_reduce_kernel(const float* __restrict__ slab, int P, int nk, long total, int max_segs, int tiles,
+                                                           int tiles_n, int M, int N, int C, int c_pad, const float* __restrict__ w, long ldw,
+                                                           float l2, float* __restrict__ out, long ldo) {
     __shared__ f32x4 part[GROUPS ? 4 : 1][64];
-    const int tile = blockIdx.y, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int r = GROUPS ? blockIdx.x >> 2 : blockIdx.x, quarter = GROUPS ? blockIdx.x & 3 : g;
-    const int tid = quarter * 64 + lane;               // the thread of the TN kernel whose float4 this lane adds
-    const long u0 = (long)tile * nk;
-    const int w_first = tn_owner(u0, P, total), w_last = tn_owner(u0 + nk - 1, P, total);
-    int wa = w_first, wb = w_last;
-    if (GROUPS) {
-        const int per = (w_last - w_first + 4) / 4;
-        wa = w_first + g * per;
-        wb = min(w_last, wa + per - 1);
-    }
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const float* base = slab + r * (256 * 4) + tid * 4;
-    for (int w0 = wa; w0 <= wb; w0 += WR_FLIGHT) {
-        f32x4 t[WR_FLIGHT];
-#pragma unroll
-        for (int q = 0; q < WR_FLIGHT; ++q) {
-            const int ww = min(w0 + q, wb);
-            const int first_tile = (int)(((long)ww * total / P) / nk);
-            t[q] = *(const f32x4*)(base + ((long)ww * max_segs + (tile - first_tile)) * (BM * BN));
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int units = tiles * 16 * (GROUPS ? 4 : 1);
+    for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const int tile = GROUPS ? unit >> 6 : unit >> 4;
+        const int r = GROUPS ? (unit >> 2) & 15 : unit & 15, quarter = GROUPS ? unit & 3 : g;
+        const int tid = quarter * 64 + lane;               // the thread of the TN kernel whose float4 this lane adds
+        const long u0 = (long)tile * nk;
+        const int w_first = tn_owner(u0, P, total), w_last = tn_owner(u0 + nk - 1, P, total);
+        int wa = w_first, wb = w_last;
+        if (GROUPS) {
+            const int per = (w_last - w_first + 4) / 4;
+            wa = w_first + g * per;
+            wb = min(w_last, wa + per - 1);
         }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const float* base = slab + r * (256 * 4) + tid * 4;
+        for (int w0 = wa; w0 <= wb; w0 += WR_FLIGHT) {
+            f32x4 t[WR_FLIGHT];
 #pragma unroll
-        for (int q = 0; q < WR_FLIGHT; ++q)
-            if (w0 + q <= wb) v += t[q];
-    }
-    if (GROUPS) {
-        part[g][lane] = v;
-        __syncthreads();
-        if (g != 0) return;
-        v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-    }
-    const int wave = tid >> 6, wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
-    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
-    const int m = tile_m * BM + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh);
-    const int n = tile_n * BN + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
-    if (n >= N) return;
+            for (int q = 0; q < WR_FLIGHT; ++q) {
+                const int ww = min(w0 + q, wb);
+                const int first_tile = (int)(((long)ww * total / P) / nk);
+                t[q] = *(const f32x4*)(base + ((long)ww * max_segs + (tile - first_tile)) * (BM * BN));
+            }
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int mm = m + a;
-        if (mm >= M) continue;
-        const int j = mm / c_pad, c = mm - j * c_pad;
-        if (c >= C) continue;                               // padded input channels (the feature layer: 30 -> 32)
-        const long row = (long)j * C + c;
-        f32x2 o = a == 0 ? f32x2{v.x, v.y} : f32x2{v.z, v.w};
-        if (w) o += l2 * *(const f32x2*)(w + row * ldw + n);
-        *(f32x2*)(out + row * ldo + n) = o;
+            for (int q = 0; q < WR_FLIGHT; ++q)
+                if (w0 + q <= wb) v += t[q];
+        }
+        if (GROUPS) {
+            __syncthreads();      // (the previous unit's sums have been read)
+            part[g][lane] = v;
+            __syncthreads();
+            if (g != 0) continue;
+            v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        }
+        const int wave = tid >> 6, wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+        const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+        const int m = tile_m * BM + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh);
+        const int n = tile_n * BN + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
+        if (n >= N) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int mm = m + a;
+            if (mm >= M) continue;
+            const int j = mm / c_pad, c = mm - j * c_pad;
+            if (c >= C) continue;                               // padded input channels (the feature layer: 30 -> 32)
+            const long row = (long)j * C + c;
+            f32x2 o = a == 0 ? f32x2{v.x, v.y} : f32x2{v.z, v.w};
+            if (w) o += l2 * *(const f32x2*)(w + row * ldw + n);
+            *(f32x2*)(out + row * ldo + n) = o;
+        }
     }
 }
 
@@ -1256,11 +1266,11 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g, int k, int C, int c_pad,
     XV_LAUNCH_CHECK();
     const int shares = xv_cdiv(q.P, q.tiles) + 1;
     if (shares >= 32)
-        hipLaunchKernelGGL(xv_tn_reduce_kernel<true>, dim3(64, q.tiles), dim3(256), 0, s, (const float*)p.slab, q.P, q.nk, q.total, q.max_segs,
-                           p.tiles_n, g.M, g.N, C, c_pad, w, ldw, l2, out, ldo);
+        hipLaunchKernelGGL(xv_tn_reduce_kernel<true>, dim3(std::min(TN_REDUCE_WGS, q.tiles * 64)), dim3(256), 0, s, (const float*)p.slab, q.P, q.nk,
+                           q.total, q.max_segs, q.tiles, p.tiles_n, g.M, g.N, C, c_pad, w, ldw, l2, out, ldo);
     else
-        hipLaunchKernelGGL(xv_tn_reduce_kernel<false>, dim3(16, q.tiles), dim3(256), 0, s, (const float*)p.slab, q.P, q.nk, q.total, q.max_segs,
-                           p.tiles_n, g.M, g.N, C, c_pad, w, ldw, l2, out, ldo);
+        hipLaunchKernelGGL(xv_tn_reduce_kernel<false>, dim3(std::min(TN_REDUCE_WGS, q.tiles * 16)), dim3(256), 0, s, (const float*)p.slab, q.P, q.nk,
+                           q.total, q.max_segs, q.tiles, p.tiles_n, g.M, g.N, C, c_pad, w, ldw, l2, out, ldo);
     XV_LAUNCH_CHECK();
     return 0;
 }

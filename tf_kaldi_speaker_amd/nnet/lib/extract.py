@@ -10,6 +10,7 @@ half-overlapping chunks whose embeddings are length-weighted averaged (reference
 """
 import os
 import sys
+import time
 
 import _cli
 from model.trainer import Trainer
@@ -50,6 +51,7 @@ def main():
     fp_out = open_or_fd(args.wspecifier, "wb")
     window, window_frames = [], 0
     pending = []           # the window whose forward passes are on the GPU while the next one is read, planned and enqueued
+    stats = {"utts": 0, "frames": 0, "t0": time.time(), "warm": None}      # warm: (time, utterances, frames) once the first window is done
 
     def submit():
         entries = list(window)
@@ -72,6 +74,10 @@ def main():
             embedding, pieces = next(results)
             log.info("[INFO] Key %s length %d%s." % (key, frames, "" if pieces == 1 else " > %d, split to %d segments" % (args.chunk_size, pieces)))
             write_vec_flt(fp_out, embedding, key=key)
+            stats["utts"] += 1
+            stats["frames"] += frames
+        if stats["warm"] is None:
+            stats["warm"] = (time.time(), stats["utts"], stats["frames"])
 
     # the reader runs ahead of the GPU in its own thread; 'CM ' matrices arrive undecoded (kaldi_io.PackedMatrix) and are decoded on the GPU
     for key, feature in prefetch_iter(read_mat_ark_packed(args.rspecifier), depth=2 * WINDOW_UTTERANCES):
@@ -82,6 +88,11 @@ def main():
             window_frames = 0
     submit()
     finish()
+    now = time.time()
+    t1, u1, f1 = stats["warm"] or (now, 0, 0)
+    rate = ", %.0f utterances/s = %.2f M frames/s after the first window" % ((stats["utts"] - u1) / (now - t1), (stats["frames"] - f1) / (now - t1) / 1e6) \
+        if stats["utts"] > u1 and now > t1 else ""
+    log.info("[INFO] Extracted %d utterances (%d frames) in %.2f s%s." % (stats["utts"], stats["frames"], now - stats["t0"], rate))
     fp_out.close()
     trainer.close()
 

@@ -61,6 +61,9 @@ def main():
                             "ark:" + os.path.join(tmp, "out%d.ark" % n)], env=env, cwd=PKG, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         times[n] = (time.perf_counter() - t0, frames)
+        last = [ln for ln in r.stderr.splitlines() if "Extracted" in ln]
+        if last:
+            print("   driver's own clock:", last[-1].split("[INFO] ", 1)[-1])
         print("%4d utterances (%.2f M frames): %.2f s wall = %.0f utterances/s incl. start-up" % (n, frames / 1e6, times[n][0], n / times[n][0]))
     per = (times[5000][0] - times[1000][0]) / 4000
     print("steady state: %.3f ms per utterance = %.0f utterances/s, %.2f M frames/s" % (per * 1e3, 1 / per, (times[5000][1] - times[1000][1]) / 4000 / per / 1e6))
