@@ -72,3 +72,24 @@ def test_engine_refuses_to_run_without_gpu():
     from tf_kaldi_speaker_amd import engine
     with pytest.raises(engine.XvError):
         engine.Engine(engine.make_config(30, 10))
+
+
+def test_unknown_environment_switches_are_refused_by_name():
+    """the library reads three documented switches; a value it does not understand or any other XV_* variable
+    (a typo, an A/B switch of an earlier round) makes engine creation fail with the name - before any GPU call, so this runs here."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
+            "from tf_kaldi_speaker_amd import _lib\n"
+            "lib = _lib.load(); cfg = _lib.XvConfig(); cfg.feat_dim = 30; h = C.c_void_p()\n"
+            "rc = lib.xv_engine_create(C.byref(cfg), C.byref(h)); print(rc, lib.xv_last_error().decode())\n" % ROOT)
+    for extra, want in (({"XV_TN_WGS": "768"}, "unknown environment switch XV_TN_WGS"), ({"XV_NT_SCHED": "fast"}, "XV_NT_SCHED=fast: expected dp or sk"),
+                        ({"XV_SEGMENT_FUSED": "yes"}, "XV_SEGMENT_FUSED=yes: expected 0 or 1")):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("XV_")}
+        env.update(extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.startswith("2 ") and want in out.stdout, (out.stdout, out.stderr[-500:])
+    env = {k: v for k, v in os.environ.items() if not k.startswith("XV_")}
+    env.update(XV_NT_SCHED="dp", XV_PRECISION="f32", XV_SHARE_GPU="1")          # documented names pass the table (the call then fails later: no GPU here)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "environment switch" not in out.stdout and "expected" not in out.stdout, out.stdout

@@ -1,6 +1,6 @@
 """Diagnosis of the evenly scheduled NT GEMM (run on the GPU box): xv_affine_forward against NumPy on shapes that share tiles, with the
 error broken down by output tile and matched against partial K sums (a lost / stale / doubled share shows as a missing or extra K range).
-usage: python tests/tools/diag_streamk.py            (XV_NT_STREAMK / XV_NT_WPC / XV_NT_CONV select the path)"""
+usage: python tests/tools/diag_streamk.py            (XV_NT_SCHED=dp|sk forces the schedule)"""
 import os
 import sys
 

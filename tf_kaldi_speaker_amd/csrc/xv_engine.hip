@@ -125,7 +125,7 @@ struct xv_engine {
     float* xnorm = nullptr;         // [B] ||out[r]||, written with the loss rows
     float* pool_wpos = nullptr;     // [B][P] share of each chunk's frame weights on ReLU-active frames (pooling forward -> BN backward)
     float* pool_amax = nullptr;     // [B][P] each chunk's largest pooled activation
-    bool pool_closed_form = true;   // XV_POOLED_CLOSED_FORM=0: the last frame layer's BN backward reduces over z directly (A/B)
+    bool pool_closed_form = true;   // the last frame layer's BN backward takes its reductions from the pooled statistics (plain ReLU)
     float* lrelu_slope = nullptr;   // network_relu_type lrelu: a constant 0.2 vector as wide as the widest layer
     // split precision state
     bool f16 = false;
@@ -471,10 +471,9 @@ int alloc_buffers(xv_engine* e) {
     e->pool_wpos = carve(e, B * (size_t)e->P);
     e->pool_amax = carve(e, B * (size_t)e->P);
     {
-        const char* v = getenv("XV_SEGMENT_FUSED");
-        e->sk = !(v && v[0] == '0');
-        v = getenv("XV_POOLED_CLOSED_FORM");
-        e->pool_closed_form = !(v && v[0] == '0');
+        const XvEnv* env = xv_env();
+        if (!env) return 2;
+        e->sk = env->segment_fused != 0;
     }
     e->ws = carve(e, ws / sizeof(float));
     e->ws_side = carve(e, ws / sizeof(float));
@@ -623,6 +622,7 @@ int bn_forward(xv_engine* e, hipStream_t s, Affine& a, int rows, bool stats_from
 
 extern "C" int xv_engine_create(const xv_config* cfg, xv_engine** out) {
     XV_REQUIRE(cfg && out, "engine_create: null argument");
+    if (!xv_env()) return 2;      // an environment switch this library does not know, or a value it does not understand: refused by name
     XV_REQUIRE(cfg->feat_dim > 0, "engine_create: feat_dim must be positive");
     XV_REQUIRE(cfg->num_nodes_pooling_layer > 0 && cfg->num_nodes_pooling_layer % 4 == 0,
                "engine_create: num_nodes_pooling_layer must be a positive multiple of 4 (got %d)", cfg->num_nodes_pooling_layer);
@@ -1166,8 +1166,7 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     // the first layer (dx == nullptr) is the end of the chain: nothing is left on `s` to overlap with, and the side stream is still
     // busy with the layer above's weight gradient - its own (small) weight gradient finishes sooner in line on `s`, beside that one
     // (round-2 timeline: 166 us of MFMA-idle tail behind tdnn2's weight gradient: tdnn1's, two slab sums, the update)
-    static const bool inline_first = !(getenv("XV_WGRAD1_INLINE") && getenv("XV_WGRAD1_INLINE")[0] == '0');      // A/B switch
-    rc = layer_wgrad(e, s, a, x, dz, segs, t_in, pad, ring && (dx != nullptr || !inline_first));
+    rc = layer_wgrad(e, s, a, x, dz, segs, t_in, pad, ring && dx != nullptr);
     if (rc) return rc;
     if (dx) {
         const float* wf = a.k > 1 ? a.wf : vptr(e, a.v_kernel);
@@ -1247,21 +1246,10 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
     }
     zr.cur ^= 1;
     if (dx) {
-        // dx is d(relu(bn(z))) of the producing layer: fold that layer's BN-backward reductions into this GEMM's epilogue - unless
-        // dx is only one of two contributions (tdnn4_relu also feeds the attention key network)
-        // [measured] off by default: the epilogue's extra z-tile reads cost each data-gradient GEMM 50-60 us at S1, the
-        // reduce kernels they replace 37 us each (3.17 vs 3.03 ms/step); XV_FUSE_BWD_STATS=1 turns it on for experiments
-        static const bool fuse_env = getenv("XV_FUSE_BWD_STATS") && getenv("XV_FUSE_BWD_STATS")[0] == '1';
-        const bool fuse = fuse_env && c.relu_type == XV_RELU_RELU && in >= 0 && is_frame(e, in) && e->L[in].has_bn && e->L[in].has_relu && !(e->att && in == e->F - 2) && e->bwd_part;
-        if (fuse) {
-            Affine& p = e->L[in];
-            rc = xv_affine_dgrad_bnstats_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WT + a.wslot, dx,
-                                               a.c_in, p.z, p.scale, p.shift, p.mean, p.invstd, e->bwd_part);
-            e->bwd_part_layer = in;
-            e->bwd_part_chunks = xv_cdiv(segs * (t_out + a.k - 1), XV_TILE_M);
-        } else {
-            rc = xv_affine_dgrad_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WT + a.wslot, dx, a.c_in);
-        }
+        // [measured, round 1] folding the producing layer's BN-backward reductions into this GEMM's epilogue (xv_affine_dgrad_bnstats_f16x3,
+        // kept parity-tested at op level) is not used: the epilogue's extra z-tile reads cost each data-gradient GEMM 50-60 us at S1, the
+        // reduce kernels they replace 37 us each (3.17 vs 3.03 ms/step)
+        rc = xv_affine_dgrad_f16x3(s, Z, zstride, zamax, segs, t_out, a.o_ld, a.k, a.wfh, a.wfh_stride, e->amax + AMAX_WT + a.wslot, dx, a.c_in);
         if (rc) return rc;
     }
     return 0;

@@ -26,6 +26,7 @@
 #include "xv_common.h"
 #include <type_traits>
 #include "xv_epilogue.h"
+#include "xv_diag.h"
 #include <algorithm>
 #include <cstdlib>
 #include <map>
@@ -58,7 +59,7 @@ struct NTArgs {
     const float* bias;
     float* part_sum; float* part_m2;
     const float* zero;
-    int stamp_half;      // diagnostics (XV_NT_STAMP)
+    int stamp_half;      // diagnostics build only (xv_diag.h): the stamp buffer half of this launch, -1 = none
     int taps; long a_rows;      // context-window form: K = taps * channels, rows of the tensor behind A
 };
 
@@ -144,48 +145,12 @@ __device__ __forceinline__ void nt_store_tile(f32x16 (&acc)[2][2], float* __rest
     }
 }
 
-#ifndef XV_NT_ABLATE
-// diagnostics only (tools/variant_libs.sh; wrong results): 1 = no LDS fragment reads, 2 = no staging DMA, 3 = MFMA only.
-// [measured, round 2, tdnn2 forward at S1] full 112.6 TF | 1: 124.5 | 2: 128.2 | 3: 138.8 (= the fp32 MFMA rate at the 2.13 GHz the
-// chip holds on this kernel).  What did NOT move the full kernel (all within +-2 %): 5 workgroups per CU, s_setprio around the
-// MFMA block, a different static priority per co-resident workgroup, a start-up stagger between them, fragments of the next
-// half K-step read before the current half's MFMAs, K-step 32; per-wave private staging without any barrier was 20 % slower.
-#define XV_NT_ABLATE 0
-#endif
-#ifndef XV_NT_STAMP
-#define XV_NT_STAMP 0
-#endif
-#ifndef XV_NT_BARRIER_END
-#define XV_NT_BARRIER_END 0
-#endif
-#if XV_NT_STAMP
-// diagnostics only (tools/gemm_probe.cpp): per-workgroup s_memtime / s_memrealtime stamps and the hardware placement of every
-// workgroup of the LAST NT launch: [wg][8] = {entry, loop start, loop end, exit, HW_ID | XCC_ID << 32, realtime at entry,
-// realtime at exit, cycles wave 0 spent in the per-K-step wait + barrier}
-#define XV_DBG_STAMP_WGS 4096
-__device__ unsigned long long xv_dbg_stamps[2 * XV_DBG_STAMP_WGS * 8];      // two halves, alternating per launch
-static int g_stamp_half = 0;
-static int read_stamps(void* dst, size_t bytes, int half) {
-    XV_REQUIRE(bytes <= sizeof(unsigned long long) * XV_DBG_STAMP_WGS * 8, "debug_read_stamps: at most %d workgroups", XV_DBG_STAMP_WGS);
-    XV_CHECK_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(xv_dbg_stamps), bytes, sizeof(unsigned long long) * XV_DBG_STAMP_WGS * 8 * half));
-    return 0;
-}
-extern "C" int xv_debug_read_stamps(void* dst, size_t bytes) { return read_stamps(dst, bytes, g_stamp_half ^ 1); }        // the last launch
-extern "C" int xv_debug_read_stamps_prev(void* dst, size_t bytes) { return read_stamps(dst, bytes, g_stamp_half); }    // the one before it
-#define XV_STAMP(slot) do { if (tid == 0 && blockIdx.x < XV_DBG_STAMP_WGS) xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define XV_STAMP(slot) ((void)0)
-#endif
-#ifndef XV_NT_ROTPRIO
-// The evenly scheduled kernel rotates the issue priority of its waves every XV_NT_ROTPRIO K-steps (0 = off): priority = (K-step + the
-// wave's slot in its SIMD) mod 4, so the co-resident workgroups take turns at the top.  [measured, round 3, stamps of tdnn2 forward at S1]
-// the arbiter serves the oldest wave first and the three workgroups of a CU finish at 384 / 444 / 481 us, the CU running two, then one
-// workgroup at the end; with the rotation 471 / 471 / 476 us.  tdnn2 / tdnn3 forward 497 -> 484 / 687 -> 669 us (rotation every step),
-// 398 -> 388 / 531 -> 521 us at 64 x 300.  NOT in the one-workgroup-per-tile kernel: a launch of several rounds (tdnn5: 2 232 tiles)
-// wants its oldest workgroups to finish first and free their slots - the rotation cost it 3-8 % (256 -> 278 us at 64 x 300).
-#define XV_NT_ROTPRIO 1
-#endif
-#if XV_NT_ROTPRIO
+// The evenly scheduled kernel rotates the issue priority of its waves every K-step: priority = (K-step + the wave's slot in its SIMD) mod 4,
+// so the co-resident workgroups take turns at the top.  [measured, round 3, stamps of tdnn2 forward at S1] the arbiter serves the oldest wave
+// first and the three workgroups of a CU finish at 384 / 444 / 481 us, the CU running two, then one workgroup at the end; with the rotation
+// 471 / 471 / 476 us.  tdnn2 / tdnn3 forward 497 -> 484 / 687 -> 669 us, 398 -> 388 / 531 -> 521 us at 64 x 300.  NOT in the
+// one-workgroup-per-tile kernel: a launch of several rounds (tdnn5: 2 232 tiles) wants its oldest workgroups to finish first and free
+// their slots - the rotation cost it 3-8 % (256 -> 278 us at 64 x 300).
 __device__ __forceinline__ int xv_wave_slot() { return __builtin_amdgcn_s_getreg(4 | (3 << 11)) & 15; }      // HW_ID.WAVE_ID: differs between the waves of one SIMD
 __device__ __forceinline__ void xv_rot_prio(int x) {
     switch (x & 3) {
@@ -195,31 +160,21 @@ __device__ __forceinline__ void xv_rot_prio(int x) {
     default: __builtin_amdgcn_s_setprio(3); break;
     }
 }
-#define XV_ROT_PRIO(kt, slot) do { if (((kt) % XV_NT_ROTPRIO) == 0) xv_rot_prio((kt) / XV_NT_ROTPRIO + (slot)); } while (0)
-#else
-#define XV_ROT_PRIO(kt, slot) ((void)0)
-#endif
+
+// [measured, round 2 / 3, tdnn2 forward at S1; the ablation builds are in the history of this file and in DESIGN.md appendix A] what did
+// NOT move this kernel (all within +-2 %): 5 workgroups per CU, s_setprio around the MFMA block, a static priority per co-resident
+// workgroup, a start-up stagger, fragments of the next half K-step read early, K-step 32, a third LDS slot (DMA two K-steps ahead: MFMA-pipe
+// occupancy 0.867 -> 0.83-0.85); per-wave private staging without any barrier was 20 % slower.  What did: the address form of the
+// LDS-DMA (xv_dma16, xv_common.h).
 template <bool STATS>
 __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(128))) void xv_gemm_nt_kernel(NTArgs p) {
-#ifndef XV_NT_LDS_PAD_KB
-#define XV_NT_LDS_PAD_KB 0      // diagnostics: extra LDS per workgroup = fewer co-resident workgroups per CU
-#endif
-// [measured, round 3] a third LDS slot (DMA two K-steps ahead, with and without the fragment reads of the next step pipelined by hand) lowers
-// the MFMA-pipe occupancy from 0.867 to 0.83-0.85: the staging cost follows the bytes in flight, not their latency
-#define XV_NT_STAGES 2
-    __shared__ __attribute__((aligned(16))) float smem[XV_NT_STAGES * 2 * BM * NT_PITCH + XV_NT_LDS_PAD_KB * 256];
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * NT_PITCH];      // two slots of [A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-#if XV_NT_STAMP
-    XV_STAMP(0);
-    if (tid == 0 && blockIdx.x < XV_DBG_STAMP_WGS) {
-        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
-                                            ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
-        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-    }
+    XV_STAMP_ENTRY(p.stamp_half);
     unsigned long long stall = 0;
-#endif
+    (void)stall;
 
     const int t = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
@@ -257,14 +212,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     auto gstage = [&](int kt, int buf) {
         const int k0 = k_begin + kt * BK;
         if (k0 + BK <= k_end) {        // full K-step (uniform): scalar bases + k0, the lane offsets never change
-#if XV_NT_ABLATE & 32
-            // diagnostics: the same DMA instructions fed from one hot KiB (no traffic past the L1)
-#pragma unroll
-            for (int i = 0; i < NT_RPT; ++i) {
-                xv_dma16(zp, lane * 16, lds0 + (buf * (2 * BM * NT_PITCH) + NT_RPI * i * NT_PITCH) * 4);
-                xv_dma16(zp, lane * 16, lds0 + (buf * (2 * BM * NT_PITCH) + BM * NT_PITCH + NT_RPI * i * NT_PITCH) * 4);
-            }
-#else
             const float* abase = p.A + k0;
             const float* bbase = p.Bt + k0;
 #pragma unroll
@@ -272,7 +219,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
                 xv_dma16(abase, aoff[i], lds0 + (buf * (2 * BM * NT_PITCH) + NT_RPI * i * NT_PITCH) * 4);
                 xv_dma16(bbase, boff[i], lds0 + (buf * (2 * BM * NT_PITCH) + BM * NT_PITCH + NT_RPI * i * NT_PITCH) * 4);
             }
-#endif
         } else {                       // ragged last step: chunks at or beyond k_end come from the zero page
             float* sa = smem + buf * (2 * BM * NT_PITCH) + NT_RPI * NT_RPT * uwave * NT_PITCH;
             float* sb = sa + BM * NT_PITCH;
@@ -301,27 +247,20 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     if (nk > 0) gstage(0, 0);
     xv_dma_wait_all();
     __syncthreads();
-    XV_STAMP(1);
+    XV_STAMP(p.stamp_half, 1);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-#if !(XV_NT_ABLATE & 2)
         if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
-#endif
         const float* sa = smem + buf * (2 * BM * NT_PITCH);
         const float* sb = sa + BM * NT_PITCH;
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 af[2], bf[2];
             const int pos = (((2 * q + lh) ^ fsw) << 2);
-#if XV_NT_ABLATE & 1
-            af[0] = af[1] = bf[0] = bf[1] = f32x4{(float)pos, 1.f, 2.f, (float)kt};
-            asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(bf[0]), "+v"(bf[1]));
-#else
             af[0] = *(const f32x4*)(sa + a_off + pos);
             af[1] = *(const f32x4*)(sa + a_off + 32 * NT_PITCH + pos);
             bf[0] = *(const f32x4*)(sb + b_off + pos);
             bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
-#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][e], bf[0][e], acc[0][0], 0, 0, 0);
@@ -331,32 +270,16 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             }
         }
         xv_dma_wait_all();      // the compiler does not see xv_dma16's loads
-#if XV_NT_BARRIER_END
-        __builtin_amdgcn_sched_barrier(0);      // keeps hipcc from hoisting the barrier above the second MFMA group
-#endif
-#if XV_NT_STAMP >= 2
-        const unsigned long long tw = __builtin_amdgcn_s_memtime();
-        __syncthreads();
-        stall += __builtin_amdgcn_s_memtime() - tw;
-#else
-        __syncthreads();
-#endif
+        XV_DIAG_BARRIER(stall);
     }
-    XV_STAMP(2);
+    XV_STAMP(p.stamp_half, 2);
 
     // ---- epilogue
     float* C = p.C + (long)blockIdx.z * p.c_split_stride;
     nt_store_tile(acc, C, p.ldc, p.bias, m0, n0, p.M, p.N, wr, wc, li, lh);
 
     if (STATS) xv_tile_stats_epilogue(acc, smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part_sum);
-#if XV_NT_STAMP
-    __builtin_amdgcn_s_waitcnt(0);      // stores issued; exit stamp = the wave is about to retire
-    XV_STAMP(3);
-    if (tid == 0 && blockIdx.x < XV_DBG_STAMP_WGS) {
-        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
-        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 7] = stall;
-    }
-#endif
+    XV_STAMP_EXIT(p.stamp_half, stall);
 }
 
 // -------------------------------------------------------------------------------------
@@ -384,18 +307,13 @@ __device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (i
 // chunk outer / tap inner, and the rows  xrow(m0) ... xrow(m0 + 127) + taps - 1  of ONE 16-channel chunk of x sit in LDS once for all
 // taps (rows of tap j = rows of tap 0 shifted by j), so x travels L2 -> LDS once instead of once per tap and only the weight tile is
 // staged per K-step.  [r02_pmc_traffic.json: the generic form moved 2.6-2.7 x the algorithmic bytes past L2 on tdnn2 / tdnn3]
-#ifndef XV_NT_WPC_DEFAULT
-#define XV_NT_WPC_DEFAULT 3                  // workgroups per CU of the even schedule
-#endif
+#define XV_NT_SK_WPC 3                       // workgroups per CU of the even schedule: one co-resident round of 768
 #define NT_WIN_ROWS 192                      // window rows per slot: 128 + (taps - 1) * (1 + chunk boundaries inside a tile), 3 DMA pieces per wave
+// Three workgroups per CU = 3 waves per SIMD = a budget of 168 VGPRs (512 / 3 in granules of 8): declared to the compiler, so the per-tile
+// set-up (row offsets, window rows, the shared-tile bookkeeping) needs no scratch.  [round 3: built for 4 per CU = 128 VGPRs, the four
+// instantiations spilled 7 / 19 / 19 / 29 registers; profiles/r04_sk_kernel_registers.txt]
 template <bool STATS, bool CONV>
-#ifndef XV_SK_VGPR_ATTR
-#define XV_SK_VGPR_ATTR __attribute__((amdgpu_num_vgpr(128)))
-#endif
-#ifndef XV_SK_NOSHARE
-#define XV_SK_NOSHARE 0         // diagnostics: 1 compiles the shared-tile path out (only valid when no tile is shared)
-#endif
-__global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt_sk_kernel(NTSKArgs q) {
+__global__ __launch_bounds__(256, XV_NT_SK_WPC) __attribute__((amdgpu_num_vgpr(168))) void xv_gemm_nt_sk_kernel(NTSKArgs q) {
     const NTArgs& p = q.g;
     constexpr int A_SLOT = CONV ? NT_WIN_ROWS * NT_PITCH : BM * NT_PITCH;       // floats per A slot
     constexpr int B_SLOT = BM * NT_PITCH;
@@ -408,16 +326,9 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
     const long u_end = (long)(w + 1) * q.total / q.P;
     long u = (long)w * q.total / q.P;
     const int first_tile = (int)(u / q.nk);
-#if XV_NT_STAMP
-    XV_STAMP(0);
-    if (tid == 0 && blockIdx.x < XV_DBG_STAMP_WGS) {
-        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
-                                            ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
-        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 1] = 0;
-    }
+    XV_STAMP_ENTRY(p.stamp_half);
     bool first_seg = true;
-#endif
+    (void)first_seg;
 
     constexpr int NT_RPI = 64 / NT_KQ;          // tile rows per wave-instruction (16 at BK=16)
     static_assert(!CONV || NT_WIN_ROWS % (4 * NT_RPI) == 0, "the window is staged in whole 1 KB pieces, equally by the 4 waves");
@@ -427,9 +338,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
     const float* __restrict__ zp = p.zero;
     const int b_off = (wc * 64 + li) * NT_PITCH;
     const int fsw = NT_SWZ(li);
-#if XV_NT_ROTPRIO
     const int wslot = xv_wave_slot();
-#endif
     // LDS byte addresses this wave's DMA pieces land at (slot 0; xv_dma16)
     const unsigned lds_a = xv_lds_addr(smem + NT_RPI * NT_RPT * uwave * NT_PITCH);
     const unsigned lds_aw = xv_lds_addr(smem + NT_RPI * (CONV ? WIN_PIECES : NT_RPT) * uwave * NT_PITCH);
@@ -437,9 +346,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
     const int taps = CONV ? p.taps : 1;
     const int C = p.K / taps;                   // channels per tap (CONV: a multiple of 16)
 
-#ifndef XV_SK_WRAP_FIRST
-#define XV_SK_WRAP_FIRST 1
-#endif
     // Order of a run that ends one tile and begins the next ([k0, nk) of tile t, then [0, k2) of tile t + 1): the BEGINNING of the next tile
     // first.  Every workgroup then walks K upwards from (about) 0 in step with the others, so the K-slices of the weight matrix in flight on
     // an XCD at any moment are the same few for all its workgroups, as in a one-workgroup-per-tile launch.  In run order the workgroups of
@@ -448,7 +354,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
     // 0.16 GB with this order (0.18 GB for one workgroup per tile); the time is the same - the Infinity Cache absorbed it.
     const long u_begin = u;
     const long u_mid = (u / q.nk + 1) * q.nk;                  // end of the first tile of the run
-    const bool wrap_first = XV_SK_WRAP_FIRST && u % q.nk != 0 && u_mid < u_end && u_end - u_mid <= q.nk;
+    const bool wrap_first = u % q.nk != 0 && u_mid < u_end && u_end - u_mid <= q.nk;
     for (int pass = 0; pass < 2; ++pass) {
     long u_stop = u_end;
     if (wrap_first) { u = pass == 0 ? u_mid : u_begin; u_stop = pass == 0 ? u_end : u_mid; }
@@ -550,12 +456,10 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
         stage_b(kt0, 0);
         xv_dma_wait_all();      // (the compiler does not see xv_dma16's loads)
         __syncthreads();
-#if XV_NT_STAMP
-        if (first_seg) { XV_STAMP(1); first_seg = false; }
-#endif
+        XV_STAMP_ONCE(p.stamp_half, 1, first_seg);
         for (int kt = kt0; kt < kt1; ++kt) {
             const int buf = (kt - kt0) & 1;
-            XV_ROT_PRIO(kt, wslot);
+            xv_rot_prio(kt + wslot);
             int tap = 0, aslot = buf;
             if (CONV) {
                 const int cc = kt / taps;
@@ -599,14 +503,10 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
             __syncthreads();
         }
         u += kt1 - kt0;
-#if XV_NT_ROTPRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
-#if XV_NT_STAMP
-        XV_STAMP(2);
-#endif
+        XV_STAMP(p.stamp_half, 2);
 
-        if (!XV_SK_NOSHARE && (kt0 != 0 || kt1 != q.nk)) {
+        if (kt0 != 0 || kt1 != q.nk) {
             // a shared tile: publish this share, take a ticket, and only the last of the tile's workgroups goes on
             // slab of a share: [register r][thread] float4 = (acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]): 1 KB of consecutive
             // bytes per wave instruction, stores and loads alike
@@ -661,14 +561,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) XV_SK_VGPR_ATTR void xv_gemm_nt
         }
     }
     }
-#if XV_NT_STAMP
-    __builtin_amdgcn_s_waitcnt(0);
-    XV_STAMP(3);
-    if (tid == 0 && blockIdx.x < XV_DBG_STAMP_WGS) {
-        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
-        xv_dbg_stamps[(p.stamp_half * XV_DBG_STAMP_WGS + blockIdx.x) * 8 + 7] = 0;
-    }
-#endif
+    XV_STAMP_EXIT(p.stamp_half, 0);
 }
 
 // out[m][n] = sum_z slab[z][m][n] (+ bias[n])
@@ -751,11 +644,6 @@ static unsigned* tn_tickets_for(hipStream_t s) {
     return t;
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     XV_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm_nt: K/lda/ldb must be multiples of 4 (K=%d lda=%ld ldb=%ld)", g.K, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0, "gemm_nt: operands must be 16-byte aligned");
@@ -766,10 +654,7 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     if (ensure_zero_page((size_t)g.K)) return 1;
     NTArgs p;
     p.zero = g_zero_page;
-    p.stamp_half = 0;
-#if XV_NT_STAMP
-    p.stamp_half = g_stamp_half; g_stamp_half ^= 1;
-#endif
+    p.stamp_half = xv_diag_half(g.M, g.N, g.K);
     p.A = g.A; p.lda = g.lda; p.a_rps = g.a_rps; p.a_pitch = g.a_pitch;
     p.Bt = g.Bt; p.ldb = g.ldb;
     p.M = g.M; p.N = g.N; p.K = g.K;
@@ -786,48 +671,44 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     // tiles) 641 -> 528 us, tdnn2 / tdnn3 forward of the 64 x 300 batch (584 / 572 tiles) 489 -> 413 / 677 -> 551 us, while the K = 512
     // layers (32 K-steps per tile) lose 10-30 % to it and stay on dp.  A tile is never split into more than 8 shares: its LAST workgroup
     // sums them alone (the few-tile, long-K problems of segment-level batches > 128).
-    // XV_NT_SCHED=dp|sk forces one; XV_NT_STREAMK=0 keeps the round-2 kernel for everything (diagnostics / A-B runs).
-    static const int use_sk = env_int("XV_NT_STREAMK", 1), wpc = std::min(std::max(env_int("XV_NT_WPC", XV_NT_WPC_DEFAULT), 1), XV_WGS_PER_CU);
-    static const char* sched_env = getenv("XV_NT_SCHED");
-    static const int use_conv = env_int("XV_NT_CONV", 1);
+    // XV_NT_SCHED=dp|sk forces one (diagnostics, tools/gpu_round_final.sh).
+    const XvEnv* env = xv_env();
+    if (!env) return 2;
+    const int wpc = XV_NT_SK_WPC;
     // context-window form: a spliced view (lda < K) of whole K-step-wide channel chunks whose window fits the LDS slot for every tile
     const int taps = (g.lda < g.K && g.K % g.lda == 0) ? (int)(g.K / g.lda) : 1;
-    const bool conv = use_conv && taps >= 2 && g.lda % BK == 0 && 127 + (127 / g.a_rps + 1) * (g.a_pitch - g.a_rps) + taps <= NT_WIN_ROWS;
+    const bool conv = taps >= 2 && g.lda % BK == 0 && 127 + (127 / g.a_rps + 1) * (g.a_pitch - g.a_rps) + taps <= NT_WIN_ROWS;
     bool sk = false;
     long p_sk = 1;
-    if (use_sk) {
+    {
         const long total = (long)tiles * ksteps;
         p_sk = std::min<long>(std::min<long>(256L * wpc, std::max<long>(1, total / 4)), 8L * tiles);
         const long t_sk = (total / p_sk) * xv_cdiv(p_sk, 256) + (15 * 16 / BK) * std::min<long>(wpc, xv_cdiv(p_sk, 256));
         const long t_dp = tiles <= XV_RESIDENT_WGS ? (long)xv_cdiv(tiles, 256) * ksteps : total / 256 + ksteps / 2;
-        // ... and only for a launch that has the chip to itself (the forward pass, extraction).  [measured, round 3, rocprofv3 timelines
-        // of the S1 step] beside the weight-gradient kernel of the other stream an unbalanced data-gradient launch costs nothing - the
-        // other kernel's workgroups take the slots its short CUs free (tdnn2's data and weight gradient together: 1 076 us with the
-        // one-tile-per-workgroup launch that takes 647 us alone, 1 113 us with the balanced one that takes 527 us alone) - while the
-        // persistent round holds its three slots per CU to the end.
-        // [measured again after the DMA / slab-sum work, medians of 4 alternated runs] with the even schedule ALSO for the launches beside
-        // the weight-gradient stream (tdnn2's data gradient at S1: 784 tiles): S1 -0.7 %, S2 -0.5 %, 64 x U{200..400} -0.3 %, S4 -0.4 %,
-        // S5 +0.1 % - the data-gradient launches now spend a good part of their time alone on the chip (the weight-gradient stream sums
-        // slabs or waits for the next dz meanwhile).  On by default; XV_NT_CORUN_SK=0 restores "launches that own the chip only".
-        static const int corun_sk = env_int("XV_NT_CORUN_SK", 1);
-        sk = sched_env ? sched_env[0] == 's' : ((!g.co_running || corun_sk) && t_sk + t_sk / 32 < t_dp);
+        // Also for a launch beside the weight-gradient stream (g.co_running: the data gradients).  [measured, round 3, rocprofv3 timelines of
+        // the S1 step, first half of the round] beside the weight-gradient kernel an unbalanced data-gradient launch cost nothing - the other
+        // kernel's workgroups took the slots its short CUs freed - while the persistent round holds its three slots per CU to the end;
+        // [measured again after the DMA / slab-sum work, medians of 4 alternated runs] with the even schedule for those launches too (tdnn2's
+        // data gradient at S1: 784 tiles): S1 -0.7 %, S2 -0.5 %, 64 x U{200..400} -0.3 %, S4 -0.4 %, S5 +0.1 % - the data-gradient launches now
+        // spend a good part of their time alone on the chip (the weight-gradient stream sums slabs or waits for the next dz meanwhile).
+        sk = env->nt_sched ? env->nt_sched == 2 : t_sk + t_sk / 32 < t_dp;
     }
     // Few tiles and no BatchNorm statistics to emit (one utterance at a time in extraction, the segment-level layers of batches > 128 chunks):
     // split-K over the whole chip + the slab-sum launch below.  [measured, round 3, tools/extract_bench.py / segment_bench.py] the
     // persistent kernel - a tile shared by at most 8 workgroups, its last arrival summing alone - was slower there: 0.214 -> 0.288 ms
     // per 300-frame utterance (12 tiles), 0.30 -> 0.35 ms at 1 000 frames, 30 -> 80 us for d out (4 tiles, K = 7 352); at 10 000 frames
     // (316 tiles) it wins, 1.45 -> 1.41 ms.
-    const bool few = !g.bn_part && tiles < 192 && ksteps >= 8 && !sched_env;
+    const bool few = !g.bn_part && tiles < 192 && ksteps >= 8 && !env->nt_sched;
     // One workgroup per tile ("dp") is the kernel below, context window or not.  [measured, round 3, after the LDS-DMA moved to scalar
     // bases] staging is cheap now (MFMA-pipe occupancy 0.939 against 0.951 without any), so what the window saves - 39 % of the staged bytes
     // at 5 taps - no longer pays for its per-step row arithmetic in a dp launch: tdnn2 / tdnn3 forward at S1 478 / 660 us with the window,
     // 447 / 621 us (144 / 140 TF) without, the S1 step 5.39 -> 5.28 ms.  The evenly scheduled launches keep it (64 x 300: 381 / 514 us
     // against 388 / 519 us).
-    if (use_sk && !few && sk) {
+    if (!few && sk) {
         NTSKArgs q;
         q.nk = ksteps;
         q.total = (long)tiles * ksteps;
-        q.P = sk ? (int)p_sk : tiles;
+        q.P = (int)p_sk;
         const bool shared_tiles = q.total % q.P != 0 || (q.total / q.P) % ksteps != 0;
         if (!shared_tiles || ((size_t)q.P * 2 * BM * BN * sizeof(float) <= g.ws_bytes && g.ws && tiles <= XV_TN_MAX_TILES)) {
             p.C = g.C; p.ldc = g.ldc; p.c_split_stride = 0; p.k_chunk = ksteps * BK;
@@ -953,11 +834,17 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     const int a_off = lh * BM + wr * 64 + 2 * li;
     const int b_off = lh * BN + wc * 64 + 2 * li;
 
-    for (int seg = 0; u < u_end; ++seg) {
-    const int t = (int)(u / p.nk);
-    const int kt0 = (int)(u - (long)t * p.nk);
-    const int nk = (int)min((long)(p.nk - kt0), u_end - u);
-    u += nk;
+    // a run is contiguous: its first segment starts in the middle of a tile, every later one at K-step 0 of the next tile (one division
+    // per workgroup, none in the loop - its reciprocal, kept in a VGPR across the K loop, was what this kernel spilled)
+    int t_cur = (int)(u / p.nk);
+    int kt_cur = (int)(u - (long)t_cur * p.nk);
+    long left = u_end - u;
+    for (int seg = 0; left > 0; ++seg) {
+    const int t = t_cur, kt0 = kt_cur;
+    const int nk = (int)min((long)(p.nk - kt0), left);
+    left -= nk;
+    t_cur += 1;
+    kt_cur = 0;
     const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int r_begin = kt0 * BK;
@@ -1095,7 +982,9 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     // Slab of a segment: [register r][thread] float4 = (acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]) - the 2 x 2 block of outputs
     // (m, n), (m, n+1), (m+1, n), (m+1, n+1) the lane holds - so a wave instruction stores 1 KB of consecutive bytes (sixteen 16-byte
     // stores per lane; the row-major slab of the first build took thirty-two 8-byte ones); xv_tn_reduce_kernel undoes the permutation.
-    float* mine = p.slab + ((long)w * p.max_segs + seg) * (BM * BN) + tid * 4;
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));      // (keeps hipcc from hoisting a per-lane 64-bit slab pointer out of the segment loop - into scratch)
+    float* mine = p.slab + ((long)w * p.max_segs + seg) * (BM * BN) + tid_e * 4;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const f32x4 v = {acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]};
@@ -1214,8 +1103,7 @@ static TNPlan tn_plan(int M, int N, int R) {
     // (a free slot per CU lets the BatchNorm kernels of the data-gradient chain in beside the weight gradient) - but the kernel itself
     // is slower with fewer workgroups: alone 1 655 -> 1 724 (768) / 1 837 us (896: 3.5 per CU is an unbalanced launch) over the five
     // frame layers, its isolated roofline fraction 0.78 -> 0.75 / 0.71.  Kept at one full round.
-    static const int target = env_int("XV_TN_WGS", XV_RESIDENT_WGS);      // (A/B switch of the co-resident workgroup target)
-    static const int min_ksteps = std::max(1, env_int("XV_TN_MIN_KSTEPS", 2));      // (A/B switch: fewest K-steps a workgroup is given)
+    const int target = XV_RESIDENT_WGS, min_ksteps = 2;      // (fewest K-steps a workgroup is given)
     q.P = (int)std::max<long>(1, std::min<long>(target, q.total / min_ksteps));
     const long run = (q.total + q.P - 1) / q.P;            // longest run of K-steps
     q.max_segs = (int)(run / q.nk) + 2;                     // a run of L steps touches at most L / nk + 2 tiles
@@ -1255,10 +1143,8 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g, int k, int C, int c_pad,
     p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
     p.P = q.P; p.nk = q.nk; p.total = q.total; p.max_segs = q.max_segs;
     p.slab = (float*)g.ws;
-    static const int ahead_min = env_int("XV_TN_AHEAD_MIN", 96);      // (A/B switch: fewest K-steps per segment that stage two steps ahead)
-    p.ahead_min = ahead_min;
-    static const int use_order = env_int("XV_TN_ORDER", 1);      // (A/B switch)
-    p.order = (use_order && q.P <= 65535) ? tn_order(q.tiles, q.nk, q.P) : nullptr;
+    p.ahead_min = 96;      // [measured, rounds 3 and 4: 48 / 64 cost tdnn5 7 %, never staging ahead costs tdnn2 / tdnn3 3 %]
+    p.order = q.P <= 65535 ? tn_order(q.tiles, q.nk, q.P) : nullptr;
     {
         XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
         hipLaunchKernelGGL(xv_gemm_tn_kernel, dim3(q.P), dim3(256), 0, s, p);

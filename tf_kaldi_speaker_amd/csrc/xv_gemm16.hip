@@ -807,8 +807,9 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
     int taps = 0;
     // XV_CONV_WR=4 (experiments, tests) forces 256-row tiles wherever they apply; as a build default they would be
     // limited to problems with at least one tile per CU
-    static const int conv_wr_env = getenv("XV_CONV_WR") ? atoi(getenv("XV_CONV_WR")) : 0;
-    const bool wr4 = conv_wr_env ? conv_wr_env == 4 : (XV16_CONV_WR == 4 && g.M >= 256 * 256);
+    const XvEnv* env = xv_env();
+    if (!env) return 2;
+    const bool wr4 = env->conv_wr ? env->conv_wr == 4 : (XV16_CONV_WR == 4 && g.M >= 256 * 256);
     // the BN-backward epilogue (an off-by-default experiment) is written for the 32x32x16 accumulator layout: with the 16x16x32
     // build of the context-window kernel such a launch takes the generic kernel
     const bool conv_ok = !(bwd && XV16_CONV_MFMA16);

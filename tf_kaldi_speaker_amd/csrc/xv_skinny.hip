@@ -286,15 +286,7 @@ __global__ __launch_bounds__(256) void xv_skinny_kernel(SkArgs p) {
     }
 }
 
-int sk_target_wgs() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("XV_SK_WGS");
-        v = e ? atoi(e) : 256;
-        if (v < 1) v = 1;
-    }
-    return v;
-}
+int sk_target_wgs() { return 256; }      // workgroup target of the split policy: one per CU
 
 }  // namespace
 

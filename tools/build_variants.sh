@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build -D variants of one translation unit of libxvector_hip.so HERE (hipcc cross-compiles gfx950 without a GPU) into
 # build_variants/<name>/libxvector_hip.so (git-ignored, travels with the gpurun snapshot), so the GPU box only runs them:
-#   tools/build_variants.sh xv_gemm.hip "base:" "stamp:-DXV_NT_STAMP=2" ...
+#   tools/build_variants.sh xv_gemm.hip "base:" "diag:-DXV_DIAG=2" ...
 # then on the box: tools/gemm_probe build_variants/<name>/libxvector_hip.so   (or XV_LIB=... python tools/gemm_bench.py)
 unit=$1; shift
 R=$(cd $(dirname $0)/.. && pwd)

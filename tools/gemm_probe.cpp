@@ -3,7 +3,7 @@
 //   build:  hipcc -O2 -std=c++17 tools/gemm_probe.cpp -o tools/gemm_probe -ldl
 //   usage:  tools/gemm_probe <libxvector_hip.so> [B=128] [T=200] [reps=20] [stamp_dump.json]
 // Prints per layer (tdnn2..tdnn5 shapes of model/tdnn.py:57-127) forward / data-gradient / weight-gradient time and TFLOP/s.
-// If the library exports xv_debug_read_stamps (built with -DXV_NT_STAMP=1|2) the per-workgroup stamps of the last tdnn2 forward
+// If the library exports xv_debug_read_stamps (built with -DXV_DIAG=1|2, csrc/xv_diag.h) the per-workgroup stamps of the last tdnn2 forward
 // launch are analysed: workgroups per CU, per-phase cycles, start / end skew.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>

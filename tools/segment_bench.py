@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Segment-level GEMMs alone: xv_segment_gemm (one launch, xv_skinny.hip) against xv_affine_forward (GEMM + slab-sum launches) on the
-chain's shapes at S1.  XV_SK_WGS=<n> (read once per process) sets the workgroup target of the split policy; 1 = no split."""
+chain's shapes at S1."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -27,7 +27,6 @@ def timed(fn):
     return a.elapsed_time(b) / iters * 1e3
 
 
-print("XV_SK_WGS=%s" % os.environ.get("XV_SK_WGS", "default"))
 for name, m, n, k in SHAPES:
     x = torch.from_numpy(rs.randn(m, k).astype(np.float32)).to(dev)
     wt = torch.from_numpy((rs.randn(n, k) / np.sqrt(k)).astype(np.float32)).to(dev)
