@@ -76,8 +76,9 @@ int xv_pad_channels(void* stream, const float* src, int rows, int c_src, float* 
  * -> out [b][t][d] float32, bit-identical to the host decoder and the reference reader.  d <= 128. */
 int xv_cm_decode(void* stream, const uint8_t* packed, int b, int t, int d, size_t chunk_stride, float* out);
 /* Ragged form for whole utterances of different lengths (batched extraction, extract.py:64-93 / kaldi_io.py:768-812 read_mat_ark): chunk i
- * is the packed image above of a matrix with rows[i] <= t frames (its bytes are [d][rows[i]]) at byte offsets[i] of `packed`; it is decoded
- * into out[i][0 .. rows[i]) of the [b][t][d] tensor and the padding rows behind it are zeroed.  offsets / rows: device arrays [b]. */
+ * is a 'CM ' matrix of rows[i] <= t frames exactly as it sits in the archive behind the "CM " token - [min f32][range f32][rows i32]
+ * [cols i32][d x (p0, p25, p75, p100) u16][d x rows[i] u8, column after column] - at byte offsets[i] of `packed`; it is decoded into
+ * out[i][0 .. rows[i]) of the [b][t][d] tensor and the padding rows behind it are zeroed.  offsets / rows: device arrays [b]. */
 int xv_cm_decode_ragged(void* stream, const uint8_t* packed, const int64_t* offsets, const int32_t* rows, int b, int t, int d, float* out);
 
 /* Kernel-layout weights for xv_affine_forward: wt[o][j*c_pad + c] = kernel[j][c][o]

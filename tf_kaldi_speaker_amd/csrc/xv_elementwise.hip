@@ -116,9 +116,10 @@ extern "C" int xv_pad_channels(void* stream, const float* src, int rows, int c_s
 #define CMD_MAX_D 128
 #define CMD_TT 128
 // Ragged form (batched extraction: whole utterances of different lengths): chunk i starts at byte offs[i], holds rows[i] frames (its bytes
-// are [D][rows[i]]) and is written to out[i][0 .. rows[i]) of a [b][T][D] tensor whose remaining rows are zeroed.
+// are [D][rows[i]]) and is written to out[i][0 .. rows[i]) of a [b][T][D] tensor whose remaining rows are zeroed.  hdr = bytes in front
+// of the column headers: 8 (min, range: the native loader's packing) or 16 (min, range, rows, cols: the matrix as it sits in the archive).
 __global__ __launch_bounds__(256) void cm_decode_kernel(const uint8_t* __restrict__ packed, long stride, int T, int D, float* __restrict__ out,
-                                                        const long* __restrict__ offs, const int* __restrict__ rows) {
+                                                        const long* __restrict__ offs, const int* __restrict__ rows, int hdr) {
 #pragma clang fp contract(off)
     __shared__ float prm[6][CMD_MAX_D];                  // p0, p25, p75, s_lo, s_mid, s_hi per column
     __shared__ uint8_t tile[CMD_MAX_D][CMD_TT + 4];
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void cm_decode_kernel(const uint8_t* __restric
     const float gs = range * 1.52590218966964e-05f;        // 1/65535
     if (tid < D) {
         unsigned short h[4];
-        memcpy(h, chunk + 8 + 8 * tid, 8);
+        memcpy(h, chunk + hdr + 8 * tid, 8);
         const float p0 = minv + gs * (float)h[0], p25 = minv + gs * (float)h[1];
         const float p75 = minv + gs * (float)h[2], p100 = minv + gs * (float)h[3];
         prm[0][tid] = p0; prm[1][tid] = p25; prm[2][tid] = p75;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void cm_decode_kernel(const uint8_t* __restric
         prm[4][tid] = (p75 - p25) / 128.0f;
         prm[5][tid] = (p100 - p75) / 63.0f;
     }
-    const uint8_t* bytes = chunk + 8 + 8 * (long)D;
+    const uint8_t* bytes = chunk + hdr + 8 * (long)D;
     float* o = out + (long)blockIdx.x * Tout * D;
     for (int t0 = 0; t0 < T; t0 += CMD_TT) {
         const int tt_n = min(CMD_TT, T - t0);
@@ -174,7 +175,7 @@ extern "C" int xv_cm_decode(void* stream, const uint8_t* packed, int b, int t, i
     XV_REQUIRE(d <= CMD_MAX_D, "cm_decode: at most %d feature dimensions (got %d)", CMD_MAX_D, d);
     XV_REQUIRE(chunk_stride >= (size_t)8 + 8 * (size_t)d + (size_t)d * t, "cm_decode: chunk stride %zu is smaller than a chunk", chunk_stride);
     hipLaunchKernelGGL(cm_decode_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, packed, (long)chunk_stride, t, d, out, (const long*)nullptr,
-                       (const int*)nullptr);
+                       (const int*)nullptr, 8);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -183,7 +184,7 @@ extern "C" int xv_cm_decode_ragged(void* stream, const uint8_t* packed, const in
     XV_REQUIRE(packed && offsets && rows && out && b > 0 && t > 0 && d > 0, "cm_decode_ragged: bad arguments");
     XV_REQUIRE(d <= CMD_MAX_D, "cm_decode_ragged: at most %d feature dimensions (got %d)", CMD_MAX_D, d);
     static_assert(sizeof(long) == sizeof(int64_t), "offsets are passed as long");
-    hipLaunchKernelGGL(cm_decode_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, packed, 0L, t, d, out, (const long*)offsets, (const int*)rows);
+    hipLaunchKernelGGL(cm_decode_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, packed, 0L, t, d, out, (const long*)offsets, (const int*)rows, 16);
     XV_LAUNCH_CHECK();
     return 0;
 }

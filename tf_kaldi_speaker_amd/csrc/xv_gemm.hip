@@ -1028,13 +1028,15 @@ __global__ __launch_bounds__(256) void xv_tn_reduce_kernel(const float* __restri
         }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const float* base = slab + r * (256 * 4) + tid * 4;
+        // the tile's first share may be a later segment of a run that began in an earlier tile; every other share's run begins inside
+        // this tile (segment 0)
+        const int seg_first = tile - (int)(((long)w_first * total / P) / nk);
         for (int w0 = wa; w0 <= wb; w0 += WR_FLIGHT) {
             f32x4 t[WR_FLIGHT];
 #pragma unroll
             for (int q = 0; q < WR_FLIGHT; ++q) {
                 const int ww = min(w0 + q, wb);
-                const int first_tile = (int)(((long)ww * total / P) / nk);
-                t[q] = *(const f32x4*)(base + ((long)ww * max_segs + (tile - first_tile)) * (BM * BN));
+                t[q] = *(const f32x4*)(base + ((long)ww * max_segs + (ww == w_first ? seg_first : 0)) * (BM * BN));
             }
 #pragma unroll
             for (int q = 0; q < WR_FLIGHT; ++q)
@@ -1088,6 +1090,9 @@ static const unsigned short* tn_order(int tiles, int nk, int P) {
     return d;
 }
 
+#ifndef XV_TN_WPC
+#define XV_TN_WPC 3      // workgroups per CU of the weight-gradient round (tools/build_variants.sh builds 4 for the A/B in tn_plan's comment)
+#endif
 // Schedule of one weight-gradient problem: workgroups, K-steps per tile, slabs per workgroup
 struct TNPlan { int tiles, nk, P, max_segs; long total; };
 static TNPlan tn_plan(int M, int N, int R) {
@@ -1095,15 +1100,14 @@ static TNPlan tn_plan(int M, int N, int R) {
     q.tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
     q.nk = xv_cdiv(R, BK);
     q.total = (long)q.tiles * q.nk;
-    // XV_WGS_PER_CU (4) workgroups are resident per CU (LDS 32 KB each): P <= XV_RESIDENT_WGS (1 024) makes the whole grid ONE co-resident
-    // round.  (On the first build - 2 per CU - 560 workgroups = 512 + a 48-workgroup second round cost 2x: 61 TF on tdnn2/3, 24 TF on tdnn5.)
-    // [measured, round 2] fewer co-resident workgroups (smaller slabs, cheaper slab sum) lose: 768 -> +0.06 ms/step, 512 -> +0.19 ms
-    // [measured, round 3, after the DMA / slab-sum work; medians of 3-4 alternated runs against 1 024, S1 | 64 x U{200..400} | S5]
-    //   896: -0.1 ... -0.4 | -1.1 | -0.2 %     768: -0.6 ... -0.8 | -0.2 ... -0.5 | -0.1 ... -0.4 %
-    // (a free slot per CU lets the BatchNorm kernels of the data-gradient chain in beside the weight gradient) - but the kernel itself
-    // is slower with fewer workgroups: alone 1 655 -> 1 724 (768) / 1 837 us (896: 3.5 per CU is an unbalanced launch) over the five
-    // frame layers, its isolated roofline fraction 0.78 -> 0.75 / 0.71.  Kept at one full round.
-    const int target = XV_RESIDENT_WGS, min_ksteps = 2;      // (fewest K-steps a workgroup is given)
+    // P = 3 workgroups per CU (768), one co-resident round, one of the CU's four slots left free.  [measured, round 4, rocprofv3 timelines of
+    // the S1 step] with equal runs every workgroup of this kernel ends at the same moment, so a launch that fills all 1 024 slots gives the
+    // other streams NOTHING until it is over: the BatchNorm-backward kernels of the data-gradient chain (main stream) and the slab sums waited
+    // 300-760 us for a slot (19 / 12 us alone) and the step went from 5.24 to 5.43-5.60 ms, although the kernel itself was no slower.
+    // (Round 3's rectangular split left 16-64 slots free by accident: 80 tiles x 12 splits = 960.)  Alone, 768 equal runs are as fast as
+    // 1 024 (gemm_probe, sum of the five layers 1 642 vs 1 663 us) and write a quarter fewer slab bytes.
+    // (On the first build - 2 per CU with rectangular splits - 560 workgroups = 512 + a 48-workgroup second round cost 2x.)
+    const int target = XV_TN_WPC * 256, min_ksteps = 2;      // (min_ksteps: fewest K-steps a workgroup is given)
     q.P = (int)std::max<long>(1, std::min<long>(target, q.total / min_ksteps));
     const long run = (q.total + q.P - 1) / q.P;            // longest run of K-steps
     q.max_segs = (int)(run / q.nk) + 2;                     // a run of L steps touches at most L / nk + 2 tiles

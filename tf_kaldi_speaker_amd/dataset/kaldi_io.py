@@ -339,14 +339,16 @@ def read_mat_ark(file_or_fd):
 
 
 class PackedMatrix(object):
-    """A Kaldi 'CM ' matrix kept as it sits in the archive - [min f32][range f32][cols x (p0, p25, p75, p100) u16][cols x rows u8,
-    column after column] - which is the image xv_cm_decode_ragged (include/xvector_hip.h) decodes on the GPU: the extraction driver
-    ships a quarter of the fp32 bytes and the host never runs the codec."""
+    """A Kaldi 'CM ' matrix kept exactly as it sits in the archive - [min f32][range f32][rows i32][cols i32][cols x (p0, p25, p75, p100)
+    u16][cols x rows u8, column after column] - which is the image xv_cm_decode_ragged (include/xvector_hip.h) decodes on the GPU: the
+    extraction driver ships a quarter of the fp32 bytes and the host never runs the codec.  `payload` is a bytes-like view (usually a
+    slice of the block the reader pulled from the archive: no copy per utterance)."""
     __slots__ = ("rows", "cols", "payload")
+    HEADER = 16
 
     def __init__(self, rows, cols, payload):
         self.rows, self.cols, self.payload = int(rows), int(cols), payload
-        assert len(payload) == 8 + 8 * self.cols + self.cols * self.rows
+        assert len(payload) == self.HEADER + 8 * self.cols + self.cols * self.rows
 
     @property
     def shape(self):
@@ -356,42 +358,94 @@ class PackedMatrix(object):
         """float32 [rows, cols] through the host codec (the reference's arithmetic, _decode_cm)."""
         buf = np.frombuffer(self.payload, np.uint8)
         gmin, grange = np.frombuffer(buf[:8].tobytes(), "<f4")
-        hdr = np.frombuffer(buf[8:8 + 8 * self.cols].tobytes(), dtype=_COL_HDR, count=self.cols)
-        data = buf[8 + 8 * self.cols:].reshape(self.cols, self.rows)
+        head = self.HEADER + 8 * self.cols
+        hdr = np.frombuffer(buf[self.HEADER:head].tobytes(), dtype=_COL_HDR, count=self.cols)
+        data = buf[head:].reshape(self.cols, self.rows)
         return _decode_cm(data, _col_percentiles(hdr, float(gmin), float(grange)))
 
     def row_range(self, start, length):
         """Rows [start, start + length) as a PackedMatrix of their own (same header: the codec is per element)."""
         assert 0 <= start and start + length <= self.rows
         buf = np.frombuffer(self.payload, np.uint8)
-        head = 8 + 8 * self.cols
+        head = self.HEADER + 8 * self.cols
         data = buf[head:].reshape(self.cols, self.rows)[:, start:start + length]
-        return PackedMatrix(length, self.cols, buf[:head].tobytes() + np.ascontiguousarray(data).tobytes())
+        return PackedMatrix(length, self.cols, buf[:8].tobytes() + struct.pack("<ii", length, self.cols) + buf[self.HEADER:head].tobytes() +
+                            np.ascontiguousarray(data).tobytes())
 
 
-def read_mat_ark_packed(file_or_fd):
-    """read_mat_ark for the batched extraction driver: 'CM ' matrices come back undecoded as PackedMatrix (one read of the payload, no
-    arithmetic on the host), every other format as the float32 matrix read_mat gives."""
+def read_mat_ark_packed(file_or_fd, block_bytes=8 << 20):
+    """read_mat_ark for the batched extraction driver: 'CM ' matrices come back undecoded as PackedMatrix, every other format as the
+    float32 matrix read_mat gives.  The archive is pulled in blocks of `block_bytes` and the records are cut out of the block as views -
+    a few microseconds of Python per utterance instead of a read() per field (this generator runs in the driver's prefetch thread, which
+    shares the interpreter lock with the thread that feeds the GPU)."""
     fd = open_or_fd(file_or_fd)
     try:
-        key = read_key(fd)
-        while key:
-            binary = fd.read(2)
-            if binary == b"\0B":
-                fmt = fd.read(3)
-                if fmt == b"CM ":
-                    g = fd.read(16)
-                    rows, cols = struct.unpack("<ii", g[8:16])
-                    body = fd.read(8 * cols + cols * rows)
-                    if len(body) != 8 * cols + cols * rows:
-                        raise BadInputFormat
-                    yield key, PackedMatrix(rows, cols, g[:8] + body)
-                else:
-                    yield key, _read_mat_binary(_Pushback(fd, fmt))
+        buf, pos, eof = b"", 0, False
+
+        def need(n):      # make buf[pos : pos + n] available; False at end of input
+            nonlocal buf, pos, eof
+            while len(buf) - pos < n and not eof:
+                more = fd.read(max(block_bytes, n - (len(buf) - pos)))
+                if not more:
+                    eof = True
+                    break
+                buf = buf[pos:] + more if pos < len(buf) else more
+                pos = 0
+            return len(buf) - pos >= n
+
+        while True:
+            # key: up to the first space
+            while True:
+                sp = buf.find(b" ", pos)
+                if sp >= 0 or eof:
+                    break
+                need(len(buf) - pos + 1)
+            if sp < 0:
+                if buf[pos:].strip():
+                    raise BadInputFormat
+                return
+            key = buf[pos:sp].decode("latin1").strip()
+            pos = sp + 1
+            if key == "":
+                return
+            assert re.match(r"^\S+$", key) is not None
+            if not need(2):
+                raise BadInputFormat
+            if buf[pos:pos + 2] != b"\0B":
+                assert buf[pos:pos + 2] == b" ["          # text archives: rare, read the slow way from here on
+                rest = _Pushback(fd, buf[pos:])
+                buf, pos, eof = b"", 0, True
+                rest.read(2)
+                yield key, _read_mat_ascii(rest)
+                k = read_key(rest)
+                while k:
+                    yield k, read_mat(rest)
+                    k = read_key(rest)
+                return
+            if not need(5):
+                raise BadInputFormat
+            fmt = buf[pos + 2:pos + 5]
+            if fmt == b"CM ":
+                if not need(5 + 16):
+                    raise BadInputFormat
+                rows, cols = struct.unpack_from("<ii", buf, pos + 5 + 8)
+                size = PackedMatrix.HEADER + 8 * cols + cols * rows
+                if not need(5 + size):
+                    raise BadInputFormat
+                yield key, PackedMatrix(rows, cols, memoryview(buf)[pos + 5:pos + 5 + size])
+                pos += 5 + size
+            elif fmt in (b"FM ", b"DM "):
+                if not need(5 + 10):
+                    raise BadInputFormat
+                _, rows, _, cols = struct.unpack_from("<bibi", buf, pos + 5)
+                dt = np.float32 if fmt == b"FM " else np.float64
+                size = rows * cols * np.dtype(dt).itemsize
+                if not need(15 + size):
+                    raise BadInputFormat
+                yield key, np.frombuffer(buf, dtype=dt, count=rows * cols, offset=pos + 15).reshape(rows, cols).copy()
+                pos += 15 + size
             else:
-                assert binary == b" ["
-                yield key, _read_mat_ascii(fd)
-            key = read_key(fd)
+                raise UnknownMatrixHeader("The header contained '%s'" % fmt.decode("latin1"))
     finally:
         if fd is not file_or_fd:
             fd.close()
@@ -401,7 +455,7 @@ class _Pushback(object):
     """A stream with a few bytes put back in front of it (pipes cannot seek)."""
 
     def __init__(self, fd, head):
-        self.fd, self.head = fd, head
+        self.fd, self.head = fd, bytes(head)
 
     def read(self, n=-1):
         if not self.head:
@@ -413,6 +467,14 @@ class _Pushback(object):
         if len(out) < n:
             out += self.fd.read(n - len(out))
         return out
+
+    def readline(self):
+        line = b""
+        while True:
+            ch = self.read(1)
+            line += ch
+            if ch in (b"", b"\n"):
+                return line
 
 
 def read_mat_scp(file_or_fd):
