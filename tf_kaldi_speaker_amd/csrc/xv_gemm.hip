@@ -309,11 +309,18 @@ __device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (i
 // staged per K-step.  [r02_pmc_traffic.json: the generic form moved 2.6-2.7 x the algorithmic bytes past L2 on tdnn2 / tdnn3]
 #define XV_NT_SK_WPC 3                       // workgroups per CU of the even schedule: one co-resident round of 768
 #define NT_WIN_ROWS 192                      // window rows per slot: 128 + (taps - 1) * (1 + chunk boundaries inside a tile), 3 DMA pieces per wave
-// Three workgroups per CU = 3 waves per SIMD = a budget of 168 VGPRs (512 / 3 in granules of 8): declared to the compiler, so the per-tile
-// set-up (row offsets, window rows, the shared-tile bookkeeping) needs no scratch.  [round 3: built for 4 per CU = 128 VGPRs, the four
-// instantiations spilled 7 / 19 / 19 / 29 registers; profiles/r04_sk_kernel_registers.txt]
+// Register budget: 128 VGPRs (4 waves per SIMD), although the launch itself is 3 workgroups per CU.  [measured, round 4, same box,
+// bench.py 64 x U{200..400}] declared at its real occupancy - 168 VGPRs, no scratch - the kernel spills nothing (at 128 the four
+// instantiations spill 7-29 registers of per-tile set-up into 32-104 B of scratch, none of it in the K loop) but the step got SLOWER, 4.34
+// -> 4.55 ms: three waves of 168 registers fill a SIMD's file, so no wave of the weight-gradient kernel on the other stream (128 VGPRs)
+// fits beside them, while three waves of 128 leave exactly that room.  The free fourth slot is worth more than the spills cost.
+// (tools/build_variants.sh "sk168:-DXV_NT_SK_VGPRS=168 -DXV_NT_SK_OCC=3" rebuilds the other form; profiles/r04_sk_registers.txt)
+#ifndef XV_NT_SK_VGPRS
+#define XV_NT_SK_VGPRS 128
+#define XV_NT_SK_OCC XV_WGS_PER_CU
+#endif
 template <bool STATS, bool CONV>
-__global__ __launch_bounds__(256, XV_NT_SK_WPC) __attribute__((amdgpu_num_vgpr(168))) void xv_gemm_nt_sk_kernel(NTSKArgs q) {
+__global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(XV_NT_SK_VGPRS))) void xv_gemm_nt_sk_kernel(NTSKArgs q) {
     const NTArgs& p = q.g;
     constexpr int A_SLOT = CONV ? NT_WIN_ROWS * NT_PITCH : BM * NT_PITCH;       // floats per A slot
     constexpr int B_SLOT = BM * NT_PITCH;
