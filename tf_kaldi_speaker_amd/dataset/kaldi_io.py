@@ -343,11 +343,14 @@ class PackedMatrix(object):
     u16][cols x rows u8, column after column] - which is the image xv_cm_decode_ragged (include/xvector_hip.h) decodes on the GPU: the
     extraction driver ships a quarter of the fp32 bytes and the host never runs the codec.  `payload` is a bytes-like view (usually a
     slice of the block the reader pulled from the archive: no copy per utterance)."""
-    __slots__ = ("rows", "cols", "payload")
+    __slots__ = ("rows", "cols", "payload", "block", "start")
     HEADER = 16
 
-    def __init__(self, rows, cols, payload):
+    def __init__(self, rows, cols, payload, block=None, start=0):
+        """block / start: the bytes object `payload` is a view of and where it begins there (the reader's archive block) - lets a consumer
+        ship whole blocks to the GPU once instead of gathering the matrices of a batch on the host."""
         self.rows, self.cols, self.payload = int(rows), int(cols), payload
+        self.block, self.start = (payload, 0) if block is None else (block, int(start))
         assert len(payload) == self.HEADER + 8 * self.cols + self.cols * self.rows
 
     @property
@@ -432,7 +435,7 @@ def read_mat_ark_packed(file_or_fd, block_bytes=8 << 20):
                 size = PackedMatrix.HEADER + 8 * cols + cols * rows
                 if not need(5 + size):
                     raise BadInputFormat
-                yield key, PackedMatrix(rows, cols, memoryview(buf)[pos + 5:pos + 5 + size])
+                yield key, PackedMatrix(rows, cols, memoryview(buf)[pos + 5:pos + 5 + size], buf, pos + 5)
                 pos += 5 + size
             elif fmt in (b"FM ", b"DM "):
                 if not need(5 + 10):
