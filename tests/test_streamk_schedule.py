@@ -108,56 +108,3 @@ def test_wrap_first_order_covers_the_same_units(rows, cols, K):
     if rows == 25088 and K == 2560:                                       # tdnn2's data gradient at S1: 784 tiles on 768 workgroups
         assert wrapped >= 700
 
-
-# ---- the weight-gradient (TN) schedule: xv_gemm_tn_kernel / xv_tn_reduce_kernel / tn_plan in csrc/xv_gemm.hip ------------------------------
-TN_SHAPES = [  # (M = k * c_pad, N, R = reduction rows): the five frame layers at S1, S2-like rows, the segment layers and the loss head of a 128-chunk batch
-    (160, 512, 25088), (2560, 512, 24576), (3584, 512, 23808), (512, 512, 23808), (512, 1500, 23808), (2560, 512, 50176), (3000, 512, 128),
-    (512, 512, 128), (512, 7352, 128), (512, 7352, 64), (160, 512, 196), (32, 4, 1), (4, 4, 17), (1504, 1500, 12000)]
-
-
-def tn_plan(M, N, R, target=768, min_ksteps=2):
-    tiles = -(-M // 128) * -(-N // 128)
-    nk = -(-R // 16)
-    total = tiles * nk
-    P = max(1, min(target, total // min_ksteps))
-    run = -(-total // P)
-    return tiles, nk, total, P, run // nk + 2
-
-
-@pytest.mark.parametrize("M,N,R", TN_SHAPES)
-@pytest.mark.parametrize("target", [768, 1024])
-def test_tn_schedule_covers_every_unit_once_and_the_reducer_finds_every_slab(M, N, R, target):
-    tiles, nk, total, P, max_segs = tn_plan(M, N, R, target)
-    owner = lambda u: ((u + 1) * P - 1) // total                         # tn_owner
-    covered, slabs = {}, {}
-    for w in range(P):                                                   # the kernel's walk
-        u, u_end = w * total // P, (w + 1) * total // P
-        assert u < u_end                                                 # every workgroup has work
-        seg = 0
-        while u < u_end:
-            t = u // nk
-            kt0 = u - t * nk
-            n = min(nk - kt0, u_end - u)
-            for kt in range(kt0, kt0 + n):
-                assert (t, kt) not in covered
-                covered[(t, kt)] = (w, seg)
-            assert seg < max_segs
-            slabs[(w, seg)] = (t, kt0, kt0 + n)
-            u += n
-            seg += 1
-    assert len(covered) == total
-    lens = [(w + 1) * total // P - w * total // P for w in range(P)]
-    assert max(lens) - min(lens) <= 1                                    # equal runs
-    for t in range(tiles):                                               # the reducer's walk
-        w_first, w_last = owner(t * nk), owner(t * nk + nk - 1)
-        got, k = [], 0
-        seg_first = t - (w_first * total // P) // nk                    # only the tile's first share can be a later segment of its run
-        for w in range(w_first, w_last + 1):
-            tile, kt0, kt1 = slabs[(w, seg_first if w == w_first else 0)]
-            assert tile == t and kt0 == k                                # this tile's slab, in K order
-            k = kt1
-            got.append(w)
-        assert k == nk
-        assert sorted(w for (w, s), (tile, _, _) in slabs.items() if tile == t) == got     # and no slab of the tile is left out
-    if (M, N, R) == (2560, 512, 24576) and target == 768:               # tdnn2 at S1: 768 equal runs of 160 K-steps (80 x 12 rectangles of 128 before)
-        assert P == 768 and min(lens) == 160

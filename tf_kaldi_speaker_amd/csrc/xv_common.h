@@ -176,18 +176,16 @@ struct XvGemmNT {
 };
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g);
 
-// out[(j*C + c)][n] = sum_r A[amap(r)][j*c_pad + c] * B[bmap(r)][n] (+ l2 * w[(j*C + c)][n])   ("TN", reduction over rows: weight gradients).
-// The reduction is split over one co-resident round of workgroups with equal runs of K-steps; their partial tiles go through `ws`
-// (xv_tn_ws_bytes) and are added in K order by a second launch.
+// P[z][m][n] = sum_{r in chunk z} A[amap(r)][m] * B[bmap(r)][n]   ("TN", reduction over rows)
 struct XvGemmTN {
-    const float* A; long lda; int a_rps; int a_pitch;   // [R] rows mapped, M = k * c_pad columns used
+    const float* A; long lda; int a_rps; int a_pitch;   // [R] rows mapped, M columns used
     const float* B; long ldb; int b_rps; int b_pitch;   // [R] rows mapped, N columns used
     int M, N, R;
-    void* ws; size_t ws_bytes;
+    float* P;            // slabs [splits][M][N]
+    int splits;          // chosen by xv_tn_splits
 };
-size_t xv_tn_ws_bytes(int M, int N, int R);
-int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g, int k, int C, int c_pad, const float* w, long ldw, float l2, float* out, long ldo);
-// slab sum of the split-precision weight-gradient kernel (xv_gemm16.hip), slabs P[split][k * c_pad][n_in]
+int xv_tn_splits(int M, int N, int R);
+int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g);
 int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int C, int c_pad, int n_in, int n_out, const float* w,
                            long ldw, float l2, float* out, long ldo);
 

@@ -372,7 +372,7 @@ int alloc_buffers(xv_engine* e) {
         Affine& a = e->L[i];
         size_t r = lrows(i);
         int M = a.k * a.c_pad, Nn = a.c_out;
-        size_t s = xv_tn_ws_bytes(M, Nn, (int)r);
+        size_t s = (size_t)xv_tn_splits(M, Nn, (int)r) * M * Nn * sizeof(float);
         if (s > ws) ws = s;
         if (e->f16 && is_frame(e, i)) {
             s = (size_t)xv_tn16_splits(M, a.o_ld, (int)r) * M * a.o_ld * sizeof(float);
@@ -380,7 +380,7 @@ int alloc_buffers(xv_engine* e) {
         }
     }
     if (e->N > 0) {
-        size_t s = xv_tn_ws_bytes(e->Lout, e->ldl, (int)B);
+        size_t s = (size_t)xv_tn_splits(e->Lout, e->ldl, (int)B) * e->Lout * e->ldl * sizeof(float);
         if (s > ws) ws = s;
         s = (size_t)16 * B * e->ldl * sizeof(float);
         if (s > ws) ws = s;
@@ -1326,8 +1326,12 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             w.A = e->out; w.lda = e->Lout; w.a_rps = b; w.a_pitch = b;
             w.B = e->dlogits; w.ldb = e->ldl; w.b_rps = b; w.b_pitch = b;
             w.M = e->Lout; w.N = e->ldl; w.R = b;
-            w.ws = lws; w.ws_bytes = e->ws_bytes;
-            rc = xv_launch_gemm_tn(ss, w, 1, e->Lout, e->Lout, nullptr, 0, 0.f, e->dwn, e->ldl);
+            w.splits = xv_tn_splits(w.M, w.N, w.R);
+            XV_REQUIRE((size_t)w.splits * w.M * w.N * sizeof(float) <= e->ws_bytes, "engine_backward: workspace too small for the loss weight gradient");
+            w.P = (float*)lws;
+            rc = xv_launch_gemm_tn(ss, w);
+            if (rc) return rc;
+            rc = xv_launch_wgrad_reduce(ss, w.P, w.splits, 1, e->Lout, e->Lout, e->ldl, e->ldl, nullptr, 0, 0.f, e->dwn, e->ldl);
             if (rc) return rc;
             if (e->with_margin && c.aux_mhe) {
                 rc = xv_mhe_add_grad(ss, e->dwn, e->Lout, e->N, e->ldl, e->mhe_coef, e->mhe_counts);

@@ -31,7 +31,6 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
-#include <tuple>
 #include <vector>
 
 #define BM XV_TILE_M
@@ -804,26 +803,15 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
 // -------------------------------------------------------------------------------------
 // TN: weight gradients
 // -------------------------------------------------------------------------------------
-// Schedule.  The reduction runs over the ~25 k (chunk, frame) rows and the output has few tiles (16 ... 112), so every tile is shared by
-// many workgroups.  The (tile, K-step) pairs are numbered tile-major, u = tile * nk + kt, and each of P workgroups (one co-resident
-// round, XV_RESIDENT_WGS) owns the equal run [w * total / P, (w + 1) * total / P): a run may end one tile and begin the next (two
-// segments), each segment's partial tile goes to a slab of its own, and xv_tn_reduce_kernel adds a tile's slabs in K order.
-// [measured, round 3, one rectangle of whole splits per workgroup] tiles x splits rarely fills the round: tdnn2 80 x 12 = 960 of 1 024
-// slots (its weight gradient ran at 127.8 TF against 134.9 TF for tdnn3 with 1 008), tdnn5 48 x 21 = 1 008.
 struct TNArgs {
     const float* A; long lda; int a_pitch;
     const float* B; long ldb; int b_pitch;
     int rps; float inv_rps;
-    int M, N, R;
+    float* P;
+    int M, N, R, r_chunk;
     int tiles_m, tiles_n;
     const float* zero;
-    int P;              // workgroups
-    int nk;             // K-steps per tile
-    long total;         // tiles * nk
-    int max_segs;       // slabs reserved per workgroup
-    float* slab;        // [P][max_segs][16][256] float4, see the epilogue
-    int ahead_min;      // fewest K-steps of a segment that run the two-steps-ahead schedule
-    const unsigned short* order;      // [P] launch slot -> run (tn_order), or null
+    int ahead;      // K-step schedule (see the kernel)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -839,44 +827,26 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    // Which run a workgroup takes: launch slots that share an XCD (contiguous after the swizzle) get the runs that start at the SAME reduction
-    // rows of their tiles (tn_order sorts the runs by their first K-step), so the rows of x and dz they stream are fetched into that XCD's
-    // L2 once for all the tiles that need them.  In run order an XCD would hold all K offsets of a few tiles: nothing shared, every
-    // operand byte from the Infinity Cache (4 x the traffic past L2 on the K = 512 layers, whose 16 tiles all read the same rows).
-    const int slot = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int w = p.order ? (int)p.order[slot] : slot;
-    long u = (long)w * p.total / p.P;
-    const long u_end = (long)(w + 1) * p.total / p.P;
-    const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    const int lc = (lane & 31) * 4;
-    const float* __restrict__ zp = p.zero;
-    const unsigned lds0 = xv_lds_addr(smem + 2 * TN_RPT * uwave * BM);
-    const unsigned a_step = (unsigned)(BK * p.lda * 4), b_step = (unsigned)(BK * p.ldb * 4);
-    const unsigned a_skip = (unsigned)((long)(p.a_pitch - p.rps) * p.lda * 4), b_skip = (unsigned)((long)(p.b_pitch - p.rps) * p.ldb * 4);
-    const bool steady = p.rps >= BK;      // at most one segment boundary per step
-    const int a_off = lh * BM + wr * 64 + 2 * li;
-    const int b_off = lh * BN + wc * 64 + 2 * li;
 
-    // a run is contiguous: its first segment starts in the middle of a tile, every later one at K-step 0 of the next tile (one division
-    // per workgroup, none in the loop - its reciprocal, kept in a VGPR across the K loop, was what this kernel spilled)
-    int t_cur = (int)(u / p.nk);
-    int kt_cur = (int)(u - (long)t_cur * p.nk);
-    long left = u_end - u;
-    for (int seg = 0; left > 0; ++seg) {
-    const int t = t_cur, kt0 = kt_cur;
-    const int nk = (int)min((long)(p.nk - kt0), left);
-    left -= nk;
-    t_cur += 1;
-    kt_cur = 0;
+    // 1-D grid over (split, tile): after the XCD swizzle every XCD owns a contiguous run, i.e. whole
+    // reduction chunks, so the rows of A and B that one chunk touches are fetched into ONE L2
+    // (the (tiles, splits) grid of the first build spread every chunk over all 8 XCDs: 51 % hits).
+    const int v = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int split = v / tiles, t = v - split * tiles;
     const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int r_begin = kt0 * BK;
-    const int r_end = min(p.R, r_begin + nk * BK);
+    const int r_begin = split * p.r_chunk;
+    const int r_end = min(p.R, r_begin + p.r_chunk);
+    const int nk = (r_end - r_begin + BK - 1) / BK;
 
     // LDS-DMA staging: one wave-instruction = 1 KiB = two whole [r][128] rows of the image; lane l lands on
     // row 2*(RPT*wave+i) + l/32, columns 4*(l%32)..+3.  The reduction-row -> address map (spliced view)
     // is evaluated per lane without an integer divide (r < 2^24, float quotient off by <= 1).
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int lc = (lane & 31) * 4;
     const bool a_cv = (m0 + lc) < p.M, b_cv = (n0 + lc) < p.N;
+    const float* __restrict__ zp = p.zero;
     const float* abase = p.A + (a_cv ? m0 + lc : 0);
     const float* bbase = p.B + (b_cv ? n0 + lc : 0);
     auto gstage_ragged = [&](int kt, int buf) {      // a K-step with rows at or beyond r_end: those read the zero page (they are summed)
@@ -886,12 +856,12 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         for (int i = 0; i < TN_RPT; ++i) {
             int r = r_begin + kt * BK + 2 * (TN_RPT * wave + i) + (lane >> 5);
             bool rv = r < r_end;
-            int sg = (int)((float)r * p.inv_rps);
-            int tt = r - sg * p.rps;
-            sg += (tt >= p.rps) - (tt < 0);
-            tt = r - sg * p.rps;
-            const float* pa = (rv && a_cv) ? abase + ((long)sg * p.a_pitch + tt) * p.lda : zp;
-            const float* pb = (rv && b_cv) ? bbase + ((long)sg * p.b_pitch + tt) * p.ldb : zp;
+            int seg = (int)((float)r * p.inv_rps);
+            int tt = r - seg * p.rps;
+            seg += (tt >= p.rps) - (tt < 0);
+            tt = r - seg * p.rps;
+            const float* pa = (rv && a_cv) ? abase + ((long)seg * p.a_pitch + tt) * p.lda : zp;
+            const float* pb = (rv && b_cv) ? bbase + ((long)seg * p.b_pitch + tt) * p.ldb : zp;
             xv_dma16_ptr(pa, sa + 2 * i * BM);
             xv_dma16_ptr(pb, sb + 2 * i * BN);
         }
@@ -900,16 +870,20 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     // spliced view is (segment, frame): frame += BK, and on crossing the segment's last frame the offset also skips the rows between two
     // segments.  (The first build resolved row -> (segment, frame) -> 64-bit address from scratch for every K-step: ~40 VALU instructions
     // per wave and step beside the MFMAs.)  Columns outside the matrix read column 0: their products are never stored.
+    const bool steady = p.rps >= BK;      // at most one segment boundary per step
     int tt_i[TN_RPT];
     unsigned aoff[TN_RPT], boff[TN_RPT];
 #pragma unroll
     for (int i = 0; i < TN_RPT; ++i) {
         const int r = min(r_begin + 2 * (TN_RPT * wave + i) + (lane >> 5), p.R - 1);
-        const int sg = r / p.rps;
-        tt_i[i] = r - sg * p.rps;
-        aoff[i] = (unsigned)((((long)sg * p.a_pitch + tt_i[i]) * p.lda + (a_cv ? m0 + lc : 0)) * 4);
-        boff[i] = (unsigned)((((long)sg * p.b_pitch + tt_i[i]) * p.ldb + (b_cv ? n0 + lc : 0)) * 4);
+        const int seg = r / p.rps;
+        tt_i[i] = r - seg * p.rps;
+        aoff[i] = (unsigned)((((long)seg * p.a_pitch + tt_i[i]) * p.lda + (a_cv ? m0 + lc : 0)) * 4);
+        boff[i] = (unsigned)((((long)seg * p.b_pitch + tt_i[i]) * p.ldb + (b_cv ? n0 + lc : 0)) * 4);
     }
+    const unsigned a_step = (unsigned)(BK * p.lda * 4), b_step = (unsigned)(BK * p.ldb * 4);
+    const unsigned a_skip = (unsigned)((long)(p.a_pitch - p.rps) * p.lda * 4), b_skip = (unsigned)((long)(p.b_pitch - p.rps) * p.ldb * 4);
+    const unsigned lds0 = xv_lds_addr(smem + 2 * TN_RPT * uwave * BM);
     auto gstage = [&](int kt, int buf) {
         if (!steady || r_begin + (kt + 1) * BK > r_end) {
             gstage_ragged(kt, buf);
@@ -936,16 +910,17 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    const int a_off = lh * BM + wr * 64 + 2 * li;
+    const int b_off = lh * BN + wc * 64 + 2 * li;
     // Schedule of a K-step, two forms.  AHEAD: all sixteen fragment reads of stage kt, the first sixteen MFMAs, then - in mid-step - the
     // wait for the DMA of stage kt + 1, the workgroup barrier (every wave has read stage kt: its slot is free; stage kt + 1 is visible),
     // the DMA of stage kt + 2 into the slot just freed, and the other sixteen MFMAs: a stage's loads have a whole K-step to land.
     // sched_barrier pins the order.  Plain: the DMA of stage kt + 1 at the top of step kt, wait + barrier where hipcc puts them (right
     // behind the fragment reads - the last MEMORY operations of the step - i.e. in front of all 32 MFMAs).
     // [measured, round 3, weight gradients incl. slab sum at S1] AHEAD wins on long runs of K-steps per workgroup and loses on short ones:
-    // tdnn2 / tdnn3 (128 / 166 K-steps) 514 -> 505 / 661 -> 648 us, tdnn5 / tdnn4 (71 / 24) 322 -> 341 / 129 -> 138 us - chosen per
-    // segment (TNArgs::ahead_min).
-    // (every wave left the previous segment's last K-step through a barrier behind its fragment reads: the slots are free)
-    gstage(0, 0);
+    // tdnn2 / tdnn3 (128 / 166 K-steps) 514 -> 505 / 661 -> 648 us, tdnn5 / tdnn4 (71 / 24) 322 -> 341 / 129 -> 138 us - the launcher
+    // chooses per problem (TNArgs::ahead).
+    if (nk > 0) gstage(0, 0);
     xv_dma_wait_all();      // (the compiler does not see xv_dma16's loads)
     __syncthreads();
     auto k_loop = [&](auto ahead_c) {
@@ -995,160 +970,61 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             }
         }
     };
-    if (nk >= p.ahead_min) k_loop(std::true_type{});
+    if (p.ahead) k_loop(std::true_type{});
     else k_loop(std::false_type{});
 
     // [measured, round 3] summing the split partials inside this kernel - the workgroup that finishes a tile last adds the slabs of the
     // others (ticket hand-over as in xv_gemm_nt_sk_kernel) - was built and dropped: ONE workgroup then reads splits x 64 KB at the ~65 GB/s
     // a single workgroup gets, serially, at the very end of the launch: tdnn2 / tdnn4 / tdnn5 weight gradients 547 -> 630, 127 -> 279,
     // 323 -> 413 us (12 / 64 / 21 splits).  The separate slab-sum launch spreads the same bytes over every CU.
-    // Slab of a segment: [register r][thread] float4 = (acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]) - the 2 x 2 block of outputs
-    // (m, n), (m, n+1), (m+1, n), (m+1, n+1) the lane holds - so a wave instruction stores 1 KB of consecutive bytes (sixteen 16-byte
-    // stores per lane; the row-major slab of the first build took thirty-two 8-byte ones); xv_tn_reduce_kernel undoes the permutation.
-    int tid_e = tid;
-    asm volatile("" : "+v"(tid_e));      // (keeps hipcc from hoisting a per-lane 64-bit slab pointer out of the segment loop - into scratch)
-    float* mine = p.slab + ((long)w * p.max_segs + seg) * (BM * BN) + tid_e * 4;
+    float* P = p.P + (long)split * p.M * p.N;
+    const int n = n0 + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const f32x4 v = {acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]};
-        *(f32x4*)(mine + r * (256 * 4)) = v;
-    }
-    }
-}
-
-__host__ __device__ __forceinline__ int tn_owner(long u, int P, long total) { return (int)((((u + 1) * P) - 1) / total); }
-
-// out[(j*C + c)][n] = sum over the slabs of tile (m = j*c_pad + c, n) in K order (+ l2 * w[(j*C + c)][n]).  A slab is [register r][thread]
-// float4 (the TN kernel's epilogue).  Unit of work = (tile, register r) = the 256 float4 one wave instruction of each of the 4 waves
-// stored; a block = 4 groups of 64 lanes.  Few shares per tile (GROUPS = false): the groups are the unit's 4 quarters and a lane adds all
-// shares of its float4 in K order.  Many shares (tdnn1: 128, the K = 512 layers: 64): a unit is (tile, r, quarter), the groups take
-// contiguous quarters of its shares and their sums are added in group order - a fixed association either way, whatever the launch
-// timing: bit-reproducible.  Eight 16-byte loads in flight per lane, 1 KB of consecutive bytes per wave instruction.
-// The grid is at most TN_REDUCE_WGS blocks that stride over the units.  [measured, round 4, rocprofv3 timeline of the S1 step] this launch
-// runs beside two GEMM kernels whose waves hold every register of the SIMDs, so each of its blocks waits for a GEMM workgroup to exit: as
-// 1 024 short blocks the sum of tdnn4's slabs took 545 us there (12 us for 256 blocks) and held up the next weight-gradient GEMM queued
-// behind it.
-#define WR_FLIGHT 8
-#define TN_REDUCE_WGS 256
-template <bool GROUPS>
-__global__ __launch_bounds__(256) void xv_tn_reduce_kernel(const float* __restrict__ slab, int P, int nk, long total, int max_segs, int tiles,
-                                                           int tiles_n, int M, int N, int C, int c_pad, const float* __restrict__ w, long ldw,
-                                                           float l2, float* __restrict__ out, long ldo) {
-    __shared__ f32x4 part[GROUPS ? 4 : 1][64];
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int units = tiles * 16 * (GROUPS ? 4 : 1);
-    for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
-        const int tile = GROUPS ? unit >> 6 : unit >> 4;
-        const int r = GROUPS ? (unit >> 2) & 15 : unit & 15, quarter = GROUPS ? unit & 3 : g;
-        const int tid = quarter * 64 + lane;               // the thread of the TN kernel whose float4 this lane adds
-        const long u0 = (long)tile * nk;
-        const int w_first = tn_owner(u0, P, total), w_last = tn_owner(u0 + nk - 1, P, total);
-        int wa = w_first, wb = w_last;
-        if (GROUPS) {
-            const int per = (w_last - w_first + 4) / 4;
-            wa = w_first + g * per;
-            wb = min(w_last, wa + per - 1);
-        }
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const float* base = slab + r * (256 * 4) + tid * 4;
-        // the tile's first share may be a later segment of a run that began in an earlier tile; every other share's run begins inside
-        // this tile (segment 0)
-        const int seg_first = tile - (int)(((long)w_first * total / P) / nk);
-        for (int w0 = wa; w0 <= wb; w0 += WR_FLIGHT) {
-            f32x4 t[WR_FLIGHT];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int q = 0; q < WR_FLIGHT; ++q) {
-                const int ww = min(w0 + q, wb);
-                t[q] = *(const f32x4*)(base + ((long)ww * max_segs + (ww == w_first ? seg_first : 0)) * (BM * BN));
+        for (int r = 0; r < 16; ++r) {
+            int m = m0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;
+            if (m < p.M && n < p.N) {
+                f32x2 v = {acc[a][0][r], acc[a][1][r]};
+                *(f32x2*)(P + (long)m * p.N + n) = v;
             }
-#pragma unroll
-            for (int q = 0; q < WR_FLIGHT; ++q)
-                if (w0 + q <= wb) v += t[q];
         }
-        if (GROUPS) {
-            __syncthreads();      // (the previous unit's sums have been read)
-            part[g][lane] = v;
-            __syncthreads();
-            if (g != 0) continue;
-            v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-        }
-        const int wave = tid >> 6, wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
-        const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
-        const int m = tile_m * BM + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh);
-        const int n = tile_n * BN + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
-        if (n >= N) continue;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int mm = m + a;
-            if (mm >= M) continue;
-            const int j = mm / c_pad, c = mm - j * c_pad;
-            if (c >= C) continue;                               // padded input channels (the feature layer: 30 -> 32)
-            const long row = (long)j * C + c;
-            f32x2 o = a == 0 ? f32x2{v.x, v.y} : f32x2{v.z, v.w};
-            if (w) o += l2 * *(const f32x2*)(w + row * ldw + n);
-            *(f32x2*)(out + row * ldo + n) = o;
-        }
-    }
 }
 
-// Launch slot -> run, sorted by the K-step a run starts at within its tile (ties in run order): see the kernel.  One small device table per
-// (tiles, nk, P), built on first use and kept (a training step repeats the same eight problems).
-static const unsigned short* tn_order(int tiles, int nk, int P) {
-    static std::mutex mu;
-    static std::map<std::tuple<int, int, int>, unsigned short*> cache;
-    std::lock_guard<std::mutex> lock(mu);
-    const auto key = std::make_tuple(tiles, nk, P);
-    auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
-    const long total = (long)tiles * nk;
-    std::vector<std::pair<int, int>> ks(P);
-    for (int w = 0; w < P; ++w) ks[w] = {(int)(((long)w * total / P) % nk), w};
-    std::sort(ks.begin(), ks.end());
-    std::vector<unsigned short> h(P);
-    for (int i = 0; i < P; ++i) h[i] = (unsigned short)ks[i].second;
-    unsigned short* d = nullptr;
-    if (hipMalloc((void**)&d, P * sizeof(unsigned short)) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, h.data(), P * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) return nullptr;      // (synchronous, once per shape)
-    cache[key] = d;
-    return d;
+int xv_tn_splits(int M, int N, int R) {
+    int tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
+    int ksteps = xv_cdiv(R, BK);
+    // XV_WGS_PER_CU (4) workgroups are resident per CU (LDS 32 KB each): keep tiles*splits <= XV_RESIDENT_WGS (1 024) so the
+    // whole grid is ONE co-resident round.  (On the first build - 2 per CU - 560 workgroups = 512 + a 48-workgroup second
+    // round cost 2x: 61 TF on tdnn2/3, 24 TF on tdnn5.)
+    // [measured, round 2] fewer co-resident workgroups (smaller slabs, cheaper slab sum) lose: 768 -> +0.06 ms/step, 512 -> +0.19 ms
+    // [measured, round 3, after the DMA / slab-sum work; medians of 3-4 alternated runs against 1 024, S1 | 64 x U{200..400} | S5]
+    //   896: -0.1 ... -0.4 | -1.1 | -0.2 %     768: -0.6 ... -0.8 | -0.2 ... -0.5 | -0.1 ... -0.4 %
+    // (a free slot per CU lets the BatchNorm kernels of the data-gradient chain in beside the weight gradient) - but the kernel itself
+    // is slower with fewer workgroups: alone 1 655 -> 1 724 (768) / 1 837 us (896: 3.5 per CU is an unbalanced launch) over the five
+    // frame layers, its isolated roofline fraction 0.78 -> 0.75 / 0.71.  Kept at one full round: the step gains are at the noise level
+    // of a box change, the kernel's loss is not.
+    // [measured, round 4] an EVEN schedule for this kernel (tile-major (tile, K-step) units in equal runs over 768 or 1 024 persistent
+    // workgroups, two segments per workgroup, lane-order slabs, per-tile slab sum; commits 8f3..c41 of round 4) was built, parity-green
+    // and faster ALONE (sum of the five layers 1 614 vs 1 658 us, tdnn2 504 -> 476 us = 135 TF: every slot of the round used instead of 960
+    // of 1 024) - and slower in every step it was tried in (same box, round-3 tree beside it: S1 +0.7 %, S2 +2.5 %, S4 +1 %, 64 x U{200..400}
+    // +4...5 %; 640 / 768 / 896 / 960 / 1 008 / 1 024 workgroups all lost): equal runs end together, so a launch that fills the round gives
+    // the other streams no slot until it is over (BatchNorm-backward kernels of the data-gradient chain and the slab sums waited 200-760 us
+    // for one, and the next weight-gradient GEMM queued behind a starved slab sum).  The rectangles below leave 0-64 slots free by
+    // accident and end at staggered times beside the other stream.  Removed; profiles/r04_tn_even_schedule_ab.txt.
+    const int target = XV_RESIDENT_WGS, min_ksteps = 2;      // (min_ksteps: fewest K-steps a workgroup is given)
+    int splits = target / tiles;
+    if (splits > ksteps / min_ksteps) splits = ksteps / min_ksteps;
+    if (splits < 1) splits = 1;
+    int chunk = xv_cdiv(ksteps, splits) * BK;
+    return xv_cdiv(R, chunk);
 }
 
-#ifndef XV_TN_WPC
-#define XV_TN_WPC 3      // workgroups per CU of the weight-gradient round (tools/build_variants.sh builds 4 for the A/B in tn_plan's comment)
-#endif
-// Schedule of one weight-gradient problem: workgroups, K-steps per tile, slabs per workgroup
-struct TNPlan { int tiles, nk, P, max_segs; long total; };
-static TNPlan tn_plan(int M, int N, int R) {
-    TNPlan q;
-    q.tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
-    q.nk = xv_cdiv(R, BK);
-    q.total = (long)q.tiles * q.nk;
-    // P = 3 workgroups per CU (768), one co-resident round, one of the CU's four slots left free.  [measured, round 4, rocprofv3 timelines of
-    // the S1 step] with equal runs every workgroup of this kernel ends at the same moment, so a launch that fills all 1 024 slots gives the
-    // other streams NOTHING until it is over: the BatchNorm-backward kernels of the data-gradient chain (main stream) and the slab sums waited
-    // 300-760 us for a slot (19 / 12 us alone) and the step went from 5.24 to 5.43-5.60 ms, although the kernel itself was no slower.
-    // (Round 3's rectangular split left 16-64 slots free by accident: 80 tiles x 12 splits = 960.)  Alone, 768 equal runs are as fast as
-    // 1 024 (gemm_probe, sum of the five layers 1 642 vs 1 663 us) and write a quarter fewer slab bytes.
-    // (On the first build - 2 per CU with rectangular splits - 560 workgroups = 512 + a 48-workgroup second round cost 2x.)
-    const int target = XV_TN_WPC * 256, min_ksteps = 2;      // (min_ksteps: fewest K-steps a workgroup is given)
-    q.P = (int)std::max<long>(1, std::min<long>(target, q.total / min_ksteps));
-    const long run = (q.total + q.P - 1) / q.P;            // longest run of K-steps
-    q.max_segs = (int)(run / q.nk) + 2;                     // a run of L steps touches at most L / nk + 2 tiles
-    return q;
-}
-
-size_t xv_tn_ws_bytes(int M, int N, int R) {
-    const TNPlan q = tn_plan(M, N, R);
-    return (size_t)q.P * q.max_segs * BM * BN * sizeof(float);
-}
-
-int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g, int k, int C, int c_pad, const float* w, long ldw, float l2, float* out, long ldo) {
+int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     XV_REQUIRE(g.M % 4 == 0 && g.N % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0,
                "gemm_tn: M/N/lda/ldb must be multiples of 4 (M=%d N=%d lda=%ld ldb=%ld)", g.M, g.N, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm_tn: operands must be 16-byte aligned");
-    XV_REQUIRE(g.M > 0 && g.N > 0 && g.R > 0, "gemm_tn: empty problem");
-    XV_REQUIRE(k >= 1 && c_pad >= C && k * c_pad == g.M && ldo % 2 == 0 && (!w || ldw % 2 == 0) && ((uintptr_t)out % 8) == 0 && (!w || ((uintptr_t)w % 8) == 0),
-               "gemm_tn: output rows are k x c_pad = M (k=%d c_pad=%d M=%d), leading dimensions even", k, c_pad, g.M);
+    XV_REQUIRE(g.M > 0 && g.N > 0 && g.R > 0 && g.splits >= 1, "gemm_tn: empty problem");
     if (ensure_zero_page()) return 1;
     TNArgs p;
     p.zero = g_zero_page;
@@ -1160,33 +1036,21 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g, int k, int C, int c_pad,
                    "gemm_tn: an operand spans 4 GB or more (%ld segments of %d / %d rows, lda=%ld ldb=%ld): split the batch", segs, g.a_pitch,
                    g.b_pitch, g.lda, g.ldb);
     }
-    const TNPlan q = tn_plan(g.M, g.N, g.R);
-    XV_REQUIRE(g.ws && ((uintptr_t)g.ws % 16) == 0 && (size_t)q.P * q.max_segs * BM * BN * sizeof(float) <= g.ws_bytes,
-               "gemm_tn: workspace too small (%zu bytes needed, %zu given)", (size_t)q.P * q.max_segs * BM * BN * sizeof(float), g.ws_bytes);
     p.A = g.A; p.lda = g.lda; p.a_pitch = g.a_pitch;
     p.B = g.B; p.ldb = g.ldb; p.b_pitch = g.b_pitch;
     p.rps = g.a_rps; p.inv_rps = 1.0f / (float)g.a_rps;
-    p.M = g.M; p.N = g.N; p.R = g.R;
+    p.P = g.P; p.M = g.M; p.N = g.N; p.R = g.R;
     p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
-    p.P = q.P; p.nk = q.nk; p.total = q.total; p.max_segs = q.max_segs;
-    p.slab = (float*)g.ws;
-    p.ahead_min = 96;      // [measured, rounds 3 and 4: 48 / 64 cost tdnn5 7 %, never staging ahead costs tdnn2 / tdnn3 3 %]
-    p.order = q.P <= 65535 ? tn_order(q.tiles, q.nk, q.P) : nullptr;
+    int ksteps = xv_cdiv(g.R, BK);
+    p.r_chunk = xv_cdiv(ksteps, g.splits) * BK;
+    p.ahead = p.r_chunk / BK >= 96;      // [measured, rounds 3 and 4: 48 / 64 cost tdnn5 7 %, never staging ahead costs tdnn2 / tdnn3 3 %]
+    int splits = xv_cdiv(g.R, p.r_chunk);
+    XV_REQUIRE(splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", splits, g.splits);
+    dim3 grid(p.tiles_m * p.tiles_n * splits, 1, 1);
     {
         XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
-        hipLaunchKernelGGL(xv_gemm_tn_kernel, dim3(q.P), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
     }
-    XV_LAUNCH_CHECK();
-    const int shares = xv_cdiv(q.P, q.tiles) + 1;
-    // GROUPS only for very many shares per tile (tdnn1: 96).  [measured, round 4, rocprofv3 timelines at S1 and 64 x 300] beside a data-gradient
-    // GEMM the grouped form (LDS + two barriers per unit) took 236-450 us for tdnn4's 48-64 shares where the plain form takes 12-30 us -
-    // and held up the weight-gradient GEMM queued behind it by as much
-    if (shares >= 80)
-        hipLaunchKernelGGL(xv_tn_reduce_kernel<true>, dim3(std::min(TN_REDUCE_WGS, q.tiles * 64)), dim3(256), 0, s, (const float*)p.slab, q.P, q.nk,
-                           q.total, q.max_segs, q.tiles, p.tiles_n, g.M, g.N, C, c_pad, w, ldw, l2, out, ldo);
-    else
-        hipLaunchKernelGGL(xv_tn_reduce_kernel<false>, dim3(std::min(TN_REDUCE_WGS, q.tiles * 16)), dim3(256), 0, s, (const float*)p.slab, q.P, q.nk,
-                           q.total, q.max_segs, q.tiles, p.tiles_n, g.M, g.N, C, c_pad, w, ldw, l2, out, ldo);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -1235,6 +1099,7 @@ extern "C" int xv_affine_dgrad(void* stream, const float* dz_pad, int segs, int 
 // its quad.  Row blocks are grid-strided (at most ~2 048 workgroups: a launch of many short workgroups crawls beside a GEMM).
 // (The first build read 4 bytes per lane with two 64-bit divisions per element: 45 us for tdnn2's 63 MB of slabs alone on the chip -
 // and the last of these launches sits between the last GEMM of a step and the update.)
+#define WR_FLIGHT 8
 template <bool ZSPLIT>
 __global__ __launch_bounds__(256) void xv_wgrad_reduce_kernel(const float* __restrict__ P, int splits, long slab, int rows, int C, int c_pad,
                                                               int n_in, int nq_out, const float* __restrict__ w, long ldw, float l2,
@@ -1304,6 +1169,12 @@ extern "C" int xv_affine_wgrad(void* stream, const float* x, int segs, int t_in,
     g.A = x; g.lda = c_pad; g.a_rps = t_out; g.a_pitch = t_in;
     g.B = dz + (long)dz_row0 * o; g.ldb = o; g.b_rps = t_out; g.b_pitch = dz_seg_pitch;
     g.M = k * c_pad; g.N = o; g.R = segs * t_out;
-    g.ws = ws; g.ws_bytes = ws_bytes;
-    return xv_launch_gemm_tn((hipStream_t)stream, g, k, c, c_pad, l2_scale != 0.f ? kernel : nullptr, o, l2_scale, dkernel, o);
+    g.splits = xv_tn_splits(g.M, g.N, g.R);
+    XV_REQUIRE((size_t)g.splits * g.M * g.N * sizeof(float) <= ws_bytes, "affine_wgrad: workspace too small (%zu needed)",
+               (size_t)g.splits * g.M * g.N * sizeof(float));
+    g.P = (float*)ws;
+    int rc = xv_launch_gemm_tn((hipStream_t)stream, g);
+    if (rc) return rc;
+    return xv_launch_wgrad_reduce((hipStream_t)stream, g.P, g.splits, k, c, c_pad, o, o, l2_scale != 0.f ? kernel : nullptr, o,
+                                  l2_scale, dkernel, o);
 }
