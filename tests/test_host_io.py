@@ -432,6 +432,12 @@ def test_packed_matrix_reader(tmp_path):
     ref = dict(kaldi_io.read_mat_ark(ark))
     got = list(kaldi_io.read_mat_ark_packed(ark))
     assert [k for k, _ in got] == ["a", "b", "c", "d"]
+    for block in (7, 64, 1000, 5000):          # records that straddle the reader's blocks (also through a pipe: no readinto, short reads)
+        for src in (ark, "cat %s |" % ark):
+            again = list(kaldi_io.read_mat_ark_packed(src, block_bytes=block))
+            assert [k for k, _ in again] == ["a", "b", "c", "d"]
+            for (k, m), (_, m0) in zip(again, got):
+                assert np.array_equal(m.decode() if isinstance(m, kaldi_io.PackedMatrix) else m, m0.decode() if isinstance(m0, kaldi_io.PackedMatrix) else m0), (block, k)
     for k, m in got:
         if k == "b":
             assert isinstance(m, np.ndarray) and np.array_equal(m, ref[k])

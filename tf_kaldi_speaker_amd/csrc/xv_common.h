@@ -98,18 +98,6 @@ __device__ __forceinline__ void xv_handoff_load8(const float* p, int stride, f32
         : "memory");
 }
 
-// four in flight (the evenly scheduled NT kernel: eight cost it sixteen more live registers beside the accumulators, i.e. scratch)
-__device__ __forceinline__ void xv_handoff_load4(const float* p, int stride, f32x4 (&v)[4]) {
-    const float *p1 = p + stride, *p2 = p + 2 * stride, *p3 = p + 3 * stride;
-    asm volatile(
-        "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
-        "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-        : "v"(p), "v"(p1), "v"(p2), "v"(p3)
-        : "memory");
-}
-
 // LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4) in the address form that costs the issuing wave least: a wave-uniform 64-bit
 // base in SGPRs + ONE 32-bit byte offset per lane, M0 = the LDS byte address the wave's 1 KB lands at.  [measured, round 3, tdnn2 forward at
 // S1, stamps] with per-lane 64-bit addresses (a v_lshl_add_u64 + a two-VGPR address read per instruction, which is what hipcc makes of the

@@ -318,9 +318,6 @@ __device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (i
 #define XV_NT_SK_VGPRS 128
 #define XV_NT_SK_OCC XV_WGS_PER_CU
 #endif
-#ifndef XV_NT_SK_FLIGHT
-#define XV_NT_SK_FLIGHT 4      // 16-byte loads in flight per lane when a shared tile's slabs are added: 8 cost sixteen more live registers
-#endif
 template <bool STATS, bool CONV>
 __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(XV_NT_SK_VGPRS))) void xv_gemm_nt_sk_kernel(NTSKArgs q) {
     const NTArgs& p = q.g;
@@ -551,27 +548,17 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
                 if (v == w && me <= 1) continue;
                 const int v_first_tile = (int)(((long)v * q.total / q.P) / q.nk);
                 const float* src = q.slab + ((long)v * 2 + (tile == v_first_tile ? 0 : 1)) * (BM * BN) + tid * 4;
-                if constexpr (XV_NT_SK_FLIGHT == 8) {
+                // eight 16-byte loads in flight per lane.  [measured, round 4, same box, 64 x U{200..400}] four in flight need sixteen fewer live
+                // registers - the two data-gradient instantiations then compile without scratch - and cost the step 1.5 % (4.39 vs 4.32 ms):
+                // a shared tile end is a latency chain, not a register problem.
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        f32x4 x[8];
-                        xv_handoff_load8(src + 8 * h * (256 * 4), 256 * 4, x);
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 x[8];
+                    xv_handoff_load8(src + 8 * h * (256 * 4), 256 * 4, x);
 #pragma unroll
-                        for (int k8 = 0; k8 < 8; ++k8) {
-                            const int r = 8 * h + k8;
-                            acc[0][0][r] += x[k8][0]; acc[0][1][r] += x[k8][1]; acc[1][0][r] += x[k8][2]; acc[1][1][r] += x[k8][3];
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        f32x4 x[4];
-                        xv_handoff_load4(src + 4 * h * (256 * 4), 256 * 4, x);
-#pragma unroll
-                        for (int k4 = 0; k4 < 4; ++k4) {
-                            const int r = 4 * h + k4;
-                            acc[0][0][r] += x[k4][0]; acc[0][1][r] += x[k4][1]; acc[1][0][r] += x[k4][2]; acc[1][1][r] += x[k4][3];
-                        }
+                    for (int k8 = 0; k8 < 8; ++k8) {
+                        const int r = 8 * h + k8;
+                        acc[0][0][r] += x[k8][0]; acc[0][1][r] += x[k8][1]; acc[1][0][r] += x[k8][2]; acc[1][1][r] += x[k8][3];
                     }
                 }
             }

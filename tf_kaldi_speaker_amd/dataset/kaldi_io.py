@@ -384,16 +384,29 @@ def read_mat_ark_packed(file_or_fd, block_bytes=8 << 20):
     fd = open_or_fd(file_or_fd)
     try:
         buf, pos, eof = b"", 0, False
+        readinto = getattr(fd, "readinto", None)
 
         def need(n):      # make buf[pos : pos + n] available; False at end of input
             nonlocal buf, pos, eof
             while len(buf) - pos < n and not eof:
-                more = fd.read(max(block_bytes, n - (len(buf) - pos)))
-                if not more:
+                # a new block = the unconsumed tail of the old one (a partial record, a few KB) + the next read, which lands in place
+                # (readinto: no second copy of the 8 MB; the old block stays alive as long as records cut out of it do)
+                rem = len(buf) - pos
+                want = max(block_bytes, n - rem)
+                new = bytearray(rem + want)
+                new[:rem] = buf[pos:]
+                if readinto is not None:
+                    got = readinto(memoryview(new)[rem:]) or 0
+                else:
+                    more = fd.read(want)
+                    got = len(more)
+                    new[rem:rem + got] = more
+                if got == 0:
                     eof = True
                     break
-                buf = buf[pos:] + more if pos < len(buf) else more
-                pos = 0
+                if got < want:
+                    del new[rem + got:]
+                buf, pos = new, 0
             return len(buf) - pos >= n
 
         while True:

@@ -479,7 +479,7 @@ class Trainer(object):
                 total += (len(it.block) + 15) // 16 * 16
         packed_dev = None
         if total:
-            host = torch.empty(total, dtype=torch.uint8).pin_memory()
+            host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
             hv = host.numpy()
             for blk in staged:
                 o = base[id(blk)]

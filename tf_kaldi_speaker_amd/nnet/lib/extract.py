@@ -8,6 +8,7 @@ Reads an ark / input pipe of feature matrices, writes a Kaldi float-vector ark o
 half-overlapping chunks whose embeddings are length-weighted averaged (reference extract.py:65-94).
 -g selects the HIP device (the reference's CPU mode `-g -1` maps to device 0: there is no CPU path).
 """
+import logging
 import os
 import sys
 import time
@@ -25,7 +26,7 @@ WINDOW_FRAMES = 400000
 
 
 def main():
-    log = _cli.logger()
+    log = _cli.logger(batched=True)
     args = _cli.parser_for("gpu", "min_chunk_size", "chunk_size", "normalize", "node", "model_dir", "rspecifier", "wspecifier").parse_args()
     # -g is an enable flag in the reference ("an arbitrary number except -1"; run_extract_embeddings.sh passes the JOB
     # number with --gpuid), device choice being left to CUDA_VISIBLE_DEVICES.  Here: among the devices HIP_VISIBLE_DEVICES
@@ -78,6 +79,8 @@ def main():
             stats["frames"] += frames
         if stats["warm"] is None:
             stats["warm"] = (time.time(), stats["utts"], stats["frames"])
+        for h in logging.getLogger().handlers:
+            h.flush()
 
     # the reader runs ahead of the GPU in its own thread; 'CM ' matrices arrive undecoded (kaldi_io.PackedMatrix) and are decoded on the GPU
     for key, feature in prefetch_iter(read_mat_ark_packed(args.rspecifier), depth=2 * WINDOW_UTTERANCES):
