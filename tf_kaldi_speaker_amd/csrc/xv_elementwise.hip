@@ -840,12 +840,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         // tensors sit in the Infinity Cache)
         for (int r = r0 + rl; r < r1; r += 4) {
             const f32x4 zz = *(const f32x4*)(z + (long)r * n + col);
-            f32x4 dn = {0, 0, 0, 0};
-            f32x4 dd = upstream_grad<false>(da, pc, 0.f, (long)r, n, col, zz, sc, sh, relu, sl, hs, want4 ? &dn : nullptr);
+            // (the prelu term d act * min(y, 0) is formed here, from the unmasked gradient: handing upstream_grad a pointer for it put
+            // the value in scratch memory - 32 bytes per lane, written and re-read once per row - in the kernel the data-gradient chain waits for)
+            const f32x4 raw = *(const f32x4*)(da + (long)r * n + col);
+            if (want4 && relu) s4 += raw * neg4(zz * sc + sh);
+            f32x4 dd = upstream_grad<false>(da, pc, 0.f, (long)r, n, col, zz, sc, sh, relu, sl, hs);
             f32x4 xh = (zz - mu) * is;
             s1 += dd;
             s2 += dd * xh;
-            s4 += dn;
             s3.x = fmaxf(s3.x, fabsf(dd.x)); s3.y = fmaxf(s3.y, fabsf(dd.y));
             s3.z = fmaxf(s3.z, fabsf(dd.z)); s3.w = fmaxf(s3.w, fabsf(dd.w));
         }

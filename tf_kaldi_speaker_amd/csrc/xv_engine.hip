@@ -115,9 +115,6 @@ struct xv_engine {
     // side-stream chain and both crawl
     struct ZRing { int cur = 0; bool pending[2] = {false, false}; hipEvent_t ev[2] = {nullptr, nullptr}; } zr[2];
     bool lw_pending = false;      // the loss head's weight gradient (side stream) - it reads no dz buffer, so it has its own event
-    float* dz_seg[2] = {nullptr, nullptr};     // XV_STAGE0_LATE == 2: the segment layers' dz outside the ring
-    hipEvent_t ev_seg = nullptr;
-    bool seg_pending = false;
     bool concurrent = true;
     void* ws_side = nullptr;
     float *scalars = nullptr;   // [0] raw loss, [1] reg loss, [2] grad sumsq
@@ -368,7 +365,6 @@ int alloc_buffers(xv_engine* e) {
     want(xv_align(maxc, 4) + 4);      // lrelu_slope
     const size_t ntick = xv_skinny_tickets((int)std::max<size_t>(std::max<size_t>(e->N, 2 * (size_t)e->P), std::max<size_t>(maxc, (size_t)e->Lout))) + 8;
     want(ntick); want(B);             // sk_tickets, xnorm
-    want(B * (size_t)std::max(512, e->Lout)); want(B * (size_t)std::max(512, e->Lout));      // dz_seg
     want(B * (size_t)e->P); want(B * (size_t)e->P);           // pool_wpos, pool_amax
     // GEMM split slabs: weight-gradient partials dominate
     size_t ws = 0;
@@ -472,8 +468,6 @@ int alloc_buffers(xv_engine* e) {
     e->sk_ntickets = ntick;
     e->sk_tickets = (uint32_t*)carve(e, ntick);       // zero (arena memset); every launch leaves them zero
     e->xnorm = carve(e, B);
-    e->dz_seg[0] = carve(e, B * (size_t)std::max(512, e->Lout));
-    e->dz_seg[1] = carve(e, B * (size_t)std::max(512, e->Lout));
     e->pool_wpos = carve(e, B * (size_t)e->P);
     e->pool_amax = carve(e, B * (size_t)e->P);
     {
@@ -498,7 +492,6 @@ int alloc_buffers(xv_engine* e) {
         for (int i = 0; i < 2; ++i) XV_CHECK_HIP(hipEventCreateWithFlags(&e->zr[r].ev[i], hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lw, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_comm, hipEventDisableTiming));
-    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_seg, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_prep, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lossprep, hipEventDisableTiming));
     for (int k = 0; k < XV_BWD_STAGES; ++k)
@@ -689,7 +682,6 @@ extern "C" void xv_engine_destroy(xv_engine* e) {
         for (int i = 0; i < 2; ++i) if (e->zr[r].ev[i]) (void)hipEventDestroy(e->zr[r].ev[i]);
     if (e->ev_lw) (void)hipEventDestroy(e->ev_lw);
     if (e->ev_comm) (void)hipEventDestroy(e->ev_comm);
-    if (e->ev_seg) (void)hipEventDestroy(e->ev_seg);
     if (e->ev_prep) (void)hipEventDestroy(e->ev_prep);
     if (e->ev_lossprep) (void)hipEventDestroy(e->ev_lossprep);
     for (int k = 0; k < XV_BWD_STAGES; ++k)
@@ -1070,10 +1062,6 @@ int join_side(xv_engine* e, hipStream_t s) {
         XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_lw, 0));
         e->lw_pending = false;
     }
-    if (e->seg_pending) {
-        XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_seg, 0));
-        e->seg_pending = false;
-    }
     return 0;
 }
 
@@ -1100,13 +1088,13 @@ float* ring_take(xv_engine* e, hipStream_t s) {
 // dz of layer `a` (fp32 path) from the gradient w.r.t. its output: BN (+activation) backward, the activation alone, or da itself.
 // *ring: dz was written into the ring's current slot (ring_take) - the caller's weight gradient then owns the slot.
 int layer_dz(xv_engine* e, hipStream_t s, Affine& a, const float* da, int segs, int t_out, int pad, const float* act_out,
-             const float** dz_out, bool* ring, float* own = nullptr) {
+             const float** dz_out, bool* ring) {
     const xv_config& c = e->cfg;
     const int lidx = (int)(&a - &e->L[0]);
     ActScope act(e, a);
     int rc;
-    *ring = own == nullptr;
-    float* Z = own ? own : ring_take(e, s);      // own: a buffer outside the ring
+    *ring = true;
+    float* Z = ring_take(e, s);
     XV_REQUIRE(Z, "engine_backward: waiting for a dz slot failed");
     if (!da) {       // tdnn5: the upstream gradient is the statistics-pooling backward of (pool, d pool)
         XV_REQUIRE(lidx == e->F - 1 && a.has_bn, "engine_backward: only the last frame layer takes its gradient from the pooling layer");
@@ -1125,7 +1113,7 @@ int layer_dz(xv_engine* e, hipStream_t s, Affine& a, const float* da, int segs, 
         rc = xv_relu_backward(s, da, act_out, (size_t)segs * t_out * a.c_out, Z);
     } else {
         *dz_out = da;
-        *ring = !own && (da == Z);       // the caller wrote d(output) into the ring's slot itself (attention key gradient)
+        *ring = (da == Z);       // the caller wrote d(output) into the ring's slot itself (attention key gradient)
         return 0;
     }
     *dz_out = Z;
@@ -1326,11 +1314,15 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
         // launched at the END of this stage (it has 3 ms of slack, and d out runs 23 instead of 49 us without it alongside) it again
         // costs fp32 0.24 ms: its many-workgroup TN kernel then competes with the first big data-gradient GEMMs
         // [measured, round 3] started right BEHIND the d-out launch instead of in front of it: no difference (5.36 / 4.42 / 12.70 ms at S1 / 64 x 300 / S5 either way)
-        auto loss_head_wgrad = [&](bool chained) -> int {
+        // [measured, round 4, same box, variant builds] started behind the d-POOL launch (the chain d out -> d tdnn6 -> d pool then runs with
+        // the chip to itself: d out 23 instead of 49 us, one event instead of three): S1 5.22 -> 5.40 ms, 64 x U{200..400} 4.32 -> 4.41 ms -
+        // with the segment layers' weight gradients moved behind it as well 5.41 / 4.44 ms.  Its slab sum and normalisation kernels then run
+        // beside the first big GEMMs and crawl (236 / 113 / 247 us for 15 / 33 / 18), and everything queued behind them starts late.
+        auto loss_head_wgrad = [&]() -> int {
             int rc = 0;
             hipStream_t ss = e->concurrent ? e->side2 : s;
             void* lws = e->concurrent ? e->ws_side2 : e->ws_side;
-            if (e->concurrent && !chained) {
+            if (e->concurrent) {
                 rc = chain(s, ss, e->ev_dz);
                 if (rc) return rc;
             }
@@ -1363,15 +1355,8 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             }
             return 0;
         };
-#ifndef XV_STAGE0_LATE
-#define XV_STAGE0_LATE 0      // A/B builds (tools/build_variants.sh xv_engine.hip): 1 = the loss head's weight gradient behind the d-pool launch, 2 = the segment layers' too
-#endif
-        const bool sk0 = e->sk && b <= XV_SEGMENT_MAX_ROWS;
-        const int late = (sk0 && e->concurrent) ? XV_STAGE0_LATE : 0;
-        if (late == 0) {
-            rc = loss_head_wgrad(false);
-            if (rc) return rc;
-        }
+        rc = loss_head_wgrad();
+        if (rc) return rc;
         // d out = dlogits . wn^T   (pad column of both is zero, so K = ldl is exact), + the gradient through ||out|| (loss.py:122,147).
         // Fused form (xv_skinny.hip): one launch, and with a BatchNorm in tdnn7 and no l2_scaling in between, tdnn7's BN backward too
         Affine &l6 = e->L[e->S0()], &l7 = e->L[e->S1()];
@@ -1384,7 +1369,7 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             g.row_coef = e->dnorm; g.row_norm = e->xnorm; g.X = e->out; g.ldx = e->Lout;
             g.ws = e->ws; g.ws_bytes = e->ws_bytes; g.tickets = e->sk_tickets;
             if (fuse7) {
-                dz7_fused = late == 2 ? e->dz_seg[0] : ring_take(e, s);
+                dz7_fused = ring_take(e, s);
                 XV_REQUIRE(dz7_fused, "engine_backward: waiting for a dz slot failed");
                 ActScope act(e, l7);
                 const XvActContext ac = xv_act_context();
@@ -1438,25 +1423,13 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
                     if (rc) return rc;
                     d = e->d_small1;
                 }
-                rc = layer_dz(e, s, l7, d, b, 1, 0, e->h7, &dz7, &ring7, late == 2 ? e->dz_seg[0] : nullptr);
+                rc = layer_dz(e, s, l7, d, b, 1, 0, e->h7, &dz7, &ring7);
                 if (rc) return rc;
             }
-            auto seg_wgrad = [&](hipStream_t st, void* wws, Affine& a, const float* x, const float* dz) -> int {
-                int r = xv_affine_wgrad(st, x, b, 1, a.c_pad, 1, a.c_in, dz, 1, 0, a.c_out, vptr(e, a.v_kernel), c.weight_l2_regularizer,
-                                        gptr(e, a.v_kernel), wws, e->ws_bytes);
-                if (r) return r;
-                return a.has_bn ? 0 : xv_colsum(st, dz, b, a.c_out, a.c_out, gptr(e, a.v_bias), wws, e->ws_bytes);
-            };
-            const bool dz7_own = dz7 == e->dz_seg[0];      // else dz7 is d out itself (no BN, no activation), which d pool overwrites below
-            if (late < 2) {
-                rc = layer_wgrad(e, s, l7, l6.a, dz7, b, 1, 0, ring7);
-                if (rc) return rc;
-            } else if (!dz7_own) {
-                rc = seg_wgrad(s, e->ws, l7, l6.a, dz7);
-                if (rc) return rc;
-            }
+            rc = layer_wgrad(e, s, l7, l6.a, dz7, b, 1, 0, ring7);
+            if (rc) return rc;
             // d a6 = dz7 . W7^T and tdnn6's BatchNorm (+ activation) backward in one launch -> dz6
-            float* dz6 = late == 2 ? e->dz_seg[1] : ring_take(e, s);
+            float* dz6 = ring_take(e, s);
             XV_REQUIRE(dz6, "engine_backward: waiting for a dz slot failed");
             XV_REQUIRE(l6.has_bn, "engine_backward: the first segment-level layer has a BatchNorm (tdnn.py:147-163)");
             {
@@ -1472,10 +1445,8 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
                 rc = xv_launch_skinny(s, g);
                 if (rc) return rc;
             }
-            if (late < 2) {
-                rc = layer_wgrad(e, s, l6, e->pool, dz6, b, 1, 0, true);
-                if (rc) return rc;
-            }
+            rc = layer_wgrad(e, s, l6, e->pool, dz6, b, 1, 0, true);
+            if (rc) return rc;
             // d pool = dz6 . W6^T (into d_small0); the pooling backward itself is evaluated inside the last frame layer's BN backward
             // (stage 1) from (pool, d pool): its d a is never written
             {
@@ -1486,27 +1457,6 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
                 rc = xv_launch_skinny(s, g);
                 if (rc) return rc;
             }
-            if (late >= 1) {
-                XV_CHECK_HIP(hipEventRecord(e->ev_dz, s));
-                XV_CHECK_HIP(hipStreamWaitEvent(e->side2, e->ev_dz, 0));
-                rc = loss_head_wgrad(true);
-                if (rc) return rc;
-            }
-            if (late == 2) {
-                XV_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_dz, 0));
-                if (dz7_own) {
-                    rc = seg_wgrad(e->side, e->ws_side, l7, l6.a, dz7);
-                    if (rc) return rc;
-                }
-                rc = seg_wgrad(e->side, e->ws_side, l6, e->pool, dz6);
-                if (rc) return rc;
-                XV_CHECK_HIP(hipEventRecord(e->ev_seg, e->side));
-                e->seg_pending = true;
-            }
-        }
-        if (late >= 1 && !sk0) {
-            rc = loss_head_wgrad(false);
-            if (rc) return rc;
         }
         if (stage == 0) { rc = end_stage(e, s, 0, defer); if (rc) return rc; }
     }
