@@ -41,6 +41,7 @@ for n in (512, 1500):
     run(lambda: ops.bn_apply_split(z, scale, shift, True, amax))
     if n == 512:
         run(lambda: ops.bn_relu_backward(da, z, B, T, gamma, mean, invstd, scale, shift, True, 4))
+        run(lambda: ops.bn_relu_backward(da, z, B * T, 1, gamma, mean, invstd, scale, shift, True, 0))      # a dense layer: no padding rows (strip form)
         run(lambda: ops.bn_relu_backward_split(da, z, B, T, gamma, mean, invstd, scale, shift, zmin, zmax, True, 4))
     else:
         pool = ops.stat_pool_forward_bn(z, B, T, scale, shift, True)

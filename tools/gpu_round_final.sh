@@ -25,4 +25,20 @@ for shape in "128 200" "64 300"; do set -- $shape
     echo "=== XV_NT_SCHED=$sched"; if [ $sched == auto ]; then tools/gemm_probe tf_kaldi_speaker_amd/libxvector_hip.so $1 $2 5; else XV_NT_SCHED=$sched tools/gemm_probe tf_kaldi_speaker_amd/libxvector_hip.so $1 $2 5; fi
   done > $O/gemm_probe_schedules_$1x$2.txt 2>&1
 done
+# the clock inside the forward GEMM of a full S1 step (diagnostics build: tools/build_variants.sh xv_gemm.hip "diag:-DXV_DIAG=1")
+if [ -f build_variants/diag/libxvector_hip.so ]; then
+  XV_LIB=$GRAFT_REPO_ROOT/build_variants/diag/libxvector_hip.so XV_DIAG_M=24576 XV_DIAG_N=512 XV_DIAG_K=2560 timeout 300 python3 tools/step_clock.py 2>&1 | grep -v amdgpu.ids > $O/step_clock.txt
+fi
+# same box, alternated: the previous round's tree (build_variants/<prev>_tree: git archive of its last commit, built) against this one
+prev=$(ls -d build_variants/r*_tree 2>/dev/null | tail -1)
+if [ -n "$prev" ]; then
+  one() { t=$1; shift; "$@" 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$t', d['ms_per_step'], d['value'])"; }
+  for i in 1 2 3; do
+    for shape in "S1|" "S3|--chunks 64 --frames 200:400" "S2|--frames 400"; do
+      name=${shape%%|*}; args=${shape#*|}
+      (cd $prev && one "$name $(basename $prev)" python3 bench.py --steps 40 --warmup 10 --single-mode --no-cpu-baseline $args)
+      one "$name $tag" python3 bench.py --steps 40 --warmup 10 --single-mode --no-cpu-baseline $args
+    done
+  done > $O/ab_same_box.txt 2>&1
+fi
 ls -la $O
