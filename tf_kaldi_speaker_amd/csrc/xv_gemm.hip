@@ -754,6 +754,10 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     if (splits == 1) {
         p.C = g.C; p.ldc = g.ldc; p.c_split_stride = 0; p.k_chunk = ksteps * BK;
         dim3 grid(tiles, 1, 1);
+        // [measured, round 4, tools/gemm_probe] three workgroups per CU (an LDS pad of 16 KB per workgroup) for launches whose tile count packs
+        // better into rounds of 768 than of 1 024 - tdnn5 forward: 2 232 tiles = 2.18 rounds of 1 024, 2.9 of 768; a per-CU model (0.85 us per
+        // K-step and workgroup while others cover its waits, 2 us when it is alone) reproduces its 294 us and predicted 256 - changed nothing:
+        // 293.5 vs 295.7 us.  The tail of such a launch is not what the model says it is; removed.
         XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
         if (g.bn_part) {
             p.part_sum = g.bn_part;
@@ -999,6 +1003,8 @@ int xv_tn_splits(int M, int N, int R) {
     // the other streams no slot until it is over (BatchNorm-backward kernels of the data-gradient chain and the slab sums waited 200-760 us
     // for one, and the next weight-gradient GEMM queued behind a starved slab sum).  The rectangles below leave 0-64 slots free by
     // accident and end at staggered times beside the other stream.  Removed; profiles/r04_tn_even_schedule_ab.txt.
+    // [measured, round 4, same box] not splitting the segment-level weight gradients at all (R = the chunks of a batch = 8 K-steps; a quarter of
+    // the slab bytes beside the latency-bound chain): no difference at S1 or 64 x U{200..400} (5.19-5.21 / 4.28-4.30 ms either way).
     const int target = XV_RESIDENT_WGS, min_ksteps = 2;      // (min_ksteps: fewest K-steps a workgroup is given)
     int splits = target / tiles;
     if (splits > ksteps / min_ksteps) splits = ksteps / min_ksteps;

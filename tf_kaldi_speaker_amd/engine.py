@@ -255,10 +255,10 @@ class Engine(object):
         """'CM ' matrices of different lengths, packed back to back in `payload` (uint8; kaldi_io.PackedMatrix images at byte
         `offsets`, `rows[i]` frames each) -> device tensor [b, t, feat_dim] with zero padding (xv_cm_decode_ragged)."""
         dev = self.device
-        pk = payload if isinstance(payload, torch.Tensor) else torch.from_numpy(payload)
+        pk = payload if isinstance(payload, torch.Tensor) else torch.from_numpy(np.array(payload, np.uint8))
         pk = pk.to(dev, non_blocking=True)
-        off = torch.as_tensor(offsets, dtype=torch.int64).to(dev, non_blocking=True)
-        rw = torch.as_tensor(rows, dtype=torch.int32).to(dev, non_blocking=True)
+        off = torch.as_tensor(offsets, dtype=torch.int64).to(dev, non_blocking=True).contiguous()
+        rw = torch.as_tensor(rows, dtype=torch.int32).to(dev, non_blocking=True).contiguous()
         b = int(rw.numel())
         out = torch.empty((b, int(t), self.config.feat_dim), dtype=torch.float32, device=dev)
         _lib.check(self.lib.xv_cm_decode_ragged(_stream(), _ptr(pk), _ptr(off), _ptr(rw), b, int(t), int(self.config.feat_dim), _ptr(out)),

@@ -485,17 +485,28 @@ class Trainer(object):
                 o = base[id(blk)]
                 hv[o:o + len(blk)] = np.frombuffer(blk, np.uint8)
             packed_dev = host.to(eng.device, non_blocking=True)
+        # byte offsets and frame counts of every batch in ONE pinned upload as well: a pageable host -> device copy per batch makes the
+        # host wait for the stream (the previous batch's forward), i.e. host and GPU work would take turns instead of overlapping
+        flat = [i for idx, _ in plan for i in idx]
+        meta = torch.empty((2, len(flat)), dtype=torch.int64, pin_memory=True)
+        mv = meta.numpy()
+        mv[0] = [base[id(items[i].block)] + items[i].start if isinstance(items[i], PackedMatrix) else 0 for i in flat]
+        mv[1] = [lengths[i] for i in flat]
+        meta_dev = meta.to(eng.device, non_blocking=True)
+        rows_dev = meta_dev[1].to(torch.int32)
+        cursor = 0
         for idx, t in plan:
             b = len(idx)
+            sl = slice(cursor, cursor + b)
+            cursor += b
             if all(isinstance(items[i], PackedMatrix) for i in idx):
-                offsets = np.fromiter((base[id(items[i].block)] + items[i].start for i in idx), np.int64, b)
-                x, rows = eng.decode_packed(packed_dev, offsets, [lengths[i] for i in idx], t)
+                x, rows = eng.decode_packed(packed_dev, meta_dev[0, sl], rows_dev[sl], t)
             else:
                 host = np.zeros((b, t, dim), np.float32)
                 for j, i in enumerate(idx):
                     m = items[i].decode() if isinstance(items[i], PackedMatrix) else np.asarray(items[i], np.float32)
                     host[j, :lengths[i]] = m
-                x, rows = host, np.asarray([lengths[i] for i in idx], np.int32)
+                x, rows = host, rows_dev[sl]
             eng.forward_lengths(x, rows)
             emb = eng.endpoint(node)
             if emb.shape[0] != b:
