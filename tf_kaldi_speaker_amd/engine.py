@@ -242,7 +242,7 @@ class Engine(object):
         """Inference forward over utterances of different lengths (xv_engine_forward_lengths): features [b, t, d] with chunk i
         holding frames[i] valid frames followed by padding; pooling uses the valid part only."""
         x = self._dev(features, torch.float32)
-        n = self._dev(frames, torch.int32)
+        n = frames if (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.dtype == torch.int32 and frames.is_contiguous()) else self._dev(frames, torch.int32)
         b, t, d = x.shape
         if d != self.config.feat_dim:
             raise ValueError("feature dim %d != %d" % (d, self.config.feat_dim))
@@ -257,8 +257,12 @@ class Engine(object):
         dev = self.device
         pk = payload if isinstance(payload, torch.Tensor) else torch.from_numpy(np.array(payload, np.uint8))
         pk = pk.to(dev, non_blocking=True)
-        off = torch.as_tensor(offsets, dtype=torch.int64).to(dev, non_blocking=True).contiguous()
-        rw = torch.as_tensor(rows, dtype=torch.int32).to(dev, non_blocking=True).contiguous()
+        def dev_ints(a, dtype):      # device tensors pass through (torch.as_tensor on them cost ~1 ms a call in the extraction driver's profile)
+            if isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == dtype:
+                return a if a.is_contiguous() else a.contiguous()
+            return torch.as_tensor(a, dtype=dtype).to(dev, non_blocking=True).contiguous()
+        off = dev_ints(offsets, torch.int64)
+        rw = dev_ints(rows, torch.int32)
         b = int(rw.numel())
         out = torch.empty((b, int(t), self.config.feat_dim), dtype=torch.float32, device=dev)
         _lib.check(self.lib.xv_cm_decode_ragged(_stream(), _ptr(pk), _ptr(off), _ptr(rw), b, int(t), int(self.config.feat_dim), _ptr(out)),

@@ -46,6 +46,20 @@ except (ImportError, ValueError):      # drop-in layout: PYTHONPATH=$TF_KALDI_RO
 
 log = logging.getLogger("tf_kaldi_speaker_amd")
 
+
+class _PendingEmbeddings(object):
+    """Embeddings of Trainer.predict_batch(..., return_device=True): still on the GPU, in batch order; cpu().numpy() reads them back and
+    puts them into the caller's order."""
+
+    def __init__(self, dev, inv):
+        self.dev, self.inv = dev, inv
+
+    def cpu(self):
+        return self
+
+    def numpy(self):
+        return self.dev.cpu().numpy()[self.inv]
+
 SOFTMAX_FAMILY = ("softmax", "asoftmax", "additive_margin_softmax", "additive_angular_margin_softmax")
 OTHER_LOSSES = ("semihard_triplet_loss", "angular_triplet_loss", "generalized_angular_triplet_loss")
 
@@ -141,7 +155,8 @@ class Trainer(object):
         eng = self.engine
         cfg = eng.config
         have_rows = cfg.max_rows if cfg.max_rows > 0 else cfg.max_batch * cfg.max_frames
-        if b <= cfg.max_batch and t <= cfg.max_frames and b * t <= have_rows:
+        need_rows = rows if rows > 0 else b * t      # (rows given: b and t are the largest batch and the longest utterance of DIFFERENT batches)
+        if b <= cfg.max_batch and t <= cfg.max_frames and need_rows <= have_rows:
             return
         values = eng.get_variables()
         opt, cnt = eng.opt_state.clone(), eng.update_count
@@ -152,7 +167,7 @@ class Trainer(object):
         if rows > 0 or cfg.max_rows > 0:
             # row-bounded capacity: chunks and frames per chunk cost nothing beyond the rows, so take them generously once instead of
             # rebuilding the engine whenever a later window holds a slightly longer utterance or a slightly larger batch
-            nrows = max(rows, b * t, cfg.max_rows)
+            nrows = max(need_rows, cfg.max_rows)
             nb, nt = max(nb, self.PREDICT_CHUNKS), max(nt, 20000)
         self._close_engine()
         self.engine = self._make_engine(self.num_speakers, self.loss_type, nb, nt, keep=values, max_rows=nrows)
@@ -516,10 +531,11 @@ class Trainer(object):
         order = np.concatenate([np.asarray(idx) for idx, _ in outs])
         inv = np.empty(n, np.int64)
         inv[order] = np.arange(n)
-        dev = dev[torch.as_tensor(inv, device=dev.device)]
         if return_device:
-            return dev
-        emb = dev.cpu().numpy()
+            # nothing here waits for the GPU (the permutation back to the caller's order is applied on the host after the read-back: an
+            # index tensor uploaded from pageable memory would have made this call wait for the whole window's forward passes)
+            return _PendingEmbeddings(dev, inv)
+        emb = dev.cpu().numpy()[inv]
         self.endpoints = OrderedDict([(node, emb)])
         return emb
 
