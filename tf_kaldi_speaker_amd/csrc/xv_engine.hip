@@ -1138,6 +1138,10 @@ int layer_wgrad(xv_engine* e, hipStream_t s, Affine& a, const float* x, const fl
         rc = chain(s, e->side, e->ev_dz);
         if (rc) return rc;
     }
+    // [measured, round 4, same box, variant builds] the LAST weight-gradient launches of the side stream (tdnn2's; tdnn2-3's; all four) as 768
+    // rectangles instead of a full round - so that the BatchNorm backward of tdnn1, which waits 250-300 us for slots beside tdnn2's weight
+    // gradient at the very end of the step, finds a free slot per CU: S1 5.22 -> 5.29 / 5.24 / 5.24 ms, 64 x U{200..400} 4.30 -> 4.33 / 4.34 /
+    // 4.35 ms.  The full round stays.
     rc = xv_affine_wgrad(ws_stream, x, segs, t_in, a.c_pad, a.k, a.c_in, dz, seg_pitch, pad, a.c_out, vptr(e, a.v_kernel),
                          c.weight_l2_regularizer, gptr(e, a.v_kernel), wws, e->ws_bytes);
     if (rc) return rc;
