@@ -100,7 +100,7 @@ struct xv_engine {
     hipStream_t side2 = nullptr;
     void* ws_side2 = nullptr;
     bool stage_lw = false;        // deferred stage 0: its slice also needs ev_lw
-    hipEvent_t ev_dz = nullptr, ev_lw = nullptr;
+    hipEvent_t ev_dz = nullptr, ev_lw = nullptr, ev_join = nullptr;
     hipEvent_t ev_prep = nullptr, ev_lossprep = nullptr;     // side-stream halves of ensure_weights
     bool prep_pending = false, lossprep_pending = false;
     hipEvent_t ev_comm = nullptr;                 // behind the most recent xv_engine_allreduce on the caller's communication stream
@@ -491,6 +491,7 @@ int alloc_buffers(xv_engine* e) {
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < 2; ++i) XV_CHECK_HIP(hipEventCreateWithFlags(&e->zr[r].ev[i], hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lw, hipEventDisableTiming));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_comm, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_prep, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lossprep, hipEventDisableTiming));
@@ -681,6 +682,7 @@ extern "C" void xv_engine_destroy(xv_engine* e) {
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < 2; ++i) if (e->zr[r].ev[i]) (void)hipEventDestroy(e->zr[r].ev[i]);
     if (e->ev_lw) (void)hipEventDestroy(e->ev_lw);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->ev_comm) (void)hipEventDestroy(e->ev_comm);
     if (e->ev_prep) (void)hipEventDestroy(e->ev_prep);
     if (e->ev_lossprep) (void)hipEventDestroy(e->ev_lossprep);
@@ -1050,17 +1052,28 @@ int chain(hipStream_t signaller, hipStream_t waiter, hipEvent_t ev) {
     return 0;
 }
 
-// All weight-gradient work enqueued on the side stream so far becomes visible to `s`.
+// All weight-gradient work enqueued on the side streams so far becomes visible to `s` - through ONE wait on `s`: the side stream is in
+// order, so an event recorded on it now covers every dz slot's event, and the loss head's stream is joined into the side stream first.
+// (tools/sync_cost_probe.cpp, profiles/r04_sync_cost.txt: in a chain of 10 us kernels a wait for another stream's fresh event costs the
+// waiting stream 4 us, a record 3 us, record + the other stream's wait 5.6 us; in the step the difference between three waits and one is
+// within the noise of a same-box A/B - as is carrying the hand-over events on the producing kernels' completion signals
+// (hipExtLaunchKernel's stopEvent, 1.5 us in the probe), which was built, verified and taken out again.)
 int join_side(xv_engine* e, hipStream_t s) {
+    bool any = false;
     for (int r = 0; r < 2; ++r)
-        for (int i = 0; i < 2; ++i)
-            if (e->zr[r].pending[i]) {
-                XV_CHECK_HIP(hipStreamWaitEvent(s, e->zr[r].ev[i], 0));
-                e->zr[r].pending[i] = false;
-            }
+        for (int i = 0; i < 2; ++i) {
+            any = any || e->zr[r].pending[i];
+            e->zr[r].pending[i] = false;
+        }
     if (e->lw_pending) {
-        XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_lw, 0));
+        if (e->side) XV_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_lw, 0));
+        else XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_lw, 0));
+        any = any || e->side;
         e->lw_pending = false;
+    }
+    if (any && e->side) {
+        XV_CHECK_HIP(hipEventRecord(e->ev_join, e->side));
+        XV_CHECK_HIP(hipStreamWaitEvent(s, e->ev_join, 0));
     }
     return 0;
 }
