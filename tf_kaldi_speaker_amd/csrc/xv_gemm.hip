@@ -1005,6 +1005,8 @@ int xv_tn_splits(int M, int N, int R) {
     // accident and end at staggered times beside the other stream.  Removed; profiles/r04_tn_even_schedule_ab.txt.
     // [measured, round 4, same box] not splitting the segment-level weight gradients at all (R = the chunks of a batch = 8 K-steps; a quarter of
     // the slab bytes beside the latency-bound chain): no difference at S1 or 64 x U{200..400} (5.19-5.21 / 4.28-4.30 ms either way).
+    // [measured, round 4, same box, variant builds] tdnn1's weight gradient (2 x 4 tiles of which 160 of 256 rows are real, 1 568 K-steps) as
+    // 512 / 256 / 128 workgroups instead of a full round: 65.6 / 72.3 / 114.0 us alone against 67.4, the step within +-0.1 % / +0.1 % / +0.6 %.
     const int target = XV_RESIDENT_WGS, min_ksteps = 2;      // (min_ksteps: fewest K-steps a workgroup is given)
     int splits = target / tiles;
     if (splits > ksteps / min_ksteps) splits = ksteps / min_ksteps;
