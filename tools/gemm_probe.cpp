@@ -1,9 +1,9 @@
 // Stand-alone micro-benchmark of the fp32 MFMA GEMM entry points of libxvector_hip.so (diagnostics, not a test, not the product path).
 // No Python / torch: starts in milliseconds, so one gpurun call can compare many variant libraries on the same box.
 //   build:  hipcc -O2 -std=c++17 tools/gemm_probe.cpp -o tools/gemm_probe -ldl
-//   usage:  tools/gemm_probe <libxvector_hip.so> [B=128] [T=200] [reps=20] [stamp_dump.json]
+//   usage:  tools/gemm_probe <libxvector_hip.so> [B=128] [T=200] [reps=20] [stamp_dump.json|-] [stamp_layer=tdnn2]
 // Prints per layer (tdnn2..tdnn5 shapes of model/tdnn.py:57-127) forward / data-gradient / weight-gradient time and TFLOP/s.
-// If the library exports xv_debug_read_stamps (built with -DXV_DIAG=1|2, csrc/xv_diag.h) the per-workgroup stamps of the last tdnn2 forward
+// If the library exports xv_debug_read_stamps (built with -DXV_DIAG=1|2, csrc/xv_diag.h) the per-workgroup stamps of the last tdnn2 (or [stamp_layer]) forward
 // launch are analysed: workgroups per CU, per-phase cycles, start / end skew.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -59,7 +59,8 @@ template <class F> static double time_us(F f, int reps) {
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s lib [B] [T] [reps] [stamps.json]\n", argv[0]); return 2; }
     const int B = argc > 2 ? atoi(argv[2]) : 128, T = argc > 3 ? atoi(argv[3]) : 200, reps = argc > 4 ? atoi(argv[4]) : 20;
-    const char* dump = argc > 5 ? argv[5] : nullptr;
+    const char* dump = (argc > 5 && strcmp(argv[5], "-")) ? argv[5] : nullptr;
+    const char* stamp_layer = argc > 6 ? argv[6] : "tdnn2";
     const float scale = getenv("XV_DATA_SCALE") ? (float)atof(getenv("XV_DATA_SCALE")) : 1.f;
     const char* only = getenv("XV_PROBE_ONLY"); if (only && !*only) only = nullptr;         // e.g. "tdnn2" : restrict the layers
     const char* ops = getenv("XV_PROBE_OPS"); if (ops && !*ops) ops = nullptr;           // subset of "fdw" (forward, dgrad, wgrad)
@@ -127,7 +128,7 @@ int main(int argc, char** argv) {
             printf("\n");
             for (auto& e : ev) CK(hipEventDestroy(e));
         }
-        if (stamps && !strcmp(l.name, "tdnn2")) {
+        if (stamps && !strcmp(l.name, stamp_layer)) {
             // the stamps of the LAST launch of a back-to-back sequence: the clock the chip sustains, not the one an idle chip starts with
             for (int i = 0; i < reps; ++i) chk(fwd(nullptr, x, segs, tin, l.c, l.k, wt, bias, z, l.o, l.o, part, ws, wsn), "fwd");
             CK(hipDeviceSynchronize());
