@@ -681,6 +681,14 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     // layers (32 K-steps per tile) lose 10-30 % to it and stay on dp.  A tile is never split into more than 8 shares: its LAST workgroup
     // sums them alone (the few-tile, long-K problems of segment-level batches > 128).
     // XV_NT_SCHED=dp|sk forces one (diagnostics, tools/gpu_round_final.sh).
+    // [measured, round 4, same box; profiles/r04_ab_variants.txt "hy"] a third schedule - the first floor(tiles / 256) * 256 tiles whole, one
+    // workgroup each at the head of the grid, the remaining tiles cut into shares of ~24 K-steps for short workgroups the hardware deals into
+    // the free slots (a quarter of the even schedule's hand-overs, plain epilogues for most tiles) - ran in this kernel: alone tdnn2's data
+    // gradient at S1 480 -> 470 us, the 64 x 300 forward GEMMs 391 -> 383 / 520 -> 519 us, tdnn3's data gradient there 498 -> 519 us, and the
+    // short-K layers of that batch 100 -> 92 / 94 -> 82 us against one workgroup per tile; in the step S1 and 64 x U{200..400} +0.3 % / +0.5 %
+    // where the even schedule ran before and -0.1 % (noise) on the short-K layers.  What holds the even schedule at 0.81-0.86 of the pipe is
+    // not the hand-overs (stamps: 28 us of tile switch + 17 us of epilogue per workgroup, hidden behind the CU's other workgroups) but this
+    // kernel's K loop itself, 8 % behind the one-workgroup-per-tile kernel on whole tiles (482 vs 448 us on tdnn2's forward at S1).  Removed.
     const XvEnv* env = xv_env();
     if (!env) return 2;
     const int wpc = XV_NT_SK_WPC;
