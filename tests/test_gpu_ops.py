@@ -551,6 +551,60 @@ SEGMENT_CASES = [(128, 512, 3000), (64, 512, 512), (128, 7351, 512), (128, 512, 
                  (1, 512, 3000), (37, 100, 68), (128, 33, 4), (2, 600, 1204)]
 
 
+# (segs, t_in, c, k, o): tile counts between one and four per CU with a remainder -> whole tiles + shares (csrc/xv_gemm.hip xv_nt_shares)
+SHARE_CASES = [
+    (130, 135, 192, 5, 512),     # forward 17 030 rows x 512 = 536 tiles (24 remaining), K = 960; data gradient 17 550 rows = 552 tiles
+    (66, 151, 64, 5, 512),       # forward 9 702 rows = 304 tiles: one whole tile per CU - shared in the forward launch only
+    (1, 5600, 512, 1, 1500),     # dense, ragged N: 44 x 12 = 528 tiles, K = 512 (32 K-steps)
+]
+
+
+@pytest.mark.parametrize("segs,t_in,c,k,o", SHARE_CASES)
+def test_whole_tiles_plus_shares(ops, segs, t_in, c, k, o):
+    """The remainder tiles of these launches are summed from K shares by their last block (slab hand-over inside xv_gemm_nt_kernel): values and
+    BatchNorm partials against the oracle, and every repetition - beside an uneven load on another stream - bit-identical to the first
+    (a stale slab word or a ticket left non-zero would show)."""
+    import torch
+    rs = np.random.RandomState(segs + t_in)
+    t_out = t_in - k + 1
+    x = rs.randn(segs, t_in, c).astype(np.float32)
+    kern = (rs.randn(k, c, o) / np.sqrt(k * c)).astype(np.float32)
+    bias = rs.randn(o).astype(np.float32)
+    xp = dev(x)
+    wt = ops.prep_weight_fwd(dev(kern), c)
+    ref = O.conv1d_valid_fwd(x.astype(np.float64), kern.astype(np.float64), bias.astype(np.float64)).reshape(-1, o)
+    z, part = ops.affine_forward(xp, k, wt, dev(bias), o, with_stats=True)
+    z, part = z.clone(), part.clone()
+    assert_close(host(z), ref, name="affine_forward (shares)")
+    rows = ref.shape[0]
+    gamma, beta = rs.rand(o).astype(np.float32) + 0.5, rs.randn(o).astype(np.float32)
+    mean, invstd, _, _ = ops.bn_finalize(part, rows, dev(gamma), dev(beta), 1e-3, 0.99, True, dev(np.zeros(o)), dev(np.ones(o)))
+    assert_close(host(mean), ref.mean(0), 2e-5, 1e-4, "bn mean")
+    assert_close(host(invstd), 1 / np.sqrt(ref.var(0) + 1e-3), 2e-5, 1e-4, "bn invstd")
+    dz = rs.randn(segs, t_out, o).astype(np.float32)
+    pad = k - 1
+    dzp = np.zeros((segs, t_out + 2 * pad, o), np.float32)
+    dzp[:, pad:pad + t_out] = dz
+    d_dzp = dev(dzp.reshape(-1, o))
+    wf = ops.prep_weight_dgrad(dev(kern))
+    dx = ops.affine_dgrad(d_dzp, segs, t_out, o, k, wf, c).clone()
+    dx_ref = O.conv1d_valid_bwd(x.astype(np.float64), kern.astype(np.float64), dz.astype(np.float64))[0]
+    assert_close(host(dx), dx_ref.reshape(-1, c), name="affine_dgrad (shares)")
+    side = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device="cuda")
+    bad = 0
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                big @ big
+        for _ in range(6):
+            z2, part2 = ops.affine_forward(xp, k, wt, dev(bias), o, with_stats=True)
+            dx2 = ops.affine_dgrad(d_dzp, segs, t_out, o, k, wf, c)
+            bad += int(not torch.equal(z2, z)) + int(not torch.equal(part2, part)) + int(not torch.equal(dx2, dx))
+        torch.cuda.synchronize()
+    assert bad == 0, "%d of 54 results differ from the first launch" % bad
+
+
 def test_split_handoff_stress(ops):
     """The split-K hand-over of the one-launch segment kernels (relaxed agent-scope stores / ticket / loads: the xv_handoff_* contract of
     csrc/xv_common.h, an architecture property of gfx950 rather than a HIP memory-model guarantee - ADVICE r02) replayed many times

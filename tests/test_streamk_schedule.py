@@ -108,3 +108,64 @@ def test_wrap_first_order_covers_the_same_units(rows, cols, K):
     if rows == 25088 and K == 2560:                                       # tdnn2's data gradient at S1: 784 tiles on 768 workgroups
         assert wrapped >= 700
 
+
+
+# ---- "whole tiles + shares" in the one-workgroup-per-tile kernel (xv_nt_shares / xv_gemm_nt_kernel) -------------------------------------
+def nt_shares(tiles, ksteps, stats, beside_wgrad, ws_bytes=1 << 40):
+    """csrc/xv_gemm.hip xv_nt_shares, restated"""
+    rem, whole = tiles % 256, tiles // 256
+    if tiles >= 1024 or rem < 1 or rem > 128:
+        return 0
+    if not (whole >= 2 or (whole == 1 and stats)) or (beside_wgrad and whole >= 3):
+        return 0
+    best, best_s = 0, 0
+    sh = 2
+    while sh <= 16 and ksteps // sh >= 6:
+        t = whole * ksteps + -(-(rem * sh) // 256) * (ksteps // sh + 10) + sh
+        if not best_s or t < best:
+            best, best_s = t, sh
+        sh += 1
+    t_dp = -(-tiles // 256) * ksteps
+    if not best_s or best + best // 32 >= t_dp or rem * best_s * 128 * 128 * 4 > ws_bytes:
+        return 0
+    return best_s
+
+
+def test_share_plan_on_the_measured_shapes():
+    """the decision table profiles/r04_nt_whole_plus_shares.txt was measured with"""
+    t = lambda rows, cols: -(-rows // 128) * -(-cols // 128)
+    # 64 x 300: tdnn2 / tdnn3 forward (584 / 572 tiles), the K = 512 layers, and their data gradients
+    assert nt_shares(t(18688, 512), 160, True, False) == 3            # 72 remaining tiles: 216 shares, at most one per CU (4: 288 = two on some)
+    assert nt_shares(t(18304, 512), 224, True, False) == 4            # 60 remaining tiles: 240 shares = 1 per CU
+    assert nt_shares(t(18304, 512), 32, True, False) in (2, 3, 4, 5)
+    assert nt_shares(t(18944, 512), 160, False, True) > 0
+    # S1: every forward launch is balanced or too large; tdnn2's data gradient (784 tiles, beside the weight gradients) keeps the even schedule
+    assert nt_shares(t(24576, 512), 160, True, False) == 0            # 768 tiles: no remainder
+    assert nt_shares(t(25088, 512), 160, False, True) == 0
+    assert nt_shares(t(25088, 512), 160, True, False) > 0             # the same tile count as a forward launch (64 x 400): shared
+    assert nt_shares(t(23808, 1500), 32, True, False) == 0            # 2 232 tiles
+    # one whole tile per CU: forward only; large remainders: never
+    assert nt_shares(424, 224, False, True) == 0 and nt_shares(424, 224, True, False) == 0      # 168 remaining tiles
+    assert nt_shares(300, 160, False, True) == 0 and nt_shares(300, 160, True, False) > 0
+    assert nt_shares(664, 160, True, False) == 0                       # 152 remaining tiles
+    assert nt_shares(100, 160, True, False) == 0 and nt_shares(1100, 160, True, False) == 0
+    # short K: a share is at least 6 K-steps
+    assert nt_shares(532, 8, True, False) == 0
+    assert nt_shares(584, 160, True, False, ws_bytes=1 << 20) == 0     # no room for the slabs
+
+
+@pytest.mark.parametrize("tiles", [257, 300, 532, 572, 584, 640, 772, 784, 896])
+@pytest.mark.parametrize("ksteps", [12, 32, 94, 160, 224])
+def test_shares_cover_every_k_step_once(tiles, ksteps):
+    sh = nt_shares(tiles, ksteps, True, False)
+    if not sh:
+        pytest.skip("schedule not used for this shape")
+    n_whole = tiles // 256 * 256
+    assert n_whole % 8 == 0                                            # both block ranges keep blockIdx % 8 = XCD
+    cover = []
+    for i in range(sh):                                                # xv_gemm_nt_kernel: share i = K-steps [i nk / S, (i + 1) nk / S)
+        k0, k1 = i * ksteps // sh, (i + 1) * ksteps // sh
+        assert k1 - k0 >= 6 or ksteps // sh >= 6
+        cover += list(range(k0, k1))
+    assert cover == list(range(ksteps))
+    assert n_whole + (tiles - n_whole) * sh < 65536 * 16

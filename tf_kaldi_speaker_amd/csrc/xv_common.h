@@ -173,6 +173,7 @@ struct XvGemmTN {
     int splits;          // chosen by xv_tn_splits
 };
 int xv_tn_splits(int M, int N, int R);
+int xv_nt_shares(int tiles, int ksteps, bool stats, bool beside_wgrad, size_t ws_bytes);      // NT: shares per remaining tile of the "whole tiles + shares" schedule (0: not used)
 int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g);
 int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int C, int c_pad, int n_in, int n_out, const float* w,
                            long ldw, float l2, float* out, long ldo);

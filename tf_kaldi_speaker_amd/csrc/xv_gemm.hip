@@ -60,6 +60,11 @@ struct NTArgs {
     const float* zero;
     int stamp_half;      // diagnostics build only (xv_diag.h): the stamp buffer half of this launch, -1 = none
     int taps; long a_rows;      // context-window form: K = taps * channels, rows of the tensor behind A
+    // "whole tiles + shares" (xv_launch_gemm_nt): blocks [0, n_whole) take one whole tile each; the tiles behind them are cut into `shares`
+    // equal K ranges, one block each (grid = n_whole + (tiles - n_whole) * shares); shares <= 1: every block a whole tile
+    int n_whole, shares;
+    float* slab;                // [(tiles - n_whole) * shares][128 * 128]: partial tiles in lane order
+    unsigned* tickets;          // one per tile, zero between launches
 };
 
 // Out-of-range rows / k read this 16-byte zero page instead of being masked after the load: the
@@ -175,11 +180,30 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     unsigned long long stall = 0;
     (void)stall;
 
-    const int t = xcd_swizzle(blockIdx.x, gridDim.x);
+    // whole tiles first: the hardware places them first (n_whole is a multiple of 256 - the same number on every CU of an empty chip), the
+    // short share blocks behind them are dealt into whatever slots are free
+    const bool shared = p.shares > 1 && (int)blockIdx.x >= p.n_whole;      // (uniform)
+    int t, share = 0;
+    if (p.shares > 1) {
+        if (shared) {
+            const int r = xcd_swizzle(blockIdx.x - p.n_whole, gridDim.x - p.n_whole);      // (n_whole % 8 == 0: the XCD of a block is blockIdx % 8 in both ranges)
+            t = p.n_whole + r / p.shares;
+            share = r - (r / p.shares) * p.shares;
+        } else {
+            t = xcd_swizzle(blockIdx.x, p.n_whole);
+        }
+    } else {
+        t = xcd_swizzle(blockIdx.x, gridDim.x);
+    }
     const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int k_begin = blockIdx.z * p.k_chunk;
-    const int k_end = min(p.K, k_begin + p.k_chunk);
+    int k_begin = blockIdx.z * p.k_chunk;
+    int k_end = min(p.K, k_begin + p.k_chunk);
+    if (shared) {      // share i of a tile: K-steps [i * nk / shares, (i + 1) * nk / shares)
+        const int nk_tile = (p.K + BK - 1) / BK;
+        k_begin = (int)((long)share * nk_tile / p.shares) * BK;
+        k_end = min(p.K, (int)((long)(share + 1) * nk_tile / p.shares) * BK);
+    }
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
     // ---- global -> LDS staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write.
@@ -273,6 +297,52 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     }
     XV_STAMP(p.stamp_half, 2);
 
+    if (shared) {
+        // a share of a tile: publish it (lane-order slab: 1 KB of consecutive bytes per wave instruction), take the tile's ticket, and only
+        // the last of the tile's blocks goes on: it sums the shares in K order - ((s0 + s1) + s2) + ... whoever it is; the first two commute,
+        // so a block that holds share 0 or 1 keeps it in registers - and runs the ordinary epilogue (xv_handoff_* contract, xv_common.h)
+        int& s_last = *(int*)smem;      // (the staging buffers are idle)
+        const int first = (t - p.n_whole) * p.shares;
+        float* mine = p.slab + (long)(first + share) * (BM * BN) + tid * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x4 v = {acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]};
+            xv_handoff_store4(mine + r * (256 * 4), v);
+        }
+        xv_handoff_drain();
+        __syncthreads();
+        if (tid == 0) s_last = xv_ticket_take(p.tickets + t, (unsigned)p.shares) ? 1 : 0;
+        __syncthreads();
+        const int last = s_last;
+        __syncthreads();                // (s_last aliases the scratch the statistics use below)
+        if (!last) {
+            XV_STAMP_EXIT(p.stamp_half, stall);
+            return;
+        }
+        if (share > 1) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        }
+        for (int i = 0; i < p.shares; ++i) {
+            const int v = share == 1 ? (i == 0 ? 1 : i == 1 ? 0 : i) : i;      // share 1: own, share 0, share 2, ...
+            if (v == share && share <= 1) continue;
+            const float* src = p.slab + (long)(first + v) * (BM * BN) + tid * 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 x[8];
+                xv_handoff_load8(src + 8 * h * (256 * 4), 256 * 4, x);
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) {
+                    const int r = 8 * h + k8;
+                    acc[0][0][r] += x[k8][0]; acc[0][1][r] += x[k8][1]; acc[1][0][r] += x[k8][2]; acc[1][1][r] += x[k8][3];
+                }
+            }
+        }
+    }
     // ---- epilogue
     float* C = p.C + (long)blockIdx.z * p.c_split_stride;
     nt_store_tile(acc, C, p.ldc, p.bias, m0, n0, p.M, p.N, wr, wc, li, lh);
@@ -653,6 +723,25 @@ static unsigned* tn_tickets_for(hipStream_t s) {
     return t;
 }
 
+// "whole tiles + shares" (xv_launch_gemm_nt): shares per remaining tile, 0 = the schedule does not apply or does not pay.
+// K-steps on the busiest CU = the whole tiles + ceil(rem * S / 256) shares of nk / S K-steps and ~10 K-steps of hand-over each; S is chosen
+// so that the shares come out as (just under) a whole number per CU - 72 remaining tiles: 3 shares each = 216, at most one per CU, not 4 (288:
+// two on some CUs) - and small on a tie (the tile's last share sums S slabs alone).  tests/test_streamk_schedule.py restates it.
+int xv_nt_shares(int tiles, int ksteps, bool stats, bool beside_wgrad, size_t ws_bytes) {
+    const int rem_tiles = tiles % 256, whole_per_cu = tiles / 256;
+    if (tiles >= 1024 || rem_tiles < 1 || rem_tiles > 128) return 0;
+    if (!(whole_per_cu >= 2 || (whole_per_cu == 1 && stats)) || (beside_wgrad && whole_per_cu >= 3)) return 0;
+    long best = 0;
+    int best_s = 0;
+    for (int sh = 2; sh <= 16 && ksteps / sh >= 6; ++sh) {
+        const long t = (long)whole_per_cu * ksteps + (long)xv_cdiv((long)rem_tiles * sh, 256) * (ksteps / sh + 10) + sh;
+        if (!best_s || t < best) { best = t; best_s = sh; }
+    }
+    const long t_dp = (long)xv_cdiv(tiles, 256) * ksteps;
+    if (!best_s || best + best / 32 >= t_dp || (size_t)rem_tiles * best_s * BM * BN * sizeof(float) > ws_bytes) return 0;
+    return best_s;
+}
+
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     XV_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm_nt: K/lda/ldb must be multiples of 4 (K=%d lda=%ld ldb=%ld)", g.K, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0, "gemm_nt: operands must be 16-byte aligned");
@@ -669,6 +758,7 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     p.M = g.M; p.N = g.N; p.K = g.K;
     p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
     p.bias = g.bias; p.part_sum = nullptr; p.part_m2 = nullptr;
+    p.n_whole = 0; p.shares = 0; p.slab = nullptr; p.tickets = nullptr;
     const int tiles = p.tiles_m * p.tiles_n;
     const int ksteps = xv_cdiv(g.K, BK);
     // Schedule (xv_gemm_nt_sk_kernel): either one workgroup per tile, dealt to the CUs by the hardware as slots free up ("dp"), or one
@@ -715,6 +805,20 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     // persistent kernel - a tile shared by at most 8 workgroups, its last arrival summing alone - was slower there: 0.214 -> 0.288 ms
     // per 300-frame utterance (12 tiles), 0.30 -> 0.35 ms at 1 000 frames, 30 -> 80 us for d out (4 tiles, K = 7 352); at 10 000 frames
     // (316 tiles) it wins, 1.45 -> 1.41 ms.
+    // Third schedule, "whole tiles + shares", in the one-workgroup-per-tile kernel: the first floor(tiles / 256) * 256 tiles go to one block
+    // each, every remaining tile is cut into `shares` K ranges for short blocks BEHIND them in the grid, which the hardware deals into the
+    // slots the whole-tile blocks leave; a tile's last share sums the others and runs the epilogue (xv_gemm_nt_kernel).  It keeps that
+    // kernel's K loop for every tile (the even schedule's is 8 % slower) and shares only the remainder (64 x 300: 72 of 584 tiles).
+    // [measured, round 4, same box; profiles/r04_nt_whole_plus_shares.txt] alone, against the schedule it replaces: 64 x 300 tdnn2 / tdnn3
+    // forward 390 -> 361 / 521 -> 476 us, tdnn4 forward / data gradient 100 -> 81 / 95 -> 75 us, 64 x 400 tdnn2 forward 514 -> 467 us; in the
+    // step 64 x U{200..400} -1.5 % (4.33 -> 4.27 ms, T-weighted 110.5 -> 111.3 TF), S1 / S2 / S4 / S5 unchanged.  Where it is NOT used:
+    //  * fewer than two whole tiles per CU (one, for the forward launches): when the shares are done the whole-tile blocks finish alone, and
+    //    one block per CU does not keep the matrix pipe busy (64 x 220, tdnn3's data gradient, 424 tiles: 370 -> 429 us);
+    //  * a remainder above 128 tiles: the even schedule is as good or better there (64 x 340, 152 remaining tiles: 564 -> 582 us);
+    //  * three whole tiles per CU beside the weight-gradient stream: tdnn2's data gradient at S1 (784 tiles) ran 477 -> 457 us alone and the
+    //    step lost 0.4 % - the shares take the fourth slot of every CU first, the even schedule leaves it to the other stream.
+    const int hy_shares = env->nt_sched || !g.ws || tiles > XV_TN_MAX_TILES ? 0 : xv_nt_shares(tiles, ksteps, g.bn_part != nullptr, g.co_running != 0, g.ws_bytes);
+    if (hy_shares) sk = false;
     const bool few = !g.bn_part && tiles < 192 && ksteps >= 8 && !env->nt_sched;
     // One workgroup per tile ("dp") is the kernel below, context window or not.  [measured, round 3, after the LDS-DMA moved to scalar
     // bases] staging is cheap now (MFMA-pipe occupancy 0.939 against 0.951 without any), so what the window saves - 39 % of the staged bytes
@@ -762,6 +866,14 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     if (splits == 1) {
         p.C = g.C; p.ldc = g.ldc; p.c_split_stride = 0; p.k_chunk = ksteps * BK;
         dim3 grid(tiles, 1, 1);
+        if (hy_shares) {
+            p.n_whole = tiles / 256 * 256;
+            p.shares = hy_shares;
+            p.slab = (float*)g.ws;
+            p.tickets = tn_tickets_for(s);
+            XV_REQUIRE(p.tickets && ((uintptr_t)p.slab % 16) == 0, "gemm_nt: hand-over buffers unavailable");
+            grid.x = p.n_whole + (tiles - p.n_whole) * hy_shares;
+        }
         // [measured, round 4, tools/gemm_probe] three workgroups per CU (an LDS pad of 16 KB per workgroup) for launches whose tile count packs
         // better into rounds of 768 than of 1 024 - tdnn5 forward: 2 232 tiles = 2.18 rounds of 1 024, 2.9 of 768; a per-CU model (0.85 us per
         // K-step and workgroup while others cover its waits, 2 us when it is alone) reproduces its 294 us and predicted 256 - changed nothing:
