@@ -204,6 +204,10 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         k_begin = (int)((long)share * nk_tile / p.shares) * BK;
         k_end = min(p.K, (int)((long)(share + 1) * nk_tile / p.shares) * BK);
     }
+    // (uniform by construction; said explicitly because xv_dma16 takes "operand base + k" in SGPRs - the diagnostics build otherwise keeps
+    // the share arithmetic in vector registers and the assembler rejects the DMA)
+    k_begin = __builtin_amdgcn_readfirstlane(k_begin);
+    k_end = __builtin_amdgcn_readfirstlane(k_end);
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
     // ---- global -> LDS staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write.
