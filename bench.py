@@ -43,8 +43,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32-input MFMA pe
 PEAK_HBM_GBS = 8000.0            # same guide: HBM3E peak (6.29 TB/s measured by a float4 copy)
 PEAK_F16_MFMA_TFLOPS = 16 * 157.3   # same guide: fp32-input MFMA = 1/16 of the BF16/F16 rate (~2.5 PF dense)
 NKINDS = 6
-KIND_NAMES = ["xv_gemm_nt_kernel<true> / xv_gemm_nt_sk_kernel<true, *> (forward conv/dense + BN stats)",
-              "xv_gemm_nt_kernel<false> / xv_gemm_nt_sk_kernel<false, *> (data gradients / logits)",
+KIND_NAMES = ["xv_gemm_nt_kernel<true> / xv_gemm_nt_sk_kernel<true> (forward conv/dense + BN stats)",
+              "xv_gemm_nt_kernel<false> / xv_gemm_nt_sk_kernel<false> (data gradients / logits)",
               "xv_gemm_tn_kernel (weight gradients)",
               "xv_gemm16_nt_kernel<true> (f16x3 forward conv/dense + BN stats)",
               "xv_gemm16_nt_kernel<false> (f16x3 data gradients)",

@@ -59,7 +59,6 @@ struct NTArgs {
     float* part_sum; float* part_m2;
     const float* zero;
     int stamp_half;      // diagnostics build only (xv_diag.h): the stamp buffer half of this launch, -1 = none
-    int taps; long a_rows;      // context-window form: K = taps * channels, rows of the tensor behind A
     // "whole tiles + shares" (xv_launch_gemm_nt): blocks [0, n_whole) take one whole tile each; the tiles behind them are cut into `shares`
     // equal K ranges, one block each (grid = n_whole + (tiles - n_whole) * shares); shares <= 1: every block a whole tile
     int n_whole, shares;
@@ -376,12 +375,13 @@ struct NTSKArgs {
 
 __device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (int)((((u + 1) * P) - 1) / total); }
 
-// CONV = the context-window form for layers with taps > 1 (tdnn.py:39-93 and their data gradients): the K-steps of a tile run channel
-// chunk outer / tap inner, and the rows  xrow(m0) ... xrow(m0 + 127) + taps - 1  of ONE 16-channel chunk of x sit in LDS once for all
-// taps (rows of tap j = rows of tap 0 shifted by j), so x travels L2 -> LDS once instead of once per tap and only the weight tile is
-// staged per K-step.  [r02_pmc_traffic.json: the generic form moved 2.6-2.7 x the algorithmic bytes past L2 on tdnn2 / tdnn3]
+// (Rounds 2-4 kept a context-window form of this kernel for layers with taps > 1: the rows of ONE 16-channel chunk of x staged once for
+// all taps, the weight tile per K-step - 39 % fewer staged bytes at 5 taps.  [measured, round 4, tools/gemm_probe XV_NT_SCHED=sk, same box]
+// since the LDS-DMA moved to scalar bases staging is cheap and the window's per-step row arithmetic (21 against 6 vector instructions per
+// K-step) costs more than it saves: tdnn2 / tdnn3 forward and data gradient 492 / 481 / 664 / 641 -> 467 / 470 / 641 / 626 us at S1,
+// 392 / 369 / 524 / 500 -> 374 / 360 / 497 / 492 us at 64 x 300; the S1 step -0.6 %, 64 x U{200..400} -0.3 %.  Removed; the split-precision
+// path keeps its window kernel (xv_gemm16.hip), where the staged bytes are what bounds it.  profiles/r04_ab_variants.txt, runs 35-36.)
 #define XV_NT_SK_WPC 3                       // workgroups per CU of the even schedule: one co-resident round of 768
-#define NT_WIN_ROWS 192                      // window rows per slot: 128 + (taps - 1) * (1 + chunk boundaries inside a tile), 3 DMA pieces per wave
 // Register budget: 128 VGPRs (4 waves per SIMD), although the launch itself is 3 workgroups per CU.  [measured, round 4, same box,
 // bench.py 64 x U{200..400}] declared at its real occupancy - 168 VGPRs, no scratch - the kernel spills nothing (at 128 the four
 // instantiations spill 7-29 registers of per-tile set-up into 32-104 B of scratch, none of it in the K loop) but the step got SLOWER, 4.34
@@ -392,13 +392,13 @@ __device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (i
 #define XV_NT_SK_VGPRS 128
 #define XV_NT_SK_OCC XV_WGS_PER_CU
 #endif
-template <bool STATS, bool CONV>
+template <bool STATS>
 __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(XV_NT_SK_VGPRS))) void xv_gemm_nt_sk_kernel(NTSKArgs q) {
     const NTArgs& p = q.g;
-    constexpr int A_SLOT = CONV ? NT_WIN_ROWS * NT_PITCH : BM * NT_PITCH;       // floats per A slot
+    constexpr int A_SLOT = BM * NT_PITCH;       // floats per A slot
     constexpr int B_SLOT = BM * NT_PITCH;
     __shared__ __attribute__((aligned(16))) float smem[2 * A_SLOT + 2 * B_SLOT];   // [A slot 0 | A slot 1 | B slot 0 | B slot 1]
-    int& s_last = *(int*)smem;      // (the staging buffers are idle when it is used; a variable of its own would be the 40 961st byte: 3 workgroups per CU)
+    int& s_last = *(int*)smem;      // (the staging buffers are idle when it is used)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -411,8 +411,6 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
     (void)first_seg;
 
     constexpr int NT_RPI = 64 / NT_KQ;          // tile rows per wave-instruction (16 at BK=16)
-    static_assert(!CONV || NT_WIN_ROWS % (4 * NT_RPI) == 0, "the window is staged in whole 1 KB pieces, equally by the 4 waves");
-    constexpr int WIN_PIECES = NT_WIN_ROWS / (4 * NT_RPI);      // per wave
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int lrow = lane / NT_KQ, lpos = lane % NT_KQ;
     const float* __restrict__ zp = p.zero;
@@ -421,10 +419,7 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
     const int wslot = xv_wave_slot();
     // LDS byte addresses this wave's DMA pieces land at (slot 0; xv_dma16)
     const unsigned lds_a = xv_lds_addr(smem + NT_RPI * NT_RPT * uwave * NT_PITCH);
-    const unsigned lds_aw = xv_lds_addr(smem + NT_RPI * (CONV ? WIN_PIECES : NT_RPT) * uwave * NT_PITCH);
     const unsigned lds_b = xv_lds_addr(smem + 2 * A_SLOT + NT_RPI * NT_RPT * uwave * NT_PITCH);
-    const int taps = CONV ? p.taps : 1;
-    const int C = p.K / taps;                   // channels per tap (CONV: a multiple of 16)
 
     // Order of a run that ends one tile and begins the next ([k0, nk) of tile t, then [0, k2) of tile t + 1): the BEGINNING of the next tile
     // first.  Every workgroup then walks K upwards from (about) 0 in step with the others, so the K-slices of the weight matrix in flight on
@@ -448,10 +443,10 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
 
         // per-lane byte offsets of this tile from p.A / p.Bt (swizzled chunk folded in; xv_dma16).  Rows outside the operand read row 0:
         // their products only reach accumulator rows / columns that are never stored, counted or - in a shared tile - used after the sum
-        unsigned aoff[CONV ? WIN_PIECES : NT_RPT];
+        unsigned aoff[NT_RPT];
         unsigned boff[NT_RPT];
         int ksrc[NT_RPT];
-        int a_row[2];                           // CONV: window row of this lane's two fragment rows at tap 0; else their LDS offset
+        int a_row[2];                           // LDS offsets of this lane's two fragment rows
 #pragma unroll
         for (int i = 0; i < NT_RPT; ++i) {
             const int row = NT_RPI * (NT_RPT * wave + i) + lrow;
@@ -459,22 +454,7 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
             const int n = n0 + row;
             boff[i] = (unsigned)(((long)(n < p.N ? n : 0) * p.ldb + ksrc[i]) * 4);
         }
-        if (CONV) {
-            const int seg0 = m0 / p.a_rps;
-            const long xrow0 = (long)seg0 * p.a_pitch + (m0 - seg0 * p.a_rps);
-#pragma unroll
-            for (int i = 0; i < WIN_PIECES; ++i) {
-                const int wrow = NT_RPI * (WIN_PIECES * wave + i) + lrow;
-                const long xr = xrow0 + wrow;
-                aoff[i] = (unsigned)(((xr < p.a_rows ? xr : 0) * p.lda + ((lpos ^ NT_SWZ(wrow)) << 2)) * 4);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int m = min(m0 + wr * 64 + a * 32 + li, p.M - 1);
-                const int seg = m / p.a_rps;
-                a_row[a] = (int)((long)seg * p.a_pitch + (m - seg * p.a_rps) - xrow0);
-            }
-        } else {
+        {
 #pragma unroll
             for (int i = 0; i < NT_RPT; ++i) {
                 const int row = NT_RPI * (NT_RPT * wave + i) + lrow;
@@ -486,10 +466,10 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
             a_row[0] = (wr * 64 + li) * NT_PITCH;
             a_row[1] = a_row[0] + 32 * NT_PITCH;
         }
-        // K-step kt of a tile: generic = columns [kt*BK, +BK) of the spliced row; CONV = channel chunk kt / taps of tap kt % taps
+        // K-step kt of a tile = columns [kt*BK, +BK) of the spliced row
         auto stage_b = [&](int kt, int slot) {
-            const int k0 = CONV ? (kt % taps) * C + (kt / taps) * BK : kt * BK;
-            if (CONV || k0 + BK <= p.K) {
+            const int k0 = kt * BK;
+            if (k0 + BK <= p.K) {
                 const float* bbase = p.Bt + k0;
 #pragma unroll
                 for (int i = 0; i < NT_RPT; ++i) xv_dma16(bbase, boff[i], lds_b + (slot * B_SLOT + NT_RPI * i * NT_PITCH) * 4);
@@ -502,24 +482,18 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
                 }
             }
         };
-        auto stage_a = [&](int kt, int slot) {      // generic: the tile's rows of K-step kt; CONV: the window of channel chunk kt / taps
-            if (CONV) {
-                const float* abase = p.A + (kt / taps) * BK;
+        auto stage_a = [&](int kt, int slot) {      // the tile's rows of K-step kt
+            const int k0 = kt * BK;
+            if (k0 + BK <= p.K) {          // full K-step (uniform): scalar base + k0, the lane offsets never change
+                const float* abase = p.A + k0;
 #pragma unroll
-                for (int i = 0; i < WIN_PIECES; ++i) xv_dma16(abase, aoff[i], lds_aw + (slot * A_SLOT + NT_RPI * i * NT_PITCH) * 4);
+                for (int i = 0; i < NT_RPT; ++i) xv_dma16(abase, aoff[i], lds_a + (slot * A_SLOT + NT_RPI * i * NT_PITCH) * 4);
             } else {
-                const int k0 = kt * BK;
-                if (k0 + BK <= p.K) {          // full K-step (uniform): scalar base + k0, the lane offsets never change
-                    const float* abase = p.A + k0;
+                float* sa = smem + slot * A_SLOT + NT_RPI * NT_RPT * uwave * NT_PITCH;
 #pragma unroll
-                    for (int i = 0; i < NT_RPT; ++i) xv_dma16(abase, aoff[i], lds_a + (slot * A_SLOT + NT_RPI * i * NT_PITCH) * 4);
-                } else {
-                    float* sa = smem + slot * A_SLOT + NT_RPI * NT_RPT * uwave * NT_PITCH;
-#pragma unroll
-                    for (int i = 0; i < NT_RPT; ++i) {
-                        const float* pa = (const float*)((const char*)(p.A + k0) + aoff[i]);
-                        xv_dma16_ptr((k0 + ksrc[i] < p.K ? pa : zp), sa + NT_RPI * i * NT_PITCH);
-                    }
+                for (int i = 0; i < NT_RPT; ++i) {
+                    const float* pa = (const float*)((const char*)(p.A + k0) + aoff[i]);
+                    xv_dma16_ptr((k0 + ksrc[i] < p.K ? pa : zp), sa + NT_RPI * i * NT_PITCH);
                 }
             }
         };
@@ -532,7 +506,7 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-        stage_a(kt0, CONV ? (kt0 / taps) & 1 : 0);
+        stage_a(kt0, 0);
         stage_b(kt0, 0);
         xv_dma_wait_all();      // (the compiler does not see xv_dma16's loads)
         __syncthreads();
@@ -540,35 +514,18 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
         for (int kt = kt0; kt < kt1; ++kt) {
             const int buf = (kt - kt0) & 1;
             xv_rot_prio(kt + wslot);
-            int tap = 0, aslot = buf;
-            if (CONV) {
-                const int cc = kt / taps;
-                tap = kt - cc * taps;
-                aslot = cc & 1;
-                if (kt + 1 < kt1) {
-                    if (tap + 1 == taps) stage_a(kt + 1, aslot ^ 1);      // the next K-step opens the next channel chunk
-                    stage_b(kt + 1, buf ^ 1);
-                }
-            } else if (kt + 1 < kt1) {
+            if (kt + 1 < kt1) {
                 stage_a(kt + 1, buf ^ 1);
                 stage_b(kt + 1, buf ^ 1);
             }
-            const float* sa = smem + aslot * A_SLOT;
+            const float* sa = smem + buf * A_SLOT;
             const float* sb = smem + 2 * A_SLOT + buf * B_SLOT;
 #pragma unroll
             for (int qq = 0; qq < BK / 8; ++qq) {
                 f32x4 af[2], bf[2];
                 const int pos = (((2 * qq + lh) ^ fsw) << 2);
-                if (CONV) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const int r = a_row[a] + tap;
-                        af[a] = *(const f32x4*)(sa + r * NT_PITCH + (((2 * qq + lh) ^ NT_SWZ(r)) << 2));
-                    }
-                } else {
-                    af[0] = *(const f32x4*)(sa + a_row[0] + pos);
-                    af[1] = *(const f32x4*)(sa + a_row[1] + pos);
-                }
+                af[0] = *(const f32x4*)(sa + a_row[0] + pos);
+                af[1] = *(const f32x4*)(sa + a_row[1] + pos);
                 bf[0] = *(const f32x4*)(sb + b_off + pos);
                 bf[1] = *(const f32x4*)(sb + b_off + 32 * NT_PITCH + pos);
 #pragma unroll
@@ -786,9 +743,6 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     const XvEnv* env = xv_env();
     if (!env) return 2;
     const int wpc = XV_NT_SK_WPC;
-    // context-window form: a spliced view (lda < K) of whole K-step-wide channel chunks whose window fits the LDS slot for every tile
-    const int taps = (g.lda < g.K && g.K % g.lda == 0) ? (int)(g.K / g.lda) : 1;
-    const bool conv = taps >= 2 && g.lda % BK == 0 && 127 + (127 / g.a_rps + 1) * (g.a_pitch - g.a_rps) + taps <= NT_WIN_ROWS;
     bool sk = false;
     long p_sk = 1;
     {
@@ -824,11 +778,10 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     const int hy_shares = env->nt_sched || !g.ws || tiles > XV_TN_MAX_TILES ? 0 : xv_nt_shares(tiles, ksteps, g.bn_part != nullptr, g.co_running != 0, g.ws_bytes);
     if (hy_shares) sk = false;
     const bool few = !g.bn_part && tiles < 192 && ksteps >= 8 && !env->nt_sched;
-    // One workgroup per tile ("dp") is the kernel below, context window or not.  [measured, round 3, after the LDS-DMA moved to scalar
-    // bases] staging is cheap now (MFMA-pipe occupancy 0.939 against 0.951 without any), so what the window saves - 39 % of the staged bytes
-    // at 5 taps - no longer pays for its per-step row arithmetic in a dp launch: tdnn2 / tdnn3 forward at S1 478 / 660 us with the window,
-    // 447 / 621 us (144 / 140 TF) without, the S1 step 5.39 -> 5.28 ms.  The evenly scheduled launches keep it (64 x 300: 381 / 514 us
-    // against 388 / 519 us).
+    // (Neither kernel stages a context window of x any more: [measured, round 3, after the LDS-DMA moved to scalar bases] staging is cheap -
+    // MFMA-pipe occupancy 0.939 against 0.951 without any - so what a window saves, 39 % of the staged bytes at 5 taps, does not pay for its
+    // per-step row arithmetic: one workgroup per tile, tdnn2 / tdnn3 forward at S1 478 / 660 us with the window, 447 / 621 us without; round 4
+    // found the same for the even schedule, see the note above xv_gemm_nt_sk_kernel.)
     if (!few && sk) {
         NTSKArgs q;
         q.nk = ksteps;
@@ -842,16 +795,9 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
             q.slab = (float*)g.ws;
             q.tickets = shared_tiles ? tn_tickets_for(s) : nullptr;
             XV_REQUIRE(!shared_tiles || (q.tickets && ((uintptr_t)q.slab % 16) == 0), "gemm_nt: hand-over buffers unavailable");
-            q.g.taps = conv ? taps : 1;
-            q.g.a_rows = (long)xv_cdiv(g.M, g.a_rps) * g.a_pitch;
             XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
-            if (conv) {
-                if (g.bn_part) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, true>), dim3(q.P), dim3(256), 0, s, q);
-                else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<false, true>), dim3(q.P), dim3(256), 0, s, q);
-            } else {
-                if (g.bn_part) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, false>), dim3(q.P), dim3(256), 0, s, q);
-                else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<false, false>), dim3(q.P), dim3(256), 0, s, q);
-            }
+            if (g.bn_part) hipLaunchKernelGGL(xv_gemm_nt_sk_kernel<true>, dim3(q.P), dim3(256), 0, s, q);
+            else hipLaunchKernelGGL(xv_gemm_nt_sk_kernel<false>, dim3(q.P), dim3(256), 0, s, q);
             XV_LAUNCH_CHECK();
             return 0;
         }

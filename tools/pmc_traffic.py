@@ -20,12 +20,12 @@ for k in sorted(f, key=lambda k: -f[k][0] * f[k][1]):
 
 def s1_algorithmic_mb(names):
     """Algorithmic MB per launch (operands read once + the result written once, fp32) of every GEMM launch of one S1 step (128 x 200 x 30,
-    tdnn.py:35-127, 7351 speakers), grouped by the kernel that runs it: the layers with taps go to the context-window kernel when the
-    trace has one (round-3 first half), else to the plain kernel with the others."""
+    tdnn.py:35-127, 7351 speakers), grouped by the kernel that runs it: the layers with taps go to the evenly scheduled kernel when the
+    trace has one (approximate: the launcher picks per launch), else to the plain kernel with the others."""
     B, T, spk = 128, 200, 7351
     layers = [(5, 32, 512), (5, 512, 512), (7, 512, 512), (1, 512, 512), (1, 512, 1500)]      # (taps, padded input channels, outputs)
     mb = lambda *els: sum(els) * 4 / 1e6
-    fwd_w, fwd_p, bwd_w, bwd_p = ("xv_gemm_nt_sk_kernel<true, true>", "xv_gemm_nt_kernel<true>", "xv_gemm_nt_sk_kernel<false, true>",
+    fwd_w, fwd_p, bwd_w, bwd_p = ("xv_gemm_nt_sk_kernel<true>", "xv_gemm_nt_kernel<true>", "xv_gemm_nt_sk_kernel<false>",
                                   "xv_gemm_nt_kernel<false>")
     has = lambda g: any(g in n for n in names)
     groups = {fwd_w: [], fwd_p: [], bwd_w: [], bwd_p: [], "xv_gemm_tn_kernel": []}
