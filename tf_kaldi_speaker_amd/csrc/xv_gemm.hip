@@ -690,8 +690,8 @@ static unsigned* tn_tickets_for(hipStream_t s) {
 // two on some CUs) - and small on a tie (the tile's last share sums S slabs alone).  tests/test_streamk_schedule.py restates it.
 int xv_nt_shares(int tiles, int ksteps, bool stats, bool beside_wgrad, size_t ws_bytes) {
     const int rem_tiles = tiles % 256, whole_per_cu = tiles / 256;
-    if (tiles >= 1024 || rem_tiles < 1 || rem_tiles > 128) return 0;
-    if (!(whole_per_cu >= 2 || (whole_per_cu == 1 && stats)) || (beside_wgrad && whole_per_cu >= 3)) return 0;
+    if (rem_tiles < 1 || rem_tiles > 128) return 0;
+    if (!(whole_per_cu >= 2 || (whole_per_cu == 1 && stats)) || (beside_wgrad && whole_per_cu == 3)) return 0;
     long best = 0;
     int best_s = 0;
     for (int sh = 2; sh <= 16 && ksteps / sh >= 6; ++sh) {
@@ -769,11 +769,13 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     // kernel's K loop for every tile (the even schedule's is 8 % slower) and shares only the remainder (64 x 300: 72 of 584 tiles).
     // [measured, round 4, same box; profiles/r04_nt_whole_plus_shares.txt] alone, against the schedule it replaces: 64 x 300 tdnn2 / tdnn3
     // forward 390 -> 361 / 521 -> 476 us, tdnn4 forward / data gradient 100 -> 81 / 95 -> 75 us, 64 x 400 tdnn2 forward 514 -> 467 us; in the
-    // step 64 x U{200..400} -1.5 % (4.33 -> 4.27 ms, T-weighted 110.5 -> 111.3 TF), S1 / S2 / S4 / S5 unchanged.  Where it is NOT used:
+    // step 64 x U{200..400} -1.5 % (4.33 -> 4.27 ms, T-weighted 110.5 -> 111.3 TF), S1 / S4 unchanged.  It also serves launches of several
+    // rounds (the share blocks come last in the grid and fill the tail): 128 x 400 tdnn2 / tdnn3 forward 973 -> 916 / 1 318 -> 1 255 us,
+    // tdnn5's data gradient 611 -> 542 us; the S2 step -0.9 %, S5 -2.2 %.  Where it is NOT used:
     //  * fewer than two whole tiles per CU (one, for the forward launches): when the shares are done the whole-tile blocks finish alone, and
     //    one block per CU does not keep the matrix pipe busy (64 x 220, tdnn3's data gradient, 424 tiles: 370 -> 429 us);
     //  * a remainder above 128 tiles: the even schedule is as good or better there (64 x 340, 152 remaining tiles: 564 -> 582 us);
-    //  * three whole tiles per CU beside the weight-gradient stream: tdnn2's data gradient at S1 (784 tiles) ran 477 -> 457 us alone and the
+    //  * exactly three whole tiles per CU beside the weight-gradient stream: tdnn2's data gradient at S1 (784 tiles) ran 477 -> 457 us alone and the
     //    step lost 0.4 % - the shares take the fourth slot of every CU first, the even schedule leaves it to the other stream.
     const int hy_shares = env->nt_sched || !g.ws || tiles > XV_TN_MAX_TILES ? 0 : xv_nt_shares(tiles, ksteps, g.bn_part != nullptr, g.co_running != 0, g.ws_bytes);
     if (hy_shares) sk = false;
