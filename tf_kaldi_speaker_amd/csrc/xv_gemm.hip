@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     }
     XV_STAMP(p.stamp_half, 2);
 
+    bool alive = true;
     if (shared) {
         // a share of a tile: publish it (lane-order slab: 1 KB of consecutive bytes per wave instruction), take the tile's ticket, and only
         // the last of the tile's blocks goes on: it sums the shares in K order - ((s0 + s1) + s2) + ... whoever it is; the first two commute,
@@ -318,11 +319,8 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         __syncthreads();
         const int last = s_last;
         __syncthreads();                // (s_last aliases the scratch the statistics use below)
-        if (!last) {
-            XV_STAMP_EXIT(p.stamp_half, stall);
-            return;
-        }
-        if (share > 1) {
+        alive = last != 0;              // (uniform) the other shares of the tile are done
+        if (alive && share > 1) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -330,7 +328,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
         }
-        for (int i = 0; i < p.shares; ++i) {
+        for (int i = 0; alive && i < p.shares; ++i) {
             const int v = share == 1 ? (i == 0 ? 1 : i == 1 ? 0 : i) : i;      // share 1: own, share 0, share 2, ...
             if (v == share && share <= 1) continue;
             const float* src = p.slab + (long)(first + v) * (BM * BN) + tid * 4;
@@ -347,10 +345,11 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         }
     }
     // ---- epilogue
-    float* C = p.C + (long)blockIdx.z * p.c_split_stride;
-    nt_store_tile(acc, C, p.ldc, p.bias, m0, n0, p.M, p.N, wr, wc, li, lh);
-
-    if (STATS) xv_tile_stats_epilogue(acc, smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part_sum);
+    if (alive) {
+        float* C = p.C + (long)blockIdx.z * p.c_split_stride;
+        nt_store_tile(acc, C, p.ldc, p.bias, m0, n0, p.M, p.N, wr, wc, li, lh);
+        if (STATS) xv_tile_stats_epilogue(acc, smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part_sum);
+    }
     XV_STAMP_EXIT(p.stamp_half, stall);
 }
 
