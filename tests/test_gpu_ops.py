@@ -84,7 +84,12 @@ def test_affine_forward_and_bn_stats(ops, segs, t_in, c, k, o):
         assert_close(host(a), np.maximum(yref, 0), 2e-5, 1e-4, "bn_apply+relu")
 
 
-@pytest.mark.parametrize("segs,t_in,c,k,o", AFFINE_CASES[:5])
+# 129 ... 160 spliced input rows (tdnn1: 5 taps x 32 padded channels): the weight gradient runs in xv_gemm_tn160_kernel - many splits,
+# fewer than 160 rows (28 channels -> 140), a ragged column tile
+WIDE_ROW_CASES = [(40, 150, 28, 5, 512), (20, 100, 30, 5, 96), (64, 204, 30, 5, 512)]
+
+
+@pytest.mark.parametrize("segs,t_in,c,k,o", AFFINE_CASES[:5] + WIDE_ROW_CASES)
 def test_affine_dgrad_wgrad(ops, segs, t_in, c, k, o):
     rs = np.random.RandomState(segs * 77 + k)
     t_out = t_in - k + 1

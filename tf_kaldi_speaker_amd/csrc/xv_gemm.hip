@@ -1053,9 +1053,146 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
         }
 }
 
+
+// ---- weight gradient of a layer with 129 ... 160 input rows (tdnn1: 5 taps x 32 padded feature channels) ----------------------------
+// On 128 x 128 tiles those rows are two tiles of which 3/8 of the second is real: 1.6 x the MFMAs, on the last weight gradient of every step
+// (nothing is left to overlap it with: 96 us in the step, 61 TF alone).  [measured, round 4, same box] 67.3 -> 55.2 us alone incl. the slab
+// sum at S1, 56 -> 47 us at 64 x 300, 115 -> 91 us at 128 x 400; the S1 step -0.3...-0.5 %.  Here a workgroup owns ALL rows x 128 columns: wave w = columns
+// 32 w .. 32 w + 31, five 32 x 32 accumulators down the rows (rows 0..127 interleaved in pairs as in xv_gemm_tn_kernel - one ds_read_b64
+// feeds two of them - rows 128..159 straight).  LDS image per stage: A [16][160] (linear: an LDS-DMA piece of 1 KB is 1.6 rows, every lane
+// resolves its own (row, column)) + B [16][128]; 2 workgroups per CU, 512 of them = one round.
+#define TNW_M 160
+#define TNW_A_PIECES (BK * TNW_M / 256)      // 1 KB pieces per stage: 10
+#define TNW_B_PIECES (BK * BN / 256)         // 8
+#define TNW_WGS 512                         // [measured] 768 / 1 024 workgroups: 59.9 / 64.4 us against 55.2 (tdnn1 at S1, incl. the slab sum)
+__global__ __launch_bounds__(256, 2) void xv_gemm_tn160_kernel(TNArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (TNW_M + BN)];      // [slot][A [16][160] | B [16][128]]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int v = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int split = v / p.tiles_n, tile_n = v - split * p.tiles_n;
+    const int n0 = tile_n * BN;
+    const int r_begin = split * p.r_chunk;
+    const int r_end = min(p.R, r_begin + p.r_chunk);
+    const int nk = (r_end - r_begin + BK - 1) / BK;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const float* __restrict__ zp = p.zero;
+    constexpr int SLOT = BK * (TNW_M + BN);
+    // pieces: A piece q (q = wave, wave + 4, wave + 8 < 10) = floats [256 q, 256 q + 256) of the stage's A image; B piece q (q = 2 wave, 2 wave + 1) =
+    // rows 2 q, 2 q + 1 of B.  Per lane and piece: the reduction row within the K-step and the byte offset of its 16 bytes in that row.
+    constexpr int NA = 3, NB = 2;
+    int rowA[NA], rowB[NB];
+    unsigned colA[NA], colB[NB];
+    bool pieceA[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int q = wave + 4 * i;
+        pieceA[i] = q < TNW_A_PIECES;
+        const int f = 256 * q + 4 * lane;
+        rowA[i] = f / TNW_M;
+        const int c = f - rowA[i] * TNW_M;
+        colA[i] = (unsigned)((c < p.M ? c : 0) * 4);      // columns beyond M (M < 160) read column 0: their products are never stored
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        rowB[i] = 2 * (NB * wave + i) + (lane >> 5);
+        const int c = n0 + 4 * (lane & 31);
+        colB[i] = (unsigned)((c < p.N ? c : 0) * 4);
+    }
+    // stage kt: every lane resolves reduction row -> (segment, frame) -> address (rows at or beyond r_end read the zero page: they are summed)
+    auto gstage = [&](int kt, int buf) {
+        float* sa = smem + buf * SLOT;
+        float* sb = sa + BK * TNW_M;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (!pieceA[i]) continue;      // (uniform per wave)
+            const int r = r_begin + kt * BK + rowA[i];
+            int seg = (int)((float)r * p.inv_rps);
+            int tt = r - seg * p.rps;
+            seg += (tt >= p.rps) - (tt < 0);
+            tt = r - seg * p.rps;
+            const float* pa = r < r_end ? (const float*)((const char*)(p.A + ((long)seg * p.a_pitch + tt) * p.lda) + colA[i]) : zp;
+            xv_dma16_ptr(pa, sa + 256 * (uwave + 4 * i));
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int r = r_begin + kt * BK + rowB[i];
+            int seg = (int)((float)r * p.inv_rps);
+            int tt = r - seg * p.rps;
+            seg += (tt >= p.rps) - (tt < 0);
+            tt = r - seg * p.rps;
+            const float* pb = r < r_end ? (const float*)((const char*)(p.B + ((long)seg * p.b_pitch + tt) * p.ldb) + colB[i]) : zp;
+            xv_dma16_ptr(pb, sb + 256 * (NB * uwave + i));
+        }
+    };
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    const int a_off = lh * TNW_M + 2 * li;              // rows 2 li, 2 li + 1 (and + 64) of reduction row 2 ks + lh
+    const int a4_off = lh * TNW_M + 128 + li;           // row 128 + li
+    const int b_off = lh * BN + 32 * wave + li;
+    // (plain double buffering.  [measured, round 4] the two-steps-ahead DMA schedule of xv_gemm_tn_kernel - all 48 fragment registers read up
+    // front, the wait and the barrier in mid-step - is slower here: 61.8 against 55.1 us incl. the slab sum.)
+    if (nk > 0) gstage(0, 0);
+    xv_dma_wait_all();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
+        const float* sa = smem + buf * SLOT;
+        const float* sb = sa + BK * TNW_M;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x2 a01[BK / 4], a23[BK / 4];
+            float a4[BK / 4], bf[BK / 4];
+#pragma unroll
+            for (int j = 0; j < BK / 4; ++j) {
+                const int ks = h * (BK / 4) + j;
+                a01[j] = *(const f32x2*)(sa + 2 * ks * TNW_M + a_off);
+                a23[j] = *(const f32x2*)(sa + 2 * ks * TNW_M + a_off + 64);
+                a4[j] = sa[2 * ks * TNW_M + a4_off];
+                bf[j] = sb[2 * ks * BN + b_off];
+            }
+#pragma unroll
+            for (int j = 0; j < BK / 4; ++j) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[j].x, bf[j], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[j].y, bf[j], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a23[j].x, bf[j], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a23[j].y, bf[j], acc[3], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], bf[j], acc[4], 0, 0, 0);
+            }
+        }
+        xv_dma_wait_all();
+        __syncthreads();
+    }
+    // slab [split][M][N]: accumulator a < 4, register r of lane (li, lh) = row 64 (a / 2) + 2 row(r, lh) + a % 2; accumulator 4 = row 128 + row(r, lh);
+    // column n0 + 32 wave + li
+    float* P = p.P + (long)split * p.M * p.N;
+    const int n = n0 + 32 * wave + li;
+    if (n < p.N) {
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ri = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = a < 4 ? 64 * (a >> 1) + 2 * ri + (a & 1) : 128 + ri;
+                if (m < p.M) P[(long)m * p.N + n] = acc[a][r];
+            }
+    }
+}
+
+static bool tn_wide_rows(int M) { return M > BM && M <= TNW_M; }
+
 int xv_tn_splits(int M, int N, int R) {
     int tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
     int ksteps = xv_cdiv(R, BK);
+    if (tn_wide_rows(M)) {      // xv_gemm_tn160_kernel: one round of 512 workgroups (2 per CU), at least 4 K-steps each
+        int splits = std::max(1, std::min(TNW_WGS / xv_cdiv(N, BN), ksteps / 4));
+        return xv_cdiv(R, xv_cdiv(ksteps, splits) * BK);
+    }
     // XV_WGS_PER_CU (4) workgroups are resident per CU (LDS 32 KB each): keep tiles*splits <= XV_RESIDENT_WGS (1 024) so the
     // whole grid is ONE co-resident round.  (On the first build - 2 per CU - 560 workgroups = 512 + a 48-workgroup second
     // round cost 2x: 61 TF on tdnn2/3, 24 TF on tdnn5.)
@@ -1115,7 +1252,8 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     dim3 grid(p.tiles_m * p.tiles_n * splits, 1, 1);
     {
         XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
-        hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
+        if (tn_wide_rows(g.M)) hipLaunchKernelGGL(xv_gemm_tn160_kernel, dim3(p.tiles_n * splits), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
     }
     XV_LAUNCH_CHECK();
     return 0;
