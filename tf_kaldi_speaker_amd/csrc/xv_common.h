@@ -217,6 +217,7 @@ struct XvPrepJob {
     long plane;                      // plane stride in elements (16-bit types)
     const unsigned* amax;
 };
+#define XV_PREP_PAD 8            // not a weight: rows [O][C] of w copied into [O][c_pad] with zero pad columns (the features of a step, riding on the first layer's launch)
 #define XV_PREP_MAX_JOBS 32      // two layouts x (XV_MAX_FRAME_LAYERS + 2 segment + 2 attention-key layers)
 struct XvPrepJobs { int n, total_tiles; XvPrepJob j[XV_PREP_MAX_JOBS]; };
 #define XV_AMAX_MAX_JOBS 16

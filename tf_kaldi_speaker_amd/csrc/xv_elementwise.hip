@@ -250,7 +250,14 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(XvPrepJobs J) {
     const int lt = blockIdx.x - q.tile0;
     const int txt = lt % q.tiles_x, tyt = lt / q.tiles_x;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const bool planes = q.type >= XV_PREP_T16;
+    if (q.type == XV_PREP_PAD) {
+        // rows r0 .. r0 + 31 of [O][C] -> [O][c_pad], columns c0 .. c0 + 31 (pad columns zero)
+        const int r0 = tyt * 32, c = txt * 32 + tx;
+        if (c < q.c_pad)
+            for (int r = r0 + ty; r < min(r0 + 32, q.O); r += 8) ((float*)q.dst)[(long)r * q.c_pad + c] = c < q.C ? q.w[(long)r * q.C + c] : 0.f;
+        return;
+    }
+    const bool planes = q.type >= XV_PREP_T16 && q.type != XV_PREP_PAD;
     const float sc = planes ? xv_pow2_scale(*q.amax) : 1.0f;
     if (q.type == XV_PREP_T32 || q.type == XV_PREP_T16) {
         // transpose through LDS: reads run along o (contiguous in w), writes along the padded k axis
@@ -309,7 +316,8 @@ int xv_prep_add(XvPrepJobs& J, int type, const float* w, int k, int C, int O, in
     XvPrepJob& q = J.j[J.n++];
     q.type = type; q.k = k; q.C = C; q.O = O; q.c_pad = c_pad; q.o_ld = o_ld; q.w = w; q.dst = dst; q.plane = plane; q.amax = amax;
     int tiles_y;
-    if (type == XV_PREP_T32 || type == XV_PREP_T16) { q.tiles_x = xv_cdiv((long)k * c_pad, 32); tiles_y = xv_cdiv(O, 32); }
+    if (type == XV_PREP_PAD) { q.tiles_x = xv_cdiv(c_pad, 32); tiles_y = xv_cdiv(O, 32); }
+    else if (type == XV_PREP_T32 || type == XV_PREP_T16) { q.tiles_x = xv_cdiv((long)k * c_pad, 32); tiles_y = xv_cdiv(O, 32); }
     else { q.tiles_x = xv_cdiv(o_ld, 32); tiles_y = xv_cdiv((long)k * C, 32); }
     q.tile0 = J.total_tiles;
     J.total_tiles += q.tiles_x * tiles_y;

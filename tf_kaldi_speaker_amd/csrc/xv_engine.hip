@@ -138,6 +138,8 @@ struct xv_engine {
     size_t ws_bytes = 0;
     int32_t* labels_dev = nullptr;   // caller's pointer of the current step
     bool weights_dirty = true;
+    const float* pad_src = nullptr;      // engine_forward -> prep_layers: the features whose channel padding rides on the first layer's weight-copy launch
+    int pad_rows = 0;
     bool reg_valid = false;
     // state of the most recent forward
     int B = 0, T = 0, training = 0;
@@ -542,6 +544,11 @@ int prep_layers(xv_engine* e, hipStream_t s, int first, int last) {
             }
         }
     }
+    if (e->pad_src && first == 0 && !e->f16) {      // the step's features ride on the first layer's launch (engine_forward)
+        int rc = xv_prep_add(J, XV_PREP_PAD, e->pad_src, 1, e->cfg.feat_dim, e->pad_rows, e->c_pad0, e->c_pad0, e->xpad, 0, nullptr);
+        if (rc) return rc;
+        e->pad_src = nullptr;
+    }
     if (A.n) {
         // one memset over the slot range of these layers (tdnn first..F-1 -> slots first..F-1, key layers -> F, F+1: contiguous)
         unsigned *lo = A.out[0], *hi = A.out[0];
@@ -760,8 +767,15 @@ int engine_forward(xv_engine* e, void* stream, const float* features, int b, int
         XV_CHECK_HIP(hipMemsetAsync(e->amax, 0, AMAX_SLOTS * sizeof(uint32_t), s));
         e->amax_wt_clean = e->amax_dz_clean = true;
     }
+    // fp32: the channel padding of the features is one more job of the first layer's weight-copy launch when that launch happens
+    // anyway (every training step); otherwise a launch of its own below
+    const bool want_pad = !e->f16 && e->weights_dirty;
+    e->pad_src = want_pad ? features : nullptr;
+    e->pad_rows = b * t;
     int rc = ensure_weights(e, s, training != 0 && e->N > 0);
     e->amax_wt_clean = false;
+    const bool padded = want_pad && e->pad_src == nullptr;      // prep_layers took the job
+    e->pad_src = nullptr;
     if (rc) return rc;
     int cur_t = t;
     e->Tl[0] = t;
@@ -854,8 +868,10 @@ int engine_forward(xv_engine* e, void* stream, const float* features, int b, int
             k0.rows = k1.rows = rows;
         }
     } else {
-        rc = xv_pad_channels(s, features, b * t, e->cfg.feat_dim, e->xpad, e->c_pad0);
-        if (rc) return rc;
+        if (!padded) {
+            rc = xv_pad_channels(s, features, b * t, e->cfg.feat_dim, e->xpad, e->c_pad0);
+            if (rc) return rc;
+        }
         const float* cur = e->xpad;
         for (int i = 0; i < F; ++i) {
             Affine& a = e->L[i];
