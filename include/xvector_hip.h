@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define XV_ABI_VERSION 1
+/* 2: xv_config starts with struct_bytes (round 5).  Bumped whenever xv_config's layout or an entry point's signature changes: a host
+ * built against another header must fail at load (xv_abi_version) or at xv_engine_create (struct_bytes), never read fields past the end
+ * of a shorter struct. */
+#define XV_ABI_VERSION 2
 
 const char* xv_last_error(void);
 int xv_abi_version(void);
@@ -355,6 +358,7 @@ int xv_sumsq(void* stream, const float* g, size_t count, float* out_accum);
 typedef struct xv_engine xv_engine;
 
 typedef struct xv_config {
+    int32_t struct_bytes;             /* = sizeof(xv_config) of the header the host was built against; anything else is refused */
     int32_t feat_dim;                 /* dim, train.py:71 */
     int32_t num_speakers;             /* train.py:74 (0 => no loss head, predict only) */
     int32_t num_nodes_pooling_layer;  /* tdnn.py:111-113, default 1500 */

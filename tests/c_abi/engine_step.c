@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
     const int dp = argc == 13;
     xv_config cfg;
     memset(&cfg, 0, sizeof cfg);
+    cfg.struct_bytes = (int32_t)sizeof cfg;
     cfg.feat_dim = atoi(argv[3]);
     cfg.num_speakers = atoi(argv[4]);
     cfg.loss_kind = atoi(argv[5]);

@@ -37,7 +37,7 @@ def test_ctypes_table_matches_header():
     from tf_kaldi_speaker_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_functions()
     lib = _lib.load()
-    assert lib.xv_abi_version() == 1
+    assert lib.xv_abi_version() == _lib.ABI_VERSION
     assert lib.xv_device_count() >= 0   # 0 here: no compute call is made without a GPU
 
 
@@ -74,16 +74,17 @@ def test_engine_refuses_to_run_without_gpu():
         engine.Engine(engine.make_config(30, 10))
 
 
-def test_unknown_environment_switches_are_refused_by_name():
-    """the library reads three documented switches; a value it does not understand or any other XV_* variable
-    (a typo, an A/B switch of an earlier round) makes engine creation fail with the name - before any GPU call, so this runs here."""
+def test_environment_switches_are_value_checked_and_unknown_ones_named():
+    """the library reads a few documented switches; a value it does not understand makes engine creation fail with
+    the name - before any GPU call, so this runs here.  Any other XV_* variable (a typo, a switch of an earlier round, another program's) is
+    named once on stderr and ignored: it must not stop a run."""
     import subprocess
     import sys
     code = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
             "from tf_kaldi_speaker_amd import _lib\n"
             "lib = _lib.load(); cfg = _lib.XvConfig(); cfg.feat_dim = 30; h = C.c_void_p()\n"
             "rc = lib.xv_engine_create(C.byref(cfg), C.byref(h)); print(rc, lib.xv_last_error().decode())\n" % ROOT)
-    for extra, want in (({"XV_TN_WGS": "768"}, "unknown environment switch XV_TN_WGS"), ({"XV_NT_SCHED": "fast"}, "XV_NT_SCHED=fast: expected dp or sk"),
+    for extra, want in (({"XV_NT_SCHED": "fast"}, "XV_NT_SCHED=fast: expected dp or sk"), ({"XV_TN_FORM": "3"}, "XV_TN_FORM=3: expected 1, 2 or 4"),
                         ({"XV_SEGMENT_FUSED": "yes"}, "XV_SEGMENT_FUSED=yes: expected 0 or 1")):
         env = {k: v for k, v in os.environ.items() if not k.startswith("XV_")}
         env.update(extra)
@@ -92,4 +93,23 @@ def test_unknown_environment_switches_are_refused_by_name():
     env = {k: v for k, v in os.environ.items() if not k.startswith("XV_")}
     env.update(XV_NT_SCHED="dp", XV_PRECISION="f32", XV_SHARE_GPU="1")          # documented names pass the table (the call then fails later: no GPU here)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert "environment switch" not in out.stdout and "expected" not in out.stdout, out.stdout
+    assert "environment switch" not in out.stdout + out.stderr and "expected" not in out.stdout, (out.stdout, out.stderr[-500:])
+    env.update(XV_TN_WGS="768")                                                 # not a name of this package: named on stderr, not a failure
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "ignoring unknown environment switch XV_TN_WGS" in out.stderr and "environment switch" not in out.stdout, (out.stdout, out.stderr[-500:])
+
+
+def test_config_struct_size_is_checked():
+    """xv_config.struct_bytes (ABI version 2): a host built against another header's xv_config is refused at xv_engine_create instead of
+    having fields read from beyond its struct."""
+    import ctypes as C
+    from tf_kaldi_speaker_amd import _lib
+    lib = _lib.load()
+    assert lib.xv_abi_version() == _lib.ABI_VERSION == 2
+    cfg = _lib.XvConfig()
+    assert cfg.struct_bytes == C.sizeof(_lib.XvConfig)
+    cfg.feat_dim = 30
+    cfg.struct_bytes -= 4
+    h = C.c_void_p()
+    assert lib.xv_engine_create(C.byref(cfg), C.byref(h)) != 0
+    assert "struct_bytes" in lib.xv_last_error().decode()

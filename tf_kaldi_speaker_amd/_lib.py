@@ -18,9 +18,19 @@ class XvError(RuntimeError):
     pass
 
 
+# include/xvector_hip.h XV_ABI_VERSION: the layout of XvConfig below and the SIGNATURES table belong to this version
+ABI_VERSION = 2
+
+
 class XvConfig(C.Structure):
-    """Mirror of `struct xv_config` (include/xvector_hip.h)."""
+    """Mirror of `struct xv_config` (include/xvector_hip.h); struct_bytes is filled in on construction."""
+
+    def __init__(self, *args, **kw):
+        super(XvConfig, self).__init__(*args, **kw)
+        self.struct_bytes = C.sizeof(XvConfig)
+
     _fields_ = [
+        ("struct_bytes", C.c_int32),
         ("feat_dim", C.c_int32),
         ("num_speakers", C.c_int32),
         ("num_nodes_pooling_layer", C.c_int32),
@@ -203,8 +213,9 @@ def load():
         fn = getattr(lib, name)   # AttributeError here == ABI mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.xv_abi_version() != 1:
-        raise XvError("ABI version mismatch: library reports %d" % lib.xv_abi_version())
+    if lib.xv_abi_version() != ABI_VERSION:
+        raise XvError("ABI version mismatch: %s reports %d, this package binds version %d (stale build? run `make -C %s`)"
+                      % (LIB_PATH, lib.xv_abi_version(), ABI_VERSION, os.path.join(_HERE, "csrc")))
     _lib = lib
     return lib
 

@@ -41,13 +41,15 @@ void xv_set_error(const char* fmt, ...);
         }                                                                               \
     } while (0)
 
-// Environment switches of the native library: the few INTEGRATION.md section 6 documents, read once, value-checked.  xv_env() returns
-// null (xv_last_error says why) when a known switch holds a value it does not understand or an XV_* variable is set that nothing in this
-// package reads - a removed A/B switch must not be ignored silently.  Every entry point that consults a switch fails with that message.
+// Environment switches of the native library: the few INTEGRATION.md section 6 documents, read once (thread-safe), value-checked.
+// xv_env() returns null (xv_last_error says why) when a known switch holds a value it does not understand; an XV_* variable that nothing in
+// this package reads is named once on stderr and ignored (it may belong to another program).  Every entry point that consults a switch
+// fails with that message.
 struct XvEnv {
     int segment_fused;      // XV_SEGMENT_FUSED=0|1 (default 1): the segment-level layers as one launch each (xv_skinny.hip)
     int nt_sched;           // XV_NT_SCHED=dp|sk: force the schedule of the fp32 NT GEMM (0 = chosen per problem, 1 = dp, 2 = sk); diagnostics
     int conv_wr;            // XV_CONV_WR=4: 256-row tiles of the f16x3 context-window GEMM (kept parity-tested, off by default)
+    int tn_form;            // XV_TN_FORM=1|2|4: force the weight-gradient kernel's in-workgroup K split (0 = chosen per problem); diagnostics
 };
 const XvEnv* xv_env();
 

@@ -20,47 +20,64 @@ void xv_set_error(const char* fmt, ...) {
 }
 // ---- environment switches (xv_common.h XvEnv) -----------------------------------------------------------------------------------
 extern char** environ;
-const XvEnv* xv_env() {
-    static XvEnv env;
-    static int state = 0;      // 0 unread, 1 ok, 2 bad
-    static char why[256];
-    if (state == 0) {
-        // every XV_* name this package reads anywhere (native library, Python host, tools/, tests/): anything else is a typo or a switch
-        // of an earlier round and is refused by name
-        static const char* known[] = {"XV_SEGMENT_FUSED", "XV_NT_SCHED", "XV_CONV_WR", "XV_PRECISION", "XV_LOADER", "XV_LOADER_PIN", "XV_SHARE_GPU",
-                                      "XV_LIB", "XV_TUNE_TIMES", "XV_DATA_SCALE", "XV_B", "XV_PROBE_OPS", "XV_PROBE_ONLY", "XV_PROBE_PERIODS",
-                                      "XV_DIAG_M", "XV_DIAG_N", "XV_DIAG_K", "XV_DIAG_REPS"};
-        state = 1;
-        for (char** e = environ; e && *e && state == 1; ++e) {
-            if (strncmp(*e, "XV_", 3) != 0) continue;
-            const char* eq = strchr(*e, '=');
-            const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);
-            bool ok = false;
-            for (const char* k : known) ok = ok || (strlen(k) == len && strncmp(k, *e, len) == 0);
-            if (!ok) { snprintf(why, sizeof why, "unknown environment switch %.*s (INTEGRATION.md section 6 lists the supported ones)", (int)len, *e); state = 2; }
-        }
-        auto flag = [&](const char* name, int dflt, int* out) {
-            const char* v = getenv(name);
-            *out = dflt;
-            if (!v || !*v) return;
-            if (!strcmp(v, "0") || !strcmp(v, "1")) *out = v[0] - '0';
-            else if (state == 1) { snprintf(why, sizeof why, "%s=%s: expected 0 or 1", name, v); state = 2; }
-        };
-        flag("XV_SEGMENT_FUSED", 1, &env.segment_fused);
-        env.nt_sched = 0;
-        if (const char* v = getenv("XV_NT_SCHED")) {
-            if (!strcmp(v, "dp")) env.nt_sched = 1;
-            else if (!strcmp(v, "sk")) env.nt_sched = 2;
-            else if (*v && state == 1) { snprintf(why, sizeof why, "XV_NT_SCHED=%s: expected dp or sk", v); state = 2; }
-        }
-        env.conv_wr = 0;
-        if (const char* v = getenv("XV_CONV_WR")) {
-            if (!strcmp(v, "4")) env.conv_wr = 4;
-            else if (*v && strcmp(v, "2") && state == 1) { snprintf(why, sizeof why, "XV_CONV_WR=%s: expected 2 or 4", v); state = 2; }
-        }
+namespace {
+struct XvEnvState { XvEnv env; bool bad; char why[256]; };
+// Read once, on first use; a C++11 function-local static is initialised under a lock, so concurrent first calls (loader threads, two
+// engines created from two host threads) see one parse.
+XvEnvState xv_env_parse() {
+    XvEnvState st;
+    st.bad = false;
+    st.why[0] = 0;
+    XvEnv& env = st.env;
+    // every XV_* name this package reads anywhere (native library, Python host, tools/, tests/).  Any other XV_* variable is reported ONCE on
+    // stderr and otherwise ignored: it may be a typo or a switch of an earlier round (worth a line), but it may equally belong to another
+    // program in the user's environment, which must not stop a training run.  A known switch with a value it does not understand still fails.
+    static const char* known[] = {"XV_SEGMENT_FUSED", "XV_NT_SCHED", "XV_CONV_WR", "XV_PRECISION", "XV_LOADER", "XV_LOADER_PIN", "XV_SHARE_GPU",
+                                  "XV_LIB", "XV_TUNE_TIMES", "XV_DATA_SCALE", "XV_B", "XV_PROBE_OPS", "XV_PROBE_ONLY", "XV_PROBE_PERIODS",
+                                  "XV_DIAG_M", "XV_DIAG_N", "XV_DIAG_K", "XV_DIAG_REPS", "XV_DIAG_B", "XV_TN_FORM"};
+    for (char** e = environ; e && *e; ++e) {
+        if (strncmp(*e, "XV_", 3) != 0) continue;
+        const char* eq = strchr(*e, '=');
+        const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);
+        bool ok = false;
+        for (const char* k : known) ok = ok || (strlen(k) == len && strncmp(k, *e, len) == 0);
+        if (!ok) fprintf(stderr, "libxvector_hip: ignoring unknown environment switch %.*s (INTEGRATION.md section 6 lists the supported ones)\n", (int)len, *e);
     }
-    if (state == 2) { xv_set_error("%s", why); return nullptr; }
-    return &env;
+    auto fail = [&](const char* fmt, const char* name, const char* v) {
+        if (!st.bad) { snprintf(st.why, sizeof st.why, fmt, name, v); st.bad = true; }
+    };
+    auto flag = [&](const char* name, int dflt, int* out) {
+        const char* v = getenv(name);
+        *out = dflt;
+        if (!v || !*v) return;
+        if (!strcmp(v, "0") || !strcmp(v, "1")) *out = v[0] - '0';
+        else fail("%s=%s: expected 0 or 1", name, v);
+    };
+    flag("XV_SEGMENT_FUSED", 1, &env.segment_fused);
+    env.nt_sched = 0;
+    if (const char* v = getenv("XV_NT_SCHED")) {
+        if (!strcmp(v, "dp")) env.nt_sched = 1;
+        else if (!strcmp(v, "sk")) env.nt_sched = 2;
+        else if (*v) fail("%s=%s: expected dp or sk", "XV_NT_SCHED", v);
+    }
+    env.conv_wr = 0;
+    if (const char* v = getenv("XV_CONV_WR")) {
+        if (!strcmp(v, "4")) env.conv_wr = 4;
+        else if (*v && strcmp(v, "2")) fail("%s=%s: expected 2 or 4", "XV_CONV_WR", v);
+    }
+    env.tn_form = 0;
+    if (const char* v = getenv("XV_TN_FORM")) {
+        if (!strcmp(v, "1") || !strcmp(v, "2") || !strcmp(v, "4")) env.tn_form = v[0] - '0';
+        else if (*v) fail("%s=%s: expected 1, 2 or 4", "XV_TN_FORM", v);
+    }
+    return st;
+}
+}  // namespace
+
+const XvEnv* xv_env() {
+    static const XvEnvState st = xv_env_parse();
+    if (st.bad) { xv_set_error("%s", st.why); return nullptr; }
+    return &st.env;
 }
 
 extern "C" const char* xv_last_error(void) { return g_err; }

@@ -631,6 +631,9 @@ int bn_forward(xv_engine* e, hipStream_t s, Affine& a, int rows, bool stats_from
 extern "C" int xv_engine_create(const xv_config* cfg, xv_engine** out) {
     XV_REQUIRE(cfg && out, "engine_create: null argument");
     if (!xv_env()) return 2;      // an environment switch this library does not know, or a value it does not understand: refused by name
+    XV_REQUIRE(cfg->struct_bytes == (int32_t)sizeof(xv_config),
+               "engine_create: xv_config.struct_bytes is %d, this library's xv_config has %d bytes (ABI version %d): rebuild the host against include/xvector_hip.h",
+               cfg->struct_bytes, (int)sizeof(xv_config), XV_ABI_VERSION);
     XV_REQUIRE(cfg->feat_dim > 0, "engine_create: feat_dim must be positive");
     XV_REQUIRE(cfg->num_nodes_pooling_layer > 0 && cfg->num_nodes_pooling_layer % 4 == 0,
                "engine_create: num_nodes_pooling_layer must be a positive multiple of 4 (got %d)", cfg->num_nodes_pooling_layer);

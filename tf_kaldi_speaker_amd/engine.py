@@ -238,6 +238,14 @@ class Engine(object):
         _lib.check(self.lib.xv_engine_forward(self.h, _stream(), _ptr(x), int(b), int(t), int(bool(training))),
                    "xv_engine_forward")
 
+    @property
+    def min_frames(self):
+        """Receptive field of the frame-level stack: the fewest frames a chunk needs for one valid output frame (15 for the
+        reference's 5 / 5 / 7 / 1 / 1 contexts, model/tdnn.py:39-127)."""
+        c = self.config
+        ctx = [c.frame_context[i] for i in range(c.num_frame_layers)] if c.num_frame_layers else [5, 5, 7, 1, 1]
+        return 1 + sum(int(k) - 1 for k in ctx)
+
     def forward_lengths(self, features, frames):
         """Inference forward over utterances of different lengths (xv_engine_forward_lengths): features [b, t, d] with chunk i
         holding frames[i] valid frames followed by padding; pooling uses the valid part only."""
@@ -248,6 +256,12 @@ class Engine(object):
             raise ValueError("feature dim %d != %d" % (d, self.config.feat_dim))
         if n.numel() != b:
             raise ValueError("%d frame counts for %d chunks" % (n.numel(), b))
+        if not isinstance(frames, torch.Tensor) or not frames.is_cuda:
+            # host-side lengths are checked here (device-resident ones are the caller's: Trainer.predict_batch validates before the upload);
+            # the kernels clamp, so a bad length would give an embedding pooled over padding instead of an error
+            fh = np.asarray(frames.cpu() if isinstance(frames, torch.Tensor) else frames).reshape(-1)
+            if fh.size and (int(fh.min()) < self.min_frames or int(fh.max()) > t):
+                raise ValueError("forward_lengths: frame counts must lie in [%d, %d] (got %d..%d)" % (self.min_frames, t, int(fh.min()), int(fh.max())))
         self._keep = [x, n]
         _lib.check(self.lib.xv_engine_forward_lengths(self.h, _stream(), _ptr(x), int(b), int(t), _ptr(n)), "xv_engine_forward_lengths")
 

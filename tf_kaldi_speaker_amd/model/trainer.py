@@ -52,13 +52,23 @@ class _PendingEmbeddings(object):
     puts them into the caller's order."""
 
     def __init__(self, dev, inv):
-        self.dev, self.inv = dev, inv
+        # the read-back is enqueued NOW, behind this window's forward passes, into pinned memory, and an event marks its end: numpy()
+        # then waits for that event only.  (A dev.cpu() at read time queues behind whatever the caller has enqueued since - the next
+        # window's decode and forward passes in extract.py - so host post-processing and GPU work took turns; ADVICE round 4.)
+        self.inv = inv
+        self.host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+        self.host.copy_(dev, non_blocking=True)
+        self.done = torch.cuda.Event()
+        self.done.record(torch.cuda.current_stream(dev.device))
+        self.dev = dev          # (kept alive until the copy has run)
 
     def cpu(self):
         return self
 
     def numpy(self):
-        return self.dev.cpu().numpy()[self.inv]
+        self.done.synchronize()
+        self.dev = None
+        return self.host.numpy()[self.inv]
 
 SOFTMAX_FAMILY = ("softmax", "asoftmax", "additive_margin_softmax", "additive_angular_margin_softmax")
 OTHER_LOSSES = ("semihard_triplet_loss", "angular_triplet_loss", "generalized_angular_triplet_loss")
@@ -478,11 +488,26 @@ class Trainer(object):
         if n == 0:
             return np.zeros((0, 0), np.float32)
         lengths = [int(it.shape[0]) for it in items]
+        dim = self.dim
+        # every matrix must have the model's feature dimension: the GPU decoder takes the column stride from `dim`, not from the archive
+        # header, so a mismatch would decode garbage (and read past the record) instead of failing; predict() rejects it through
+        # Engine.forward, this is the same check for the batched path
+        for i, it in enumerate(items):
+            if len(it.shape) != 2 or int(it.shape[1]) != dim:
+                raise ValueError("predict_batch: item %d has shape %s, the model expects [frames, %d]" % (i, tuple(it.shape), dim))
+        # an utterance shorter than the network's receptive field has no valid output frame (predict() refuses it in Engine.forward; here the
+        # pooling would clamp to one frame that already sees zero padding); longer than max_frames cannot happen: the plan pads to the longest
+        min_frames = self.engine.min_frames
+        for i, t in enumerate(lengths):
+            if t < min_frames:
+                raise ValueError("predict_batch: item %d has %d frames, fewer than the network's receptive field (%d)" % (i, t, min_frames))
+        # the on-GPU 'CM ' decoder handles at most 128 feature dimensions (one lane per column header); wider archives go through the host codec
+        if dim > 128:
+            items = [it.decode() if isinstance(it, PackedMatrix) else it for it in items]
         node = self.params.embedding_node
         plan = plan_length_batches(lengths, self.PREDICT_ROWS, self.PREDICT_CHUNKS)
         self._ensure_capacity(max(len(idx) for idx, _ in plan), max(t for _, t in plan), rows=max(self.PREDICT_ROWS, max(len(idx) * t for idx, t in plan)))
         eng = self.engine
-        dim = self.dim
         outs = []
         # 'CM ' matrices stay where the reader cut them out: the archive blocks they are views of go to the GPU whole, once per call (a
         # quarter of the fp32 bytes, no per-batch gather on the host); a batch is then a list of byte offsets for the on-GPU decode
