@@ -28,6 +28,7 @@ __device__ __forceinline__ float key_act(float z, int act) { return act == 3 ? t
 // score[r] = scale * sum_c act(zk[r][c]) * q[c]; block = 4 waves = 4 rows
 __global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict__ zk, int rows, int n, long ldz, int act,
                                                         const float* __restrict__ q, float scale, float* __restrict__ score) {
+    XV_EW_PRIORITY();
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* z = zk + (long)row * ldz;
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict_
 // flen (batched extraction): chunk b has flen[b] - shrink valid frames; the padding behind them gets weight 0
 __global__ __launch_bounds__(256) void softmax_segments_kernel(const float* __restrict__ score, int t, float* __restrict__ w,
                                                                const int* __restrict__ flen, int shrink) {
+    XV_EW_PRIORITY();
     __shared__ float red[4];
     const float* s = score + (long)blockIdx.x * t;
     float* o = w + (long)blockIdx.x * t;
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(256) void softmax_segments_kernel(const float* __re
 // ds[b][t] = w (dw - sum_t' w dw)
 __global__ __launch_bounds__(256) void softmax_segments_bwd_kernel(const float* __restrict__ w, const float* __restrict__ dw, int t,
                                                                    float* __restrict__ ds) {
+    XV_EW_PRIORITY();
     __shared__ float red[4];
     const long base = (long)blockIdx.x * t;
     float z = 0.f;
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(256) void att_pool_dw_kernel(const float* __restric
                                                           const float* __restrict__ scale, const float* __restrict__ shift, int relu,
                                                           const float* __restrict__ pool, const float* __restrict__ dpool,
                                                           float* __restrict__ dw, const float* __restrict__ slope) {
+    XV_EW_PRIORITY();
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const int b = row / t;
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(256) void att_pool_dw_kernel(const float* __restric
 __global__ __launch_bounds__(256) void att_key_bwd_kernel(const float* __restrict__ zk, int rows, int n, int act,
                                                           const float* __restrict__ q, float scale, const float* __restrict__ ds,
                                                           float* __restrict__ dzk, float* __restrict__ part /* [chunks][2][n] */) {
+    XV_EW_PRIORITY();
     __shared__ f32x4 red[2][4][64];
     const int qx = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + qx) * 4;
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(256) void att_key_bwd_kernel(const float* __restric
 }
 
 __global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, size_t count4) {
+    XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (size_t)gridDim.x * blockDim.x) {
         f32x4 a = ((const f32x4*)y)[i], b = ((const f32x4*)x)[i];
         ((f32x4*)y)[i] = a + b;
@@ -223,6 +229,7 @@ extern "C" int xv_att_key_backward(void* stream, const float* zk, int rows, int 
 // endpoints of common.py's dense_relu / dense_tanh for callers of model.pooling.self_attention (the score kernels apply
 // the activation themselves and never need this tensor)
 __global__ __launch_bounds__(256) void key_activation_kernel(const float* __restrict__ z, size_t count, int act, float* __restrict__ y) {
+    XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) y[i] = key_act(z[i], act);
 }
 

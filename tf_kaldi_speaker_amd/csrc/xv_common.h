@@ -50,8 +50,28 @@ struct XvEnv {
     int nt_sched;           // XV_NT_SCHED=dp|sk: force the schedule of the fp32 NT GEMM (0 = chosen per problem, 1 = dp, 2 = sk); diagnostics
     int conv_wr;            // XV_CONV_WR=4: 256-row tiles of the f16x3 context-window GEMM (kept parity-tested, off by default)
     int tn_form;            // XV_TN_FORM=1|2|4: force the weight-gradient kernel's in-workgroup K split (0 = chosen per problem); diagnostics
+    int gemm_slots;         // XV_GEMM_SLOTS=3|3b: at most three fp32 GEMM workgroups per CU (an LDS pad), 3b: backward launches only; diagnostics (0 = four)
+    int tn_target;          // XV_TN_TARGET=n: workgroups a weight-gradient launch aims at (0 = one co-resident round); diagnostics
 };
 const XvEnv* xv_env();
+
+// Wave priority of the kernels that are NOT fp32-MFMA GEMMs (element-wise, reductions, the segment-level chain).  On gfx950 a vector
+// instruction and an fp32-input MFMA share one ALU (profiles/r04_valu_mfma_probe.txt) and the arbiter serves the highest priority, then the
+// OLDEST wave: beside a GEMM whose waves always have an MFMA ready, a younger element-wise wave at priority 0 issues only in the gaps -
+// such kernels ran 6-10 x slower beside the weight-gradient GEMM even with a free slot on every CU (profiles/r05_ew_priority.txt).  At
+// priority 3 their few vector instructions go first; the GEMM loses the cycles they take, nothing else.
+#ifndef XV_EW_PRIO
+#define XV_EW_PRIO 3
+#endif
+#if XV_EW_PRIO
+#define XV_EW_PRIORITY() __builtin_amdgcn_s_setprio(XV_EW_PRIO)
+#else
+#define XV_EW_PRIORITY() ((void)0)
+#endif
+// ... except the kernels that only fill a side stream with hours of slack (weight-layout copies and the loss head's weight preparation
+// beside the forward GEMMs, the loss head's weight gradient beside the first data gradient): at priority 3 they finished three times
+// sooner than anyone needs them and took 11 us from tdnn2's forward GEMM (profiles/r05_ew_priority.txt)
+#define XV_EW_FILLER() ((void)0)
 
 static inline int xv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t xv_align(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -34,7 +34,7 @@ XvEnvState xv_env_parse() {
     // program in the user's environment, which must not stop a training run.  A known switch with a value it does not understand still fails.
     static const char* known[] = {"XV_SEGMENT_FUSED", "XV_NT_SCHED", "XV_CONV_WR", "XV_PRECISION", "XV_LOADER", "XV_LOADER_PIN", "XV_SHARE_GPU",
                                   "XV_LIB", "XV_TUNE_TIMES", "XV_DATA_SCALE", "XV_B", "XV_PROBE_OPS", "XV_PROBE_ONLY", "XV_PROBE_PERIODS",
-                                  "XV_DIAG_M", "XV_DIAG_N", "XV_DIAG_K", "XV_DIAG_REPS", "XV_DIAG_B", "XV_TN_FORM"};
+                                  "XV_DIAG_M", "XV_DIAG_N", "XV_DIAG_K", "XV_DIAG_REPS", "XV_DIAG_B", "XV_TN_FORM", "XV_GEMM_SLOTS", "XV_TN_TARGET"};
     for (char** e = environ; e && *e; ++e) {
         if (strncmp(*e, "XV_", 3) != 0) continue;
         const char* eq = strchr(*e, '=');
@@ -69,6 +69,17 @@ XvEnvState xv_env_parse() {
     if (const char* v = getenv("XV_TN_FORM")) {
         if (!strcmp(v, "1") || !strcmp(v, "2") || !strcmp(v, "4")) env.tn_form = v[0] - '0';
         else if (*v) fail("%s=%s: expected 1, 2 or 4", "XV_TN_FORM", v);
+    }
+    env.gemm_slots = 0;
+    if (const char* v = getenv("XV_GEMM_SLOTS")) {
+        if (!strcmp(v, "3")) env.gemm_slots = 3;
+        else if (!strcmp(v, "3b")) env.gemm_slots = 2;
+        else if (*v && strcmp(v, "4")) fail("%s=%s: expected 3, 3b or 4", "XV_GEMM_SLOTS", v);
+    }
+    env.tn_target = 0;
+    if (const char* v = getenv("XV_TN_TARGET")) {
+        env.tn_target = atoi(v);
+        if (*v && (env.tn_target < 256 || env.tn_target > 8192)) fail("%s=%s: expected 256..8192", "XV_TN_TARGET", v);
     }
     return st;
 }
@@ -106,6 +117,7 @@ extern "C" int xv_copy_2d(void* stream, float* dst, size_t ldd, const float* src
 // layout prep
 // ------------------------------------------------------------------------------------
 __global__ void pad_channels_kernel(const float* __restrict__ src, long rows, int c_src, float* __restrict__ dst, int c_dst) {
+    XV_EW_FILLER();
     long total = rows * c_dst;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i / c_dst;
@@ -138,6 +150,7 @@ extern "C" int xv_pad_channels(void* stream, const float* src, int rows, int c_s
 __global__ __launch_bounds__(256) void cm_decode_kernel(const uint8_t* __restrict__ packed, long stride, int T, int D, float* __restrict__ out,
                                                         const long* __restrict__ offs, const int* __restrict__ rows, int hdr) {
 #pragma clang fp contract(off)
+    XV_EW_FILLER();
     __shared__ float prm[6][CMD_MAX_D];                  // p0, p25, p75, s_lo, s_mid, s_hi per column
     __shared__ uint8_t tile[CMD_MAX_D][CMD_TT + 4];
     const uint8_t* chunk = packed + (offs ? offs[blockIdx.x] : (long)blockIdx.x * stride);
@@ -209,6 +222,7 @@ extern "C" int xv_cm_decode_ragged(void* stream, const uint8_t* packed, const in
 // wt[o][j*c_pad + c] = kernel[(j*C + c)*O + o], zero for c >= C.  32x32 LDS-tiled transpose:
 // reads run along o (contiguous in kernel), writes run along the padded k axis (contiguous in wt).
 __global__ void prep_weight_fwd_kernel(const float* __restrict__ w, int k, int C, int O, float* __restrict__ wt, int c_pad) {
+    XV_EW_FILLER();
     __shared__ float tile[32][33];
     const int kp = k * c_pad;
     const int kk0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
@@ -238,6 +252,7 @@ extern "C" int xv_prep_weight_fwd(void* stream, const float* kernel, int k, int 
 }
 
 __global__ void prep_weight_dgrad_kernel(const float* __restrict__ w, int k, int C, int O, float* __restrict__ wf) {
+    XV_EW_FILLER();
     long total = (long)k * C * O;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int o = (int)(i % O);
@@ -259,6 +274,7 @@ extern "C" int xv_prep_weight_dgrad(void* stream, const float* kernel, int k, in
 // multi-job weight preparation (xv_common.h): one launch for every layout copy of every layer
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void weight_prep_multi_kernel(XvPrepJobs J) {
+    XV_EW_FILLER();
     __shared__ float tile[32][33];
     int ji = 0;
 #pragma unroll 1
@@ -350,6 +366,7 @@ int xv_launch_weight_prep(hipStream_t s, const XvPrepJobs& J) {
 
 // max |x| of up to 8 tensors in one launch: blockIdx.y = tensor, one atomicMax per workgroup (slots zeroed by the caller)
 __global__ __launch_bounds__(256) void amax_multi_kernel(XvAmaxJobs J) {
+    XV_EW_FILLER();
     __shared__ float red[4];
     const float* x = J.x[blockIdx.y];
     const size_t count = J.count[blockIdx.y];
@@ -381,6 +398,7 @@ int xv_launch_amax_multi(hipStream_t s, const XvAmaxJobs& J) {
 // block = 256 threads = 64 columns x 4 row lanes; row lanes are combined in a fixed order
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, int rows, int n, long lda,
                                                              float* __restrict__ part) {
+    XV_EW_PRIORITY();
     __shared__ float red[4][64];
     const int cx = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cx;
@@ -401,6 +419,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 }
 // block = 256 threads = 32 columns x 8 chunk lanes
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ out) {
+    XV_EW_PRIORITY();
     __shared__ float red[8][32];
     const int cx = threadIdx.x & 31, cl = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + cx;
@@ -434,6 +453,7 @@ extern "C" int xv_colsum(void* stream, const float* a, int rows, int n, int lda,
 // squares centred on the tile mean) with fixed-order combines through LDS.  Output layout: xv_epilogue.h.
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ z, int rows, int n, long ldz,
                                                         float* __restrict__ part, int tiles) {
+    XV_EW_PRIORITY();
     __shared__ float red[8][32], rmin[8][32], rmax[8][32];
     __shared__ float s_mean[32];
     const int cx = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -485,6 +505,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
 // form above: 128 bytes per row, every element read twice - 0.24-0.30 of the HBM rate in round 2).  Same fixed-order combines.
 __global__ __launch_bounds__(256) void col_stats4_kernel(const float* __restrict__ z, int rows, int n, long ldz, float* __restrict__ part,
                                                          int tiles) {
+    XV_EW_PRIORITY();
     __shared__ f32x4 red[8][32], rmin[8][32], rmax[8][32];
     __shared__ f32x4 s_mean[32];
     const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -605,6 +626,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ shift_o, float* __restrict__ zmin_o,
                                                           float* __restrict__ zmax_o, unsigned* __restrict__ amax_o, int relu,
                                                           const float* __restrict__ slope) {
+    XV_EW_PRIORITY();
     __shared__ double s_cnt[FIN_LANES][FIN_CH], s_mean[FIN_LANES][FIN_CH], s_m2[FIN_LANES][FIN_CH];
     __shared__ float s_mn[FIN_LANES][FIN_CH], s_mx[FIN_LANES][FIN_CH];
     const int cx = threadIdx.x & (FIN_CH - 1), tl = threadIdx.x / FIN_CH;
@@ -704,6 +726,7 @@ extern "C" int xv_bn_finalize(void* stream, const float* bn_part, int rows, int 
 __global__ void bn_output_range_kernel(const float* __restrict__ part, int rows, int n, int tiles, const float* __restrict__ scale,
                                        const float* __restrict__ shift, int relu, float* __restrict__ zmin_o,
                                        float* __restrict__ zmax_o, unsigned* __restrict__ amax_o, const float* __restrict__ slope) {
+    XV_EW_PRIORITY();
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     float mn = INFINITY, mx = -INFINITY;
@@ -731,6 +754,7 @@ extern "C" int xv_bn_output_range(void* stream, const float* bn_part, int rows, 
 __global__ void bn_inference_scale_kernel(int n, const float* __restrict__ gamma, const float* __restrict__ beta,
                                           const float* __restrict__ mmean, const float* __restrict__ mvar, float eps,
                                           float* __restrict__ scale, float* __restrict__ shift) {
+    XV_EW_PRIORITY();
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     float sc = gamma[c] * (1.0f / sqrtf(mvar[c] + eps));
@@ -754,6 +778,7 @@ extern "C" int xv_bn_inference_scale(void* stream, int n, const float* gamma, co
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, int rows, int nq, long ldz, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int relu, float* __restrict__ a, long lda,
                                                        const float* __restrict__ slope) {
+    XV_EW_PRIORITY();
     const int q = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     if (q >= nq) return;
     const f32x4 sc = *(const f32x4*)(scale + 4 * q), sh = *(const f32x4*)(shift + 4 * q);
@@ -849,6 +874,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ shift, int relu,
                                                             float* __restrict__ part /* [chunks][nstat][n]: sum dy, sum dy*xhat, max |dy| (, sum d act*min(y,0)) */,
                                                             const float* __restrict__ slope, int nstat) {
+    XV_EW_PRIORITY();
     __shared__ f32x4 red[4][4][64];
     const int qx = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + qx) * 4;
@@ -910,6 +936,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(PoolGrad pg, 
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    float* __restrict__ part /* [chunks * nsub][nstat][n] */,
                                                                    const float* __restrict__ slope, int nstat) {
+    XV_EW_PRIORITY();
     __shared__ f32x4 red[4][4][64];
     const int qx = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + qx) * 4;
@@ -1000,6 +1027,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               float* __restrict__ dbias, const float* __restrict__ mean,
                                                               const float* __restrict__ zmin, const float* __restrict__ zmax,
                                                               unsigned* __restrict__ dz_amax, int nstat, float* __restrict__ dalpha) {
+    XV_EW_PRIORITY();
     __shared__ float r1[FIN_LANES][FIN_CH], r2[FIN_LANES][FIN_CH], r3[FIN_LANES][FIN_CH], r4[FIN_LANES][FIN_CH];
     const int cx = threadIdx.x & (FIN_CH - 1), cl = threadIdx.x / FIN_CH;
     const int c = blockIdx.x * FIN_CH + cx;
@@ -1056,6 +1084,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ coef, int relu, int pad,
                                                            float* __restrict__ dz, const float* __restrict__ slope) {
+    XV_EW_PRIORITY();
     const int tp = t + 2 * pad;
     const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int rl = threadIdx.x >> 6;
@@ -1111,6 +1140,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dense_kernel(const float* __
                                                                  const float* __restrict__ invstd, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, const float* __restrict__ coef, int relu,
                                                                  float* __restrict__ dz, const float* __restrict__ slope) {
+    XV_EW_PRIORITY();
     constexpr int NR = BAF_ROWS / 4;
     const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int rl = threadIdx.x >> 6;
@@ -1211,6 +1241,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split_kernel(const float* __
                                                                  const float* __restrict__ coef, int relu, int pad,
                                                                  const unsigned* __restrict__ amax, unsigned short* __restrict__ dst,
                                                                  long ldd, long plane_stride, const float* __restrict__ slope) {
+    XV_EW_PRIORITY();
     const float s = xv_pow2_scale(*amax);
     const int tp = t + 2 * pad;
     const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 8;
@@ -1297,6 +1328,7 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_stats_kernel(PoolGrad pg, i
                                                                   float* __restrict__ coef, float* __restrict__ dbias,
                                                                   const float* __restrict__ zmin, const float* __restrict__ zmax,
                                                                   unsigned* __restrict__ dz_amax) {
+    XV_EW_PRIORITY();
     __shared__ f32x4 r1[PS_LANES][PS_QUADS], r2[PS_LANES][PS_QUADS], r3[PS_LANES][PS_QUADS];
     const int cq = threadIdx.x & (PS_QUADS - 1), bl = threadIdx.x / PS_QUADS;
     const int col = (blockIdx.x * PS_QUADS + cq) * 4;
@@ -1550,6 +1582,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
                                                            float* __restrict__ invstd_o, float* __restrict__ scale_o,
                                                            float* __restrict__ shift_o, int relu, float* __restrict__ a,
                                                            const float* __restrict__ slope) {
+    XV_EW_PRIORITY();
     __shared__ float red[16][16];
     const int cx = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
@@ -1595,6 +1628,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ dbias, const float* __restrict__ slope,
                                                            float* __restrict__ dalpha) {
+    XV_EW_PRIORITY();
     __shared__ float red[16][16];
     const int cx = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
@@ -1639,6 +1673,7 @@ int xv_bn_small_backward(hipStream_t s, const float* da, const float* z, int row
 }
 
 __global__ void relu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ a, size_t count, float* __restrict__ dz) {
+    XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
         dz[i] = a[i] > 0.f ? da[i] : 0.f;
 }
@@ -1646,6 +1681,7 @@ __global__ void relu_bwd_kernel(const float* __restrict__ da, const float* __res
 __global__ __launch_bounds__(256) void act_small_kernel(const float* __restrict__ da, const float* __restrict__ z, int rows, int n,
                                                         const float* __restrict__ slope, float* __restrict__ out,
                                                         float* __restrict__ dalpha) {
+    XV_EW_PRIORITY();
     __shared__ float red[16][16];
     const int cx = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
@@ -1677,6 +1713,7 @@ int xv_act_small(hipStream_t s, const float* da, const float* z, int rows, int n
 
 // y[r][c] = x > 0 ? x : alpha[c] * x  (common.py:27-42 prelu = relu(x) + alpha (x - |x|) / 2; a constant alpha = leaky ReLU)
 __global__ void prelu_fwd_kernel(const float* __restrict__ x, size_t count, int n, const float* __restrict__ alpha, float* __restrict__ y) {
+    XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) y[i] = act1(x[i], alpha[i % n]);
 }
 extern "C" int xv_prelu_forward(void* stream, const float* x, int rows, int n, const float* alpha, float* y) {
@@ -1723,6 +1760,7 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
                                                             float* __restrict__ out, const float* __restrict__ slope,
                                                             float* __restrict__ wpos, float* __restrict__ amax_o,
                                                             const int* __restrict__ flen, int shrink) {
+    XV_EW_PRIORITY();
     __shared__ f32x4 s_mean[4][64], s_m2[4][64], s_wp[4][64], s_mx[4][64];
     __shared__ float s_n[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1845,6 +1883,7 @@ extern "C" int xv_stat_pool_forward_bn(void* stream, const float* z, int b, int 
 
 __global__ void stat_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ out, const float* __restrict__ dout,
                                      int T, int cq, float* __restrict__ dx, long total) {
+    XV_EW_PRIORITY();
     const int C = cq * 4;
     const float invT = 1.f / (float)T;
     const float sd_eps = sqrtf(1e-12f);
@@ -1883,6 +1922,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __global__ void l2_scaling_fwd_kernel(const float* __restrict__ x, int rows, int n, float factor, float* __restrict__ y) {
+    XV_EW_PRIORITY();
     int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (long)row * n;
@@ -1894,6 +1934,7 @@ __global__ void l2_scaling_fwd_kernel(const float* __restrict__ x, int rows, int
 }
 __global__ void l2_scaling_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int rows, int n, float factor,
                                       float* __restrict__ dx) {
+    XV_EW_PRIORITY();
     int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (long)row * n;
@@ -1923,6 +1964,7 @@ extern "C" int xv_l2_scaling_backward(void* stream, const float* x, const float*
 // scalar reductions (reporting / clip-by-global-norm only) and optimisers
 // ------------------------------------------------------------------------------------
 __global__ void sumsq_kernel(const float* __restrict__ w, size_t count, float scale, float* __restrict__ out) {
+    XV_EW_PRIORITY();
     __shared__ float red[4];
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) s += w[i] * w[i];
@@ -1945,11 +1987,13 @@ extern "C" int xv_sumsq(void* stream, const float* g, size_t count, float* out_a
 }
 
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, size_t count, float lr, float gs) {
+    XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
         p[i] = p[i] - lr * (g[i] * gs);
 }
 __global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc, size_t count, float lr,
                                 float mom, int nesterov, float gs) {
+    XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
         float gi = g[i] * gs;
         float a = mom * acc[i] + gi;
@@ -1959,6 +2003,7 @@ __global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             size_t count, float lr_t, float b1, float b2, float eps, float gs) {
+    XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
         float gi = g[i] * gs;
         float mi = b1 * m[i] + (1.f - b1) * gi;

@@ -92,6 +92,14 @@ static int ensure_zero_page(size_t floats = XV_ZERO_PAGE_FLOATS) {
 }
 const float* xv_zero_page(size_t floats) { return ensure_zero_page(floats) ? nullptr : g_zero_page; }
 
+// Dynamic LDS added to a GEMM launch so that at most three of these workgroups fit a CU (3 x 42 KB <= 160 KB < 4 x 42 KB): the fourth wave slot
+// of every SIMD, 128 VGPRs and 34 KB of LDS then stay open for the element-wise kernels of the other stream (XV_GEMM_SLOTS; diagnostics)
+static unsigned xv_gemm_lds_pad(bool backward) {
+    const XvEnv* env = xv_env();
+    if (!env || !env->gemm_slots) return 0;
+    return (env->gemm_slots == 3 || backward) ? 10 * 1024 : 0;
+}
+
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     // blocks b and b+8 share an XCD (round-robin dispatch): hand each XCD a contiguous run of
     // tiles so the n-tiles of one m-tile (same A rows) and neighbouring m-tiles (overlapping
@@ -606,6 +614,7 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
 // out[m][n] = sum_z slab[z][m][n] (+ bias[n])
 __global__ void xv_splitk_reduce_kernel(const float* __restrict__ slab, int splits, long split_stride, int M, int N,
                                         int lds, const float* __restrict__ bias, float* __restrict__ out, long ldo) {
+    XV_EW_PRIORITY();
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = (long)M * N;
     for (; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -797,8 +806,8 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
             q.tickets = shared_tiles ? tn_tickets_for(s) : nullptr;
             XV_REQUIRE(!shared_tiles || (q.tickets && ((uintptr_t)q.slab % 16) == 0), "gemm_nt: hand-over buffers unavailable");
             XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
-            if (g.bn_part) hipLaunchKernelGGL(xv_gemm_nt_sk_kernel<true>, dim3(q.P), dim3(256), 0, s, q);
-            else hipLaunchKernelGGL(xv_gemm_nt_sk_kernel<false>, dim3(q.P), dim3(256), 0, s, q);
+            if (g.bn_part) hipLaunchKernelGGL(xv_gemm_nt_sk_kernel<true>, dim3(q.P), dim3(256), xv_gemm_lds_pad(false), s, q);
+            else hipLaunchKernelGGL(xv_gemm_nt_sk_kernel<false>, dim3(q.P), dim3(256), xv_gemm_lds_pad(g.co_running != 0), s, q);
             XV_LAUNCH_CHECK();
             return 0;
         }
@@ -833,9 +842,9 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
         if (g.bn_part) {
             p.part_sum = g.bn_part;
             p.part_m2 = nullptr;
-            hipLaunchKernelGGL(xv_gemm_nt_kernel<true>, grid, dim3(256), 0, s, p);
+            hipLaunchKernelGGL(xv_gemm_nt_kernel<true>, grid, dim3(256), xv_gemm_lds_pad(false), s, p);
         } else {
-            hipLaunchKernelGGL(xv_gemm_nt_kernel<false>, grid, dim3(256), 0, s, p);
+            hipLaunchKernelGGL(xv_gemm_nt_kernel<false>, grid, dim3(256), xv_gemm_lds_pad(g.co_running != 0), s, p);
         }
         XV_LAUNCH_CHECK();
         return 0;
@@ -877,16 +886,30 @@ struct TNArgs {
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef XV_TN_FORM_DEFAULT
+#define XV_TN_FORM_DEFAULT 1      // wave groups per weight-gradient workgroup unless XV_TN_FORM says otherwise (xv_tn_plan)
+#endif
 
 // LDS image [r][128] (output index contiguous, exactly as it sits in HBM: no transpose).
 // Fragment reads are ds_read_b64: lane i of a lane-half takes output rows 2i and 2i+1 of the
 // wave's 64 at reduction row r = 2*ks + half, which feed the two 32x32 accumulators in that
 // direction (the MFMA only needs A and B to agree on r).  So accumulator (a,b) register reg of
 // lane l holds  m = m0 + wr*64 + 2*row(reg,l) + a,  n = n0 + wc*64 + 2*(l&31) + b.
-__global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(128))) void xv_gemm_tn_kernel(TNArgs p) {
+//
+// G = wave groups per workgroup (256 G threads).  Every group is what a whole workgroup is at G = 1 - four waves on one 128 x 128 tile with
+// a double-buffered 32 KB LDS image of their own - and the G groups of a workgroup take G consecutive reduction chunks of the SAME tile.
+// After the K loop they add their accumulators through the (then idle) LDS, ((g0 + g2) + (g1 + g3)) - a fixed association - and group 0
+// alone stores the slab: 1 / G of the slab bytes written here and read back by xv_wgrad_reduce_kernel.  The workgroup barrier of a K-step
+// spans all groups; in the two-steps-ahead form it sits in mid-step, where every wave still holds sixteen MFMAs' worth of fragments.
 #define XV_TN_STAGES 2
-    __shared__ __attribute__((aligned(16))) float smem[XV_TN_STAGES * 2 * BK * BM];   // [slot][A|B][BK][128]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <int G>
+__global__ __launch_bounds__(256 * G, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(128))) void xv_gemm_tn_kernel(TNArgs p) {
+    constexpr int GRP = XV_TN_STAGES * 2 * BK * BM;      // floats of one group's image: [slot][A|B][BK][128]
+    __shared__ __attribute__((aligned(16))) float smem_all[G * GRP];
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int uwave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int grp = G == 1 ? 0 : uwave_all >> 2;         // (wave-uniform)
+    float* smem = smem_all + grp * GRP;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
@@ -898,14 +921,16 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     const int split = v / tiles, t = v - split * tiles;
     const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int r_begin = split * p.r_chunk;
+    const int r_begin = (split * G + grp) * p.r_chunk;
     const int r_end = min(p.R, r_begin + p.r_chunk);
-    const int nk = (r_end - r_begin + BK - 1) / BK;
+    const int nk = max(0, (r_end - r_begin + BK - 1) / BK);
+    // K-steps of the workgroup's loop = group 0's (the largest: only the last chunk of the reduction can be short or empty)
+    const int nk_wg = G == 1 ? nk : (min(p.R, split * G * p.r_chunk + p.r_chunk) - split * G * p.r_chunk + BK - 1) / BK;
 
     // LDS-DMA staging: one wave-instruction = 1 KiB = two whole [r][128] rows of the image; lane l lands on
     // row 2*(RPT*wave+i) + l/32, columns 4*(l%32)..+3.  The reduction-row -> address map (spliced view)
     // is evaluated per lane without an integer divide (r < 2^24, float quotient off by <= 1).
-    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int uwave = uwave_all & 3;
     const int lc = (lane & 31) * 4;
     const bool a_cv = (m0 + lc) < p.M, b_cv = (n0 + lc) < p.N;
     const float* __restrict__ zp = p.zero;
@@ -928,40 +953,55 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
             xv_dma16_ptr(pb, sb + 2 * i * BN);
         }
     };
-    // Full K-steps (every row below r_end): scalar bases + 32-bit lane offsets (xv_dma16) that ADVANCE by BK rows per step - a row of the
-    // spliced view is (segment, frame): frame += BK, and on crossing the segment's last frame the offset also skips the rows between two
-    // segments.  (The first build resolved row -> (segment, frame) -> 64-bit address from scratch for every K-step: ~40 VALU instructions
-    // per wave and step beside the MFMAs.)  Columns outside the matrix read column 0: their products are never stored.
+    // Full K-steps (every row below r_end): the K-step's first row r0 is resolved to (segment, frame) in SCALAR registers and advanced
+    // there - frame += BK, and on crossing the segment's last frame the base also skips the rows between two segments; a lane adds its
+    // constant offset (its row j of the 16, its four columns), taken from the "next segment" copy when frame + j lies beyond the segment:
+    // one compare and two selects per DMA pair.  (The first build resolved row -> (segment, frame) -> 64-bit address from scratch for every
+    // K-step: ~40 vector instructions per wave and step; rounds 1-4 advanced per-lane offsets: 14 - and a vector instruction takes its ALU
+    // cycles from the fp32 MFMAs.)  Columns outside the matrix read column 0: their products are never stored.
     const bool steady = p.rps >= BK;      // at most one segment boundary per step
-    int tt_i[TN_RPT];
-    unsigned aoff[TN_RPT], boff[TN_RPT];
-#pragma unroll
-    for (int i = 0; i < TN_RPT; ++i) {
-        const int r = min(r_begin + 2 * (TN_RPT * wave + i) + (lane >> 5), p.R - 1);
-        const int seg = r / p.rps;
-        tt_i[i] = r - seg * p.rps;
-        aoff[i] = (unsigned)((((long)seg * p.a_pitch + tt_i[i]) * p.lda + (a_cv ? m0 + lc : 0)) * 4);
-        boff[i] = (unsigned)((((long)seg * p.b_pitch + tt_i[i]) * p.ldb + (b_cv ? n0 + lc : 0)) * 4);
-    }
+    int jrow[TN_RPT];
+    unsigned aoff[TN_RPT], boff[TN_RPT], aoff_w[TN_RPT], boff_w[TN_RPT];
     const unsigned a_step = (unsigned)(BK * p.lda * 4), b_step = (unsigned)(BK * p.ldb * 4);
     const unsigned a_skip = (unsigned)((long)(p.a_pitch - p.rps) * p.lda * 4), b_skip = (unsigned)((long)(p.b_pitch - p.rps) * p.ldb * 4);
+#pragma unroll
+    for (int i = 0; i < TN_RPT; ++i) {
+        jrow[i] = 2 * (TN_RPT * wave + i) + (lane >> 5);
+        aoff[i] = (unsigned)(((long)jrow[i] * p.lda + (a_cv ? m0 + lc : 0)) * 4);
+        boff[i] = (unsigned)(((long)jrow[i] * p.ldb + (b_cv ? n0 + lc : 0)) * 4);
+        aoff_w[i] = aoff[i] + a_skip;
+        boff_w[i] = boff[i] + b_skip;
+    }
+    // scalar state of the next K-step to stage: frame of its first row within its segment, byte offsets of that row in A and B
+    int s_tt;
+    unsigned s_a, s_b;
+    {
+        const int r0 = __builtin_amdgcn_readfirstlane(min(r_begin, p.R - 1));
+        const int seg0 = r0 / p.rps;
+        s_tt = r0 - seg0 * p.rps;
+        s_a = (unsigned)(((long)seg0 * p.a_pitch + s_tt) * p.lda * 4);
+        s_b = (unsigned)(((long)seg0 * p.b_pitch + s_tt) * p.ldb * 4);
+    }
     const unsigned lds0 = xv_lds_addr(smem + 2 * TN_RPT * uwave * BM);
     auto gstage = [&](int kt, int buf) {
         if (!steady || r_begin + (kt + 1) * BK > r_end) {
             gstage_ragged(kt, buf);
             return;
         }
-        // (kt counts up by one per call, so the offsets are at step kt here)
+        // (kt counts up by one per call, so the scalar state is at step kt here)
+        const float* sa = (const float*)((const char*)p.A + s_a);
+        const float* sb = (const float*)((const char*)p.B + s_b);
+        const int thr = p.rps - s_tt;      // rows j >= thr of this K-step belong to the next segment
 #pragma unroll
         for (int i = 0; i < TN_RPT; ++i) {
-            xv_dma16(p.A, aoff[i], lds0 + (buf * (2 * BK * BM) + 2 * i * BM) * 4);
-            xv_dma16(p.B, boff[i], lds0 + (buf * (2 * BK * BM) + BK * BM + 2 * i * BN) * 4);
-            tt_i[i] += BK;
-            const bool wrap = tt_i[i] >= p.rps;
-            tt_i[i] -= wrap ? p.rps : 0;
-            aoff[i] += a_step + (wrap ? a_skip : 0u);
-            boff[i] += b_step + (wrap ? b_skip : 0u);
+            const bool w = jrow[i] >= thr;
+            xv_dma16(sa, w ? aoff_w[i] : aoff[i], lds0 + (buf * (2 * BK * BM) + 2 * i * BM) * 4);
+            xv_dma16(sb, w ? boff_w[i] : boff[i], lds0 + (buf * (2 * BK * BM) + BK * BM + 2 * i * BN) * 4);
         }
+        s_tt += BK;
+        s_a += a_step;
+        s_b += b_step;
+        if (s_tt >= p.rps) { s_tt -= p.rps; s_a += a_skip; s_b += b_skip; }
     };
 
     f32x16 acc[2][2];
@@ -978,39 +1018,40 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     // wait for the DMA of stage kt + 1, the workgroup barrier (every wave has read stage kt: its slot is free; stage kt + 1 is visible),
     // the DMA of stage kt + 2 into the slot just freed, and the other sixteen MFMAs: a stage's loads have a whole K-step to land.
     // sched_barrier pins the order.  Plain: the DMA of stage kt + 1 at the top of step kt, wait + barrier where hipcc puts them (right
-    // behind the fragment reads - the last MEMORY operations of the step - i.e. in front of all 32 MFMAs).
-    // [measured, round 3, weight gradients incl. slab sum at S1] AHEAD wins on long runs of K-steps per workgroup and loses on short ones:
-    // tdnn2 / tdnn3 (128 / 166 K-steps) 514 -> 505 / 661 -> 648 us, tdnn5 / tdnn4 (71 / 24) 322 -> 341 / 129 -> 138 us - the launcher
-    // chooses per problem (TNArgs::ahead).
+    // behind the fragment reads - the last MEMORY operations of the step - i.e. in front of all 32 MFMAs).  The launcher chooses per
+    // problem (TNArgs::ahead).
     if (nk > 0) gstage(0, 0);
     xv_dma_wait_all();      // (the compiler does not see xv_dma16's loads)
     __syncthreads();
     auto k_loop = [&](auto ahead_c) {
         constexpr bool AHEAD = decltype(ahead_c)::value;
         if (AHEAD && nk > 1) gstage(1, 1);
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = 0; kt < nk_wg; ++kt) {
             const int buf = kt & 1;
+            const bool live = G == 1 || kt < nk;      // (wave-uniform) a short last chunk: its group only keeps the barriers
             if (!AHEAD && kt + 1 < nk) gstage(kt + 1, buf ^ 1);
             const float* sa = smem + buf * (2 * BK * BM) + a_off;
             const float* sb = smem + buf * (2 * BK * BM) + BK * BM + b_off;
             f32x2 af[BK / 4], bf[BK / 4], an[BK / 4], bn[BK / 4];
+            if (live) {
 #pragma unroll
-            for (int j = 0; j < BK / 4; ++j) {
-                af[j] = *(const f32x2*)(sa + 2 * j * BM);
-                bf[j] = *(const f32x2*)(sb + 2 * j * BN);
-            }
+                for (int j = 0; j < BK / 4; ++j) {
+                    af[j] = *(const f32x2*)(sa + 2 * j * BM);
+                    bf[j] = *(const f32x2*)(sb + 2 * j * BN);
+                }
 #pragma unroll
-            for (int j = 0; j < BK / 4; ++j) {
-                an[j] = *(const f32x2*)(sa + 2 * (BK / 4 + j) * BM);
-                bn[j] = *(const f32x2*)(sb + 2 * (BK / 4 + j) * BN);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < BK / 4; ++j) {
+                    an[j] = *(const f32x2*)(sa + 2 * (BK / 4 + j) * BM);
+                    bn[j] = *(const f32x2*)(sb + 2 * (BK / 4 + j) * BN);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < BK / 4; ++j) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].y, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].x, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[1][1], 0, 0, 0);
+                for (int j = 0; j < BK / 4; ++j) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].y, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].x, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[1][1], 0, 0, 0);
+                }
             }
             if (AHEAD) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -1019,12 +1060,14 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
                 if (kt + 2 < nk) gstage(kt + 2, buf);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (live) {
 #pragma unroll
-            for (int j = 0; j < BK / 4; ++j) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].x, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].y, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].x, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].y, acc[1][1], 0, 0, 0);
+                for (int j = 0; j < BK / 4; ++j) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].x, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].y, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].x, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].y, acc[1][1], 0, 0, 0);
+                }
             }
             if (!AHEAD) {
                 xv_dma_wait_all();
@@ -1035,10 +1078,38 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     if (p.ahead) k_loop(std::true_type{});
     else k_loop(std::false_type{});
 
-    // [measured, round 3] summing the split partials inside this kernel - the workgroup that finishes a tile last adds the slabs of the
-    // others (ticket hand-over as in xv_gemm_nt_sk_kernel) - was built and dropped: ONE workgroup then reads splits x 64 KB at the ~65 GB/s
-    // a single workgroup gets, serially, at the very end of the launch: tdnn2 / tdnn4 / tdnn5 weight gradients 547 -> 630, 127 -> 279,
-    // 323 -> 413 us (12 / 64 / 21 splits).  The separate slab-sum launch spreads the same bytes over every CU.
+    if (G > 1) {
+        // in-workgroup sum of the groups' partial tiles through LDS (every stage has been read: the loop ends behind a barrier).  Image of one
+        // group's tile: [register r][thread] float4 = (acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]) = 64 KB, lane-linear 16-byte
+        // accesses (no bank conflicts).  Group g + half hands its tile to group g through image g in the first round and through image g + half
+        // afterwards: that is the image group g + half itself read in the round before, and a lane only ever touches its own addresses, so no
+        // group writes an image another group may still be reading.
+        f32x4* img = (f32x4*)smem_all;
+#pragma unroll
+        for (int half = G / 2; half >= 1; half /= 2) {
+            const int first = half == G / 2 ? 0 : half;      // image of the pair (0, half); pair (g, g + half) uses image first + g
+            if (grp >= half && grp < 2 * half) {
+                f32x4* dst = img + (first + grp - half) * (16 * 256) + tid;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 x = {acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]};
+                    dst[r * 256] = x;
+                }
+            }
+            __syncthreads();
+            if (grp < half) {
+                const f32x4* src = img + (first + grp) * (16 * 256) + tid;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 x = src[r * 256];
+                    acc[0][0][r] += x[0]; acc[0][1][r] += x[1]; acc[1][0][r] += x[2]; acc[1][1][r] += x[3];
+                }
+            }
+        }
+        if (grp != 0) return;
+    }
+    // (Summing the split partials of DIFFERENT workgroups inside this kernel - the last arrival adds the others' slabs - was built and dropped in
+    // round 3: one workgroup reads splits x 64 KB serially at the end of the launch; DESIGN.md Appendix A.)
     float* P = p.P + (long)split * p.M * p.N;
     const int n = n0 + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
 #pragma unroll
@@ -1186,42 +1257,34 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_tn160_kernel(TNArgs p) {
 
 static bool tn_wide_rows(int M) { return M > BM && M <= TNW_M; }
 
-int xv_tn_splits(int M, int N, int R) {
-    int tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
-    int ksteps = xv_cdiv(R, BK);
+// Decomposition of a weight-gradient GEMM: `form` wave groups per workgroup (the kernel's G), `splits` slabs (workgroups per tile), `chunk`
+// reduction rows per group.  One co-resident round: XV_WGS_PER_CU (4) 256-thread workgroups fit a CU (LDS 32 KB, 128 VGPRs each), i.e. 1 024 / G
+// workgroups of G groups - more costs a second round (2 x on the first build), fewer leaves matrix pipes idle.  The history of this choice
+// (768 / 896 workgroups, an even schedule, unsplit segment-level gradients, tdnn1 as 128 ... 512 workgroups) is DESIGN.md Appendix A.
+struct XvTnPlan { int form, splits, chunk; };
+static XvTnPlan xv_tn_plan(int M, int N, int R) {
+    const int tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
+    const int ksteps = xv_cdiv(R, BK);
+    XvTnPlan pl = {1, 1, 0};
     if (tn_wide_rows(M)) {      // xv_gemm_tn160_kernel: one round of 512 workgroups (2 per CU), at least 4 K-steps each
-        int splits = std::max(1, std::min(TNW_WGS / xv_cdiv(N, BN), ksteps / 4));
-        return xv_cdiv(R, xv_cdiv(ksteps, splits) * BK);
+        const int splits = std::max(1, std::min(TNW_WGS / xv_cdiv(N, BN), ksteps / 4));
+        pl.chunk = xv_cdiv(ksteps, splits) * BK;
+        pl.splits = xv_cdiv(R, pl.chunk);
+        return pl;
     }
-    // XV_WGS_PER_CU (4) workgroups are resident per CU (LDS 32 KB each): keep tiles*splits <= XV_RESIDENT_WGS (1 024) so the
-    // whole grid is ONE co-resident round.  (On the first build - 2 per CU - 560 workgroups = 512 + a 48-workgroup second
-    // round cost 2x: 61 TF on tdnn2/3, 24 TF on tdnn5.)
-    // [measured, round 2] fewer co-resident workgroups (smaller slabs, cheaper slab sum) lose: 768 -> +0.06 ms/step, 512 -> +0.19 ms
-    // [measured, round 3, after the DMA / slab-sum work; medians of 3-4 alternated runs against 1 024, S1 | 64 x U{200..400} | S5]
-    //   896: -0.1 ... -0.4 | -1.1 | -0.2 %     768: -0.6 ... -0.8 | -0.2 ... -0.5 | -0.1 ... -0.4 %
-    // (a free slot per CU lets the BatchNorm kernels of the data-gradient chain in beside the weight gradient) - but the kernel itself
-    // is slower with fewer workgroups: alone 1 655 -> 1 724 (768) / 1 837 us (896: 3.5 per CU is an unbalanced launch) over the five
-    // frame layers, its isolated roofline fraction 0.78 -> 0.75 / 0.71.  Kept at one full round: the step gains are at the noise level
-    // of a box change, the kernel's loss is not.
-    // [measured, round 4] an EVEN schedule for this kernel (tile-major (tile, K-step) units in equal runs over 768 or 1 024 persistent
-    // workgroups, two segments per workgroup, lane-order slabs, per-tile slab sum; commits 8f3..c41 of round 4) was built, parity-green
-    // and faster ALONE (sum of the five layers 1 614 vs 1 658 us, tdnn2 504 -> 476 us = 135 TF: every slot of the round used instead of 960
-    // of 1 024) - and slower in every step it was tried in (same box, round-3 tree beside it: S1 +0.7 %, S2 +2.5 %, S4 +1 %, 64 x U{200..400}
-    // +4...5 %; 640 / 768 / 896 / 960 / 1 008 / 1 024 workgroups all lost): equal runs end together, so a launch that fills the round gives
-    // the other streams no slot until it is over (BatchNorm-backward kernels of the data-gradient chain and the slab sums waited 200-760 us
-    // for one, and the next weight-gradient GEMM queued behind a starved slab sum).  The rectangles below leave 0-64 slots free by
-    // accident and end at staggered times beside the other stream.  Removed; profiles/r04_tn_even_schedule_ab.txt.
-    // [measured, round 4, same box] not splitting the segment-level weight gradients at all (R = the chunks of a batch = 8 K-steps; a quarter of
-    // the slab bytes beside the latency-bound chain): no difference at S1 or 64 x U{200..400} (5.19-5.21 / 4.28-4.30 ms either way).
-    // [measured, round 4, same box, variant builds] tdnn1's weight gradient (2 x 4 tiles of which 160 of 256 rows are real, 1 568 K-steps) as
-    // 512 / 256 / 128 workgroups instead of a full round: 65.6 / 72.3 / 114.0 us alone against 67.4, the step within +-0.1 % / +0.1 % / +0.6 %.
-    const int target = XV_RESIDENT_WGS, min_ksteps = 2;      // (min_ksteps: fewest K-steps a workgroup is given)
-    int splits = target / tiles;
-    if (splits > ksteps / min_ksteps) splits = ksteps / min_ksteps;
-    if (splits < 1) splits = 1;
-    int chunk = xv_cdiv(ksteps, splits) * BK;
-    return xv_cdiv(R, chunk);
+    const XvEnv* env = xv_env();
+    int form = env && env->tn_form ? env->tn_form : XV_TN_FORM_DEFAULT;
+    while (form > 1 && tiles * form > XV_RESIDENT_WGS) form /= 2;      // more tiles than workgroup slots of that size: smaller workgroups
+    const int min_ksteps = 2;                                          // fewest K-steps a group is given
+    const int target = env && env->tn_target ? env->tn_target : (env && env->gemm_slots ? 768 : XV_RESIDENT_WGS);
+    int groups = std::max(1, target / form / tiles) * form;
+    if (groups > ksteps / min_ksteps) groups = std::max(1, ksteps / min_ksteps);
+    pl.form = form;
+    pl.chunk = xv_cdiv(ksteps, groups) * BK;
+    pl.splits = xv_cdiv(xv_cdiv(R, pl.chunk), form);
+    return pl;
 }
+int xv_tn_splits(int M, int N, int R) { return xv_tn_plan(M, N, R).splits; }
 
 int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     XV_REQUIRE(g.M % 4 == 0 && g.N % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0,
@@ -1241,19 +1304,26 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     }
     p.A = g.A; p.lda = g.lda; p.a_pitch = g.a_pitch;
     p.B = g.B; p.ldb = g.ldb; p.b_pitch = g.b_pitch;
-    p.rps = g.a_rps; p.inv_rps = 1.0f / (float)g.a_rps;
+    p.rps = g.a_rps;
+    // Rows without gaps between the segments (pitch == rows per segment in both operands: every dense layer, whose "segments" are single
+    // frames) are ONE segment of R rows: the kernel's cheap K-step form - scalar bases, lane offsets that advance by a constant - needs
+    // at least BK rows per segment, and with one-row segments every K-step took the form meant for ragged ends (a row -> address
+    // resolution and a 64-bit address per lane: tdnn4 / tdnn5 ran 104 / 115 TF against 128-135 for the layers with taps; round 5).
+    if (g.a_pitch == g.a_rps && g.b_pitch == g.b_rps) { p.rps = g.R; p.a_pitch = g.R; p.b_pitch = g.R; }
+    p.inv_rps = 1.0f / (float)p.rps;
     p.P = g.P; p.M = g.M; p.N = g.N; p.R = g.R;
     p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
-    int ksteps = xv_cdiv(g.R, BK);
-    p.r_chunk = xv_cdiv(ksteps, g.splits) * BK;
+    const XvTnPlan pl = xv_tn_plan(g.M, g.N, g.R);
+    XV_REQUIRE(pl.splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", pl.splits, g.splits);
+    p.r_chunk = pl.chunk;
     p.ahead = p.r_chunk / BK >= 96;      // [measured, rounds 3 and 4: 48 / 64 cost tdnn5 7 %, never staging ahead costs tdnn2 / tdnn3 3 %]
-    int splits = xv_cdiv(g.R, p.r_chunk);
-    XV_REQUIRE(splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", splits, g.splits);
-    dim3 grid(p.tiles_m * p.tiles_n * splits, 1, 1);
+    const int wgs = p.tiles_m * p.tiles_n * pl.splits;
     {
         XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
-        if (tn_wide_rows(g.M)) hipLaunchKernelGGL(xv_gemm_tn160_kernel, dim3(p.tiles_n * splits), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(xv_gemm_tn_kernel, grid, dim3(256), 0, s, p);
+        if (tn_wide_rows(g.M)) hipLaunchKernelGGL(xv_gemm_tn160_kernel, dim3(p.tiles_n * pl.splits), dim3(256), 0, s, p);
+        else if (pl.form == 4) hipLaunchKernelGGL(xv_gemm_tn_kernel<4>, dim3(wgs), dim3(1024), 0, s, p);
+        else if (pl.form == 2) hipLaunchKernelGGL(xv_gemm_tn_kernel<2>, dim3(wgs), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL(xv_gemm_tn_kernel<1>, dim3(wgs), dim3(256), xv_gemm_lds_pad(true), s, p);
     }
     XV_LAUNCH_CHECK();
     return 0;
@@ -1308,6 +1378,7 @@ template <bool ZSPLIT>
 __global__ __launch_bounds__(256) void xv_wgrad_reduce_kernel(const float* __restrict__ P, int splits, long slab, int rows, int C, int c_pad,
                                                               int n_in, int nq_out, const float* __restrict__ w, long ldw, float l2,
                                                               float* __restrict__ out, long ldo) {
+    XV_EW_PRIORITY();
     __shared__ f32x4 part[ZSPLIT ? 4 : 1][64];
     const int qx = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int q = blockIdx.x * 64 + qx;

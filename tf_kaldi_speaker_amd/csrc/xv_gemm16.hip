@@ -1086,7 +1086,10 @@ int xv_launch_gemm16_tn(hipStream_t s, const XvGemm16TN& g) {
     TN16Args p;
     p.A = (const u16*)g.A; p.lda = g.lda; p.a_plane = g.a_plane; p.a_pitch = g.a_pitch;
     p.B = (const u16*)g.B; p.ldb = g.ldb; p.b_plane = g.b_plane; p.b_pitch = g.b_pitch;
-    p.rps = g.rps; p.inv_rps = 1.0f / (float)g.rps;
+    p.rps = g.rps;
+    // gap-free rows (every dense layer: one-frame "segments") are one segment of R rows, so the K-steps take the cheap form (xv_launch_gemm_tn)
+    if (g.a_pitch == g.rps && g.b_pitch == g.rps) { p.rps = g.R; p.a_pitch = g.R; p.b_pitch = g.R; }
+    p.inv_rps = 1.0f / (float)p.rps;
     p.P = g.P; p.M = g.M; p.N = g.N; p.R = g.R;
     p.tiles_m = xv_cdiv(g.M, 128); p.tiles_n = xv_cdiv(g.N, 128);
     int ksteps = xv_cdiv(g.R, 32);

@@ -34,6 +34,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // block = 256 threads = 32 columns x 8 row lanes (rows c = lane, lane+8, ...), fixed-order combine
 __global__ __launch_bounds__(256) void col_inv_norm_kernel(const float* __restrict__ w, int C, int N, int normalize,
                                                            float* __restrict__ inv) {
+    XV_EW_FILLER();
     __shared__ float red[8][32];
     const int cx = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + cx;
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(256) void col_inv_norm_kernel(const float* __restri
 // wn[c][ldn] = w[c][n]*inv[n] (pad columns zero), wnt[n][C] = wn^T through a 32x32 LDS tile
 __global__ void loss_prep_weight_kernel(const float* __restrict__ w, int C, int N, const float* __restrict__ inv,
                                         float* __restrict__ wn, int ldn, float* __restrict__ wnt) {
+    XV_EW_FILLER();
     __shared__ float tile[32][33];
     const int c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void margin_softmax_rows_kernel(int kind, cons
                                                                   float* __restrict__ dlogits, float* __restrict__ dnorm,
                                                                   float* __restrict__ row_loss, float* __restrict__ xnorm,
                                                                   unsigned* __restrict__ ticket, float* __restrict__ loss_out) {
+    XV_EW_PRIORITY();
     __shared__ float red[4];
     __shared__ float s_upd, s_dsel, s_dn;
     __shared__ int s_last;
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(256) void margin_softmax_rows_kernel(int kind, cons
 }
 
 __global__ void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    XV_EW_PRIORITY();
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) s += v[i];
@@ -253,6 +257,7 @@ int xv_margin_softmax_rows_ex(hipStream_t s, int kind, const float* logits, int 
 // dx[r][:] += dnorm[r] * x[r][:] / ||x[r]||
 __global__ void add_norm_grad_kernel(const float* __restrict__ x, const float* __restrict__ dnorm, int rows, int C,
                                      float* __restrict__ dx) {
+    XV_EW_PRIORITY();
     int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (long)row * C;
@@ -273,6 +278,7 @@ extern "C" int xv_add_norm_grad(void* stream, const float* x, const float* dnorm
 // dot[n] = sum_c dwn[c][n] * wn[c][n]      (32 columns x 8 row lanes per block)
 __global__ __launch_bounds__(256) void col_dot_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
                                                       int C, int N, float* __restrict__ dot) {
+    XV_EW_FILLER();
     __shared__ float red[8][32];
     const int cx = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + cx;
@@ -290,6 +296,7 @@ __global__ __launch_bounds__(256) void col_dot_kernel(const float* __restrict__ 
 __global__ void loss_weight_bwd_kernel(const float* __restrict__ dwn, long lddwn, const float* __restrict__ wn, long ldn,
                                        const float* __restrict__ inv, const float* __restrict__ dot, const float* __restrict__ w,
                                        int C, int N, int normalize, float l2, float* __restrict__ dw) {
+    XV_EW_FILLER();
     long total = (long)C * N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int c = (int)(i / N), n = (int)(i - (long)c * N);
@@ -332,6 +339,7 @@ extern "C" int xv_loss_weight_backward(void* stream, const float* dwn, int lddwn
 __global__ __launch_bounds__(256) void ring_loss_kernel(const float* __restrict__ x, int rows, int n, long ldx, const float* __restrict__ r,
                                                         float lambda, float* __restrict__ loss_accum, float* __restrict__ dnorm,
                                                         float* __restrict__ dr) {
+    XV_EW_PRIORITY();
     __shared__ float s_sq[4], s_d[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float rr = *r;
@@ -368,6 +376,7 @@ extern "C" int xv_ring_loss(void* stream, const float* x, int rows, int n, int l
 // u = sum_b wn[:,y_b], v = sum_n wn[:,n];  loss = lambda / (M + 1e-6);  d loss / d wn[:,n] = g (u + cnt_n v),
 // g = 2 lambda / ((M + 1e-6)^2 B N), cnt_n = #{b : y_b = n}.   coef = [g | u[c] | v[c]], counts = int32 [n].
 __global__ void mhe_counts_kernel(const int* __restrict__ labels, int rows, int n, int* __restrict__ counts) {
+    XV_EW_FILLER();
     for (int i = threadIdx.x; i < n; i += blockDim.x) counts[i] = 0;
     __syncthreads();
     for (int b = threadIdx.x; b < rows; b += blockDim.x) {
@@ -377,6 +386,7 @@ __global__ void mhe_counts_kernel(const int* __restrict__ labels, int rows, int 
 }
 __global__ __launch_bounds__(256) void mhe_uv_kernel(const float* __restrict__ wn, int n, long ldn, const int* __restrict__ labels, int rows,
                                                      float* __restrict__ coef, int c_total) {
+    XV_EW_PRIORITY();
     __shared__ float red[4];
     const int c = blockIdx.x;
     const float* w = wn + (long)c * ldn;
@@ -392,6 +402,7 @@ __global__ __launch_bounds__(256) void mhe_uv_kernel(const float* __restrict__ w
 }
 __global__ __launch_bounds__(256) void mhe_finalize_kernel(float* __restrict__ coef, int c_total, int rows, int n, float lambda,
                                                            float* __restrict__ loss_accum) {
+    XV_EW_PRIORITY();
     __shared__ float red[4];
     float d = 0.f;
     for (int c = threadIdx.x; c < c_total; c += 256) d += coef[1 + c] * coef[1 + c_total + c];
@@ -405,6 +416,7 @@ __global__ __launch_bounds__(256) void mhe_finalize_kernel(float* __restrict__ c
 }
 __global__ void mhe_add_grad_kernel(float* __restrict__ dwn, int c_total, int n, long ldn, const float* __restrict__ coef,
                                     const int* __restrict__ counts) {
+    XV_EW_FILLER();
     const float g = coef[0];
     const long total = (long)c_total * n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Same-box, alternated in-step A/B of run-time switches (and, optionally, of another tree) on the GPU box:
+#   tools/ab_env.sh <out.txt> <rounds> "<shape args>|<shape args>..." "name1:ENV=a ENV2=b" "name2:" "tree:build_variants/r04_tree" ...
+# Every (shape, variant) pair runs `bench.py --single-mode --no-cpu-baseline` once per round; one line per run: shape variant ms/step chunks/s.
+out=$1; rounds=$2; shapes=$3; shift 3
+R=${GRAFT_REPO_ROOT:-$PWD}
+one() { "$@" 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); r=d.get('roofline',{}); print(d['ms_per_step'], d['value'], 'dominant', r.get('avg_launch_ms'), r.get('frac'))"; }
+IFS='|' read -ra SH <<< "$shapes"
+for i in $(seq 1 $rounds); do
+  for sh in "${SH[@]}"; do
+    for v in "$@"; do
+      name=${v%%:*}; spec=${v#*:}
+      if [ "$name" == "tree" ]; then
+        echo -n "[$sh] $(basename $spec) "; (cd $R/$spec && one python3 bench.py --steps 40 --warmup 10 --single-mode --no-cpu-baseline $sh)
+      else
+        echo -n "[$sh] $name "; (cd $R && one env $spec python3 bench.py --steps 40 --warmup 10 --single-mode --no-cpu-baseline $sh)
+      fi
+    done
+  done
+done 2>&1 | tee $out
