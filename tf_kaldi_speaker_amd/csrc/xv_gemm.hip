@@ -64,6 +64,7 @@ struct NTArgs {
     int n_whole, shares;
     float* slab;                // [(tiles - n_whole) * shares][128 * 128]: partial tiles in lane order
     unsigned* tickets;          // one per tile, zero between launches
+    int row_store;              // epilogue through LDS with 16-byte row stores (nt_store_tile_rows): C / ldc 16-byte aligned, N % 4 == 0
 };
 
 // Out-of-range rows / k read this 16-byte zero page instead of being masked after the load: the
@@ -156,6 +157,49 @@ __device__ __forceinline__ void nt_store_tile(f32x16 (&acc)[2][2], float* __rest
     }
 }
 
+// The same epilogue through the (idle) staging LDS: the accumulators of one 32-row block per wave - 64 rows x 128 columns of the tile, exactly
+// the 32 KB of the two stages - are written as they stand (one column per lane: 128 consecutive bytes per half wave, no bank conflict), the
+// workgroup meets, and every thread reads whole-row float4 and stores 16 bytes: a half wave stores one 512-byte row segment per instruction,
+// 16 store instructions per lane and tile instead of 64 four-byte ones (whose latency chain was the 10 us epilogue of a 32-K-step tile,
+// exposed whenever the workgroups of a launch end together: every one-round launch).  Two passes (a = 0, 1).  Needs C and ldc 16-byte aligned
+// and N a multiple of 4; the caller falls back to nt_store_tile otherwise.  Ends behind a barrier (the LDS may be reused at once).
+__device__ __forceinline__ void nt_store_tile_rows(f32x16 (&acc)[2][2], float* smem, float* __restrict__ C, long ldc, const float* __restrict__ bias,
+                                                   int m0, int n0, int M, int N, int tid, int wr, int wc, int li, int lh) {
+    if (bias) {
+        float bias_v[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bias_v[b] = bias[min(n0 + wc * 64 + b * 32 + li, N - 1)];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] += bias_v[b];
+    }
+    // image [64 rows: wr * 32 + row of the 32-row block][128 columns]
+    float* wbase = smem + (wr * 32 + 4 * lh) * BN + wc * 64 + li;
+    const int rq = tid >> 5, cq = (tid & 31) * 4;                // reader: rows rq, rq + 8, ... of the image, columns cq .. cq + 3
+    const bool col_ok = n0 + cq < N;                              // (N % 4 == 0: all four or none)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wbase[((r & 3) + 8 * (r >> 2)) * BN + b * 32] = acc[a][b][r];
+        __syncthreads();
+        f32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = *(const f32x4*)(smem + (rq + 8 * i) * BN + cq);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = rq + 8 * i;                             // image row: wr' = q / 32, row of the block = q % 32
+            const int m = m0 + (q >> 5) * 64 + a * 32 + (q & 31);
+            if (m < M && col_ok) *(f32x4*)(C + (long)m * ldc + n0 + cq) = v[i];
+        }
+        __syncthreads();
+    }
+}
+
 // The evenly scheduled kernel rotates the issue priority of its waves every K-step: priority = (K-step + the wave's slot in its SIMD) mod 4,
 // so the co-resident workgroups take turns at the top.  [measured, round 3, stamps of tdnn2 forward at S1] the arbiter serves the oldest wave
 // first and the three workgroups of a CU finish at 384 / 444 / 481 us, the CU running two, then one workgroup at the end; with the rotation
@@ -177,7 +221,7 @@ __device__ __forceinline__ void xv_rot_prio(int x) {
 // workgroup, a start-up stagger, fragments of the next half K-step read early, K-step 32, a third LDS slot (DMA two K-steps ahead: MFMA-pipe
 // occupancy 0.867 -> 0.83-0.85); per-wave private staging without any barrier was 20 % slower.  What did: the address form of the
 // LDS-DMA (xv_dma16, xv_common.h).
-template <bool STATS>
+template <bool STATS, bool ROWS>
 __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(128))) void xv_gemm_nt_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * NT_PITCH];      // two slots of [A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -355,7 +399,8 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     // ---- epilogue
     if (alive) {
         float* C = p.C + (long)blockIdx.z * p.c_split_stride;
-        nt_store_tile(acc, C, p.ldc, p.bias, m0, n0, p.M, p.N, wr, wc, li, lh);
+        if (ROWS) nt_store_tile_rows(acc, smem, C, p.ldc, p.bias, m0, n0, p.M, p.N, tid, wr, wc, li, lh);
+        else nt_store_tile(acc, C, p.ldc, p.bias, m0, n0, p.M, p.N, wr, wc, li, lh);
         if (STATS) xv_tile_stats_epilogue(acc, smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part_sum);
     }
     XV_STAMP_EXIT(p.stamp_half, stall);
@@ -399,7 +444,7 @@ __device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (i
 #define XV_NT_SK_VGPRS 128
 #define XV_NT_SK_OCC XV_WGS_PER_CU
 #endif
-template <bool STATS>
+template <bool STATS, bool ROWS>
 __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(XV_NT_SK_VGPRS))) void xv_gemm_nt_sk_kernel(NTSKArgs q) {
     const NTArgs& p = q.g;
     constexpr int A_SLOT = BM * NT_PITCH;       // floats per A slot
@@ -601,7 +646,8 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
                 }
             }
         }
-        nt_store_tile(acc, p.C, p.ldc, p.bias, m0, n0, p.M, p.N, wr, wc, li, lh);
+        if (ROWS) nt_store_tile_rows(acc, smem, p.C, p.ldc, p.bias, m0, n0, p.M, p.N, tid, wr, wc, li, lh);
+        else nt_store_tile(acc, p.C, p.ldc, p.bias, m0, n0, p.M, p.N, wr, wc, li, lh);
         if (STATS) {
             xv_tile_stats_epilogue(acc, smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part_sum);
             __syncthreads();                             // the statistics use the staging buffers as scratch
@@ -728,6 +774,11 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
     p.bias = g.bias; p.part_sum = nullptr; p.part_m2 = nullptr;
     p.n_whole = 0; p.shares = 0; p.slab = nullptr; p.tickets = nullptr;
+#ifdef XV_NT_NO_ROWS      // (A/B build constant: the four-byte-store epilogue everywhere)
+    p.row_store = 0;
+#else
+    p.row_store = (g.N % 4 == 0 && g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0) ? 1 : 0;
+#endif
     const int tiles = p.tiles_m * p.tiles_n;
     const int ksteps = xv_cdiv(g.K, BK);
     // Schedule (xv_gemm_nt_sk_kernel): either one workgroup per tile, dealt to the CUs by the hardware as slots free up ("dp"), or one
@@ -806,8 +857,14 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
             q.tickets = shared_tiles ? tn_tickets_for(s) : nullptr;
             XV_REQUIRE(!shared_tiles || (q.tickets && ((uintptr_t)q.slab % 16) == 0), "gemm_nt: hand-over buffers unavailable");
             XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
-            if (g.bn_part) hipLaunchKernelGGL(xv_gemm_nt_sk_kernel<true>, dim3(q.P), dim3(256), xv_gemm_lds_pad(false), s, q);
-            else hipLaunchKernelGGL(xv_gemm_nt_sk_kernel<false>, dim3(q.P), dim3(256), xv_gemm_lds_pad(g.co_running != 0), s, q);
+            const unsigned pad = xv_gemm_lds_pad(!g.bn_part && g.co_running != 0);
+            if (g.bn_part) {
+                if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, true>), dim3(q.P), dim3(256), pad, s, q);
+                else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, false>), dim3(q.P), dim3(256), pad, s, q);
+            } else {
+                if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<false, true>), dim3(q.P), dim3(256), pad, s, q);
+                else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<false, false>), dim3(q.P), dim3(256), pad, s, q);
+            }
             XV_LAUNCH_CHECK();
             return 0;
         }
@@ -842,9 +899,11 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
         if (g.bn_part) {
             p.part_sum = g.bn_part;
             p.part_m2 = nullptr;
-            hipLaunchKernelGGL(xv_gemm_nt_kernel<true>, grid, dim3(256), xv_gemm_lds_pad(false), s, p);
+            if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_kernel<true, true>), grid, dim3(256), xv_gemm_lds_pad(false), s, p);
+            else hipLaunchKernelGGL((xv_gemm_nt_kernel<true, false>), grid, dim3(256), xv_gemm_lds_pad(false), s, p);
         } else {
-            hipLaunchKernelGGL(xv_gemm_nt_kernel<false>, grid, dim3(256), xv_gemm_lds_pad(g.co_running != 0), s, p);
+            if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_kernel<false, true>), grid, dim3(256), xv_gemm_lds_pad(g.co_running != 0), s, p);
+            else hipLaunchKernelGGL((xv_gemm_nt_kernel<false, false>), grid, dim3(256), xv_gemm_lds_pad(g.co_running != 0), s, p);
         }
         XV_LAUNCH_CHECK();
         return 0;
@@ -853,13 +912,17 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     const long np = (long)xv_align(g.N, 4);
     XV_REQUIRE((size_t)splits * g.M * np * sizeof(float) <= g.ws_bytes, "gemm_nt: workspace too small (%zu bytes)", g.ws_bytes);
     p.C = (float*)g.ws; p.ldc = np; p.c_split_stride = (long)g.M * np;
+#ifndef XV_NT_NO_ROWS
+    p.row_store = g.N % 4 == 0 ? 1 : 0;      // (the slab is 256-byte aligned, np and M * np are multiples of 4)
+#endif
     p.k_chunk = xv_cdiv(ksteps, splits) * BK;
     splits = xv_cdiv(g.K, p.k_chunk);
     p.bias = nullptr;
     dim3 grid(tiles, 1, splits);
     {
         XvProfScope prof(s, 1, 2.0 * g.M * g.N * g.K);
-        hipLaunchKernelGGL(xv_gemm_nt_kernel<false>, grid, dim3(256), 0, s, p);
+        if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_kernel<false, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((xv_gemm_nt_kernel<false, false>), grid, dim3(256), 0, s, p);
     }
     XV_LAUNCH_CHECK();
     long total = (long)g.M * g.N;
