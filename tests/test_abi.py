@@ -84,7 +84,7 @@ def test_environment_switches_are_value_checked_and_unknown_ones_named():
             "from tf_kaldi_speaker_amd import _lib\n"
             "lib = _lib.load(); cfg = _lib.XvConfig(); cfg.feat_dim = 30; h = C.c_void_p()\n"
             "rc = lib.xv_engine_create(C.byref(cfg), C.byref(h)); print(rc, lib.xv_last_error().decode())\n" % ROOT)
-    for extra, want in (({"XV_NT_SCHED": "fast"}, "XV_NT_SCHED=fast: expected dp or sk"), ({"XV_TN_FORM": "3"}, "XV_TN_FORM=3: expected 1, 2 or 4"),
+    for extra, want in (({"XV_NT_SCHED": "fast"}, "XV_NT_SCHED=fast: expected dp or sk"), ({"XV_CONV_WR": "3"}, "XV_CONV_WR=3: expected 2 or 4"),
                         ({"XV_SEGMENT_FUSED": "yes"}, "XV_SEGMENT_FUSED=yes: expected 0 or 1")):
         env = {k: v for k, v in os.environ.items() if not k.startswith("XV_")}
         env.update(extra)

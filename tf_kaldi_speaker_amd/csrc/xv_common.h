@@ -49,9 +49,6 @@ struct XvEnv {
     int segment_fused;      // XV_SEGMENT_FUSED=0|1 (default 1): the segment-level layers as one launch each (xv_skinny.hip)
     int nt_sched;           // XV_NT_SCHED=dp|sk: force the schedule of the fp32 NT GEMM (0 = chosen per problem, 1 = dp, 2 = sk); diagnostics
     int conv_wr;            // XV_CONV_WR=4: 256-row tiles of the f16x3 context-window GEMM (kept parity-tested, off by default)
-    int tn_form;            // XV_TN_FORM=1|2|4: force the weight-gradient kernel's in-workgroup K split (0 = chosen per problem); diagnostics
-    int gemm_slots;         // XV_GEMM_SLOTS=3|3b: at most three fp32 GEMM workgroups per CU (an LDS pad), 3b: backward launches only; diagnostics (0 = four)
-    int tn_target;          // XV_TN_TARGET=n: workgroups a weight-gradient launch aims at (0 = one co-resident round); diagnostics
 };
 const XvEnv* xv_env();
 

@@ -34,7 +34,7 @@ XvEnvState xv_env_parse() {
     // program in the user's environment, which must not stop a training run.  A known switch with a value it does not understand still fails.
     static const char* known[] = {"XV_SEGMENT_FUSED", "XV_NT_SCHED", "XV_CONV_WR", "XV_PRECISION", "XV_LOADER", "XV_LOADER_PIN", "XV_SHARE_GPU",
                                   "XV_LIB", "XV_TUNE_TIMES", "XV_DATA_SCALE", "XV_B", "XV_PROBE_OPS", "XV_PROBE_ONLY", "XV_PROBE_PERIODS",
-                                  "XV_DIAG_M", "XV_DIAG_N", "XV_DIAG_K", "XV_DIAG_REPS", "XV_DIAG_B", "XV_TN_FORM", "XV_GEMM_SLOTS", "XV_TN_TARGET"};
+                                  "XV_DIAG_M", "XV_DIAG_N", "XV_DIAG_K", "XV_DIAG_REPS", "XV_DIAG_B"};
     for (char** e = environ; e && *e; ++e) {
         if (strncmp(*e, "XV_", 3) != 0) continue;
         const char* eq = strchr(*e, '=');
@@ -64,22 +64,6 @@ XvEnvState xv_env_parse() {
     if (const char* v = getenv("XV_CONV_WR")) {
         if (!strcmp(v, "4")) env.conv_wr = 4;
         else if (*v && strcmp(v, "2")) fail("%s=%s: expected 2 or 4", "XV_CONV_WR", v);
-    }
-    env.tn_form = 0;
-    if (const char* v = getenv("XV_TN_FORM")) {
-        if (!strcmp(v, "1") || !strcmp(v, "2") || !strcmp(v, "4")) env.tn_form = v[0] - '0';
-        else if (*v) fail("%s=%s: expected 1, 2 or 4", "XV_TN_FORM", v);
-    }
-    env.gemm_slots = 0;
-    if (const char* v = getenv("XV_GEMM_SLOTS")) {
-        if (!strcmp(v, "3")) env.gemm_slots = 3;
-        else if (!strcmp(v, "3b")) env.gemm_slots = 2;
-        else if (*v && strcmp(v, "4")) fail("%s=%s: expected 3, 3b or 4", "XV_GEMM_SLOTS", v);
-    }
-    env.tn_target = 0;
-    if (const char* v = getenv("XV_TN_TARGET")) {
-        env.tn_target = atoi(v);
-        if (*v && (env.tn_target < 256 || env.tn_target > 8192)) fail("%s=%s: expected 256..8192", "XV_TN_TARGET", v);
     }
     return st;
 }

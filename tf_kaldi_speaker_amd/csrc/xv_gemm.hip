@@ -93,14 +93,6 @@ static int ensure_zero_page(size_t floats = XV_ZERO_PAGE_FLOATS) {
 }
 const float* xv_zero_page(size_t floats) { return ensure_zero_page(floats) ? nullptr : g_zero_page; }
 
-// Dynamic LDS added to a GEMM launch so that at most three of these workgroups fit a CU (3 x 42 KB <= 160 KB < 4 x 42 KB): the fourth wave slot
-// of every SIMD, 128 VGPRs and 34 KB of LDS then stay open for the element-wise kernels of the other stream (XV_GEMM_SLOTS; diagnostics)
-static unsigned xv_gemm_lds_pad(bool backward) {
-    const XvEnv* env = xv_env();
-    if (!env || !env->gemm_slots) return 0;
-    return (env->gemm_slots == 3 || backward) ? 10 * 1024 : 0;
-}
-
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     // blocks b and b+8 share an XCD (round-robin dispatch): hand each XCD a contiguous run of
     // tiles so the n-tiles of one m-tile (same A rows) and neighbouring m-tiles (overlapping
@@ -857,7 +849,7 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
             q.tickets = shared_tiles ? tn_tickets_for(s) : nullptr;
             XV_REQUIRE(!shared_tiles || (q.tickets && ((uintptr_t)q.slab % 16) == 0), "gemm_nt: hand-over buffers unavailable");
             XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
-            const unsigned pad = xv_gemm_lds_pad(!g.bn_part && g.co_running != 0);
+            const unsigned pad = 0;
             if (g.bn_part) {
                 if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, true>), dim3(q.P), dim3(256), pad, s, q);
                 else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, false>), dim3(q.P), dim3(256), pad, s, q);
@@ -899,11 +891,11 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
         if (g.bn_part) {
             p.part_sum = g.bn_part;
             p.part_m2 = nullptr;
-            if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_kernel<true, true>), grid, dim3(256), xv_gemm_lds_pad(false), s, p);
-            else hipLaunchKernelGGL((xv_gemm_nt_kernel<true, false>), grid, dim3(256), xv_gemm_lds_pad(false), s, p);
+            if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_kernel<true, true>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((xv_gemm_nt_kernel<true, false>), grid, dim3(256), 0, s, p);
         } else {
-            if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_kernel<false, true>), grid, dim3(256), xv_gemm_lds_pad(g.co_running != 0), s, p);
-            else hipLaunchKernelGGL((xv_gemm_nt_kernel<false, false>), grid, dim3(256), xv_gemm_lds_pad(g.co_running != 0), s, p);
+            if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_kernel<false, true>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((xv_gemm_nt_kernel<false, false>), grid, dim3(256), 0, s, p);
         }
         XV_LAUNCH_CHECK();
         return 0;
@@ -949,30 +941,19 @@ struct TNArgs {
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-#ifndef XV_TN_FORM_DEFAULT
-#define XV_TN_FORM_DEFAULT 1      // wave groups per weight-gradient workgroup unless XV_TN_FORM says otherwise (xv_tn_plan)
-#endif
 
 // LDS image [r][128] (output index contiguous, exactly as it sits in HBM: no transpose).
 // Fragment reads are ds_read_b64: lane i of a lane-half takes output rows 2i and 2i+1 of the
 // wave's 64 at reduction row r = 2*ks + half, which feed the two 32x32 accumulators in that
 // direction (the MFMA only needs A and B to agree on r).  So accumulator (a,b) register reg of
 // lane l holds  m = m0 + wr*64 + 2*row(reg,l) + a,  n = n0 + wc*64 + 2*(l&31) + b.
-//
-// G = wave groups per workgroup (256 G threads).  Every group is what a whole workgroup is at G = 1 - four waves on one 128 x 128 tile with
-// a double-buffered 32 KB LDS image of their own - and the G groups of a workgroup take G consecutive reduction chunks of the SAME tile.
-// After the K loop they add their accumulators through the (then idle) LDS, ((g0 + g2) + (g1 + g3)) - a fixed association - and group 0
-// alone stores the slab: 1 / G of the slab bytes written here and read back by xv_wgrad_reduce_kernel.  The workgroup barrier of a K-step
-// spans all groups; in the two-steps-ahead form it sits in mid-step, where every wave still holds sixteen MFMAs' worth of fragments.
+// (Round 5 built wave groups on top of this kernel - 512 / 1 024-thread workgroups whose groups take consecutive reduction chunks of ONE tile
+// and add their accumulators through LDS before a single slab store, 1/2 or 1/4 of the slab bytes: parity-green, no faster alone, 3 % slower
+// in the step; removed.  profiles/r05_tn_wave_groups.txt, DESIGN.md Appendix A.)
 #define XV_TN_STAGES 2
-template <int G>
-__global__ __launch_bounds__(256 * G, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(128))) void xv_gemm_tn_kernel(TNArgs p) {
-    constexpr int GRP = XV_TN_STAGES * 2 * BK * BM;      // floats of one group's image: [slot][A|B][BK][128]
-    __shared__ __attribute__((aligned(16))) float smem_all[G * GRP];
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    const int uwave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int grp = G == 1 ? 0 : uwave_all >> 2;         // (wave-uniform)
-    float* smem = smem_all + grp * GRP;
+__global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[XV_TN_STAGES * 2 * BK * BM];   // [slot][A|B][BK][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
@@ -984,16 +965,14 @@ __global__ __launch_bounds__(256 * G, XV_WGS_PER_CU) __attribute__((amdgpu_num_v
     const int split = v / tiles, t = v - split * tiles;
     const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int r_begin = (split * G + grp) * p.r_chunk;
+    const int r_begin = split * p.r_chunk;
     const int r_end = min(p.R, r_begin + p.r_chunk);
-    const int nk = max(0, (r_end - r_begin + BK - 1) / BK);
-    // K-steps of the workgroup's loop = group 0's (the largest: only the last chunk of the reduction can be short or empty)
-    const int nk_wg = G == 1 ? nk : (min(p.R, split * G * p.r_chunk + p.r_chunk) - split * G * p.r_chunk + BK - 1) / BK;
+    const int nk = (r_end - r_begin + BK - 1) / BK;
 
     // LDS-DMA staging: one wave-instruction = 1 KiB = two whole [r][128] rows of the image; lane l lands on
     // row 2*(RPT*wave+i) + l/32, columns 4*(l%32)..+3.  The reduction-row -> address map (spliced view)
     // is evaluated per lane without an integer divide (r < 2^24, float quotient off by <= 1).
-    const int uwave = uwave_all & 3;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int lc = (lane & 31) * 4;
     const bool a_cv = (m0 + lc) < p.M, b_cv = (n0 + lc) < p.N;
     const float* __restrict__ zp = p.zero;
@@ -1089,32 +1068,29 @@ __global__ __launch_bounds__(256 * G, XV_WGS_PER_CU) __attribute__((amdgpu_num_v
     auto k_loop = [&](auto ahead_c) {
         constexpr bool AHEAD = decltype(ahead_c)::value;
         if (AHEAD && nk > 1) gstage(1, 1);
-        for (int kt = 0; kt < nk_wg; ++kt) {
+        for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
-            const bool live = G == 1 || kt < nk;      // (wave-uniform) a short last chunk: its group only keeps the barriers
             if (!AHEAD && kt + 1 < nk) gstage(kt + 1, buf ^ 1);
             const float* sa = smem + buf * (2 * BK * BM) + a_off;
             const float* sb = smem + buf * (2 * BK * BM) + BK * BM + b_off;
             f32x2 af[BK / 4], bf[BK / 4], an[BK / 4], bn[BK / 4];
-            if (live) {
 #pragma unroll
-                for (int j = 0; j < BK / 4; ++j) {
-                    af[j] = *(const f32x2*)(sa + 2 * j * BM);
-                    bf[j] = *(const f32x2*)(sb + 2 * j * BN);
-                }
+            for (int j = 0; j < BK / 4; ++j) {
+                af[j] = *(const f32x2*)(sa + 2 * j * BM);
+                bf[j] = *(const f32x2*)(sb + 2 * j * BN);
+            }
 #pragma unroll
-                for (int j = 0; j < BK / 4; ++j) {
-                    an[j] = *(const f32x2*)(sa + 2 * (BK / 4 + j) * BM);
-                    bn[j] = *(const f32x2*)(sb + 2 * (BK / 4 + j) * BN);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < BK / 4; ++j) {
+                an[j] = *(const f32x2*)(sa + 2 * (BK / 4 + j) * BM);
+                bn[j] = *(const f32x2*)(sb + 2 * (BK / 4 + j) * BN);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < BK / 4; ++j) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].y, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].x, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[1][1], 0, 0, 0);
-                }
+            for (int j = 0; j < BK / 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[1][1], 0, 0, 0);
             }
             if (AHEAD) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -1123,14 +1099,12 @@ __global__ __launch_bounds__(256 * G, XV_WGS_PER_CU) __attribute__((amdgpu_num_v
                 if (kt + 2 < nk) gstage(kt + 2, buf);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (live) {
 #pragma unroll
-                for (int j = 0; j < BK / 4; ++j) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].x, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].y, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].x, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].y, acc[1][1], 0, 0, 0);
-                }
+            for (int j = 0; j < BK / 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].x, bn[j].y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j].y, bn[j].y, acc[1][1], 0, 0, 0);
             }
             if (!AHEAD) {
                 xv_dma_wait_all();
@@ -1141,50 +1115,35 @@ __global__ __launch_bounds__(256 * G, XV_WGS_PER_CU) __attribute__((amdgpu_num_v
     if (p.ahead) k_loop(std::true_type{});
     else k_loop(std::false_type{});
 
-    if (G > 1) {
-        // in-workgroup sum of the groups' partial tiles through LDS (every stage has been read: the loop ends behind a barrier).  Image of one
-        // group's tile: [register r][thread] float4 = (acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]) = 64 KB, lane-linear 16-byte
-        // accesses (no bank conflicts).  Group g + half hands its tile to group g through image g in the first round and through image g + half
-        // afterwards: that is the image group g + half itself read in the round before, and a lane only ever touches its own addresses, so no
-        // group writes an image another group may still be reading.
-        f32x4* img = (f32x4*)smem_all;
-#pragma unroll
-        for (int half = G / 2; half >= 1; half /= 2) {
-            const int first = half == G / 2 ? 0 : half;      // image of the pair (0, half); pair (g, g + half) uses image first + g
-            if (grp >= half && grp < 2 * half) {
-                f32x4* dst = img + (first + grp - half) * (16 * 256) + tid;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const f32x4 x = {acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]};
-                    dst[r * 256] = x;
-                }
-            }
-            __syncthreads();
-            if (grp < half) {
-                const f32x4* src = img + (first + grp) * (16 * 256) + tid;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const f32x4 x = src[r * 256];
-                    acc[0][0][r] += x[0]; acc[0][1][r] += x[1]; acc[1][0][r] += x[2]; acc[1][1][r] += x[3];
-                }
-            }
-        }
-        if (grp != 0) return;
-    }
     // (Summing the split partials of DIFFERENT workgroups inside this kernel - the last arrival adds the others' slabs - was built and dropped in
     // round 3: one workgroup reads splits x 64 KB serially at the end of the launch; DESIGN.md Appendix A.)
+    // The slab tile goes out through the group's (idle) staging LDS in whole rows of 16 bytes per lane, as in nt_store_tile_rows: pass a writes
+    // the tile's rows 2 q + a (q = wr * 32 + the accumulator's row) as a [64][128] image - a lane holds two neighbouring columns of a row, one
+    // ds_write_b64 - and every thread stores eight float4 of whole rows (16 store instructions per lane instead of 32 eight-byte ones).
+    // (M and N are multiples of 4 and the slab base is 16-byte aligned: xv_launch_gemm_tn.)
     float* P = p.P + (long)split * p.M * p.N;
-    const int n = n0 + wc * 64 + 2 * li;          // columns n, n+1 (N is a multiple of 4 => both or neither valid)
+    __syncthreads();                              // (every fragment read of the last stage is done)
+    float* wbase = smem + (wr * 32 + 4 * lh) * BN + wc * 64 + 2 * li;
+    const int rq = tid >> 5, cq = (tid & 31) * 4;
+    const bool col_ok = n0 + cq < p.N;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int m = m0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;
-            if (m < p.M && n < p.N) {
-                f32x2 v = {acc[a][0][r], acc[a][1][r]};
-                *(f32x2*)(P + (long)m * p.N + n) = v;
-            }
+            const f32x2 v = {acc[a][0][r], acc[a][1][r]};
+            *(f32x2*)(wbase + ((r & 3) + 8 * (r >> 2)) * BN) = v;
         }
+        __syncthreads();
+        f32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = *(const f32x4*)(smem + (rq + 8 * i) * BN + cq);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + 2 * (rq + 8 * i) + a;
+            if (m < p.M && col_ok) *(f32x4*)(P + (long)m * p.N + n0 + cq) = v[i];
+        }
+        if (a == 0) __syncthreads();
+    }
 }
 
 
@@ -1320,31 +1279,26 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_tn160_kernel(TNArgs p) {
 
 static bool tn_wide_rows(int M) { return M > BM && M <= TNW_M; }
 
-// Decomposition of a weight-gradient GEMM: `form` wave groups per workgroup (the kernel's G), `splits` slabs (workgroups per tile), `chunk`
-// reduction rows per group.  One co-resident round: XV_WGS_PER_CU (4) 256-thread workgroups fit a CU (LDS 32 KB, 128 VGPRs each), i.e. 1 024 / G
-// workgroups of G groups - more costs a second round (2 x on the first build), fewer leaves matrix pipes idle.  The history of this choice
-// (768 / 896 workgroups, an even schedule, unsplit segment-level gradients, tdnn1 as 128 ... 512 workgroups) is DESIGN.md Appendix A.
-struct XvTnPlan { int form, splits, chunk; };
+// Decomposition of a weight-gradient GEMM: `splits` slabs (workgroups per tile), `chunk` reduction rows per workgroup.  One co-resident round:
+// XV_WGS_PER_CU (4) workgroups fit a CU (LDS 32 KB, 128 VGPRs each), i.e. 1 024 - more costs a second round (2 x on the first build, +2 % in
+// the round-5 step at 1 536 / 2 048), fewer leaves matrix pipes idle.  The history of this choice (768 / 896 workgroups, an even schedule,
+// unsplit segment-level gradients, tdnn1 as 128 ... 512 workgroups, wave groups) is DESIGN.md Appendix A.
+struct XvTnPlan { int splits, chunk; };
 static XvTnPlan xv_tn_plan(int M, int N, int R) {
     const int tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
     const int ksteps = xv_cdiv(R, BK);
-    XvTnPlan pl = {1, 1, 0};
+    XvTnPlan pl = {1, 0};
     if (tn_wide_rows(M)) {      // xv_gemm_tn160_kernel: one round of 512 workgroups (2 per CU), at least 4 K-steps each
         const int splits = std::max(1, std::min(TNW_WGS / xv_cdiv(N, BN), ksteps / 4));
         pl.chunk = xv_cdiv(ksteps, splits) * BK;
         pl.splits = xv_cdiv(R, pl.chunk);
         return pl;
     }
-    const XvEnv* env = xv_env();
-    int form = env && env->tn_form ? env->tn_form : XV_TN_FORM_DEFAULT;
-    while (form > 1 && tiles * form > XV_RESIDENT_WGS) form /= 2;      // more tiles than workgroup slots of that size: smaller workgroups
-    const int min_ksteps = 2;                                          // fewest K-steps a group is given
-    const int target = env && env->tn_target ? env->tn_target : (env && env->gemm_slots ? 768 : XV_RESIDENT_WGS);
-    int groups = std::max(1, target / form / tiles) * form;
-    if (groups > ksteps / min_ksteps) groups = std::max(1, ksteps / min_ksteps);
-    pl.form = form;
-    pl.chunk = xv_cdiv(ksteps, groups) * BK;
-    pl.splits = xv_cdiv(xv_cdiv(R, pl.chunk), form);
+    const int min_ksteps = 2;                                          // fewest K-steps a workgroup is given
+    int splits = std::max(1, XV_RESIDENT_WGS / tiles);
+    if (splits > ksteps / min_ksteps) splits = std::max(1, ksteps / min_ksteps);
+    pl.chunk = xv_cdiv(ksteps, splits) * BK;
+    pl.splits = xv_cdiv(R, pl.chunk);
     return pl;
 }
 int xv_tn_splits(int M, int N, int R) { return xv_tn_plan(M, N, R).splits; }
@@ -1384,9 +1338,7 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     {
         XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
         if (tn_wide_rows(g.M)) hipLaunchKernelGGL(xv_gemm_tn160_kernel, dim3(p.tiles_n * pl.splits), dim3(256), 0, s, p);
-        else if (pl.form == 4) hipLaunchKernelGGL(xv_gemm_tn_kernel<4>, dim3(wgs), dim3(1024), 0, s, p);
-        else if (pl.form == 2) hipLaunchKernelGGL(xv_gemm_tn_kernel<2>, dim3(wgs), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL(xv_gemm_tn_kernel<1>, dim3(wgs), dim3(256), xv_gemm_lds_pad(true), s, p);
+        else hipLaunchKernelGGL(xv_gemm_tn_kernel, dim3(wgs), dim3(256), 0, s, p);
     }
     XV_LAUNCH_CHECK();
     return 0;
