@@ -45,8 +45,8 @@ int xv_device_count(void);
 
 /* Live kernel timing for bench.py's roofline leg: while enabled, every launch of the three MFMA
  * GEMM kernels is bracketed by hipEvents on the stream it is launched on.
- *   kind 0 = xv_gemm_nt_kernel<true> / xv_gemm_nt_sk_kernel<true, *>   (forward conv/dense + BN-statistics epilogue)
- *   kind 1 = xv_gemm_nt_kernel<false> / xv_gemm_nt_sk_kernel<false, *> (data gradients, logits)
+ *   kind 0 = xv_gemm_nt_kernel<true, *> / xv_gemm_nt_sk_kernel<true, *>   (forward conv/dense + BN-statistics epilogue)
+ *   kind 1 = xv_gemm_nt_kernel<false, *> / xv_gemm_nt_sk_kernel<false, *> (data gradients, logits)
  *   kind 2 = xv_gemm_tn_kernel        (weight gradients)
  *   kind 3 = xv_gemm16_nt_kernel<true>, kind 4 = xv_gemm16_nt_kernel<false>, kind 5 = xv_gemm16_tn_kernel
  *            (the same three roles on fp16 hi/lo planes, XV_PRECISION_F16X3)
@@ -58,6 +58,11 @@ int xv_profile_begin(int max_launches);
 int xv_profile_begin_kinds(int max_launches, uint32_t kind_mask);
 #define XV_PROFILE_KINDS 6
 int xv_profile_end(int64_t launches[XV_PROFILE_KINDS], double ms[XV_PROFILE_KINDS], double flops[XV_PROFILE_KINDS]);
+/* Diagnostics: the schedule xv_affine_forward / xv_affine_dgrad pick for C[M][N] = A[M][K] . Bt[N][K]^T given ample workspace
+ * (stats: the launch emits BatchNorm statistics = a forward launch; co_running: a data gradient beside the weight-gradient stream):
+ * 0 one workgroup per tile (xv_gemm_nt_kernel), 1 the evenly scheduled kernel (xv_gemm_nt_sk_kernel), 2 whole tiles + shares of the
+ * remaining tiles (xv_gemm_nt_kernel), 3 split-K + slab sum.  tools/pmc_traffic.py attributes layers to kernels with it. */
+int xv_debug_nt_schedule(int M, int N, int K, int stats, int co_running);
 
 /* dst[r][0..cols) = src[r][0..cols) for r < rows (device to device, pitches in floats). */
 int xv_copy_2d(void* stream, float* dst, size_t ldd, const float* src, size_t lds, int rows, int cols);

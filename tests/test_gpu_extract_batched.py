@@ -159,3 +159,39 @@ def test_extract_driver_batched_equals_one_at_a_time(tmp_path):
         embs = [O.tdnn_forward(V, f[None, s:s + n], cfg_o, False)[1]["tdnn6_dense"][0] for s, n in chunks]
         ref = (np.array(embs) * np.array([n for _, n in chunks])[:, None]).sum(0) / sum(n for _, n in chunks)
         assert rel_err(out[k], ref) <= 5e-5, (k, rel_err(out[k], ref))
+
+
+def test_predict_batch_rejects_wrong_dimension_and_short_items(tmp_path):
+    """the GPU 'CM ' decoder takes the column stride from the model's feature dimension, so a matrix of another width must
+    be refused (it would decode garbage and read past its record), and an utterance shorter than the network's receptive field has no valid
+    output frame (the pooling would clamp to a frame that sees padding): both raise before anything is enqueued."""
+    from tf_kaldi_speaker_amd.dataset import kaldi_io
+    import io
+    model = str(tmp_path / "exp")
+    _write_model(model)
+    sys.path.insert(0, PKG)
+    try:
+        from model.trainer import Trainer
+        from misc.utils import Params
+        tr = Trainer(Params(os.path.join(model, "nnet", "config.json")), model, single_cpu=True)
+        tr.build("predict", dim=30)
+        rs = np.random.RandomState(3)
+        good = rs.randn(40, 30).astype(np.float32)
+        assert tr.predict_batch([good]).shape == (1, 512)
+        assert tr.engine.min_frames == 15
+        with pytest.raises(ValueError, match="expects \\[frames, 30\\]"):
+            tr.predict_batch([good, rs.randn(40, 24).astype(np.float32)])
+        buf = io.BytesIO()
+        kaldi_io.write_compressed_mat(buf, rs.randn(50, 24).astype(np.float32), key="narrow")
+        buf.seek(0)
+        packed = [m for _, m in kaldi_io.read_mat_ark_packed(buf)]
+        assert isinstance(packed[0], kaldi_io.PackedMatrix) and packed[0].shape == (50, 24)
+        with pytest.raises(ValueError, match="expects \\[frames, 30\\]"):
+            tr.predict_batch(packed)
+        with pytest.raises(ValueError, match="receptive field"):
+            tr.predict_batch([good, rs.randn(14, 30).astype(np.float32)])
+        with pytest.raises(ValueError, match="frame counts must lie in"):
+            tr.engine.forward_lengths(np.zeros((2, 40, 30), np.float32), np.array([40, 9], np.int32))
+        tr.close()
+    finally:
+        sys.path.remove(PKG)

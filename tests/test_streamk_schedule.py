@@ -170,3 +170,19 @@ def test_shares_cover_every_k_step_once(tiles, ksteps):
         cover += list(range(k0, k1))
     assert cover == list(range(ksteps))
     assert n_whole + (tiles - n_whole) * sh < 65536 * 16 and tiles <= 16384                  # XV_TN_MAX_TILES tickets
+
+
+def test_library_reports_the_schedule_the_launcher_picks():
+    """xv_debug_nt_schedule (include/xvector_hip.h): the launcher's own choice among one workgroup per tile (0), the even schedule (1),
+    whole tiles + shares (2) and split-K (3), for the S1 and 64 x 300 layer shapes - what tools/pmc_traffic.py attributes layers to kernels
+    with.  No GPU needed: it is host arithmetic."""
+    from tf_kaldi_speaker_amd import _lib
+    f = _lib.load().xv_debug_nt_schedule
+    # S1 (128 x 200): every forward launch and tdnn3-5's data gradients one workgroup per tile; tdnn2's data gradient (784 tiles, three whole
+    # tiles per CU beside the weight-gradient stream) on the even schedule
+    assert [f(24576, 512, 2560, 1, 0), f(23808, 512, 3584, 1, 0), f(23808, 512, 512, 1, 0), f(23808, 1500, 512, 1, 0)] == [0, 0, 0, 0]
+    assert [f(25088, 512, 2560, 0, 1), f(24576, 512, 3584, 0, 1), f(23808, 512, 512, 0, 1), f(23808, 512, 1500, 0, 1)] == [1, 0, 0, 0]
+    # 64 x 300: 584 / 572 tiles = two whole tiles per CU + 72 / 60 shared ones
+    assert f(64 * 292, 512, 2560, 1, 0) == 2 and f(64 * 286, 512, 3584, 1, 0) == 2
+    # one 300-frame utterance of an extraction run: 12 tiles, no statistics -> split-K
+    assert f(286, 512, 3584, 0, 0) == 3

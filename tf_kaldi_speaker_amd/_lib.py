@@ -100,6 +100,7 @@ SIGNATURES = {
     "xv_profile_begin": (_I, [_I]),
     "xv_profile_begin_kinds": (_I, [_I, C.c_uint32]),
     "xv_profile_end": (_I, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "xv_debug_nt_schedule": (_I, [_I, _I, _I, _I, _I]),
     "xv_copy_2d": (_I, [_VP, _VP, _SZ, _VP, _SZ, _I, _I]),
     "xv_op_workspace_bytes": (_SZ, [_I, _I, _I]),
     "xv_pad_channels": (_I, [_VP, _VP, _I, _I, _VP, _I]),

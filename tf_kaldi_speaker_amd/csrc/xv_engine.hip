@@ -1368,11 +1368,14 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             w.M = e->Lout; w.N = e->ldl; w.R = b;
             w.splits = xv_tn_splits(w.M, w.N, w.R);
             XV_REQUIRE((size_t)w.splits * w.M * w.N * sizeof(float) <= e->ws_bytes, "engine_backward: workspace too small for the loss weight gradient");
-            w.P = (float*)lws;
+            // unsplit (xv_tn_plan: a short reduction over many tiles): the one "slab" IS d wn [Lout][ldl] - no slab sum
+            w.P = w.splits == 1 ? e->dwn : (float*)lws;
             rc = xv_launch_gemm_tn(ss, w);
             if (rc) return rc;
-            rc = xv_launch_wgrad_reduce(ss, w.P, w.splits, 1, e->Lout, e->Lout, e->ldl, e->ldl, nullptr, 0, 0.f, e->dwn, e->ldl);
-            if (rc) return rc;
+            if (w.splits > 1) {
+                rc = xv_launch_wgrad_reduce(ss, w.P, w.splits, 1, e->Lout, e->Lout, e->ldl, e->ldl, nullptr, 0, 0.f, e->dwn, e->ldl);
+                if (rc) return rc;
+            }
             if (e->with_margin && c.aux_mhe) {
                 rc = xv_mhe_add_grad(ss, e->dwn, e->Lout, e->N, e->ldl, e->mhe_coef, e->mhe_counts);
                 if (rc) return rc;

@@ -192,12 +192,9 @@ __device__ __forceinline__ void nt_store_tile_rows(f32x16 (&acc)[2][2], float* s
     }
 }
 
-// The evenly scheduled kernel rotates the issue priority of its waves every K-step: priority = (K-step + the wave's slot in its SIMD) mod 4,
-// so the co-resident workgroups take turns at the top.  [measured, round 3, stamps of tdnn2 forward at S1] the arbiter serves the oldest wave
-// first and the three workgroups of a CU finish at 384 / 444 / 481 us, the CU running two, then one workgroup at the end; with the rotation
-// 471 / 471 / 476 us.  tdnn2 / tdnn3 forward 497 -> 484 / 687 -> 669 us, 398 -> 388 / 531 -> 521 us at 64 x 300.  NOT in the
-// one-workgroup-per-tile kernel: a launch of several rounds (tdnn5: 2 232 tiles) wants its oldest workgroups to finish first and free
-// their slots - the rotation cost it 3-8 % (256 -> 278 us at 64 x 300).
+// The evenly scheduled kernel rotates the issue priority of its waves every K-step - priority = (K-step + the wave's slot in its SIMD) mod 4 -
+// so that the co-resident workgroups take turns at the top and finish together; NOT in the one-workgroup-per-tile kernel, whose multi-round
+// launches want their oldest workgroups to finish first (note 1).
 __device__ __forceinline__ int xv_wave_slot() { return __builtin_amdgcn_s_getreg(4 | (3 << 11)) & 15; }      // HW_ID.WAVE_ID: differs between the waves of one SIMD
 __device__ __forceinline__ void xv_rot_prio(int x) {
     switch (x & 3) {
@@ -208,11 +205,7 @@ __device__ __forceinline__ void xv_rot_prio(int x) {
     }
 }
 
-// [measured, round 2 / 3, tdnn2 forward at S1; the ablation builds are in the history of this file and in DESIGN.md appendix A] what did
-// NOT move this kernel (all within +-2 %): 5 workgroups per CU, s_setprio around the MFMA block, a static priority per co-resident
-// workgroup, a start-up stagger, fragments of the next half K-step read early, K-step 32, a third LDS slot (DMA two K-steps ahead: MFMA-pipe
-// occupancy 0.867 -> 0.83-0.85); per-wave private staging without any barrier was 20 % slower.  What did: the address form of the
-// LDS-DMA (xv_dma16, xv_common.h).
+// (What did and did not move this kernel's K loop: DESIGN.md Appendix B, note 2.)
 template <bool STATS, bool ROWS>
 __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(128))) void xv_gemm_nt_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * NT_PITCH];      // two slots of [A | B]
@@ -404,10 +397,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
 // [w * total / P, (w + 1) * total / P) - a run that may start and end in the middle of a tile.  A tile whose K-steps were shared
 // stores its partial accumulators as slabs (the lane-order layout of the TN kernel), and the workgroup that finishes its share
 // LAST sums them in K order (xv_handoff_* contract) and runs the ordinary epilogue (bias, store, BatchNorm statistics).
-// Why [measured, round 3, tools/gemm_probe]: with one workgroup per tile the time of a launch is set by the CU with the most tiles:
-// tdnn2's data gradient at S1 (784 tiles = 768 + 16: sixteen CUs run a fourth tile) ran at 101 TF against 134 TF for tdnn3's
-// (768 tiles), and the shipped batch shape (64 x T~300: 584 / 572 tiles = 2.3 per CU, some CUs 3) ran tdnn2 / tdnn3 forward in the
-// time of the 128 x 200 batch (100 TF).  It also replaces the launcher's split-K + xv_splitk_reduce_kernel for few-tile problems.
+// It exists for tile-count quantisation (784 tiles on 768 slots, 2.3 tiles per CU in the shipped batch): DESIGN.md Appendix B, note 3.
 struct NTSKArgs {
     NTArgs g;
     int P;                    // workgroups (grid size)
@@ -419,19 +409,10 @@ struct NTSKArgs {
 
 __device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (int)((((u + 1) * P) - 1) / total); }
 
-// (Rounds 2-4 kept a context-window form of this kernel for layers with taps > 1: the rows of ONE 16-channel chunk of x staged once for
-// all taps, the weight tile per K-step - 39 % fewer staged bytes at 5 taps.  [measured, round 4, tools/gemm_probe XV_NT_SCHED=sk, same box]
-// since the LDS-DMA moved to scalar bases staging is cheap and the window's per-step row arithmetic (21 against 6 vector instructions per
-// K-step) costs more than it saves: tdnn2 / tdnn3 forward and data gradient 492 / 481 / 664 / 641 -> 467 / 470 / 641 / 626 us at S1,
-// 392 / 369 / 524 / 500 -> 374 / 360 / 497 / 492 us at 64 x 300; the S1 step -0.6 %, 64 x U{200..400} -0.3 %.  Removed; the split-precision
-// path keeps its window kernel (xv_gemm16.hip), where the staged bytes are what bounds it.  profiles/r04_ab_variants.txt, runs 35-36.)
+// (Its context-window form of rounds 2-4 - the rows of one 16-channel chunk of x staged once for all taps - is gone: DESIGN.md Appendix B, note 4.)
 #define XV_NT_SK_WPC 3                       // workgroups per CU of the even schedule: one co-resident round of 768
-// Register budget: 128 VGPRs (4 waves per SIMD), although the launch itself is 3 workgroups per CU.  [measured, round 4, same box,
-// bench.py 64 x U{200..400}] declared at its real occupancy - 168 VGPRs, no scratch - the kernel spills nothing (at 128 the four
-// instantiations spill 7-29 registers of per-tile set-up into 32-104 B of scratch, none of it in the K loop) but the step got SLOWER, 4.34
-// -> 4.55 ms: three waves of 168 registers fill a SIMD's file, so no wave of the weight-gradient kernel on the other stream (128 VGPRs)
-// fits beside them, while three waves of 128 leave exactly that room.  The free fourth slot is worth more than the spills cost.
-// (tools/build_variants.sh "sk168:-DXV_NT_SK_VGPRS=168 -DXV_NT_SK_OCC=3" rebuilds the other form; profiles/r04_sk_registers.txt)
+// Register budget: 128 VGPRs (4 waves per SIMD) although the launch is 3 workgroups per CU - the free fourth slot is worth more to the other
+// stream than the 7-23 spilled set-up registers cost (note 5; tools/build_variants.sh "sk168:-DXV_NT_SK_VGPRS=168 -DXV_NT_SK_OCC=3").
 #ifndef XV_NT_SK_VGPRS
 #define XV_NT_SK_VGPRS 128
 #define XV_NT_SK_OCC XV_WGS_PER_CU
@@ -469,8 +450,7 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
     // first.  Every workgroup then walks K upwards from (about) 0 in step with the others, so the K-slices of the weight matrix in flight on
     // an XCD at any moment are the same few for all its workgroups, as in a one-workgroup-per-tile launch.  In run order the workgroups of
     // an XCD sit at all K offsets at once, their weight slices do not fit the L2 together and are re-fetched from the Infinity Cache
-    // [measured, FETCH_SIZE, tdnn2's data gradient at S1: 784 tiles on 768 workgroups] 1.45 GB fetched past the L2 per launch in run order,
-    // 0.16 GB with this order (0.18 GB for one workgroup per tile); the time is the same - the Infinity Cache absorbed it.
+    // (1.45 -> 0.16 GB past the L2 per launch, same time: DESIGN.md Appendix B, note 6.)
     const long u_begin = u;
     const long u_mid = (u / q.nk + 1) * q.nk;                  // end of the first tile of the run
     const bool wrap_first = u % q.nk != 0 && u_mid < u_end && u_end - u_mid <= q.nk;
@@ -623,9 +603,7 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
                 if (v == w && me <= 1) continue;
                 const int v_first_tile = (int)(((long)v * q.total / q.P) / q.nk);
                 const float* src = q.slab + ((long)v * 2 + (tile == v_first_tile ? 0 : 1)) * (BM * BN) + tid * 4;
-                // eight 16-byte loads in flight per lane.  [measured, round 4, same box, 64 x U{200..400}] four in flight need sixteen fewer live
-                // registers - the two data-gradient instantiations then compile without scratch - and cost the step 1.5 % (4.39 vs 4.32 ms):
-                // a shared tile end is a latency chain, not a register problem.
+                // eight 16-byte loads in flight per lane: a shared tile end is a latency chain (four in flight: no scratch, step +1.5 %; DESIGN.md Appendix B, note 7)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     f32x4 x[8];
@@ -749,6 +727,53 @@ int xv_nt_shares(int tiles, int ksteps, bool stats, bool beside_wgrad, size_t ws
     return best_s;
 }
 
+// Which schedule an NT launch runs (DESIGN.md section 4 "fp32 GEMM design" states the three and where each wins; the measurements behind every
+// constant here are DESIGN.md Appendix A, rounds 3-4, and profiles/r04_nt_whole_plus_shares.txt / r04_ab_variants.txt):
+//   DP      one workgroup per tile, dealt to the CUs by the hardware: cost ceil(tiles / 256) K-loops on the busiest CU
+//   SK      one co-resident round of <= 768 persistent workgroups with equal runs of K-steps, tiles shared through slabs: total / 256 K-steps
+//           + ~15 K-steps of hand-over per workgroup; its K loop is 4-8 % slower than DP's, so it only wins on tile-count quantisation
+//   SHARES  DP for the first floor(tiles / 256) * 256 tiles, every remaining tile cut into `shares` K ranges behind them (xv_nt_shares)
+//   SPLIT   few tiles and no BatchNorm statistics: split-K over the whole chip + a slab-sum launch (extraction one utterance at a time,
+//           segment-level layers of batches > 128 chunks)
+enum { XV_NT_DP = 0, XV_NT_SK = 1, XV_NT_SHARES = 2, XV_NT_SPLIT = 3 };
+struct XvNtPlan { int kind, p_sk, shares, splits; };
+static XvNtPlan xv_nt_plan(int M, int N, int K, bool stats, bool co_running, bool have_ws, size_t ws_bytes, int forced /* XvEnv::nt_sched */) {
+    const int tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN), ksteps = xv_cdiv(K, BK);
+    XvNtPlan pl = {XV_NT_DP, 1, 0, 1};
+    const long total = (long)tiles * ksteps;
+    const long p_sk = std::min<long>(std::min<long>(256L * XV_NT_SK_WPC, std::max<long>(1, total / 4)), 8L * tiles);
+    const long t_sk = (total / p_sk) * xv_cdiv(p_sk, 256) + (15 * 16 / BK) * std::min<long>(XV_NT_SK_WPC, xv_cdiv(p_sk, 256));
+    const long t_dp = tiles <= XV_RESIDENT_WGS ? (long)xv_cdiv(tiles, 256) * ksteps : total / 256 + ksteps / 2;
+    bool sk = forced ? forced == 2 : t_sk + t_sk / 32 < t_dp;
+    const int shares = forced || !have_ws || tiles > XV_TN_MAX_TILES ? 0 : xv_nt_shares(tiles, ksteps, stats, co_running, ws_bytes);
+    if (shares) sk = false;
+    const bool few = !stats && tiles < 192 && ksteps >= 8 && !forced;
+    if (!few && sk) {
+        const bool shared_tiles = total % p_sk != 0 || (total / p_sk) % ksteps != 0;
+        if (!shared_tiles || ((size_t)p_sk * 2 * BM * BN * sizeof(float) <= ws_bytes && have_ws && tiles <= XV_TN_MAX_TILES)) {
+            pl.kind = XV_NT_SK; pl.p_sk = (int)p_sk;
+            return pl;
+        }
+    }
+    int splits = 1;
+    if (!stats && tiles < XV_RESIDENT_WGS / 2 && ksteps >= 8) {
+        splits = std::max(1, std::min(XV_RESIDENT_WGS / tiles, ksteps / 4));
+        const long np = (long)xv_align(N, 4);
+        // the slabs are written and read back: beyond ~8 MB the reduce costs more than the extra workgroups buy
+        const long slab_cap = std::max<long>(8, (8L << 20) / ((long)M * np * (long)sizeof(float)));
+        if (splits > slab_cap) splits = (int)slab_cap;
+        while (splits > 1 && (size_t)splits * M * np * sizeof(float) > ws_bytes) --splits;
+    }
+    if (splits > 1) { pl.kind = XV_NT_SPLIT; pl.splits = splits; }
+    else if (shares) { pl.kind = XV_NT_SHARES; pl.shares = shares; }
+    return pl;
+}
+// diagnostics (tools/pmc_traffic.py maps S1's layers to the kernels that ran them with this): the schedule of an NT problem given ample workspace
+extern "C" int xv_debug_nt_schedule(int M, int N, int K, int stats, int co_running) {
+    const XvEnv* env = xv_env();
+    return xv_nt_plan(M, N, K, stats != 0, co_running != 0, true, (size_t)1 << 32, env ? env->nt_sched : 0).kind;
+}
+
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     XV_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm_nt: K/lda/ldb must be multiples of 4 (K=%d lda=%ld ldb=%ld)", g.K, g.lda, g.ldb);
     XV_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.Bt % 16) == 0, "gemm_nt: operands must be 16-byte aligned");
@@ -773,121 +798,45 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
 #endif
     const int tiles = p.tiles_m * p.tiles_n;
     const int ksteps = xv_cdiv(g.K, BK);
-    // Schedule (xv_gemm_nt_sk_kernel): either one workgroup per tile, dealt to the CUs by the hardware as slots free up ("dp"), or one
-    // co-resident round of XV_NT_WPC x 256 workgroups with equal runs of K-steps ("sk", tiles shared through slabs).  In K-steps on the
-    // busiest CU: dp = ceil(tiles / 256) * nk while the tiles fit the resident slots (beyond that the hardware's dealing evens out to
-    // about half a tile), sk = total / 256 + what the hand-overs cost: [measured, round 3, tools/gemm_probe on the S1 and 64 x 300 layer
-    // shapes] 15 K-steps of BK = 16 per workgroup (two shared tile ends each: 64 KB slab store + drain + ticket, the last arrival
-    // reads a slab and runs the tile's epilogue), which reproduces every measured time within 2 %: tdnn2's data gradient at S1 (784
-    // tiles) 641 -> 528 us, tdnn2 / tdnn3 forward of the 64 x 300 batch (584 / 572 tiles) 489 -> 413 / 677 -> 551 us, while the K = 512
-    // layers (32 K-steps per tile) lose 10-30 % to it and stay on dp.  A tile is never split into more than 8 shares: its LAST workgroup
-    // sums them alone (the few-tile, long-K problems of segment-level batches > 128).
-    // XV_NT_SCHED=dp|sk forces one (diagnostics, tools/gpu_round_final.sh).
-    // [measured, round 4, same box; profiles/r04_ab_variants.txt "hy"] a third schedule - the first floor(tiles / 256) * 256 tiles whole, one
-    // workgroup each at the head of the grid, the remaining tiles cut into shares of ~24 K-steps for short workgroups the hardware deals into
-    // the free slots (a quarter of the even schedule's hand-overs, plain epilogues for most tiles) - ran in this kernel: alone tdnn2's data
-    // gradient at S1 480 -> 470 us, the 64 x 300 forward GEMMs 391 -> 383 / 520 -> 519 us, tdnn3's data gradient there 498 -> 519 us, and the
-    // short-K layers of that batch 100 -> 92 / 94 -> 82 us against one workgroup per tile; in the step S1 and 64 x U{200..400} +0.3 % / +0.5 %
-    // where the even schedule ran before and -0.1 % (noise) on the short-K layers.  What holds the even schedule at 0.81-0.86 of the pipe is
-    // not the hand-overs (stamps: 28 us of tile switch + 17 us of epilogue per workgroup, hidden behind the CU's other workgroups) but this
-    // kernel's K loop itself, 8 % behind the one-workgroup-per-tile kernel on whole tiles (482 vs 448 us on tdnn2's forward at S1).  Removed.
     const XvEnv* env = xv_env();
     if (!env) return 2;
-    const int wpc = XV_NT_SK_WPC;
-    bool sk = false;
-    long p_sk = 1;
-    {
-        const long total = (long)tiles * ksteps;
-        p_sk = std::min<long>(std::min<long>(256L * wpc, std::max<long>(1, total / 4)), 8L * tiles);
-        const long t_sk = (total / p_sk) * xv_cdiv(p_sk, 256) + (15 * 16 / BK) * std::min<long>(wpc, xv_cdiv(p_sk, 256));
-        const long t_dp = tiles <= XV_RESIDENT_WGS ? (long)xv_cdiv(tiles, 256) * ksteps : total / 256 + ksteps / 2;
-        // Also for a launch beside the weight-gradient stream (g.co_running: the data gradients).  [measured, round 3, rocprofv3 timelines of
-        // the S1 step, first half of the round] beside the weight-gradient kernel an unbalanced data-gradient launch cost nothing - the other
-        // kernel's workgroups took the slots its short CUs freed - while the persistent round holds its three slots per CU to the end;
-        // [measured again after the DMA / slab-sum work, medians of 4 alternated runs] with the even schedule for those launches too (tdnn2's
-        // data gradient at S1: 784 tiles): S1 -0.7 %, S2 -0.5 %, 64 x U{200..400} -0.3 %, S4 -0.4 %, S5 +0.1 % - the data-gradient launches now
-        // spend a good part of their time alone on the chip (the weight-gradient stream sums slabs or waits for the next dz meanwhile).
-        sk = env->nt_sched ? env->nt_sched == 2 : t_sk + t_sk / 32 < t_dp;
-    }
-    // Few tiles and no BatchNorm statistics to emit (one utterance at a time in extraction, the segment-level layers of batches > 128 chunks):
-    // split-K over the whole chip + the slab-sum launch below.  [measured, round 3, tools/extract_bench.py / segment_bench.py] the
-    // persistent kernel - a tile shared by at most 8 workgroups, its last arrival summing alone - was slower there: 0.214 -> 0.288 ms
-    // per 300-frame utterance (12 tiles), 0.30 -> 0.35 ms at 1 000 frames, 30 -> 80 us for d out (4 tiles, K = 7 352); at 10 000 frames
-    // (316 tiles) it wins, 1.45 -> 1.41 ms.
-    // Third schedule, "whole tiles + shares", in the one-workgroup-per-tile kernel: the first floor(tiles / 256) * 256 tiles go to one block
-    // each, every remaining tile is cut into `shares` K ranges for short blocks BEHIND them in the grid, which the hardware deals into the
-    // slots the whole-tile blocks leave; a tile's last share sums the others and runs the epilogue (xv_gemm_nt_kernel).  It keeps that
-    // kernel's K loop for every tile (the even schedule's is 8 % slower) and shares only the remainder (64 x 300: 72 of 584 tiles).
-    // [measured, round 4, same box; profiles/r04_nt_whole_plus_shares.txt] alone, against the schedule it replaces: 64 x 300 tdnn2 / tdnn3
-    // forward 390 -> 361 / 521 -> 476 us, tdnn4 forward / data gradient 100 -> 81 / 95 -> 75 us, 64 x 400 tdnn2 forward 514 -> 467 us; in the
-    // step 64 x U{200..400} -1.5 % (4.33 -> 4.27 ms, T-weighted 110.5 -> 111.3 TF), S1 / S4 unchanged.  It also serves launches of several
-    // rounds (the share blocks come last in the grid and fill the tail): 128 x 400 tdnn2 / tdnn3 forward 973 -> 916 / 1 318 -> 1 255 us,
-    // tdnn5's data gradient 611 -> 542 us; the S2 step -0.9 %, S5 -2.2 %.  Where it is NOT used:
-    //  * fewer than two whole tiles per CU (one, for the forward launches): when the shares are done the whole-tile blocks finish alone, and
-    //    one block per CU does not keep the matrix pipe busy (64 x 220, tdnn3's data gradient, 424 tiles: 370 -> 429 us);
-    //  * a remainder above 128 tiles: the even schedule is as good or better there (64 x 340, 152 remaining tiles: 564 -> 582 us);
-    //  * exactly three whole tiles per CU beside the weight-gradient stream: tdnn2's data gradient at S1 (784 tiles) ran 477 -> 457 us alone and the
-    //    step lost 0.4 % - the shares take the fourth slot of every CU first, the even schedule leaves it to the other stream.
-    const int hy_shares = env->nt_sched || !g.ws || tiles > XV_TN_MAX_TILES ? 0 : xv_nt_shares(tiles, ksteps, g.bn_part != nullptr, g.co_running != 0, g.ws_bytes);
-    if (hy_shares) sk = false;
-    const bool few = !g.bn_part && tiles < 192 && ksteps >= 8 && !env->nt_sched;
-    // (Neither kernel stages a context window of x any more: [measured, round 3, after the LDS-DMA moved to scalar bases] staging is cheap -
-    // MFMA-pipe occupancy 0.939 against 0.951 without any - so what a window saves, 39 % of the staged bytes at 5 taps, does not pay for its
-    // per-step row arithmetic: one workgroup per tile, tdnn2 / tdnn3 forward at S1 478 / 660 us with the window, 447 / 621 us without; round 4
-    // found the same for the even schedule, see the note above xv_gemm_nt_sk_kernel.)
-    if (!few && sk) {
+    const XvNtPlan pl = xv_nt_plan(g.M, g.N, g.K, g.bn_part != nullptr, g.co_running != 0, g.ws != nullptr, g.ws_bytes, env->nt_sched);
+    const int stats_kind = g.bn_part ? 0 : 1;      // XvProfScope kind
+    if (pl.kind == XV_NT_SK) {
         NTSKArgs q;
         q.nk = ksteps;
         q.total = (long)tiles * ksteps;
-        q.P = (int)p_sk;
+        q.P = pl.p_sk;
         const bool shared_tiles = q.total % q.P != 0 || (q.total / q.P) % ksteps != 0;
-        if (!shared_tiles || ((size_t)q.P * 2 * BM * BN * sizeof(float) <= g.ws_bytes && g.ws && tiles <= XV_TN_MAX_TILES)) {
-            p.C = g.C; p.ldc = g.ldc; p.c_split_stride = 0; p.k_chunk = ksteps * BK;
-            p.part_sum = g.bn_part; p.part_m2 = nullptr;
-            q.g = p;
-            q.slab = (float*)g.ws;
-            q.tickets = shared_tiles ? tn_tickets_for(s) : nullptr;
-            XV_REQUIRE(!shared_tiles || (q.tickets && ((uintptr_t)q.slab % 16) == 0), "gemm_nt: hand-over buffers unavailable");
-            XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
-            const unsigned pad = 0;
-            if (g.bn_part) {
-                if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, true>), dim3(q.P), dim3(256), pad, s, q);
-                else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, false>), dim3(q.P), dim3(256), pad, s, q);
-            } else {
-                if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<false, true>), dim3(q.P), dim3(256), pad, s, q);
-                else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<false, false>), dim3(q.P), dim3(256), pad, s, q);
-            }
-            XV_LAUNCH_CHECK();
-            return 0;
+        p.C = g.C; p.ldc = g.ldc; p.c_split_stride = 0; p.k_chunk = ksteps * BK;
+        p.part_sum = g.bn_part; p.part_m2 = nullptr;
+        q.g = p;
+        q.slab = (float*)g.ws;
+        q.tickets = shared_tiles ? tn_tickets_for(s) : nullptr;
+        XV_REQUIRE(!shared_tiles || (q.tickets && ((uintptr_t)q.slab % 16) == 0), "gemm_nt: hand-over buffers unavailable");
+        XvProfScope prof(s, stats_kind, 2.0 * g.M * g.N * g.K);
+        if (g.bn_part) {
+            if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, true>), dim3(q.P), dim3(256), 0, s, q);
+            else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<true, false>), dim3(q.P), dim3(256), 0, s, q);
+        } else {
+            if (p.row_store) hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<false, true>), dim3(q.P), dim3(256), 0, s, q);
+            else hipLaunchKernelGGL((xv_gemm_nt_sk_kernel<false, false>), dim3(q.P), dim3(256), 0, s, q);
         }
+        XV_LAUNCH_CHECK();
+        return 0;
     }
-    int splits = 1;
-    if (!g.bn_part && tiles < XV_RESIDENT_WGS / 2 && ksteps >= 8) {
-        splits = XV_RESIDENT_WGS / tiles;
-        if (splits > ksteps / 4) splits = ksteps / 4;
-        if (splits < 1) splits = 1;
-        const long np = (long)xv_align(g.N, 4);
-        // the slabs are written and read back: beyond ~8 MB the reduce costs more than the extra workgroups buy
-        const long slab_cap = std::max<long>(8, (8L << 20) / ((long)g.M * np * (long)sizeof(float)));
-        if (splits > slab_cap) splits = (int)slab_cap;
-        while (splits > 1 && (size_t)splits * g.M * np * sizeof(float) > g.ws_bytes) --splits;
-    }
-    if (splits == 1) {
+    if (pl.kind != XV_NT_SPLIT) {      // one workgroup per tile, or whole tiles + shares of the remaining ones
         p.C = g.C; p.ldc = g.ldc; p.c_split_stride = 0; p.k_chunk = ksteps * BK;
         dim3 grid(tiles, 1, 1);
-        if (hy_shares) {
+        if (pl.kind == XV_NT_SHARES) {
             p.n_whole = tiles / 256 * 256;
-            p.shares = hy_shares;
+            p.shares = pl.shares;
             p.slab = (float*)g.ws;
             p.tickets = tn_tickets_for(s);
             XV_REQUIRE(p.tickets && ((uintptr_t)p.slab % 16) == 0, "gemm_nt: hand-over buffers unavailable");
-            grid.x = p.n_whole + (tiles - p.n_whole) * hy_shares;
+            grid.x = p.n_whole + (tiles - p.n_whole) * pl.shares;
         }
-        // [measured, round 4, tools/gemm_probe] three workgroups per CU (an LDS pad of 16 KB per workgroup) for launches whose tile count packs
-        // better into rounds of 768 than of 1 024 - tdnn5 forward: 2 232 tiles = 2.18 rounds of 1 024, 2.9 of 768; a per-CU model (0.85 us per
-        // K-step and workgroup while others cover its waits, 2 us when it is alone) reproduces its 294 us and predicted 256 - changed nothing:
-        // 293.5 vs 295.7 us.  The tail of such a launch is not what the model says it is; removed.
-        XvProfScope prof(s, g.bn_part ? 0 : 1, 2.0 * g.M * g.N * g.K);
+        XvProfScope prof(s, stats_kind, 2.0 * g.M * g.N * g.K);
         if (g.bn_part) {
             p.part_sum = g.bn_part;
             p.part_m2 = nullptr;
@@ -900,7 +849,8 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
         XV_LAUNCH_CHECK();
         return 0;
     }
-    XV_REQUIRE(!g.bn_part, "gemm_nt: bn statistics are not available on the split path");
+    // split-K over the whole chip + a slab-sum launch (few tiles, no BatchNorm statistics to emit)
+    int splits = pl.splits;
     const long np = (long)xv_align(g.N, 4);
     XV_REQUIRE((size_t)splits * g.M * np * sizeof(float) <= g.ws_bytes, "gemm_nt: workspace too small (%zu bytes)", g.ws_bytes);
     p.C = (float*)g.ws; p.ldc = np; p.c_split_stride = (long)g.M * np;
@@ -1148,16 +1098,15 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p
 
 
 // ---- weight gradient of a layer with 129 ... 160 input rows (tdnn1: 5 taps x 32 padded feature channels) ----------------------------
-// On 128 x 128 tiles those rows are two tiles of which 3/8 of the second is real: 1.6 x the MFMAs, on the last weight gradient of every step
-// (nothing is left to overlap it with: 96 us in the step, 61 TF alone).  [measured, round 4, same box] 67.3 -> 55.2 us alone incl. the slab
-// sum at S1, 56 -> 47 us at 64 x 300, 115 -> 91 us at 128 x 400; the S1 step -0.3...-0.5 %.  Here a workgroup owns ALL rows x 128 columns: wave w = columns
-// 32 w .. 32 w + 31, five 32 x 32 accumulators down the rows (rows 0..127 interleaved in pairs as in xv_gemm_tn_kernel - one ds_read_b64
-// feeds two of them - rows 128..159 straight).  LDS image per stage: A [16][160] (linear: an LDS-DMA piece of 1 KB is 1.6 rows, every lane
-// resolves its own (row, column)) + B [16][128]; 2 workgroups per CU, 512 of them = one round.
+// On 128 x 128 tiles those rows are two tiles of which 3/8 of the second is real: 1.6 x the MFMAs, on the last weight gradient of every step.
+// Here a workgroup owns ALL rows x 128 columns: wave w = columns 32 w .. 32 w + 31, five 32 x 32 accumulators down the rows (rows 0..127
+// interleaved in pairs as in xv_gemm_tn_kernel - one ds_read_b64 feeds two of them - rows 128..159 straight).  LDS image per stage: A [16][160]
+// (linear: an LDS-DMA piece of 1 KB is 1.6 rows, every lane resolves its own (row, column)) + B [16][128]; 2 workgroups per CU, 512 of them =
+// one round.  (67 -> 55 us alone at S1; workgroup counts and schedules tried: DESIGN.md Appendix B, note 8.)
 #define TNW_M 160
 #define TNW_A_PIECES (BK * TNW_M / 256)      // 1 KB pieces per stage: 10
 #define TNW_B_PIECES (BK * BN / 256)         // 8
-#define TNW_WGS 512                         // [measured] 768 / 1 024 workgroups: 59.9 / 64.4 us against 55.2 (tdnn1 at S1, incl. the slab sum)
+#define TNW_WGS 512                         // (768 / 1 024 workgroups were slower: Appendix B, note 8)
 __global__ __launch_bounds__(256, 2) void xv_gemm_tn160_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (TNW_M + BN)];      // [slot][A [16][160] | B [16][128]]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1227,8 +1176,7 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_tn160_kernel(TNArgs p) {
     const int a_off = lh * TNW_M + 2 * li;              // rows 2 li, 2 li + 1 (and + 64) of reduction row 2 ks + lh
     const int a4_off = lh * TNW_M + 128 + li;           // row 128 + li
     const int b_off = lh * BN + 32 * wave + li;
-    // (plain double buffering.  [measured, round 4] the two-steps-ahead DMA schedule of xv_gemm_tn_kernel - all 48 fragment registers read up
-    // front, the wait and the barrier in mid-step - is slower here: 61.8 against 55.1 us incl. the slab sum.)
+    // (plain double buffering: the two-steps-ahead form of xv_gemm_tn_kernel was slower here, Appendix B note 8)
     if (nk > 0) gstage(0, 0);
     xv_dma_wait_all();
     __syncthreads();
@@ -1297,6 +1245,10 @@ static XvTnPlan xv_tn_plan(int M, int N, int R) {
     const int min_ksteps = 2;                                          // fewest K-steps a workgroup is given
     int splits = std::max(1, XV_RESIDENT_WGS / tiles);
     if (splits > ksteps / min_ksteps) splits = std::max(1, ksteps / min_ksteps);
+    // A short reduction over many tiles (the loss head's weight gradient: 232 tiles x 8 K-steps at 128 chunks) is not split: four splits of two
+    // K-steps each wrote and re-read 60 MB of slabs beside the latency-bound chain of the segment layers (its d-out launch ran 45 instead of
+    // 23 us); one workgroup per tile can store the result where it belongs (xv_engine.hip, loss_head_wgrad)
+    if (ksteps <= 16 && tiles >= 128) splits = 1;
     pl.chunk = xv_cdiv(ksteps, splits) * BK;
     pl.splits = xv_cdiv(R, pl.chunk);
     return pl;
@@ -1333,7 +1285,7 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     const XvTnPlan pl = xv_tn_plan(g.M, g.N, g.R);
     XV_REQUIRE(pl.splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", pl.splits, g.splits);
     p.r_chunk = pl.chunk;
-    p.ahead = p.r_chunk / BK >= 96;      // [measured, rounds 3 and 4: 48 / 64 cost tdnn5 7 %, never staging ahead costs tdnn2 / tdnn3 3 %]
+    p.ahead = p.r_chunk / BK >= 96;      // (thresholds of 48 / 64 cost tdnn5 7 %, never staging ahead costs tdnn2 / tdnn3 3 %: Appendix B, note 9)
     const int wgs = p.tiles_m * p.tiles_n * pl.splits;
     {
         XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);

@@ -18,24 +18,29 @@ for k in sorted(f, key=lambda k: -f[k][0] * f[k][1]):
                   "bytes_per_launch_corrected": int((2.0 * fk + wk) * 1024)}
 
 
+def nt_kernel_of(M, N, K, stats, co_running):
+    """The kernel xv_launch_gemm_nt gives this problem - asked of the library itself (xv_debug_nt_schedule), so the map follows the launcher."""
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tf_kaldi_speaker_amd import _lib
+    kind = _lib.load().xv_debug_nt_schedule(int(M), int(N), int(K), int(stats), int(co_running))
+    return ("xv_gemm_nt_sk_kernel<%s," if kind == 1 else "xv_gemm_nt_kernel<%s,") % ("true" if stats else "false")
+
+
 def s1_algorithmic_mb(names):
     """Algorithmic MB per launch (operands read once + the result written once, fp32) of every GEMM launch of one S1 step (128 x 200 x 30,
-    tdnn.py:35-127, 7351 speakers), grouped by the kernel that runs it: the layers with taps go to the evenly scheduled kernel when the
-    trace has one (approximate: the launcher picks per launch), else to the plain kernel with the others."""
+    tdnn.py:35-127, 7351 speakers), grouped by the kernel the launcher runs it on (nt_kernel_of)."""
     B, T, spk = 128, 200, 7351
     layers = [(5, 32, 512), (5, 512, 512), (7, 512, 512), (1, 512, 512), (1, 512, 1500)]      # (taps, padded input channels, outputs)
     mb = lambda *els: sum(els) * 4 / 1e6
-    fwd_w, fwd_p, bwd_w, bwd_p = ("xv_gemm_nt_sk_kernel<true>", "xv_gemm_nt_kernel<true>", "xv_gemm_nt_sk_kernel<false>",
-                                  "xv_gemm_nt_kernel<false>")
-    has = lambda g: any(g in n for n in names)
-    groups = {fwd_w: [], fwd_p: [], bwd_w: [], bwd_p: [], "xv_gemm_tn_kernel": []}
+    groups = collections.defaultdict(list)
     t_in = T
     for i, (k, c, o) in enumerate(layers):
         t_out = t_in - k + 1
         x, w, y = B * t_in * c, k * c * o, B * t_out * o
-        groups[fwd_w if k > 1 and has(fwd_w) else fwd_p].append(mb(x, w, y))              # forward
+        groups[nt_kernel_of(B * t_out, o, k * c, True, False)].append(mb(x, w, y))                          # forward
         if i > 0:
-            groups[bwd_w if k > 1 and has(bwd_w) else bwd_p].append(mb(y, w, x))          # data gradient
+            groups[nt_kernel_of(B * (t_out + k - 1), c, k * o, False, True)].append(mb(y, w, x))            # data gradient
         groups["xv_gemm_tn_kernel"].append(mb(x, y, w))                                   # weight gradient
         t_in = t_out
     for m, n in ((3000, 512), (512, 512), (512, spk + 1)):            # tdnn6, tdnn7, the loss head: weight gradients of [B][m]^T . [B][n]
@@ -71,8 +76,8 @@ def direction_ratios():
         t_in = t_out
     for m, nn in ((3000, 512), (512, 512), (512, spk + 1)):
         alg["weight_gradient"] += mb(B * m, B * nn, m * nn); n["weight_gradient"] += 1
-    pick = {"forward": lambda k: "gemm_nt" in k and "16" not in k and "<true" in k,
-            "data_gradient": lambda k: "gemm_nt" in k and "16" not in k and "<false" in k,
+    pick = {"forward": lambda k: "gemm_nt" in k and "16" not in k and "<true," in k,
+            "data_gradient": lambda k: "gemm_nt" in k and "16" not in k and "<false," in k,
             "weight_gradient": lambda k: "xv_gemm_tn_kernel" in k}
     out = {}
     for d, f in pick.items():
