@@ -11,9 +11,9 @@ for i in $(seq 1 $rounds); do
     for v in "$@"; do
       name=${v%%:*}; spec=${v#*:}
       if [ "$name" == "tree" ]; then
-        echo -n "[$sh] $(basename $spec) "; (cd $R/$spec && one python3 bench.py --steps 40 --warmup 10 --single-mode --no-cpu-baseline $sh)
+        echo -n "[$sh] $(basename $spec) "; (cd $R/$spec && one timeout 300 python3 bench.py --steps 40 --warmup 10 --single-mode --no-cpu-baseline $sh)
       else
-        echo -n "[$sh] $name "; (cd $R && one env $spec python3 bench.py --steps 40 --warmup 10 --single-mode --no-cpu-baseline $sh)
+        echo -n "[$sh] $name "; (cd $R && one timeout 300 env $spec python3 bench.py --steps 40 --warmup 10 --single-mode --no-cpu-baseline $sh)
       fi
     done
   done

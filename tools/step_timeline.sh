@@ -8,7 +8,7 @@ case $out in /*) ;; *) out=$R/$out ;; esac
 export TMPDIR=/tmp
 for e in "${envs[@]}"; do export "$e"; done
 d=$(mktemp -d /tmp/xvtl.XXXX)
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --steps 24 --warmup 5 --single-mode --no-cpu-baseline "$@" > $out.json 2> $out.log)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --steps 24 --warmup 5 --single-mode --no-cpu-baseline "$@" > $out.json 2> $out.log)
 tr=$(find $d -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/trace_timeline.py $tr 15 > $out.timeline.txt 2>> $out.log
 python3 $R/tools/trace_gaps.py $tr 24 > $out.gaps.txt 2>> $out.log
