@@ -1141,8 +1141,9 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_tn160_kernel(TNArgs p) {
         const int c = n0 + 4 * (lane & 31);
         colB[i] = (unsigned)((c < p.N ? c : 0) * 4);
     }
-    // stage kt: every lane resolves reduction row -> (segment, frame) -> address (rows at or beyond r_end read the zero page: they are summed)
-    auto gstage = [&](int kt, int buf) {
+    // a K-step with rows at or beyond r_end (they read the zero page: they are summed) or of a layer with segments shorter than a K-step: every
+    // lane resolves reduction row -> (segment, frame) -> address
+    auto gstage_ragged = [&](int kt, int buf) {
         float* sa = smem + buf * SLOT;
         float* sb = sa + BK * TNW_M;
 #pragma unroll
@@ -1166,6 +1167,49 @@ __global__ __launch_bounds__(256, 2) void xv_gemm_tn160_kernel(TNArgs p) {
             const float* pb = r < r_end ? (const float*)((const char*)(p.B + ((long)seg * p.b_pitch + tt) * p.ldb) + colB[i]) : zp;
             xv_dma16_ptr(pb, sb + 256 * (NB * uwave + i));
         }
+    };
+    // full K-steps: the scheme of xv_gemm_tn_kernel - the K-step's first row lives in scalar registers as (frame within its segment, byte
+    // offsets in A and B) and advances there; a lane adds the constant offset of its row of the 16 and of its columns, from the "next
+    // segment" copy when frame + row lies beyond the segment.  (Rounds 4's form resolved every lane's row with a float multiply, two
+    // conversions and 64-bit address arithmetic per piece: ~100 vector instructions per wave and K-step beside 20 MFMAs.)
+    const bool steady = p.rps >= BK;
+    const unsigned a_skip = (unsigned)((long)(p.a_pitch - p.rps) * p.lda * 4), b_skip = (unsigned)((long)(p.b_pitch - p.rps) * p.ldb * 4);
+    const unsigned a_step = (unsigned)(BK * p.lda * 4), b_step = (unsigned)(BK * p.ldb * 4);
+    unsigned offA[NA], offA_w[NA], offB[NB], offB_w[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { offA[i] = (unsigned)((long)rowA[i] * p.lda * 4) + colA[i]; offA_w[i] = offA[i] + a_skip; }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { offB[i] = (unsigned)((long)rowB[i] * p.ldb * 4) + colB[i]; offB_w[i] = offB[i] + b_skip; }
+    int s_tt;
+    unsigned s_a, s_b;
+    {
+        const int r0 = __builtin_amdgcn_readfirstlane(min(r_begin, p.R - 1));
+        const int seg0 = r0 / p.rps;
+        s_tt = r0 - seg0 * p.rps;
+        s_a = (unsigned)(((long)seg0 * p.a_pitch + s_tt) * p.lda * 4);
+        s_b = (unsigned)(((long)seg0 * p.b_pitch + s_tt) * p.ldb * 4);
+    }
+    const unsigned lds_a0 = xv_lds_addr(smem + 256 * uwave), lds_b0 = xv_lds_addr(smem + BK * TNW_M + 256 * NB * uwave);
+    auto gstage = [&](int kt, int buf) {
+        if (!steady || r_begin + (kt + 1) * BK > r_end) {
+            gstage_ragged(kt, buf);
+            return;
+        }
+        // (kt counts up by one per call, so the scalar state is at step kt here)
+        const float* sa = (const float*)((const char*)p.A + s_a);
+        const float* sb = (const float*)((const char*)p.B + s_b);
+        const int thr = p.rps - s_tt;      // rows >= thr of this K-step belong to the next segment
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (!pieceA[i]) continue;      // (uniform per wave)
+            xv_dma16(sa, rowA[i] >= thr ? offA_w[i] : offA[i], lds_a0 + (buf * SLOT + 256 * 4 * i) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) xv_dma16(sb, rowB[i] >= thr ? offB_w[i] : offB[i], lds_b0 + (buf * SLOT + 256 * i) * 4);
+        s_tt += BK;
+        s_a += a_step;
+        s_b += b_step;
+        if (s_tt >= p.rps) { s_tt -= p.rps; s_a += a_skip; s_b += b_skip; }
     };
 
     f32x16 acc[5];
