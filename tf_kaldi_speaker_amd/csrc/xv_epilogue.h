@@ -12,6 +12,9 @@ template <int NB>
 __device__ __forceinline__ void xv_tile_stats_epilogue(const f32x16 (&acc)[2][NB], float* red /* >= 1024 floats of LDS, free */,
                                                        int tid, int wr, int wc, int li, int lh, int m0, int n0, int M, int N,
                                                        int tile_m, int tiles_m, float* __restrict__ part) {
+    // (opaque copies: called inside the tile loop of the evenly scheduled kernel, where hipcc otherwise hoists the lane constants derived from
+    // these out of the loop and keeps them live - spilled - across the K loop)
+    asm volatile("" : "+v"(tid), "+v"(wr), "+v"(wc), "+v"(li), "+v"(lh));
     float* r_sum = red;          // [2][128]
     float* r_m2 = red + 256;
     float* r_min = red + 512;

@@ -108,6 +108,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 // tiles store without predication.
 __device__ __forceinline__ void nt_store_tile(f32x16 (&acc)[2][2], float* __restrict__ C, long ldc, const float* __restrict__ bias,
                                               int m0, int n0, int M, int N, int wr, int wc, int li, int lh) {
+    asm volatile("" : "+v"(wr), "+v"(wc), "+v"(li), "+v"(lh));      // (opaque copies: see nt_store_tile_rows)
     if (bias) {
         float bias_v[2];
 #pragma unroll
@@ -157,6 +158,9 @@ __device__ __forceinline__ void nt_store_tile(f32x16 (&acc)[2][2], float* __rest
 // and N a multiple of 4; the caller falls back to nt_store_tile otherwise.  Ends behind a barrier (the LDS may be reused at once).
 __device__ __forceinline__ void nt_store_tile_rows(f32x16 (&acc)[2][2], float* smem, float* __restrict__ C, long ldc, const float* __restrict__ bias,
                                                    int m0, int n0, int M, int N, int tid, int wr, int wc, int li, int lh) {
+    // (opaque copies: in the evenly scheduled kernel this runs inside the loop over a workgroup's tiles, and hipcc otherwise hoists the lane
+    // constants below out of it - live across the K loop, they were what that kernel spilled)
+    asm volatile("" : "+v"(tid), "+v"(wr), "+v"(wc), "+v"(li), "+v"(lh));
     if (bias) {
         float bias_v[2];
 #pragma unroll
@@ -195,6 +199,9 @@ __device__ __forceinline__ void nt_store_tile_rows(f32x16 (&acc)[2][2], float* s
 // The evenly scheduled kernel rotates the issue priority of its waves every K-step - priority = (K-step + the wave's slot in its SIMD) mod 4 -
 // so that the co-resident workgroups take turns at the top and finish together; NOT in the one-workgroup-per-tile kernel, whose multi-round
 // launches want their oldest workgroups to finish first (note 1).
+// the lane's index from the hardware (two vector instructions) instead of from threadIdx.x: code behind the K loop of the evenly scheduled kernel
+// rebuilds its thread coordinates from this and the (scalar) wave index, so nothing derived from threadIdx.x stays live - spilled - across the loop
+__device__ __forceinline__ int xv_lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ int xv_wave_slot() { return __builtin_amdgcn_s_getreg(4 | (3 << 11)) & 15; }      // HW_ID.WAVE_ID: differs between the waves of one SIMD
 __device__ __forceinline__ void xv_rot_prio(int x) {
     switch (x & 3) {
@@ -471,6 +478,11 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
         unsigned boff[NT_RPT];
         int ksrc[NT_RPT];
         int a_row[2];                           // LDS offsets of this lane's two fragment rows
+        // (the ragged last K-step of a row needs each piece's k offset again: rebuilt from the hardware lane index there, not kept in a register)
+        auto ksrc_now = [&](int i) {
+            const int l = xv_lane_id();
+            return (((l % NT_KQ) ^ NT_SWZ(NT_RPI * (NT_RPT * uwave + i) + l / NT_KQ)) << 2);
+        };
 #pragma unroll
         for (int i = 0; i < NT_RPT; ++i) {
             const int row = NT_RPI * (NT_RPT * wave + i) + lrow;
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
 #pragma unroll
                 for (int i = 0; i < NT_RPT; ++i) {
                     const float* pb = (const float*)((const char*)(p.Bt + k0) + boff[i]);
-                    xv_dma16_ptr((k0 + ksrc[i] < p.K ? pb : zp), sb + NT_RPI * i * NT_PITCH);
+                    xv_dma16_ptr((k0 + ksrc_now(i) < p.K ? pb : zp), sb + NT_RPI * i * NT_PITCH);
                 }
             }
         };
@@ -517,7 +529,7 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
 #pragma unroll
                 for (int i = 0; i < NT_RPT; ++i) {
                     const float* pa = (const float*)((const char*)(p.A + k0) + aoff[i]);
-                    xv_dma16_ptr((k0 + ksrc[i] < p.K ? pa : zp), sa + NT_RPI * i * NT_PITCH);
+                    xv_dma16_ptr((k0 + ksrc_now(i) < p.K ? pa : zp), sa + NT_RPI * i * NT_PITCH);
                 }
             }
         };
@@ -571,7 +583,8 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
             // a shared tile: publish this share, take a ticket, and only the last of the tile's workgroups goes on
             // slab of a share: [register r][thread] float4 = (acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]): 1 KB of consecutive
             // bytes per wave instruction, stores and loads alike
-            float* mine = q.slab + ((long)w * 2 + (tile == first_tile ? 0 : 1)) * (BM * BN) + tid * 4;
+            const int tid_h = uwave * 64 + xv_lane_id();      // (rebuilt: keeps the slab addresses out of the registers that live across the K loop)
+            float* mine = q.slab + ((long)w * 2 + (tile == first_tile ? 0 : 1)) * (BM * BN) + tid_h * 4;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const f32x4 v = {acc[0][0][r], acc[0][1][r], acc[1][0][r], acc[1][1][r]};
@@ -602,7 +615,7 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
                 const int v = w_first + (me == 1 ? (i == 0 ? 1 : i == 1 ? 0 : i) : i);      // me == 1: own, share 0, share 2, ...
                 if (v == w && me <= 1) continue;
                 const int v_first_tile = (int)(((long)v * q.total / q.P) / q.nk);
-                const float* src = q.slab + ((long)v * 2 + (tile == v_first_tile ? 0 : 1)) * (BM * BN) + tid * 4;
+                const float* src = q.slab + ((long)v * 2 + (tile == v_first_tile ? 0 : 1)) * (BM * BN) + tid_h * 4;
                 // eight 16-byte loads in flight per lane: a shared tile end is a latency chain (four in flight: no scratch, step +1.5 %; DESIGN.md Appendix B, note 7)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -616,10 +629,11 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
                 }
             }
         }
-        if (ROWS) nt_store_tile_rows(acc, smem, p.C, p.ldc, p.bias, m0, n0, p.M, p.N, tid, wr, wc, li, lh);
-        else nt_store_tile(acc, p.C, p.ldc, p.bias, m0, n0, p.M, p.N, wr, wc, li, lh);
+        const int lane_e = xv_lane_id(), tid_e = uwave * 64 + lane_e, wr_e = uwave >> 1, wc_e = uwave & 1, li_e = lane_e & 31, lh_e = lane_e >> 5;
+        if (ROWS) nt_store_tile_rows(acc, smem, p.C, p.ldc, p.bias, m0, n0, p.M, p.N, tid_e, wr_e, wc_e, li_e, lh_e);
+        else nt_store_tile(acc, p.C, p.ldc, p.bias, m0, n0, p.M, p.N, wr_e, wc_e, li_e, lh_e);
         if (STATS) {
-            xv_tile_stats_epilogue(acc, smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part_sum);
+            xv_tile_stats_epilogue(acc, smem, tid_e, wr_e, wc_e, li_e, lh_e, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part_sum);
             __syncthreads();                             // the statistics use the staging buffers as scratch
         }
     }

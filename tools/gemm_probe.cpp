@@ -75,10 +75,16 @@ int main(int argc, char** argv) {
     stamps_t stamps_prev = (stamps_t)dlsym(h, "xv_debug_read_stamps_prev");
     if (!fwd || !dgrad || !wgrad || !wsb) { fprintf(stderr, "missing symbols\n"); return 1; }
 
-    struct L { const char* name; int t_in, c, k, o; };
-    const L layers[] = {{"tdnn1", T, 32, 5, 512}, {"tdnn2", T - 4, 512, 5, 512}, {"tdnn3", T - 8, 512, 7, 512}, {"tdnn4", T - 14, 512, 1, 512}, {"tdnn5", T - 14, 512, 1, 1500}};
+    struct L { const char* name; int t_in, c, k, o; bool extra; };
+    // tdnn1..5: model/tdnn.py:35-127; XV_PROBE_EXTRA=1 adds the attention key network of nnet_conf/*_tdnn4_att.json (pooling.py:84-96: 512 -> 1500 ->
+    // 1500 on the pooled frames) and a k = 3 layer of the extended stack (BASELINE configs[4]: contexts 5 1 3 1 3 1 3 1 1 1)
+    const L layers[] = {{"tdnn1", T, 32, 5, 512, false}, {"tdnn2", T - 4, 512, 5, 512, false}, {"tdnn3", T - 8, 512, 7, 512, false},
+                        {"tdnn4", T - 14, 512, 1, 512, false}, {"tdnn5", T - 14, 512, 1, 1500, false},
+                        {"att_key0", T - 14, 512, 1, 1500, true}, {"att_key1", T - 14, 1500, 1, 1500, true}, {"ext_k3", T - 4, 512, 3, 512, true}};
+    const bool extra = getenv("XV_PROBE_EXTRA") && atoi(getenv("XV_PROBE_EXTRA"));
     double sum_us = 0, sum_fl = 0;
     for (const L& l : layers) {
+        if (l.extra && !extra) continue;
         if (only && !strstr(only, l.name)) continue;
         const int segs = l.k > 1 ? B : B * l.t_in, tin = l.k > 1 ? l.t_in : 1, tout = tin - l.k + 1;
         const long rows_in = (long)segs * tin, rows_out = (long)segs * tout;

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 for prec in f32 f16x3; do
   # 1. kernel trace + stats of the bench command in this mode (CPU leg off, one mode per run so the stats are not mixed)
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$prec -- python3 $R/bench.py --steps 30 --warmup 5 --single-mode --precision $prec --no-cpu-baseline > $out/bench_profiled_$prec.json 2> $out/stats_$prec.log
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$prec -- python3 $R/bench.py --steps 30 --warmup 5 --single-mode --precision $prec --no-cpu-baseline > $out/bench_profiled_$prec.json 2> $out/stats_$prec.log
   cp $(find $out/stats_$prec -name "*kernel_stats.csv" | head -1) $out/kernel_stats_$prec.csv
   python3 $R/tools/trace_gaps.py $(find $out/stats_$prec -name "*kernel_trace.csv" | head -1) 30 > $out/trace_summary_$prec.txt
   python3 $R/tools/trace_timeline.py $(find $out/stats_$prec -name "*kernel_trace.csv" | head -1) 20 > $out/step_timeline_$prec.txt
@@ -18,11 +18,11 @@ for prec in f32 f16x3; do
 done
 # 2. HBM-side traffic of the GEMM kernels: separate PMC passes (no trace domains) over the default (headline) run
 cmd="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/fetch.log
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/write.log
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/fetch.log
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/write.log
 python3 $R/tools/pmc_traffic.py $(find $out/fetch -name "*counter_collection.csv" | head -1) $(find $out/write -name "*counter_collection.csv" | head -1) $out/pmc_traffic.json "$cmd" > /dev/null
 rm -rf $out/fetch $out/write $out/*.log
 # 3. the bench line itself (with the traffic file in place so `roofline.traffic` is filled), CPU baseline included
 mkdir -p $R/profiles && cp $out/pmc_traffic.json $R/profiles/${tag}_pmc_traffic.json
-cd $R && python3 bench.py --steps 30 --warmup 5 | tail -1 > $out/bench.json
+cd $R && timeout 900 python3 bench.py --steps 30 --warmup 5 | tail -1 > $out/bench.json
 python3 tools/bench_summary.py $out/bench.json
