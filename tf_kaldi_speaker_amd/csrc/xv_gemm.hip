@@ -915,6 +915,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // and add their accumulators through LDS before a single slab store, 1/2 or 1/4 of the slab bytes: parity-green, no faster alone, 3 % slower
 // in the step; removed.  profiles/r05_tn_wave_groups.txt, DESIGN.md Appendix A.)
 #define XV_TN_STAGES 2
+#ifndef XV_TN_AHEAD_MIN
+#define XV_TN_AHEAD_MIN 16      // K-steps per workgroup from which the two-steps-ahead DMA schedule is used (xv_launch_gemm_tn; 96 until the staging addresses went scalar)
+#endif
 __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[XV_TN_STAGES * 2 * BK * BM];   // [slot][A|B][BK][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1343,7 +1346,7 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     const XvTnPlan pl = xv_tn_plan(g.M, g.N, g.R);
     XV_REQUIRE(pl.splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", pl.splits, g.splits);
     p.r_chunk = pl.chunk;
-    p.ahead = p.r_chunk / BK >= 96;      // (thresholds of 48 / 64 cost tdnn5 7 %, never staging ahead costs tdnn2 / tdnn3 3 %: Appendix B, note 9)
+    p.ahead = p.r_chunk / BK >= XV_TN_AHEAD_MIN;      // (Appendix B, note 9)
     const int wgs = p.tiles_m * p.tiles_n * pl.splits;
     {
         XvProfScope prof(s, 2, 2.0 * g.M * g.N * g.R);
