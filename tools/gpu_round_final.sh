@@ -45,4 +45,5 @@ if [ -n "$prev" ]; then
     done
   done > $O/ab_same_box.txt 2>&1
 fi
+timeout 600 python3 tests/tools/determinism.py 2>&1 | grep -v amdgpu.ids > $O/determinism.txt
 ls -la $O
