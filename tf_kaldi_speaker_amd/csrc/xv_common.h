@@ -182,6 +182,11 @@ struct XvGemmNT {
     int co_running;         // 1: another GEMM shares the chip (the backward pass: data gradient beside weight gradient) - see xv_launch_gemm_nt
 };
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g);
+// xv_affine_dgrad / xv_affine_wgrad (include/xvector_hip.h) for a dz whose rows are ldo >= o floats apart (the pooled layer's, on the 128-byte grid)
+int xv_affine_dgrad_ld(hipStream_t stream, const float* dz_pad, int ldo, int segs, int t_out, int o, int k, const float* wf, float* dx, int c,
+                       void* ws, size_t ws_bytes);
+int xv_affine_wgrad_ld(hipStream_t stream, const float* x, int segs, int t_in, int c_pad, int k, int c, const float* dz, int ldo, int dz_seg_pitch,
+                       int dz_row0, int o, const float* kernel, float l2_scale, float* dkernel, void* ws, size_t ws_bytes);
 
 // P[z][m][n] = sum_{r in chunk z} A[amap(r)][m] * B[bmap(r)][n]   ("TN", reduction over rows)
 struct XvGemmTN {
@@ -296,12 +301,14 @@ size_t xv_skinny_tickets(int max_n);
 // frames (optional, device [b]) / shrink: chunk i pools only its first frames[i] - shrink rows (batched extraction: utterances of different
 // lengths padded to t rows; shrink = the frames the frame layers consumed)
 int xv_stat_pool_forward_bn_ex(hipStream_t s, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
-                               const float* weights, float* out, float* wpos, float* amax, const int32_t* frames = nullptr, int shrink = 0);
+                               const float* weights, float* out, float* wpos, float* amax, const int32_t* frames = nullptr, int shrink = 0,
+                               int ldz = 0 /* floats per row of z; 0 = c */);
 // softmax over the first frames[i] - shrink scores of chunk i (weights beyond are 0); frames == nullptr: all t (xv_attention.hip)
 int xv_softmax_segments_ex(hipStream_t s, const float* score, int b, int t, float* weights, const int32_t* frames, int shrink);
 int xv_bn_relu_backward_pooled_ex(hipStream_t s, const float* pool_out, const float* dpool, const float* weights, const float* wpos, int b, int t,
                                   const float* z, int n, const float* gamma, const float* mean, const float* invstd, const float* scale,
-                                  const float* shift, int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes);
+                                  const float* shift, int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                                  int ldz = 0 /* floats per row of z and dz; 0 = n; a pitch needs wpos (the closed form) and a plain ReLU */);
 
 // xv_margin_softmax_rows in one launch (mean folded in through a ticket) that also writes ||x[r]|| (xv_loss.hip)
 int xv_margin_softmax_rows_ex(hipStream_t s, int kind, const float* logits, int rows, int n, int ldl, const float* x, int c,

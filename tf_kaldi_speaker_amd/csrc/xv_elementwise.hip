@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int t, int n, const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ coef, int relu, int pad,
-                                                           float* __restrict__ dz, const float* __restrict__ slope) {
+                                                           float* __restrict__ dz, const float* __restrict__ slope, int ldz /* rows of z and dz */) {
     XV_EW_PRIORITY();
     const int tp = t + 2 * pad;
     const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
@@ -1101,12 +1101,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 }
                 invT = pool_frame_weight(pg, r);
             }
-            const f32x4 zz = *(const f32x4*)(z + r * n + col);
+            const f32x4 zz = *(const f32x4*)(z + r * ldz + col);
             const f32x4 dd = upstream_grad<POOLED>(da, pc, invT, r, n, col, zz, sc, sh, relu, sl, hs);
             const f32x4 xh = (zz - mu) * is;
             out = g_is * (dd - c1 - xh * c2);
         }
-        *(f32x4*)(dz + (long)dr * n + col) = out;
+        *(f32x4*)(dz + (long)dr * ldz + col) = out;
         u += 4;
         while (u >= tp) { u -= tp; ++seg; }
     }
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dense_kernel(const float* __
                                                                  int n, const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, const float* __restrict__ coef, int relu,
-                                                                 float* __restrict__ dz, const float* __restrict__ slope) {
+                                                                 float* __restrict__ dz, const float* __restrict__ slope, int ldz /* rows of z and dz */) {
     XV_EW_PRIORITY();
     constexpr int NR = BAF_ROWS / 4;
     const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dense_kernel(const float* __
     const int r0 = blockIdx.y * BAF_ROWS + rl;
     f32x4 zz[NR], dd[NR];
 #pragma unroll
-    for (int j = 0; j < NR; ++j) zz[j] = *(const f32x4*)(z + (long)min(r0 + 4 * j, rows - 1) * n + col);
+    for (int j = 0; j < NR; ++j) zz[j] = *(const f32x4*)(z + (long)min(r0 + 4 * j, rows - 1) * ldz + col);
     if (!POOLED) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) dd[j] = *(const f32x4*)(da + (long)min(r0 + 4 * j, rows - 1) * n + col);
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dense_kernel(const float* __
                 on.x = y.x > 0.f ? on.x : off.x; on.y = y.y > 0.f ? on.y : off.y;
                 on.z = y.z > 0.f ? on.z : off.z; on.w = y.w > 0.f ? on.w : off.w;
             }
-            if (r < rows) *(f32x4*)(dz + (long)r * n + col) = on;
+            if (r < rows) *(f32x4*)(dz + (long)r * ldz + col) = on;
         }
         return;
     }
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dense_kernel(const float* __
             }
         }
         const f32x4 xh = (zz[j] - mu) * is;
-        if (r < rows) *(f32x4*)(dz + (long)r * n + col) = g_is * (d - c1 - xh * c2);
+        if (r < rows) *(f32x4*)(dz + (long)r * ldz + col) = g_is * (d - c1 - xh * c2);
     }
 }
 
@@ -1373,8 +1373,11 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_stats_kernel(PoolGrad pg, i
 
 static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, const float* z, int segs, int t, int n, const float* gamma,
                                  const float* mean, const float* invstd, const float* scale, const float* shift, int relu, int pad,
-                                 float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
+                                 float* dz_pad, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, int ldz = 0) {
     XV_REQUIRE(segs > 0 && t > 0 && n > 0 && n % 4 == 0 && pad >= 0, "bn_relu_backward: bad shape (n=%d must be a multiple of 4)", n);
+    // ldz: leading dimension of z and dz when their rows are padded (the pooled layer: rows on the 128-byte grid); closed-form pooled path only
+    if (ldz == 0) ldz = n;
+    XV_REQUIRE(ldz >= n && ldz % 4 == 0 && (ldz == n || (pg.out && pg.wpos && !(relu && g_act.slope))), "bn_relu_backward: a row pitch is only supported on the closed-form pooled path");
     XV_REQUIRE((long)segs * (t + 2 * pad) * (n / 4) < (1L << 31), "bn_relu_backward: tensor too large for 32-bit indexing");
     const int rows = segs * t;
     const bool pooled = pg.out != nullptr;
@@ -1406,10 +1409,10 @@ static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, co
     dim3 agrid(xv_cdiv(n / 4, 64), xv_cdiv(segs * (t + 2 * pad), BAF_ROWS));
     if (pad == 0 && (!pooled || pg.t >= BAF_ROWS))
         hipLaunchKernelGGL(pooled ? bn_bwd_apply_dense_kernel<true> : bn_bwd_apply_dense_kernel<false>, agrid, dim3(256), 0, s, da, pg, z, rows, n, gamma,
-                           mean, invstd, scale, shift, (const float*)coef, relu, dz_pad, relu ? act.slope : nullptr);
+                           mean, invstd, scale, shift, (const float*)coef, relu, dz_pad, relu ? act.slope : nullptr, ldz);
     else
         hipLaunchKernelGGL(pooled ? bn_bwd_apply_kernel<true> : bn_bwd_apply_kernel<false>, agrid, dim3(256), 0, s, da,
-                           pg, z, segs, t, n, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad, dz_pad, relu ? act.slope : nullptr);
+                           pg, z, segs, t, n, gamma, mean, invstd, scale, shift, (const float*)coef, relu, pad, dz_pad, relu ? act.slope : nullptr, ldz);
     XV_LAUNCH_CHECK();
     return 0;
 }
@@ -1523,16 +1526,16 @@ extern "C" int xv_bn_relu_backward_pooled_aux(void* stream, const float* pool_ou
                                               float* dbias, void* ws, size_t ws_bytes) {
     XV_REQUIRE(wpos, "bn_relu_backward_pooled_aux: wpos is required");
     return xv_bn_relu_backward_pooled_ex((hipStream_t)stream, pool_out, dpool, weights, wpos, b, t, z, n, gamma, mean, invstd, scale, shift, relu,
-                                         dz, dgamma, dbeta, dbias, ws, ws_bytes);
+                                         dz, dgamma, dbeta, dbias, ws, ws_bytes, 0);
 }
 
 // Engine form: wpos from xv_stat_pool_forward_bn_ex (see PoolGrad) - the reductions then need no pass over z
 int xv_bn_relu_backward_pooled_ex(hipStream_t s, const float* pool_out, const float* dpool, const float* weights, const float* wpos, int b, int t,
                                   const float* z, int n, const float* gamma, const float* mean, const float* invstd, const float* scale,
-                                  const float* shift, int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes) {
+                                  const float* shift, int relu, float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, int ldz) {
     XV_REQUIRE(pool_out && dpool && b > 0 && t > 0, "bn_relu_backward_pooled: bad arguments");
     PoolGrad pg = {pool_out, dpool, t, weights, wpos, nullptr};
-    return bn_relu_backward_impl(s, nullptr, pg, z, b * t, 1, n, gamma, mean, invstd, scale, shift, relu, 0, dz, dgamma, dbeta, dbias, ws, ws_bytes);
+    return bn_relu_backward_impl(s, nullptr, pg, z, b * t, 1, n, gamma, mean, invstd, scale, shift, relu, 0, dz, dgamma, dbeta, dbias, ws, ws_bytes, ldz);
 }
 
 extern "C" int xv_bn_relu_backward_pooled_split(void* stream, const float* pool_out, const float* dpool, const float* weights, int b, int t,
@@ -1743,7 +1746,7 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
                                                             const float* __restrict__ shift, int relu, const float* __restrict__ wts,
                                                             float* __restrict__ out, const float* __restrict__ slope,
                                                             float* __restrict__ wpos, float* __restrict__ amax_o,
-                                                            const int* __restrict__ flen, int shrink) {
+                                                            const int* __restrict__ flen, int shrink, int ld /* floats per row of x (>= C) */) {
     XV_EW_PRIORITY();
     __shared__ f32x4 s_mean[4][64], s_m2[4][64], s_wp[4][64], s_mx[4][64];
     __shared__ float s_n[4];
@@ -1751,7 +1754,7 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
     const int col = (blockIdx.x * 64 + lane) * 4;
     const int b = blockIdx.y;
     const bool cv = col < C;
-    const float* xp = x + (long)b * T * C + (cv ? col : 0);
+    const float* xp = x + (long)b * T * ld + (cv ? col : 0);
     // flen (batched extraction): chunk b holds flen[b] - shrink valid frames, the rest of its T rows is padding that is not pooled
     const int Tstride = T;
     if (flen) T = max(1, min(T, flen[b] - shrink));
@@ -1787,7 +1790,7 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
         f32x4 v[8];
         float w[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(xp + (long)(t + 4 * u) * C);
+        for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(xp + (long)(t + 4 * u) * ld);
 #pragma unroll
         for (int u = 0; u < 8; ++u) w[u] = wp ? wp[t + 4 * u] : 1.f;
 #pragma unroll
@@ -1799,7 +1802,7 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
         }
     }
     for (; t < T; t += 4) {
-        const f32x4 a0 = act(*(const f32x4*)(xp + (long)t * C));
+        const f32x4 a0 = act(*(const f32x4*)(xp + (long)t * ld));
         const float w0 = wp ? wp[t] : 1.f;
         XV_POOL_STEP2(mean0, m20, n0, a0, w0)
         if (wpos) on(a0, w0);
@@ -1839,17 +1842,19 @@ extern "C" int xv_stat_pool_forward(void* stream, const float* x, int b, int t, 
     XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0, "stat_pool_forward: bad shape (c=%d must be a multiple of 4)", c);
     hipLaunchKernelGGL(stat_pool_fwd_kernel<false>, dim3(xv_cdiv(c / 4, 64), b), dim3(256), 0, (hipStream_t)stream, x, t, c,
                        (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, out, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
-                       (const int*)nullptr, 0);
+                       (const int*)nullptr, 0, c);
     XV_LAUNCH_CHECK();
     return 0;
 }
 
 // wpos, amax (optional, [b][c]): see PoolGrad
 int xv_stat_pool_forward_bn_ex(hipStream_t s, const float* z, int b, int t, int c, const float* scale, const float* shift, int relu,
-                               const float* weights, float* out, float* wpos, float* amax, const int32_t* frames, int shrink) {
+                               const float* weights, float* out, float* wpos, float* amax, const int32_t* frames, int shrink, int ldz) {
     XV_REQUIRE(b > 0 && t > 0 && c > 0 && c % 4 == 0 && scale && shift, "stat_pool_forward_bn: bad shape (c=%d must be a multiple of 4)", c);
+    if (ldz == 0) ldz = c;
+    XV_REQUIRE(ldz >= c && ldz % 4 == 0, "stat_pool_forward_bn: bad row pitch %d", ldz);
     hipLaunchKernelGGL(stat_pool_fwd_kernel<true>, dim3(xv_cdiv(c / 4, 64), b), dim3(256), 0, s, z, t, c, scale, shift,
-                       relu, weights, out, relu ? g_act.slope : nullptr, wpos, wpos ? amax : nullptr, (const int*)frames, shrink);
+                       relu, weights, out, relu ? g_act.slope : nullptr, wpos, wpos ? amax : nullptr, (const int*)frames, shrink, ldz);
     XV_LAUNCH_CHECK();
     return 0;
 }

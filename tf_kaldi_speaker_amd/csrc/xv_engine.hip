@@ -47,6 +47,7 @@ struct Affine {   // one conv/dense layer (+ optional BN, ReLU)
     unsigned short *wth = nullptr, *wfh = nullptr, *ah = nullptr;
     size_t wth_stride = 0, wfh_stride = 0;    // plane strides (elements)
     int o_ld = 0;                             // plane pitch of c_out (multiple of 8)
+    int ldz = 0;                              // floats per row of z and of this layer's dz (= c_out except the pooled layer: rows on the 128-byte grid)
     float *zmin = nullptr, *zmax = nullptr;
     int rows;                             // rows of the most recent forward
     std::string scope;                    // variable scope under "tdnn/" ("" or "attention/att_key0/")
@@ -245,6 +246,10 @@ void build_variables(xv_engine* e) {
         // operand pitch: 16-byte chunks of fp16 planes need multiples of 8 (feature layer 30 -> 32, att_key1 1500 -> 1504)
         a.c_pad = (int)xv_align(s.cin, (i == 0 || (e->f16 && is_frame(e, i))) ? 8 : 4);
         a.o_ld = (int)xv_align(s.cout, 8);
+        // The pooled layer's pre-BN tensor and its gradient are the largest tensors of the step and are streamed by HBM-bound kernels (pooling, the
+        // pooled BatchNorm backward) and by the GEMMs' LDS-DMA: 1 500 channels = 6 000-byte rows start off the 128-byte grid (nine cache lines
+        // per KiB instead of eight).  Plain fp32 path with statistics pooling and a plain ReLU only (the kernels of the other paths take dense rows).
+        a.ldz = (i == F - 1 && !e->f16 && !e->att && c.relu_type == XV_RELU_RELU && s.k == 1) ? (int)xv_align(s.cout, 32) : s.cout;
         a.has_bn = s.bn; a.has_relu = s.relu; a.fused_bn = s.fused;
         a.wslot = i < F ? i : i - 2;          // amax slots of the weights: tdnn1..F -> 0..F-1, att_key0/1 -> F, F+1
         a.aslot = i < F ? i : F - 1;          // BN+ReLU output planes: tdnn1..F-1 -> 0..F-2, att_key0 -> F-1
@@ -320,7 +325,7 @@ int alloc_buffers(xv_engine* e) {
         size_t r = lrows(i);
         want((size_t)a.c_out * a.k * a.c_pad);                 // wt
         if (a.k > 1) want((size_t)a.c_in * a.k * a.c_out);     // wf
-        want(r * a.c_out); want(r * a.c_out);                  // z, a
+        want(r * a.ldz); want(r * a.c_out);                    // z, a
         want(4 * (size_t)xv_cdiv(r, XV_TILE_M) * a.c_out);     // bn_part
         for (int j = 0; j < 4; ++j) want(a.c_out);
     }
@@ -355,7 +360,7 @@ int alloc_buffers(xv_engine* e) {
         const size_t r_out = lrows(i), r_in = i < F ? rows[i] : rows_pool;
         bufd = std::max(bufd, std::max(r_out * a.c_out, r_in * (size_t)a.c_in));
         const size_t padded = r_out + B * 2 * (size_t)(a.k - 1);
-        bufz = std::max(bufz, padded * a.c_out);
+        bufz = std::max(bufz, padded * (size_t)a.ldz);
         max_pad_rows = std::max(max_pad_rows, padded);
     }
     want(bufd); want(bufz); want(bufz);
@@ -406,7 +411,7 @@ int alloc_buffers(xv_engine* e) {
         size_t r = lrows(i);
         a.wt = carve(e, (size_t)a.c_out * a.k * a.c_pad);
         a.wf = a.k > 1 ? carve(e, (size_t)a.c_in * a.k * a.c_out) : nullptr;
-        a.z = carve(e, r * a.c_out);
+        a.z = carve(e, r * a.ldz);
         a.a = carve(e, r * a.c_out);
         a.bn_part = carve(e, 4 * (size_t)xv_cdiv(r, XV_TILE_M) * a.c_out);
         a.mean = carve(e, a.c_out); a.invstd = carve(e, a.c_out);
@@ -611,7 +616,7 @@ int bn_forward(xv_engine* e, hipStream_t s, Affine& a, int rows, bool stats_from
                                    a.scale, a.shift, a.has_relu ? 1 : 0, dst_a);
     if (e->training) {
         if (!stats_from_gemm) {
-            rc = xv_col_stats(s, a.z, rows, a.c_out, a.c_out, a.bn_part);
+            rc = xv_col_stats(s, a.z, rows, a.c_out, a.ldz, a.bn_part);
             if (rc) return rc;
         }
         rc = xv_bn_finalize(s, a.bn_part, rows, a.c_out, vptr(e, a.v_gamma), vptr(e, a.v_beta), c.bn_epsilon, c.batchnorm_momentum,
@@ -623,7 +628,7 @@ int bn_forward(xv_engine* e, hipStream_t s, Affine& a, int rows, bool stats_from
     }
     if (rc) return rc;
     if (!dst_a) return 0;       // the consumer applies scale/shift itself (tdnn5: statistics pooling)
-    return xv_bn_apply(s, a.z, rows, a.c_out, a.c_out, a.scale, a.shift, a.has_relu ? 1 : 0, dst_a, a.c_out);
+    return xv_bn_apply(s, a.z, rows, a.c_out, a.ldz, a.scale, a.shift, a.has_relu ? 1 : 0, dst_a, a.c_out);
 }
 
 }  // namespace
@@ -881,7 +886,7 @@ int engine_forward(xv_engine* e, void* stream, const float* features, int b, int
             int t_out = cur_t - a.k + 1;
             int rows = b * t_out;
             if (i == 1) { rc = wait_prep(e, s); if (rc) return rc; }
-            rc = xv_affine_forward(s, cur, b, cur_t, a.c_pad, a.k, a.wt, vptr(e, a.v_bias), a.z, a.c_out, a.c_out,
+            rc = xv_affine_forward(s, cur, b, cur_t, a.c_pad, a.k, a.wt, vptr(e, a.v_bias), a.z, a.c_out, a.ldz,
                                    training ? a.bn_part : nullptr, e->ws, e->ws_bytes);
             if (rc) return rc;
             rc = bn_forward(e, s, a, rows, true, i < F - 1 ? a.a : nullptr);
@@ -923,7 +928,7 @@ int engine_forward(xv_engine* e, void* stream, const float* features, int b, int
     {
         ActScope act(e, e->L[F - 1]);
         rc = xv_stat_pool_forward_bn_ex(s, e->L[F - 1].z, b, cur_t, e->P, e->L[F - 1].scale, e->L[F - 1].shift, 1, frame_w, e->pool,
-                                        training ? e->pool_wpos : nullptr, e->pool_amax, frames, t - cur_t);
+                                        training ? e->pool_wpos : nullptr, e->pool_amax, frames, t - cur_t, e->L[F - 1].ldz);
     }
     if (rc) return rc;
     // segment-level layers: dense (+ BatchNorm + activation).  With <= XV_SEGMENT_MAX_ROWS chunks the GEMM, its split-K sum and the
@@ -1132,7 +1137,7 @@ int layer_dz(xv_engine* e, hipStream_t s, Affine& a, const float* da, int segs, 
         XV_REQUIRE(lidx == e->F - 1 && a.has_bn, "engine_backward: only the last frame layer takes its gradient from the pooling layer");
         rc = xv_bn_relu_backward_pooled_ex(s, e->pool, e->d_small0, e->att ? e->att_w : nullptr, e->pool_closed_form ? e->pool_wpos : nullptr, e->B, e->Tl[e->F], a.z, a.c_out,
                                            vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift, 1, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta),
-                                           gptr(e, a.v_bias), e->ws, e->ws_bytes);
+                                           gptr(e, a.v_bias), e->ws, e->ws_bytes, a.ldz);
     } else if (a.has_bn && pad == 0 && segs * t_out <= XV_BN_SMALL_MAX_ROWS && !is_frame(e, lidx)) {      // segment-level layers: one launch
         rc = xv_bn_small_backward(s, da, a.z, segs * t_out, a.c_out, vptr(e, a.v_gamma), a.mean, a.invstd, a.scale, a.shift,
                                   a.has_relu ? 1 : 0, Z, gptr(e, a.v_gamma), gptr(e, a.v_beta), gptr(e, a.v_bias));
@@ -1174,8 +1179,8 @@ int layer_wgrad(xv_engine* e, hipStream_t s, Affine& a, const float* x, const fl
     // rectangles instead of a full round - so that the BatchNorm backward of tdnn1, which waits 250-300 us for slots beside tdnn2's weight
     // gradient at the very end of the step, finds a free slot per CU: S1 5.22 -> 5.29 / 5.24 / 5.24 ms, 64 x U{200..400} 4.30 -> 4.33 / 4.34 /
     // 4.35 ms.  The full round stays.
-    rc = xv_affine_wgrad(ws_stream, x, segs, t_in, a.c_pad, a.k, a.c_in, dz, seg_pitch, pad, a.c_out, vptr(e, a.v_kernel),
-                         c.weight_l2_regularizer, gptr(e, a.v_kernel), wws, e->ws_bytes);
+    rc = xv_affine_wgrad_ld(ws_stream, x, segs, t_in, a.c_pad, a.k, a.c_in, dz, a.ldz, seg_pitch, pad, a.c_out, vptr(e, a.v_kernel),
+                            c.weight_l2_regularizer, gptr(e, a.v_kernel), wws, e->ws_bytes);
     if (rc) return rc;
     if (!a.has_bn) {      // a bias in front of a BN gets its (zero + rounding noise) gradient from the BN backward
         rc = xv_colsum(ws_stream, dz, segs * seg_pitch, a.c_out, a.c_out, gptr(e, a.v_bias), wws, e->ws_bytes);
@@ -1206,7 +1211,7 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     if (rc) return rc;
     if (dx) {
         const float* wf = a.k > 1 ? a.wf : vptr(e, a.v_kernel);
-        rc = xv_affine_dgrad(s, dz, segs, t_out, a.c_out, a.k, wf, dx, a.c_in, e->ws, e->ws_bytes);
+        rc = xv_affine_dgrad_ld(s, dz, a.ldz, segs, t_out, a.c_out, a.k, wf, dx, a.c_in, e->ws, e->ws_bytes);
         if (rc) return rc;
     }
     return 0;
@@ -1683,11 +1688,11 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
     auto set = [&](float* p, int r, int c, int l) { *ptr = p; *rows = r; *cols = c; *ld = l; return 0; };
     for (int i = 0; i < e->NL; ++i) {
         Affine& a = e->L[i];
-        if (n == a.prefix + "_" + a.kind) return set(a.z, a.rows, a.c_out, a.c_out);
+        if (n == a.prefix + "_" + a.kind) return set(a.z, a.rows, a.c_out, a.ldz);
         if (n == a.prefix + "_relu" && a.has_relu) {
             if ((e->f16 && (i < e->F - 1 || i == e->K0())) || i == e->F - 1) {     // not materialised on the hot path (fp16 planes / fused into pooling): rebuild on demand
                 ActScope act(e, a);
-                int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 1, a.a, a.c_out);
+                int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.ldz, a.scale, a.shift, 1, a.a, a.c_out);
                 if (rc) return rc;
             }
             return set(i == e->S1() ? e->h7 : a.a, a.rows, a.c_out, a.c_out);
@@ -1695,7 +1700,7 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
         if (n == a.prefix + "_bn" && a.has_bn) {
             if (!a.has_relu) return set(i == e->S1() ? e->h7 : a.a, a.rows, a.c_out, a.c_out);
             // BN output is never materialised on the hot path (fused with ReLU): rebuild on demand
-            int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.c_out, a.scale, a.shift, 0, e->bufZ[0], a.c_out);
+            int rc = xv_bn_apply(e->last_stream, a.z, a.rows, a.c_out, a.ldz, a.scale, a.shift, 0, e->bufZ[0], a.c_out);
             if (rc) return rc;
             return set(e->bufZ[0], a.rows, a.c_out, a.c_out);
         }
@@ -1704,7 +1709,7 @@ extern "C" int xv_engine_endpoint(xv_engine* e, const char* name, float** ptr, i
     if (n == "debug:da5") {     // evaluated on demand with the standalone pooling backward (valid after backward stage 0, before stage 1)
         Affine& a5 = e->L[e->F - 1];
         ActScope act(e, a5);
-        int rc = xv_bn_apply(e->last_stream, a5.z, a5.rows, a5.c_out, a5.c_out, a5.scale, a5.shift, 1, a5.a, a5.c_out);
+        int rc = xv_bn_apply(e->last_stream, a5.z, a5.rows, a5.c_out, a5.ldz, a5.scale, a5.shift, 1, a5.a, a5.c_out);
         if (rc) return rc;
         rc = xv_stat_pool_backward(e->last_stream, a5.a, e->pool, e->d_small0, e->B, e->Tl[e->F], e->P, e->bufD);
         if (rc) return rc;

@@ -1381,17 +1381,21 @@ extern "C" int xv_affine_forward(void* stream, const float* x, int segs, int t_i
     return xv_launch_gemm_nt((hipStream_t)stream, g);
 }
 
-extern "C" int xv_affine_dgrad(void* stream, const float* dz_pad, int segs, int t_out, int o, int k, const float* wf, float* dx,
-                               int c, void* ws, size_t ws_bytes) {
-    XV_REQUIRE(segs > 0 && k >= 1 && t_out >= 1 && o > 0 && c > 0, "affine_dgrad: bad shape");
+int xv_affine_dgrad_ld(hipStream_t stream, const float* dz_pad, int ldo, int segs, int t_out, int o, int k, const float* wf, float* dx, int c,
+                       void* ws, size_t ws_bytes) {
+    XV_REQUIRE(segs > 0 && k >= 1 && t_out >= 1 && o > 0 && c > 0 && ldo >= o && (ldo == o || k == 1), "affine_dgrad: bad shape (a row pitch needs k = 1)");
     XvGemmNT g = {};
-    g.A = dz_pad; g.lda = o; g.a_rps = t_out + k - 1; g.a_pitch = t_out + 2 * (k - 1);
+    g.A = dz_pad; g.lda = ldo; g.a_rps = t_out + k - 1; g.a_pitch = t_out + 2 * (k - 1);
     g.Bt = wf; g.ldb = (long)k * o;
     g.C = dx; g.ldc = c;
     g.M = segs * (t_out + k - 1); g.N = c; g.K = k * o;
     g.ws = ws; g.ws_bytes = ws_bytes;
     g.co_running = 1;          // the data gradient runs beside the layer's weight gradient (xv_engine.hip: two streams)
-    return xv_launch_gemm_nt((hipStream_t)stream, g);
+    return xv_launch_gemm_nt(stream, g);
+}
+extern "C" int xv_affine_dgrad(void* stream, const float* dz_pad, int segs, int t_out, int o, int k, const float* wf, float* dx,
+                               int c, void* ws, size_t ws_bytes) {
+    return xv_affine_dgrad_ld((hipStream_t)stream, dz_pad, o, segs, t_out, o, k, wf, dx, c, ws, ws_bytes);
 }
 
 // out[(j*C + c)][n] = sum_z P[z][j*c_pad + c][n] (+ l2 * w[(j*C + c)][n])
@@ -1463,21 +1467,26 @@ int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int
     return 0;
 }
 
-extern "C" int xv_affine_wgrad(void* stream, const float* x, int segs, int t_in, int c_pad, int k, int c, const float* dz,
-                               int dz_seg_pitch, int dz_row0, int o, const float* kernel, float l2_scale, float* dkernel, void* ws,
-                               size_t ws_bytes) {
-    XV_REQUIRE(segs > 0 && k >= 1 && t_in >= k && c_pad >= c && o > 0 && o % 4 == 0, "affine_wgrad: bad shape (o=%d must be a multiple of 4)", o);
+int xv_affine_wgrad_ld(hipStream_t stream, const float* x, int segs, int t_in, int c_pad, int k, int c, const float* dz, int ldo, int dz_seg_pitch,
+                       int dz_row0, int o, const float* kernel, float l2_scale, float* dkernel, void* ws, size_t ws_bytes) {
+    XV_REQUIRE(segs > 0 && k >= 1 && t_in >= k && c_pad >= c && o > 0 && o % 4 == 0 && ldo >= o && ldo % 4 == 0,
+               "affine_wgrad: bad shape (o=%d must be a multiple of 4)", o);
     const int t_out = t_in - k + 1;
     XvGemmTN g = {};
     g.A = x; g.lda = c_pad; g.a_rps = t_out; g.a_pitch = t_in;
-    g.B = dz + (long)dz_row0 * o; g.ldb = o; g.b_rps = t_out; g.b_pitch = dz_seg_pitch;
+    g.B = dz + (long)dz_row0 * ldo; g.ldb = ldo; g.b_rps = t_out; g.b_pitch = dz_seg_pitch;
     g.M = k * c_pad; g.N = o; g.R = segs * t_out;
     g.splits = xv_tn_splits(g.M, g.N, g.R);
     XV_REQUIRE((size_t)g.splits * g.M * g.N * sizeof(float) <= ws_bytes, "affine_wgrad: workspace too small (%zu needed)",
                (size_t)g.splits * g.M * g.N * sizeof(float));
     g.P = (float*)ws;
-    int rc = xv_launch_gemm_tn((hipStream_t)stream, g);
+    int rc = xv_launch_gemm_tn(stream, g);
     if (rc) return rc;
-    return xv_launch_wgrad_reduce((hipStream_t)stream, g.P, g.splits, k, c, c_pad, o, o, l2_scale != 0.f ? kernel : nullptr, o,
+    return xv_launch_wgrad_reduce(stream, g.P, g.splits, k, c, c_pad, o, o, l2_scale != 0.f ? kernel : nullptr, o,
                                   l2_scale, dkernel, o);
+}
+extern "C" int xv_affine_wgrad(void* stream, const float* x, int segs, int t_in, int c_pad, int k, int c, const float* dz,
+                               int dz_seg_pitch, int dz_row0, int o, const float* kernel, float l2_scale, float* dkernel, void* ws,
+                               size_t ws_bytes) {
+    return xv_affine_wgrad_ld((hipStream_t)stream, x, segs, t_in, c_pad, k, c, dz, o, dz_seg_pitch, dz_row0, o, kernel, l2_scale, dkernel, ws, ws_bytes);
 }
