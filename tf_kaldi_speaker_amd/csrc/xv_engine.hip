@@ -59,6 +59,8 @@ struct Affine {   // one conv/dense layer (+ optional BN, ReLU)
 
 }  // namespace
 
+constexpr int XV_Z_SLOTS = 16;
+
 struct xv_engine {
     xv_config cfg;
     std::vector<Var> vars;
@@ -93,7 +95,7 @@ struct xv_engine {
     float *h7 = nullptr, *out = nullptr;   // views of the most recent forward (may alias tdnn7's z / h7)
     float *logits = nullptr, *dlogits = nullptr, *dnorm = nullptr, *row_loss = nullptr;
     float *inv_norm = nullptr, *wn = nullptr, *wnt = nullptr, *dwn = nullptr;
-    float *bufD = nullptr, *bufZ[2] = {nullptr, nullptr}, *d_small0 = nullptr, *d_small1 = nullptr;
+    float *bufD = nullptr, *bufZ[XV_Z_SLOTS] = {}, *d_small0 = nullptr, *d_small1 = nullptr;
     // second stream: weight gradients run beside the data-gradient chain (they only share dz)
     hipStream_t side = nullptr;
     // third stream: the loss head's weight gradient (5 launches, ~0.1 ms alone) starts as soon as dlogits exist and never sits in
@@ -114,7 +116,14 @@ struct xv_engine {
     // [measured, same box] giving fp32 mode that second ring as well (it removes a 77 us wait of the last frame layer's BN backward
     // for the slot tdnn7's weight gradient reads) makes the step 0.07 ms SLOWER: the BN backward then runs beside the loss head's
     // side-stream chain and both crawl
-    struct ZRing { int cur = 0; bool pending[2] = {false, false}; hipEvent_t ev[2] = {nullptr, nullptr}; } zr[2];
+    // fp32 mode has a slot per layer when the arena can afford it (`z_private`): no slot is rewritten inside a step, so the data-gradient
+    // chain never waits for a weight gradient and the side stream records nothing per layer - every wait / record is a barrier packet
+    // that costs the stream it sits on 5-6 us (profiles/r05_event_packets.txt).
+    struct ZRing { int cur = 0, n = 2; bool pending[XV_Z_SLOTS] = {}; hipEvent_t ev[XV_Z_SLOTS] = {}; } zr[2];
+    int nz = 2;                   // slots of bufZ
+    bool z_private = false;       // nz covers every dz of a step
+    bool side_dirty = false;      // weight-gradient work is on the side stream since the last join
+    int z_taken = 0;              // slots handed to the side stream since the last join
     bool lw_pending = false;      // the loss head's weight gradient (side stream) - it reads no dz buffer, so it has its own event
     bool concurrent = true;
     void* ws_side = nullptr;
@@ -363,7 +372,16 @@ int alloc_buffers(xv_engine* e) {
         bufz = std::max(bufz, padded * (size_t)a.ldz);
         max_pad_rows = std::max(max_pad_rows, padded);
     }
-    want(bufd); want(bufz); want(bufz);
+    // a dz slot per layer (+ the attention key gradient) while that stays below 1/16 of the card; the two-slot ring otherwise
+    e->nz = 2;
+#ifndef XV_Z_TWO_SLOTS
+    if (!e->f16 && e->NL + 2 <= XV_Z_SLOTS && (size_t)(e->NL + 2) * bufz * sizeof(float) <= ((size_t)18 << 30)) e->nz = e->NL + 2;
+#endif
+    e->z_private = e->nz > 2;
+    e->zr[0].n = e->f16 ? 2 : e->nz;
+    e->zr[1].n = 2;
+    want(bufd);
+    for (int i = 0; i < e->nz; ++i) want(bufz);
     if (e->f16) want((size_t)xv_cdiv(rows[1], XV_TILE_M) * 3 * maxc);
     const size_t dzh_halfs = xv_align(max_pad_rows * (size_t)xv_align(maxc, 8), 8);
     if (e->f16) { want(dzh_halfs); want(dzh_halfs); }
@@ -455,8 +473,7 @@ int alloc_buffers(xv_engine* e) {
         e->dwn = carve(e, (size_t)e->Lout * e->ldl);
     }
     e->bufD = carve(e, bufd);
-    e->bufZ[0] = carve(e, bufz);
-    e->bufZ[1] = carve(e, bufz);
+    for (int i = 0; i < e->nz; ++i) e->bufZ[i] = carve(e, bufz);
     if (e->f16) e->bwd_part = carve(e, (size_t)xv_cdiv(rows[1], XV_TILE_M) * 3 * maxc);
     if (e->f16) {
         e->dzh_halfs = dzh_halfs;
@@ -494,14 +511,22 @@ int alloc_buffers(xv_engine* e) {
         XV_CHECK_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
         XV_CHECK_HIP(hipStreamCreateWithPriority(&e->side2, hipStreamNonBlocking, least));
     }
-    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_dz, hipEventDisableTiming));
+    // Events between the engine's own streams order kernels of ONE device: no system-scope fence (cache write-back towards the host and
+    // peers) when they are recorded.  The stage / communication events, which a collective on another stream - read by peer GPUs - may
+    // wait on, keep the default.
+#ifdef XV_EVENT_SYSTEM_FENCE
+    const unsigned local = hipEventDisableTiming;
+#else
+    const unsigned local = hipEventDisableTiming | hipEventDisableSystemFence;
+#endif
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_dz, local));
     for (int r = 0; r < 2; ++r)
-        for (int i = 0; i < 2; ++i) XV_CHECK_HIP(hipEventCreateWithFlags(&e->zr[r].ev[i], hipEventDisableTiming));
-    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lw, hipEventDisableTiming));
-    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        for (int i = 0; i < e->zr[r].n; ++i) XV_CHECK_HIP(hipEventCreateWithFlags(&e->zr[r].ev[i], local));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lw, local));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join, local));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_comm, hipEventDisableTiming));
-    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_prep, hipEventDisableTiming));
-    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lossprep, hipEventDisableTiming));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_prep, local));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lossprep, local));
     for (int k = 0; k < XV_BWD_STAGES; ++k)
         for (int j = 0; j < 2; ++j) XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_stage[k][j], hipEventDisableTiming));
     return 0;
@@ -695,7 +720,7 @@ extern "C" void xv_engine_destroy(xv_engine* e) {
     if (e->side2) { (void)hipStreamSynchronize(e->side2); (void)hipStreamDestroy(e->side2); }
     if (e->ev_dz) (void)hipEventDestroy(e->ev_dz);
     for (int r = 0; r < 2; ++r)
-        for (int i = 0; i < 2; ++i) if (e->zr[r].ev[i]) (void)hipEventDestroy(e->zr[r].ev[i]);
+        for (int i = 0; i < XV_Z_SLOTS; ++i) if (e->zr[r].ev[i]) (void)hipEventDestroy(e->zr[r].ev[i]);
     if (e->ev_lw) (void)hipEventDestroy(e->ev_lw);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->ev_comm) (void)hipEventDestroy(e->ev_comm);
@@ -1083,9 +1108,11 @@ int chain(hipStream_t signaller, hipStream_t waiter, hipEvent_t ev) {
 // within the noise of a same-box A/B - as is carrying the hand-over events on the producing kernels' completion signals
 // (hipExtLaunchKernel's stopEvent, 1.5 us in the probe), which was built, verified and taken out again.)
 int join_side(xv_engine* e, hipStream_t s) {
-    bool any = false;
+    bool any = e->side_dirty;
+    e->side_dirty = false;
+    e->z_taken = 0;
     for (int r = 0; r < 2; ++r)
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < XV_Z_SLOTS; ++i) {
             any = any || e->zr[r].pending[i];
             e->zr[r].pending[i] = false;
         }
@@ -1115,6 +1142,7 @@ int layer_backward_f16(xv_engine* e, hipStream_t s, int li, const float* da, int
 float* ring_take(xv_engine* e, hipStream_t s) {
     xv_engine::ZRing& zr = e->zr[e->f16 ? 1 : 0];
     const int zi = zr.cur;
+    if (e->z_private && e->z_taken >= zr.n && join_side(e, s)) return nullptr;      // (a caller that never finishes a backward pass)
     if (zr.pending[zi]) {                       // WAR
         if (hipStreamWaitEvent(s, zr.ev[zi], 0) != hipSuccess) return nullptr;
         zr.pending[zi] = false;
@@ -1187,10 +1215,13 @@ int layer_wgrad(xv_engine* e, hipStream_t s, Affine& a, const float* x, const fl
         if (rc) return rc;
     }
     if (concurrent) {
-        XV_CHECK_HIP(hipEventRecord(zr.ev[zi], e->side));
-        zr.pending[zi] = true;
+        if (e->z_private) { e->side_dirty = true; ++e->z_taken; }      // the slot is not taken again before the join at the end of the step
+        else {
+            XV_CHECK_HIP(hipEventRecord(zr.ev[zi], e->side));
+            zr.pending[zi] = true;
+        }
     }
-    if (ring) zr.cur ^= 1;
+    if (ring) zr.cur = (zr.cur + 1) % zr.n;
     return 0;
 }
 

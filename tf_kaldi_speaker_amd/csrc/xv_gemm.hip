@@ -682,7 +682,9 @@ extern "C" int xv_profile_begin_kinds(int max_launches, uint32_t kind_mask) {
     g_prof_mask = kind_mask;
     while (g_prof_events.size() < (size_t)2 * max_launches) {
         hipEvent_t ev;
-        XV_CHECK_HIP(hipEventCreate(&ev));
+        // device-scope release: the pair brackets one launch on its own stream; a system-scope fence per record (the default) would be
+        // measurement overhead inside the region bench.py times
+        XV_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventReleaseToDevice));
         g_prof_events.push_back(ev);
     }
     g_prof.clear();
