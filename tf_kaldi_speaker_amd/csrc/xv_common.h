@@ -48,6 +48,7 @@ void xv_set_error(const char* fmt, ...);
 struct XvEnv {
     int segment_fused;      // XV_SEGMENT_FUSED=0|1 (default 1): the segment-level layers as one launch each (xv_skinny.hip)
     int nt_sched;           // XV_NT_SCHED=dp|sk: force the schedule of the fp32 NT GEMM (0 = chosen per problem, 1 = dp, 2 = sk); diagnostics
+    int dz_slots;           // XV_DZ_SLOTS=2: the two-slot dz ring in fp32 mode too (what an arena too large for a slot per layer gets; A/B and test switch)
     int conv_wr;            // XV_CONV_WR=4: 256-row tiles of the f16x3 context-window GEMM (kept parity-tested, off by default)
 };
 const XvEnv* xv_env();

@@ -374,9 +374,11 @@ int alloc_buffers(xv_engine* e) {
     }
     // a dz slot per layer (+ the attention key gradient) while that stays below 1/16 of the card; the two-slot ring otherwise
     e->nz = 2;
-#ifndef XV_Z_TWO_SLOTS
-    if (!e->f16 && e->NL + 2 <= XV_Z_SLOTS && (size_t)(e->NL + 2) * bufz * sizeof(float) <= ((size_t)18 << 30)) e->nz = e->NL + 2;
-#endif
+    {
+        const XvEnv* env = xv_env();
+        if (!env) return 2;
+        if (env->dz_slots != 2 && !e->f16 && e->NL + 2 <= XV_Z_SLOTS && (size_t)(e->NL + 2) * bufz * sizeof(float) <= ((size_t)18 << 30)) e->nz = e->NL + 2;
+    }
     e->z_private = e->nz > 2;
     e->zr[0].n = e->f16 ? 2 : e->nz;
     e->zr[1].n = 2;

@@ -26,6 +26,7 @@ def nbytes(name, n):
     if "bn_bwd_apply_kernel<true>" in name or "bn_bwd_apply_split_kernel<true>" in name: return 2 * t
     if "bn_bwd_apply_kernel<false>" in name or "bn_bwd_apply_split_kernel<false>" in name: return 3 * t * (1 + 8.0 / T / 3)
     if name.startswith("sgd_kernel"): return 9.83e6 * 12
+    if "vectorized_elementwise_kernel" in name: return 2 * t      # the yardstick: torch.add(z, 1, out=tmp)
     return None
 
 
