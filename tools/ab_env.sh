@@ -10,7 +10,7 @@ for i in $(seq 1 $rounds); do
   for sh in "${SH[@]}"; do
     for v in "$@"; do
       name=${v%%:*}; spec=${v#*:}
-      if [ "$name" == "tree" ]; then
+      if [ "$name" == "tree" ] && [ -n "$spec" ]; then
         echo -n "[$sh] $(basename $spec) "; (cd $R/$spec && one timeout 300 python3 bench.py --steps 40 --warmup 10 --single-mode --no-cpu-baseline $sh)
       else
         echo -n "[$sh] $name "; (cd $R && one timeout 300 env $spec python3 bench.py --steps 40 --warmup 10 --single-mode --no-cpu-baseline $sh)
