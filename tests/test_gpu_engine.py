@@ -193,13 +193,12 @@ def test_train_step_matches_oracle_unfused_segment_layers(kw):
 
 
 def test_train_step_matches_oracle_under_the_alternate_switches(xv_precision):
-    """XV_SEGMENT_FUSED=0 (separate launches for <= 128 chunks too), XV_DZ_SLOTS=2 (the two-slot dz ring in fp32 mode) and
-    XV_HANDOVER=event (event records instead of start flags): the library
+    """XV_SEGMENT_FUSED=0 (separate launches for <= 128 chunks too) and XV_DZ_SLOTS=2 (the two-slot dz ring in fp32 mode): the library
     reads its switches once per process, so the train-step oracle comparisons of this module run again in a child process under them."""
     import os, subprocess, sys
     if xv_precision != "f32":
         pytest.skip("the child process runs both precisions")
-    env = dict(os.environ, XV_SEGMENT_FUSED="0", XV_DZ_SLOTS="2", XV_HANDOVER="event")
+    env = dict(os.environ, XV_SEGMENT_FUSED="0", XV_DZ_SLOTS="2")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
                         "test_train_step_matches_oracle and not alternate_switches"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -48,7 +48,6 @@ void xv_set_error(const char* fmt, ...);
 struct XvEnv {
     int segment_fused;      // XV_SEGMENT_FUSED=0|1 (default 1): the segment-level layers as one launch each (xv_skinny.hip)
     int nt_sched;           // XV_NT_SCHED=dp|sk: force the schedule of the fp32 NT GEMM (0 = chosen per problem, 1 = dp, 2 = sk); diagnostics
-    int handover_event;     // XV_HANDOVER=event: every cross-stream hand-over through an event record (default: start flags where the next kernel can carry one)
     int dz_slots;           // XV_DZ_SLOTS=2: the two-slot dz ring in fp32 mode too (what an arena too large for a slot per layer gets; A/B and test switch)
     int conv_wr;            // XV_CONV_WR=4: 256-row tiles of the f16x3 context-window GEMM (kept parity-tested, off by default)
 };
@@ -173,16 +172,6 @@ const float* xv_zero_page(size_t floats = XV_ZERO_PAGE_FLOATS);
 // Internal GEMM launchers (xv_gemm.hip).
 // C[m][n] (+)= sum_k A[rowmap(m)][k] * Bt[n][k]   ("NT", both operands k-contiguous)
 // rowmap(m) = (m / a_rps) * a_pitch + (m % a_rps) rows of lda floats.
-// Hand-over without a packet on the producing stream: a launch that carries a start flag stores `value` to `flag` (8 bytes of
-// hipMallocSignalMemory) with its first thread.  A kernel starts only after everything in front of it on its stream has completed and been
-// released, so the store announces "my predecessors' results are in memory"; a consumer stream waits for it with hipStreamWaitValue32.
-// An event record in the same place is a barrier packet that costs the producing stream 1-3 us (tools/sync_cost_probe: nextflag +0.02 us).
-struct XvStartFlag { unsigned* flag = nullptr; unsigned value = 0; };
-__device__ __forceinline__ void xv_start_flag_store(unsigned* flag, unsigned value) {
-    if (flag && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
-        __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (relaxed: the kernel boundary in front ordered the data)
-}
-
 struct XvGemmNT {
     const float* A; long lda; int a_rps; int a_pitch;
     const float* Bt; long ldb;
@@ -192,12 +181,11 @@ struct XvGemmNT {
     float* bn_part;         // optional, [4][tiles_m][N]: sum, centred squares, min, max (xv_epilogue.h)
     void* ws; size_t ws_bytes;
     int co_running;         // 1: another GEMM shares the chip (the backward pass: data gradient beside weight gradient) - see xv_launch_gemm_nt
-    XvStartFlag start;      // optional hand-over flag stored by the launch's first thread (XvStartFlag)
 };
 int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g);
 // xv_affine_dgrad / xv_affine_wgrad (include/xvector_hip.h) for a dz whose rows are ldo >= o floats apart (the pooled layer's, on the 128-byte grid)
 int xv_affine_dgrad_ld(hipStream_t stream, const float* dz_pad, int ldo, int segs, int t_out, int o, int k, const float* wf, float* dx, int c,
-                       void* ws, size_t ws_bytes, XvStartFlag start = XvStartFlag());
+                       void* ws, size_t ws_bytes);
 int xv_affine_wgrad_ld(hipStream_t stream, const float* x, int segs, int t_in, int c_pad, int k, int c, const float* dz, int ldo, int dz_seg_pitch,
                        int dz_row0, int o, const float* kernel, float l2_scale, float* dkernel, void* ws, size_t ws_bytes);
 
@@ -303,7 +291,6 @@ struct XvSkinny {
     int relu; const float* slope; float* a_out;
     const float* z; float* dgamma; float* dbeta; float* dbias; float* dalpha;
     void* ws; size_t ws_bytes; uint32_t* tickets;
-    XvStartFlag start;                       // optional hand-over flag stored by the launch's first thread
 };
 int xv_launch_skinny(hipStream_t s, const XvSkinny& g);
 size_t xv_skinny_tickets(int max_n);

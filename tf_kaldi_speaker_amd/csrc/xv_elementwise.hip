@@ -34,7 +34,7 @@ XvEnvState xv_env_parse() {
     // program in the user's environment, which must not stop a training run.  A known switch with a value it does not understand still fails.
     static const char* known[] = {"XV_SEGMENT_FUSED", "XV_NT_SCHED", "XV_CONV_WR", "XV_PRECISION", "XV_LOADER", "XV_LOADER_PIN", "XV_SHARE_GPU",
                                   "XV_LIB", "XV_TUNE_TIMES", "XV_DATA_SCALE", "XV_B", "XV_PROBE_OPS", "XV_PROBE_ONLY", "XV_PROBE_PERIODS",
-                                  "XV_DIAG_M", "XV_DIAG_N", "XV_DIAG_K", "XV_DIAG_REPS", "XV_DIAG_B", "XV_PROBE_EXTRA", "XV_DZ_SLOTS", "XV_HANDOVER"};
+                                  "XV_DIAG_M", "XV_DIAG_N", "XV_DIAG_K", "XV_DIAG_REPS", "XV_DIAG_B", "XV_PROBE_EXTRA", "XV_DZ_SLOTS"};
     for (char** e = environ; e && *e; ++e) {
         if (strncmp(*e, "XV_", 3) != 0) continue;
         const char* eq = strchr(*e, '=');
@@ -59,11 +59,6 @@ XvEnvState xv_env_parse() {
         if (!strcmp(v, "dp")) env.nt_sched = 1;
         else if (!strcmp(v, "sk")) env.nt_sched = 2;
         else if (*v) fail("%s=%s: expected dp or sk", "XV_NT_SCHED", v);
-    }
-    env.handover_event = 0;
-    if (const char* v = getenv("XV_HANDOVER")) {
-        if (!strcmp(v, "event")) env.handover_event = 1;
-        else if (*v && strcmp(v, "flag")) fail("%s=%s: expected event or flag", "XV_HANDOVER", v);
     }
     env.dz_slots = 0;
     if (const char* v = getenv("XV_DZ_SLOTS")) {

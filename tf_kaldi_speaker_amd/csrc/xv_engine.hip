@@ -124,14 +124,6 @@ struct xv_engine {
     bool z_private = false;       // nz covers every dz of a step
     bool side_dirty = false;      // weight-gradient work is on the side stream since the last join
     int z_taken = 0;              // slots handed to the side stream since the last join
-    // Hand-over of the compute stream's results to a side stream without a packet on the compute stream (XvStartFlag, xv_common.h): the side
-    // stream waits (hipStreamWaitValue32) for `epoch` in `sig`, and the NEXT kernel launched on the compute stream stores it as it starts.
-    // flag_pending: a wait has been enqueued whose flag no launch carries yet - the next data-gradient / segment GEMM takes it (take_flag);
-    // anything that makes the compute stream wait for a side stream, and the end of every backward call, writes it out first (flush_flag):
-    // a side stream that waits for a flag nobody will store while the compute stream waits for that side stream would never finish.
-    uint32_t* sig = nullptr;      // 8 bytes of hipMallocSignalMemory; nullptr: event records (the device has no stream wait-value, or XV_HANDOVER=event)
-    uint32_t epoch = 0;
-    bool flag_pending = false;
     bool lw_pending = false;      // the loss head's weight gradient (side stream) - it reads no dz buffer, so it has its own event
     bool concurrent = true;
     void* ws_side = nullptr;
@@ -521,17 +513,6 @@ int alloc_buffers(xv_engine* e) {
         XV_CHECK_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
         XV_CHECK_HIP(hipStreamCreateWithPriority(&e->side2, hipStreamNonBlocking, least));
     }
-    {   // start-flag hand-overs (struct xv_engine: sig): 8 bytes of signal memory - any other size is refused
-        const XvEnv* env = xv_env();
-        if (!env) return 2;
-        int dev = 0, can = 0;
-        XV_CHECK_HIP(hipGetDevice(&dev));
-        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess) { can = 0; (void)hipGetLastError(); }
-        if (can && !env->handover_event) {
-            if (hipExtMallocWithFlags((void**)&e->sig, 8, hipMallocSignalMemory) != hipSuccess) { e->sig = nullptr; (void)hipGetLastError(); }
-            else { e->sig[0] = 0; e->sig[1] = 0; }
-        }
-    }
     // Events between the engine's own streams order kernels of ONE device: no system-scope fence (cache write-back towards the host and
     // peers) when they are recorded.  The stage / communication events, which a collective on another stream - read by peer GPUs - may
     // wait on, keep the default.
@@ -750,7 +731,6 @@ extern "C" void xv_engine_destroy(xv_engine* e) {
     for (int k = 0; k < XV_BWD_STAGES; ++k)
         for (int j = 0; j < 2; ++j) if (e->ev_stage[k][j]) (void)hipEventDestroy(e->ev_stage[k][j]);
 
-    if (e->sig) (void)hipFree(e->sig);
     if (e->arena) (void)hipFree(e->arena);
     delete e;
 }
@@ -1123,28 +1103,6 @@ int chain(hipStream_t signaller, hipStream_t waiter, hipEvent_t ev) {
     return 0;
 }
 
-// `waiter` waits for everything enqueued so far on the compute stream `s` - through a start flag (no packet on `s`; the caller's next GEMM on `s`
-// must take_flag()) or, without signal memory, through ev_dz.
-int hand_over(xv_engine* e, hipStream_t s, hipStream_t waiter) {
-    if (!e->sig) return chain(s, waiter, e->ev_dz);
-    ++e->epoch;
-    XV_CHECK_HIP(hipStreamWaitValue32(waiter, e->sig, e->epoch, hipStreamWaitValueGte, 0xFFFFFFFFu));
-    e->flag_pending = true;
-    return 0;
-}
-XvStartFlag take_flag(xv_engine* e) {
-    XvStartFlag f;
-    if (e->flag_pending) { f.flag = e->sig; f.value = e->epoch; e->flag_pending = false; }
-    return f;
-}
-int flush_flag(xv_engine* e, hipStream_t s) {
-    if (e->flag_pending) {
-        XV_CHECK_HIP(hipStreamWriteValue32(s, e->sig, e->epoch, 0));
-        e->flag_pending = false;
-    }
-    return 0;
-}
-
 // All weight-gradient work enqueued on the side streams so far becomes visible to `s` - through ONE wait on `s`: the side stream is in
 // order, so an event recorded on it now covers every dz slot's event, and the loss head's stream is joined into the side stream first.
 // (tools/sync_cost_probe.cpp, profiles/r04_sync_cost.txt: in a chain of 10 us kernels a wait for another stream's fresh event costs the
@@ -1152,14 +1110,6 @@ int flush_flag(xv_engine* e, hipStream_t s) {
 // within the noise of a same-box A/B - as is carrying the hand-over events on the producing kernels' completion signals
 // (hipExtLaunchKernel's stopEvent, 1.5 us in the probe), which was built, verified and taken out again.)
 int join_side(xv_engine* e, hipStream_t s) {
-    if (flush_flag(e, s)) return 1;
-    if (e->epoch > 0x60000000u) {      // (a wait compares signed 64-bit signal values: start again long before the counter's sign bit)
-        XV_CHECK_HIP(hipStreamSynchronize(s));
-        if (e->side) XV_CHECK_HIP(hipStreamSynchronize(e->side));
-        if (e->side2) XV_CHECK_HIP(hipStreamSynchronize(e->side2));
-        e->sig[0] = 0;
-        e->epoch = 0;
-    }
     bool any = e->side_dirty;
     e->side_dirty = false;
     e->z_taken = 0;
@@ -1196,7 +1146,6 @@ float* ring_take(xv_engine* e, hipStream_t s) {
     const int zi = zr.cur;
     if (e->z_private && e->z_taken >= zr.n && join_side(e, s)) return nullptr;      // (a caller that never finishes a backward pass)
     if (zr.pending[zi]) {                       // WAR
-        if (flush_flag(e, s)) return nullptr;
         if (hipStreamWaitEvent(s, zr.ev[zi], 0) != hipSuccess) return nullptr;
         zr.pending[zi] = false;
     }
@@ -1253,7 +1202,7 @@ int layer_wgrad(xv_engine* e, hipStream_t s, Affine& a, const float* x, const fl
     void* wws = concurrent ? e->ws_side : e->ws;
     int rc;
     if (concurrent) {
-        rc = hand_over(e, s, e->side);
+        rc = chain(s, e->side, e->ev_dz);
         if (rc) return rc;
     }
     // [measured, round 4, same box, variant builds] the LAST weight-gradient launches of the side stream (tdnn2's; tdnn2-3's; all four) as 768
@@ -1295,10 +1244,10 @@ int layer_backward(xv_engine* e, hipStream_t s, Affine& a, const float* da, cons
     if (rc) return rc;
     if (dx) {
         const float* wf = a.k > 1 ? a.wf : vptr(e, a.v_kernel);
-        rc = xv_affine_dgrad_ld(s, dz, a.ldz, segs, t_out, a.c_out, a.k, wf, dx, a.c_in, e->ws, e->ws_bytes, take_flag(e));
+        rc = xv_affine_dgrad_ld(s, dz, a.ldz, segs, t_out, a.c_out, a.k, wf, dx, a.c_in, e->ws, e->ws_bytes);
         if (rc) return rc;
     }
-    return flush_flag(e, s);      // (no data gradient behind the hand-over: write the flag out)
+    return 0;
 }
 
 // Split-precision backward of a frame layer: dz is written once as fp16 planes (padded layout) and feeds both the
@@ -1389,7 +1338,6 @@ namespace {
 // consumes the slice waits for the pair (xv_engine_stage_wait) on its own stream.
 int end_stage(xv_engine* e, hipStream_t s, int stage, bool defer) {
     if (!defer) return join_side(e, s);
-    if (flush_flag(e, s)) return 1;
     const bool last = stage == XV_BWD_STAGES - 1;
     if (last) {                       // the optimiser step follows on `s`: join here, the event on `s` then covers both streams
         int rc = join_side(e, s);
@@ -1449,7 +1397,7 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             hipStream_t ss = e->concurrent ? e->side2 : s;
             void* lws = e->concurrent ? e->ws_side2 : e->ws_side;
             if (e->concurrent) {
-                rc = hand_over(e, s, ss);
+                rc = chain(s, ss, e->ev_dz);
                 if (rc) return rc;
             }
             XvGemmTN w = {};
@@ -1509,7 +1457,6 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             } else {
                 g.epi = XV_SK_PLAIN; g.C = e->d_small0; g.ldc = e->Lout;
             }
-            g.start = take_flag(e);
             rc = xv_launch_skinny(s, g);
             if (rc) return rc;
         } else {
@@ -1519,7 +1466,6 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             g.C = e->d_small0; g.ldc = e->Lout;
             g.M = b; g.N = e->Lout; g.K = e->ldl;
             g.ws = e->ws; g.ws_bytes = e->ws_bytes;
-            g.start = take_flag(e);
             rc = xv_launch_gemm_nt(s, g);
             if (rc) return rc;
             rc = xv_add_norm_grad(s, e->out, e->dnorm, b, e->Lout, e->d_small0);
@@ -1573,7 +1519,6 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
                 g.relu = l6.has_relu ? 1 : 0; g.slope = l6.has_relu ? ac.slope : nullptr; g.dalpha = (l6.has_relu && ac.slope) ? ac.dalpha : nullptr;
                 g.dgamma = gptr(e, l6.v_gamma); g.dbeta = gptr(e, l6.v_beta); g.dbias = gptr(e, l6.v_bias);
                 g.ws = e->ws; g.ws_bytes = e->ws_bytes; g.tickets = e->sk_tickets;
-                g.start = take_flag(e);
                 rc = xv_launch_skinny(s, g);
                 if (rc) return rc;
             }
@@ -1586,7 +1531,6 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
                 g.A = dz6; g.lda = l6.c_out; g.Bt = vptr(e, l6.v_kernel); g.ldb = l6.c_out; g.M = b; g.N = l6.c_in; g.K = l6.c_out;
                 g.epi = XV_SK_PLAIN; g.C = e->d_small0; g.ldc = l6.c_in;
                 g.ws = e->ws; g.ws_bytes = e->ws_bytes; g.tickets = e->sk_tickets;
-                g.start = take_flag(e);
                 rc = xv_launch_skinny(s, g);
                 if (rc) return rc;
             }

@@ -65,7 +65,6 @@ struct NTArgs {
     float* slab;                // [(tiles - n_whole) * shares][128 * 128]: partial tiles in lane order
     unsigned* tickets;          // one per tile, zero between launches
     int row_store;              // epilogue through LDS with 16-byte row stores (nt_store_tile_rows): C / ldc 16-byte aligned, N % 4 == 0
-    unsigned* start_flag; unsigned start_value;      // XvStartFlag (xv_common.h)
 };
 
 // Out-of-range rows / k read this 16-byte zero page instead of being masked after the load: the
@@ -223,7 +222,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     XV_STAMP_ENTRY(p.stamp_half);
     unsigned long long stall = 0;
     (void)stall;
-    xv_start_flag_store(p.start_flag, p.start_value);
 
     // whole tiles first: the hardware places them first (n_whole is a multiple of 256 - the same number on every CU of an empty chip), the
     // short share blocks behind them are dealt into whatever slots are free
@@ -436,7 +434,6 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    xv_start_flag_store(p.start_flag, p.start_value);
     const int w = xcd_swizzle(blockIdx.x, gridDim.x);
     const long u_end = (long)(w + 1) * q.total / q.P;
     long u = (long)w * q.total / q.P;
@@ -810,7 +807,6 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
     p.bias = g.bias; p.part_sum = nullptr; p.part_m2 = nullptr;
     p.n_whole = 0; p.shares = 0; p.slab = nullptr; p.tickets = nullptr;
-    p.start_flag = g.start.flag; p.start_value = g.start.value;
 #ifdef XV_NT_NO_ROWS      // (A/B build constant: the four-byte-store epilogue everywhere)
     p.row_store = 0;
 #else
@@ -1388,7 +1384,7 @@ extern "C" int xv_affine_forward(void* stream, const float* x, int segs, int t_i
 }
 
 int xv_affine_dgrad_ld(hipStream_t stream, const float* dz_pad, int ldo, int segs, int t_out, int o, int k, const float* wf, float* dx, int c,
-                       void* ws, size_t ws_bytes, XvStartFlag start) {
+                       void* ws, size_t ws_bytes) {
     XV_REQUIRE(segs > 0 && k >= 1 && t_out >= 1 && o > 0 && c > 0 && ldo >= o && (ldo == o || k == 1), "affine_dgrad: bad shape (a row pitch needs k = 1)");
     XvGemmNT g = {};
     g.A = dz_pad; g.lda = ldo; g.a_rps = t_out + k - 1; g.a_pitch = t_out + 2 * (k - 1);
@@ -1397,7 +1393,6 @@ int xv_affine_dgrad_ld(hipStream_t stream, const float* dz_pad, int ldo, int seg
     g.M = segs * (t_out + k - 1); g.N = c; g.K = k * o;
     g.ws = ws; g.ws_bytes = ws_bytes;
     g.co_running = 1;          // the data gradient runs beside the layer's weight gradient (xv_engine.hip: two streams)
-    g.start = start;
     return xv_launch_gemm_nt(stream, g);
 }
 extern "C" int xv_affine_dgrad(void* stream, const float* dz_pad, int segs, int t_out, int o, int k, const float* wf, float* dx,

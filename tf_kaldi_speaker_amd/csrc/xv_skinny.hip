@@ -49,7 +49,6 @@ __device__ __forceinline__ float sk_col_sum(float v, float (*red)[SK_COLS], int 
 template <int EPI>
 __global__ __launch_bounds__(256) void xv_skinny_kernel(SkArgs p) {
     XV_EW_PRIORITY();
-    xv_start_flag_store(p.g.start.flag, p.g.start.value);
     __shared__ __attribute__((aligned(16))) float smem[2 * SK_STAGE];
     __shared__ float red[4][SK_COLS];
     __shared__ int s_last;
