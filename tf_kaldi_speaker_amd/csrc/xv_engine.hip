@@ -524,7 +524,7 @@ int alloc_buffers(xv_engine* e) {
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_dz, local));
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < e->zr[r].n; ++i) XV_CHECK_HIP(hipEventCreateWithFlags(&e->zr[r].ev[i], local));
-    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lw, local));
+    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lw, hipEventDisableTiming));      // (xv_engine_stage_wait: a collective's stream may wait on it)
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join, local));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_comm, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_prep, local));
