@@ -516,11 +516,7 @@ int alloc_buffers(xv_engine* e) {
     // Events between the engine's own streams order kernels of ONE device: no system-scope fence (cache write-back towards the host and
     // peers) when they are recorded.  The stage / communication events, which a collective on another stream - read by peer GPUs - may
     // wait on, keep the default.
-#ifdef XV_EVENT_SYSTEM_FENCE
-    const unsigned local = hipEventDisableTiming;
-#else
     const unsigned local = hipEventDisableTiming | hipEventDisableSystemFence;
-#endif
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_dz, local));
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < e->zr[r].n; ++i) XV_CHECK_HIP(hipEventCreateWithFlags(&e->zr[r].ev[i], local));
