@@ -194,10 +194,6 @@ struct NT16Args {
     XvBwdStats bwd;         // EPI == 2 only
 };
 
-#ifndef XV16_ABL
-#define XV16_ABL 0     // ablation builds only (tools/variant_bench16.sh; results are wrong): 1 = no LDS-DMA, 2 = no LDS reads (generic NT kernel);
-                       // 16 = no weight-tile DMA, 32 = no x-row DMA (context-window NT kernel)
-#endif
 #ifndef XV16_BK
 #define XV16_BK 32
 #endif
@@ -210,18 +206,7 @@ struct NT16Args {
 #define WN16 (XV16_WAVES / 2)          // waves along N
 #define NB16 (4 / WN16)                // 32-column accumulator blocks per wave
 #define BK16 XV16_BK
-#ifndef XV16_MFMA16
-#define XV16_MFMA16 0    // 1: v_mfma_f32_16x16x32_f16 in the generic NT kernel (4 x 4 accumulator blocks per wave), BK = 32 and 4 waves only
-#endif
-#if XV16_MFMA16
-// 16x16x32 operands: lane l reads row base + (l & 15), 16-byte chunk l >> 4 of a 64-byte row.  chunk ^= 2 * ((row >> 2) & 1) puts the
-// 16 lanes of every ds_read_b128 lane group on 16 distinct 4-bank columns for ANY base row (exhaustive check over the four
-// lane groups and all 16 alignments; a context-window read shifts the rows by the tap) - the same involution is applied to the
-// LDS-DMA source chunk.
-#define SWZ16(row) ((((row) >> 2) & 1) << 1)
-#else
 #define SWZ16(row) (BK16 == 64 ? (((row) >> 1) & 7) : BK16 == 32 ? (((row) >> 2) & 3) : 0)
-#endif
 #define CQ16 (BK16 / 8)
 #define PLANE_HALFS (128 * BK16)
 #define BUF_HALFS (4 * PLANE_HALFS)
@@ -294,75 +279,6 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
         }
     };
 
-#if XV16_MFMA16
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int lc = lane & 15, lg = lane >> 4;
-    int a_off[4], b_off[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ra = wr * 64 + q * 16 + lc, rb = wc * 64 + q * 16 + lc;
-        a_off[q] = ra * BK16 + ((lg ^ SWZ16(ra)) << 3);
-        b_off[q] = rb * BK16 + ((lg ^ SWZ16(rb)) << 3);
-    }
-    if (nk > 0) gstage(0, 0);
-    xv16_sync();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
-        const u16* base = smem + buf * BUF_HALFS;
-        f32x4 af[2][4], bf[2][4];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                af[pl][q] = *(const f32x4*)(base + pl * PLANE_HALFS + a_off[q]);
-                bf[pl][q] = *(const f32x4*)(base + (2 + pl) * PLANE_HALFS + b_off[q]);
-            }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-#define MM(i, j) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i][a]), __builtin_bit_cast(f16x8, bf[j][b]), acc[a][b], 0, 0, 0)
-                MM(0, 1); MM(1, 0); MM(0, 0);
-#undef MM
-            }
-        xv16_sync();
-    }
-    const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
-    // scale + bias in a pass of their own, THEN the stores: with both in one predicated block per element hipcc put the
-    // s_waitcnt vmcnt(0) of the amax / bias loads in front of every store, and stores count on vmcnt - each store waited for
-    // the previous one to retire
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int n = n0 + wc * 64 + b * 16 + lc;
-        const float bias_v = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[a][b][jj] = acc[a][b][jj] * out_scale + bias_v;
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(acc[a][b]));      // keeps hipcc from sinking the pass back into the store blocks
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int n = n0 + wc * 64 + b * 16 + lc;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int m = m0 + wr * 64 + a * 16 + lg * 4 + jj;
-                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = acc[a][b][jj];
-            }
-    }
-    if (EPI == 1) xv_tile_stats_epilogue16(acc, (float*)smem, tid, wr, wc, lane, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
-}
-#else
     f32x16 acc[2][NB16];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -377,24 +293,12 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
     xv16_sync();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-#if !(XV16_ABL & 1)
         if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
-#endif
         const u16* base = smem + buf * BUF_HALFS;
 #pragma unroll
         for (int kb = 0; kb < BK16 / 16; ++kb) {
             const int pos = (((2 * kb + lh) ^ fsw) << 3);
             f32x4 af[2][2], bf[2][NB16];
-#if XV16_ABL & 2
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    af[pl][q] = (f32x4){(float)kt, (float)lane, (float)pl, (float)q};
-                    bf[pl][q % NB16] = (f32x4){(float)q, (float)kt, (float)lane, (float)pl};
-                    asm volatile("" : "+v"(af[pl][q]), "+v"(bf[pl][q % NB16]));
-                }
-#else
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
                 af[pl][0] = *(const f32x4*)(base + pl * PLANE_HALFS + a_row + pos);
@@ -402,7 +306,6 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
 #pragma unroll
                 for (int nb = 0; nb < NB16; ++nb) bf[pl][nb] = *(const f32x4*)(base + (2 + pl) * PLANE_HALFS + b_row + nb * 32 * BK16 + pos);
             }
-#endif
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -446,7 +349,6 @@ __global__ __launch_bounds__(64 * XV16_WAVES, XV16_WGS) void xv_gemm16_nt_kernel
     if (EPI == 1) xv_tile_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.tiles_m, p.part);
     if (EPI == 2) xv_tile_bwd_stats_epilogue(acc, (float*)smem, tid, wr, wc, li, lh, m0, n0, p.M, p.N, tile_m, p.bwd);
 }
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // Context-window ("conv") form of the NT kernel: K = taps x C with A row (m, tap j) = x row xrow(m) + j.
@@ -484,18 +386,11 @@ template <int WR> struct ConvGeom {
     static constexpr int LDS_HALFS = 2 * ABUF + 2 * CONV_BBUF;
 };
 
-// XV16_CONV_MFMA16=1: v_mfma_f32_16x16x32_f16 (one instruction spans the whole 32-channel K-step; 4 x 4 accumulator blocks of
-// 16 x 16 per wave) instead of v_mfma_f32_32x32x16_f16.  The 16-byte chunk swizzle changes with the fragment shape: the
+// The context-window kernel contracts on v_mfma_f32_16x16x32_f16 (one instruction spans the whole 32-channel K-step; 4 x 4 accumulator
+// blocks of 16 x 16 per wave), not v_mfma_f32_32x32x16_f16.  The 16-byte chunk swizzle changes with the fragment shape: the
 // 16-lane groups of a ds_read_b128 must land on distinct bank columns for any tap offset (see SWZ16 above).
 // [measured] tdnn2 / tdnn3 at S1: forward 236 -> 218 us / 309 -> 300 us, data gradient 242 -> 234 us / 286 -> 270 us (+3 ... +8 %).
-#ifndef XV16_CONV_MFMA16
-#define XV16_CONV_MFMA16 1
-#endif
-#if XV16_CONV_MFMA16
 #define CONV_SWZ(row) ((((row) >> 2) & 1) << 1)
-#else
-#define CONV_SWZ(row) (((row) >> 2) & 3)
-#endif
 
 template <int EPI, int WR>
 __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16ConvArgs q) {
@@ -559,7 +454,6 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
         }
     };
 
-#if XV16_CONV_MFMA16
     // (EPI == 2, the BN-backward epilogue, exists for the 32x32x16 accumulator layout only: the launcher refuses it in this build)
     f32x4 acc[4][4];
 #pragma unroll
@@ -643,96 +537,6 @@ __global__ __launch_bounds__(128 * WR, 2) void xv_gemm16_nt_conv_kernel(NT16Conv
             xv_tile_stats_epilogue16(acc, red, tid & 255, wr & 1, wc, lane, m0 + 128 * half, n0, p.M, p.N, (WR / 2) * tile_m + half, tiles128, p.part);
     }
     (void)li; (void)lh;
-#else
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int b_row = (wc * 64 + li) * 32;
-    const int bsw = (li >> 2) & 3;
-    stage_a(0, 0, 0, 1);
-    stage_b(0, 0, 0);
-    xv16_sync();
-    int st = 0;
-    for (int cc = 0; cc < nc; ++cc) {
-        const u16* abase = sA + (cc & 1) * G::ABUF;
-        for (int j = 0; j < taps; ++j, ++st) {
-            // prefetch: next step's weight tile, and this step's slice of the next chunk's x rows
-#if !(XV16_ABL & 16)
-            if (j + 1 < taps) stage_b(cc, j + 1, (st + 1) & 1);
-            else if (cc + 1 < nc) stage_b(cc + 1, 0, (st + 1) & 1);
-#endif
-#if !(XV16_ABL & 32)
-            if (cc + 1 < nc) stage_a(cc + 1, (cc + 1) & 1, j, taps);
-#endif
-            const u16* bbase = sB + (st & 1) * CONV_BBUF;
-            const int r0 = arow[0] + j, r1 = arow[1] + j;
-            const int asw0 = (r0 >> 2) & 3, asw1 = (r1 >> 2) & 3;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const int c = 2 * kb + lh;
-                f32x4 af[2][2], bf[2][2];
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    af[pl][0] = *(const f32x4*)(abase + pl * G::APLANE + r0 * 32 + ((c ^ asw0) << 3));
-                    af[pl][1] = *(const f32x4*)(abase + pl * G::APLANE + r1 * 32 + ((c ^ asw1) << 3));
-                    bf[pl][0] = *(const f32x4*)(bbase + pl * CONV_BPLANE + b_row + ((c ^ bsw) << 3));
-                    bf[pl][1] = *(const f32x4*)(bbase + pl * CONV_BPLANE + b_row + 32 * 32 + ((c ^ bsw) << 3));
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-#define MM(i, jj) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][a]), __builtin_bit_cast(f16x8, bf[jj][b]), acc[a][b], 0, 0, 0)
-                        MM(0, 1); MM(1, 0); MM(0, 0);
-#undef MM
-                    }
-            }
-            xv16_sync();
-        }
-    }
-
-    const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
-    float bias_v[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        int n = n0 + wc * 64 + b * 32 + li;
-        bias_v[b] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)      // scale + bias first, stores afterwards
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = acc[a][b][r] * out_scale + bias_v[b];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(acc[a][b]));
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            int n = n0 + wc * 64 + b * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = acc[a][b][r];
-            }
-        }
-    // the statistics epilogues work on 128-row tiles: each group of 4 waves is one (own scratch, same barriers)
-    const int half = wr >> 1;
-    const int tiles128 = (p.M + 127) / 128;
-    float* red = (float*)smem + half * 1024;
-    if (EPI == 1)
-        xv_tile_stats_epilogue(acc, red, tid & 255, wr & 1, wc, li, lh, m0 + 128 * half, n0, p.M, p.N, (WR / 2) * tile_m + half, tiles128, p.part);
-    if (EPI == 2)
-        xv_tile_bwd_stats_epilogue(acc, red, tid & 255, wr & 1, wc, li, lh, m0 + 128 * half, n0, p.M, p.N, (WR / 2) * tile_m + half, p.bwd);
-#endif
 }
 
 #ifndef XV16_CONV
@@ -799,7 +603,7 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
     p.bias = g.bias; p.part = g.bn_part; p.a_amax = g.a_amax; p.b_amax = g.b_amax; p.zero = g_zero16;
     const bool bwd = g.bwd_part != nullptr;
     XV_REQUIRE(!(bwd && g.bn_part), "gemm16_nt: one epilogue at a time");
-    XV_REQUIRE(!bwd || (g.bwd_z && g.bwd_scale && g.bwd_shift && g.bwd_mean && g.bwd_invstd && !XV16_MFMA16 && XV16_WAVES == 4),
+    XV_REQUIRE(!bwd || (g.bwd_z && g.bwd_scale && g.bwd_shift && g.bwd_mean && g.bwd_invstd && XV16_WAVES == 4),
                "gemm16_nt: incomplete BN-backward epilogue arguments");
     p.bwd = XvBwdStats{g.bwd_z, g.bwd_scale, g.bwd_shift, g.bwd_mean, g.bwd_invstd, g.bwd_part};
     dim3 grid(p.tiles_m * p.tiles_n);
@@ -812,7 +616,7 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
     const bool wr4 = env->conv_wr ? env->conv_wr == 4 : (XV16_CONV_WR == 4 && g.M >= 256 * 256);
     // the BN-backward epilogue (an off-by-default experiment) is written for the 32x32x16 accumulator layout: with the 16x16x32
     // build of the context-window kernel such a launch takes the generic kernel
-    const bool conv_ok = !(bwd && XV16_CONV_MFMA16);
+    const bool conv_ok = !bwd;
     if (conv_ok && wr4 && conv_form_applies(g, 256, &taps)) return launch_conv<4>(s, g, p, taps, bwd);
     if (conv_ok && conv_form_applies(g, 128, &taps)) return launch_conv<2>(s, g, p, taps, bwd);
     if (g.bn_part) hipLaunchKernelGGL(xv_gemm16_nt_kernel<1>, grid, dim3(64 * XV16_WAVES), 0, s, p);
@@ -830,9 +634,6 @@ int xv_launch_gemm16_nt(hipStream_t s, const XvGemm16NT& g) {
 // Rows are 256 B = one full bank row apart, so the 32-byte column blocks are XOR-swizzled by the row
 // (block ^= 2*(row&3)) on the DMA source address and on the read address: conflict-free.
 // ---------------------------------------------------------------------------------------------
-#ifndef XV16_TN_MFMA16
-#define XV16_TN_MFMA16 1      // v_mfma_f32_16x16x32_f16 (0: v_mfma_f32_32x32x16_f16)
-#endif
 
 struct TN16Args {
     const u16* A; long lda; long a_plane; int a_pitch;
@@ -865,17 +666,10 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
 
     // DMA: one wave-instruction = 4 image rows x 256 B; lane -> row l>>4, 16-byte chunk position l&15
     const int drow = lane >> 4, dpos = lane & 15;
-#if XV16_TN_MFMA16
     // 16x16x32: the four 16-lane groups of a transposed read sit on rows 8g + {0..3} (+4) of one 32-byte column block; the block
     // position is XOR-ed with 2*(row&3) ^ ((row>>3)&1) so that the 8 (group, row) pairs of each half-wave take 8 distinct blocks
     const int scol = (((((dpos >> 1) ^ (2 * drow) ^ (wave & 1)) << 1) | (dpos & 1))) * 8;    // rows 8*wave + 4*i + drow: (row>>3)&1 = wave&1
-#else
-    const int scol = (((((dpos >> 1) ^ (2 * drow)) << 1) | (dpos & 1))) * 8;    // source column (16-bit elements)
-#endif
     const bool a_cv = (m0 + scol) < p.M, b_cv = (n0 + scol) < p.N;
-#ifndef XV16_TN_ABLATE
-#define XV16_TN_ABLATE 0      // diagnostics only (tools/variant_libs.sh; wrong results): 1 = the A (x) planes are staged for the first stage only, 2 = the B (dz) planes
-#endif
     auto gstage_ragged = [&](int kt, int buf) {      // a stage with rows at or beyond r_end: those read the zero page (they are summed)
         u16* base = smem + buf * BH;
 #pragma unroll
@@ -925,8 +719,8 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                if (!(XV16_TN_ABLATE & 1) || kt < 2) xv_dma16((const float*)(p.A + pl * p.a_plane), aoff[i], lds0 + (buf * BH + pl * PH + 4 * i * 128) * 2);
-                if (!(XV16_TN_ABLATE & 2) || kt < 2) xv_dma16((const float*)(p.B + pl * p.b_plane), boff[i], lds0 + (buf * BH + (2 + pl) * PH + 4 * i * 128) * 2);
+                xv_dma16((const float*)(p.A + pl * p.a_plane), aoff[i], lds0 + (buf * BH + pl * PH + 4 * i * 128) * 2);
+                xv_dma16((const float*)(p.B + pl * p.b_plane), boff[i], lds0 + (buf * BH + (2 + pl) * PH + 4 * i * 128) * 2);
             }
             tt_i[i] += BR;
             const bool wrap = tt_i[i] >= p.rps;
@@ -936,7 +730,6 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
         }
     };
 
-#if XV16_TN_MFMA16
     f32x4 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -996,73 +789,6 @@ __global__ __launch_bounds__(256, 2) void xv_gemm16_tn_kernel(TN16Args p) {
         }
     (void)li; (void)lh;
 }
-#else
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    // transposed-read lane geometry: 16-lane group g = lane>>4: column half g&1, k half g>>1 (== lh)
-    const int tq = (lane & 15) >> 2, tp = lane & 3;
-    const int ghalf = (lane >> 4) & 1;
-    auto tr_off = [&](int colbase /* multiple of 32 */, int row0) {
-        const int r = row0 + tq;
-        return r * 128 + ((((colbase >> 4) + ghalf) ^ (2 * (r & 3))) << 4) + tp * 4;
-    };
-    typedef __attribute__((address_space(3))) s16x4* ltr_t;
-    if (nk > 0) gstage(0, 0);
-    xv16_sync();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gstage(kt + 1, buf ^ 1);
-        const u16* base = smem + buf * BH;
-#pragma unroll
-        for (int kb = 0; kb < BR / 16; ++kb) {
-            const int row0 = kb * 16 + 8 * lh;
-            s16x8 af[2][2], bf[2][2];
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const u16* ia = base + pl * PH;
-                    const u16* ib = base + (2 + pl) * PH;
-                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(ia + tr_off(wr * 64 + s * 32, row0)));
-                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(ia + tr_off(wr * 64 + s * 32, row0 + 4)));
-                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(ib + tr_off(wc * 64 + s * 32, row0)));
-                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(ib + tr_off(wc * 64 + s * 32, row0 + 4)));
-                    af[pl][s] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    bf[pl][s] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-#define MM(i, j) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][a]), __builtin_bit_cast(f16x8, bf[j][b]), acc[a][b], 0, 0, 0)
-                    MM(0, 1); MM(1, 0); MM(0, 0);
-#undef MM
-                }
-        }
-        xv16_sync();
-    }
-
-    const float out_scale = 1.0f / (xv_pow2_scale(p.a_amax ? *p.a_amax : 0u) * xv_pow2_scale(p.b_amax ? *p.b_amax : 0u));
-    float* P = p.P + (long)split * p.M * p.N;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            int n = n0 + wc * 64 + b * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M && n < p.N) P[(long)m * p.N + n] = acc[a][b][r] * out_scale;
-            }
-        }
-}
-#endif
 
 int xv_tn16_splits(int M, int N, int R) {
     int tiles = xv_cdiv(M, 128) * xv_cdiv(N, 128);
