@@ -387,8 +387,10 @@ template <int WR> struct ConvGeom {
 };
 
 // The context-window kernel contracts on v_mfma_f32_16x16x32_f16 (one instruction spans the whole 32-channel K-step; 4 x 4 accumulator
-// blocks of 16 x 16 per wave), not v_mfma_f32_32x32x16_f16.  The 16-byte chunk swizzle changes with the fragment shape: the
-// 16-lane groups of a ds_read_b128 must land on distinct bank columns for any tap offset (see SWZ16 above).
+// blocks of 16 x 16 per wave), not v_mfma_f32_32x32x16_f16.  Operands: lane l reads row base + (l & 15), 16-byte chunk
+// l >> 4 of a 64-byte row; chunk ^= 2 * ((row >> 2) & 1) puts the 16 lanes of every ds_read_b128 lane group on 16 distinct 4-bank columns
+// for ANY base row (exhaustive check over the four lane groups and all 16 alignments; a context-window read shifts the rows by the tap) -
+// the same involution is applied to the LDS-DMA source chunk.
 // [measured] tdnn2 / tdnn3 at S1: forward 236 -> 218 us / 309 -> 300 us, data gradient 242 -> 234 us / 286 -> 270 us (+3 ... +8 %).
 #define CONV_SWZ(row) ((((row) >> 2) & 1) << 1)
 
