@@ -372,12 +372,13 @@ int alloc_buffers(xv_engine* e) {
         bufz = std::max(bufz, padded * (size_t)a.ldz);
         max_pad_rows = std::max(max_pad_rows, padded);
     }
-    // a dz slot per layer (+ the attention key gradient) while that stays below 1/16 of the card; the two-slot ring otherwise
+    // a dz slot per layer (+ the attention key gradient) while that stays below 6 GiB (S5, the extended model at 128 x 400: 4.3 GB); the two-slot
+    // ring otherwise - an engine sized for batched extraction (hundreds of thousands of rows, never a backward pass) does not pay for the slots
     e->nz = 2;
     {
         const XvEnv* env = xv_env();
         if (!env) return 2;
-        if (env->dz_slots != 2 && !e->f16 && e->NL + 2 <= XV_Z_SLOTS && (size_t)(e->NL + 2) * bufz * sizeof(float) <= ((size_t)18 << 30)) e->nz = e->NL + 2;
+        if (env->dz_slots != 2 && !e->f16 && e->NL + 2 <= XV_Z_SLOTS && (size_t)(e->NL + 2) * bufz * sizeof(float) <= ((size_t)6 << 30)) e->nz = e->NL + 2;
     }
     e->z_private = e->nz > 2;
     e->zr[0].n = e->f16 ? 2 : e->nz;
