@@ -206,6 +206,18 @@ def test_statistics_pooling_adversarial(ops):
     assert_close(dx[1], np.broadcast_to(dout[1, None, :c] / t, (t, c)), 1e-6, 1e-5, "pool dx zero row")
 
 
+def test_statistics_pooling_matches_reference_numpy(ops):
+    """xv_stat_pool_forward vs the reference's own NumPy (compute_self_attention with a zero query = uniform weights over time,
+    model/test_utils.py:320-372; tests/golden/make_pooling_golden.py) on inputs with the reference self-test's adversarial rows."""
+    from test_oracle_golden import _pooling_golden_cases, check_pooling_against_reference
+    n = 0
+    for i, x, ref in _pooling_golden_cases():
+        got = host(ops.stat_pool_forward(dev(x)))
+        check_pooling_against_reference(got, ref, x, 2e-6, 2e-5, "case %d" % i)
+        n += 1
+    assert n == 5
+
+
 @pytest.mark.parametrize("t", [1, 7, 15, 186, 401])
 def test_statistics_pooling_lengths(ops, t):
     rs = np.random.RandomState(t)

@@ -73,3 +73,47 @@ def test_auxiliary_losses_match_reference_numpy_oracles():
         assert np.isclose(ring, float(g["ring_%d" % i]), rtol=1e-12)
         mhe, _ = O.mhe_loss(g["w_%d" % i], g["labels_%d" % i], lam)
         assert np.isclose(mhe, float(g["mhe_%d" % i]), rtol=5e-6), (mhe, float(g["mhe_%d" % i]))
+
+
+def _pooling_golden_cases():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from pooling_cases import pooling_cases
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pooling_golden.npz"))
+    xs = list(pooling_cases())
+    assert len(xs) == int(g["num_cases"])
+    for i, x in enumerate(xs):
+        x64 = x.astype(np.float64)
+        # the regenerated input is the one the reference function saw
+        assert np.allclose([x64.sum(), np.abs(x64).sum()], g["x_sum_%d" % i], rtol=1e-13, atol=0)
+        yield i, x, g["pool_%d" % i]
+
+
+def check_pooling_against_reference(got, ref, x, rel_mean, rel_std, name):
+    """Shared by the oracle test and the GPU test.  The reference function returns sqrt(var + 1e-12) where the graph (pooling.py:28-29)
+    returns sqrt(var) for var > 1e-12 and 1e-6 otherwise: identical at a constant chunk (1e-6), 5e-13 / var relative elsewhere.  The
+    x 1e-8 row has var ~ 8e-18, far below the mask threshold, so both say 1e-6 there too."""
+    c = x.shape[2]
+    scale = np.abs(x.astype(np.float64)).max(axis=(1, 2))[:, None] + 1e-30
+    assert got.shape == ref.shape, name
+    assert np.all(np.isfinite(got)), name
+    assert np.all(np.abs(got[:, :c] - ref[:, :c]) <= rel_mean * scale), (name, np.abs(got[:, :c] - ref[:, :c]).max())
+    var_ref = ref[:, c:] ** 2 - 1e-12
+    floor = var_ref <= 1e-9                     # constant / zero / x 1e-8 rows and T = 1: the epsilon decides
+    assert np.allclose(got[:, c:][floor], 1e-6, rtol=1e-3, atol=0), name
+    rest = ~floor
+    err = np.abs(got[:, c:] - ref[:, c:])
+    assert np.all(err[rest] <= (rel_std * np.broadcast_to(scale, err.shape))[rest] + 1e-3 * 1e-6), (name, err[rest].max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_statistics_pooling_matches_reference_numpy(dtype):
+    """oracle.statistics_pooling_fwd (model/pooling.py:9-34) vs the reference's compute_self_attention with a zero query = uniform
+    weights (tests/golden/make_pooling_golden.py): the one frame-level row of SURVEY 8(a) the reference's own code can pin."""
+    n = 0
+    for i, x, ref in _pooling_golden_cases():
+        got, _ = O.statistics_pooling_fwd(x.astype(dtype))
+        tol = (1e-12, 1e-9) if dtype == np.float64 else (2e-6, 2e-5)
+        check_pooling_against_reference(np.asarray(got, np.float64), ref, x, tol[0], tol[1], "case %d" % i)
+        n += 1
+    assert n == 5
