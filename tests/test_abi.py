@@ -105,7 +105,7 @@ def test_config_struct_size_is_checked():
     import ctypes as C
     from tf_kaldi_speaker_amd import _lib
     lib = _lib.load()
-    assert lib.xv_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.xv_abi_version() == _lib.ABI_VERSION == 3
     cfg = _lib.XvConfig()
     assert cfg.struct_bytes == C.sizeof(_lib.XvConfig)
     cfg.feat_dim = 30

@@ -417,3 +417,4 @@ def test_trainer_reads_and_writes_tensorflow_checkpoints(tmp_path, xv_precision)
     for k, v in got.items():
         assert np.array_equal(want[k], v), k
     tr2.close()
+

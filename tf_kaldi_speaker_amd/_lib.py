@@ -19,14 +19,16 @@ class XvError(RuntimeError):
 
 
 # include/xvector_hip.h XV_ABI_VERSION: the layout of XvConfig below and the SIGNATURES table belong to this version
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class XvConfig(C.Structure):
     """Mirror of `struct xv_config` (include/xvector_hip.h); struct_bytes is filled in on construction."""
 
     def __init__(self, *args, **kw):
-        super(XvConfig, self).__init__(*args, **kw)
+        if args:      # struct_bytes is the first field: a positional XvConfig(feat_dim, ...) would shift every value by one, silently
+            raise TypeError("XvConfig takes keyword arguments only (its first field is struct_bytes, filled in here)")
+        super(XvConfig, self).__init__(**kw)
         self.struct_bytes = C.sizeof(XvConfig)
 
     _fields_ = [
@@ -184,6 +186,8 @@ SIGNATURES = {
     "xv_engine_allreduce_wait": (_I, [_VP, _VP]),
     "xv_engine_stage_grad_range": (_I, [_VP, _I, C.POINTER(_SZ), C.POINTER(_SZ)]),
     "xv_engine_apply": (_I, [_VP, _VP, _F, _F, _I]),
+    "xv_engine_backward_update": (_I, [_VP, _VP, _F, _F, _I]),
+    "xv_engine_arena_bytes": (_SZ, [_VP]),
     "xv_engine_loss_ptrs": (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),
     "xv_engine_endpoint": (_I, [_VP, C.c_char_p, C.POINTER(_VP), c_int32_p, c_int32_p, c_int32_p]),
     "xv_engine_set_concurrency": (_I, [_VP, _I]),

@@ -50,6 +50,8 @@ struct XvEnv {
     int nt_sched;           // XV_NT_SCHED=dp|sk: force the schedule of the fp32 NT GEMM (0 = chosen per problem, 1 = dp, 2 = sk); diagnostics
     int dz_slots;           // XV_DZ_SLOTS=2: the two-slot dz ring in fp32 mode too (what an arena too large for a slot per layer gets; A/B and test switch)
     int conv_wr;            // XV_CONV_WR=4: 256-row tiles of the f16x3 context-window GEMM (kept parity-tested, off by default)
+    int seg_wgrad;          // XV_SEG_WGRAD=0|1|2 (default 1): hand-over of the two segment-level layers' weight gradients - one event record each (0), one for both after dz6 (1), none of their own: with the last frame layer's (2); A/B switch
+    int eager_update;       // XV_EAGER_UPDATE=0|1 (default 1): xv_engine_backward_update schedules the update per backward stage; 0 = backward, then apply (A/B switch)
 };
 const XvEnv* xv_env();
 
@@ -195,9 +197,12 @@ struct XvGemmTN {
     const float* B; long ldb; int b_rps; int b_pitch;   // [R] rows mapped, N columns used
     int M, N, R;
     float* P;            // slabs [splits][M][N]
-    int splits;          // chosen by xv_tn_splits
+    int splits;          // chosen by xv_tn_splits (xv_tn_splits_direct when `direct`)
+    int direct;          // 1: the caller stores an unsplit result straight into its destination (P = the [M][N] result when splits == 1): a short
+                         // reduction over many tiles is then not split at all (the loss head's weight gradient)
 };
 int xv_tn_splits(int M, int N, int R);
+int xv_tn_splits_direct(int M, int N, int R);
 int xv_nt_shares(int tiles, int ksteps, bool stats, bool beside_wgrad, size_t ws_bytes);      // NT: shares per remaining tile of the "whole tiles + shares" schedule (0: not used)
 int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g);
 int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int C, int c_pad, int n_in, int n_out, const float* w,
@@ -244,7 +249,7 @@ struct XvPrepJob {
 };
 #define XV_PREP_PAD 8            // not a weight: rows [O][C] of w copied into [O][c_pad] with zero pad columns (the features of a step, riding on the first layer's launch)
 #define XV_PREP_MAX_JOBS 32      // two layouts x (XV_MAX_FRAME_LAYERS + 2 segment + 2 attention-key layers)
-struct XvPrepJobs { int n, total_tiles; XvPrepJob j[XV_PREP_MAX_JOBS]; };
+struct XvPrepJobs { int n, total_tiles; int prio; /* 1: not a filler (XV_EW_PRIORITY) */ XvPrepJob j[XV_PREP_MAX_JOBS]; };
 #define XV_AMAX_MAX_JOBS 16
 struct XvAmaxJobs { int n; const float* x[XV_AMAX_MAX_JOBS]; size_t count[XV_AMAX_MAX_JOBS]; unsigned* out[XV_AMAX_MAX_JOBS]; };
 int xv_prep_add(XvPrepJobs& J, int type, const float* w, int k, int C, int O, int c_pad, int o_ld, void* dst, long plane, const unsigned* amax);

@@ -34,7 +34,7 @@ XvEnvState xv_env_parse() {
     // program in the user's environment, which must not stop a training run.  A known switch with a value it does not understand still fails.
     static const char* known[] = {"XV_SEGMENT_FUSED", "XV_NT_SCHED", "XV_CONV_WR", "XV_PRECISION", "XV_LOADER", "XV_LOADER_PIN", "XV_SHARE_GPU",
                                   "XV_LIB", "XV_TUNE_TIMES", "XV_DATA_SCALE", "XV_B", "XV_PROBE_OPS", "XV_PROBE_ONLY", "XV_PROBE_PERIODS",
-                                  "XV_DIAG_M", "XV_DIAG_N", "XV_DIAG_K", "XV_DIAG_REPS", "XV_DIAG_B", "XV_PROBE_EXTRA", "XV_DZ_SLOTS"};
+                                  "XV_DIAG_M", "XV_DIAG_N", "XV_DIAG_K", "XV_DIAG_REPS", "XV_DIAG_B", "XV_PROBE_EXTRA", "XV_DZ_SLOTS", "XV_EAGER_UPDATE", "XV_SEG_WGRAD"};
     for (char** e = environ; e && *e; ++e) {
         if (strncmp(*e, "XV_", 3) != 0) continue;
         const char* eq = strchr(*e, '=');
@@ -54,6 +54,7 @@ XvEnvState xv_env_parse() {
         else fail("%s=%s: expected 0 or 1", name, v);
     };
     flag("XV_SEGMENT_FUSED", 1, &env.segment_fused);
+    flag("XV_EAGER_UPDATE", 1, &env.eager_update);
     env.nt_sched = 0;
     if (const char* v = getenv("XV_NT_SCHED")) {
         if (!strcmp(v, "dp")) env.nt_sched = 1;
@@ -64,6 +65,11 @@ XvEnvState xv_env_parse() {
     if (const char* v = getenv("XV_DZ_SLOTS")) {
         if (!strcmp(v, "2")) env.dz_slots = 2;
         else if (*v) fail("%s=%s: expected 2", "XV_DZ_SLOTS", v);
+    }
+    env.seg_wgrad = 1;
+    if (const char* v = getenv("XV_SEG_WGRAD")) {
+        if (!strcmp(v, "0") || !strcmp(v, "1") || !strcmp(v, "2")) env.seg_wgrad = v[0] - '0';
+        else if (*v) fail("%s=%s: expected 0, 1 or 2", "XV_SEG_WGRAD", v);
     }
     env.conv_wr = 0;
     if (const char* v = getenv("XV_CONV_WR")) {
@@ -263,7 +269,7 @@ extern "C" int xv_prep_weight_dgrad(void* stream, const float* kernel, int k, in
 // multi-job weight preparation (xv_common.h): one launch for every layout copy of every layer
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void weight_prep_multi_kernel(XvPrepJobs J) {
-    XV_EW_FILLER();
+    if (J.prio) XV_EW_PRIORITY();      // (a filler beside the forward GEMMs otherwise: XV_EW_FILLER)
     __shared__ float tile[32][33];
     int ji = 0;
 #pragma unroll 1

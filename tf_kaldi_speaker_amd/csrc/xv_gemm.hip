@@ -1295,7 +1295,7 @@ static bool tn_wide_rows(int M) { return M > BM && M <= TNW_M; }
 // the round-5 step at 1 536 / 2 048), fewer leaves matrix pipes idle.  The history of this choice (768 / 896 workgroups, an even schedule,
 // unsplit segment-level gradients, tdnn1 as 128 ... 512 workgroups, wave groups) is DESIGN.md Appendix A.
 struct XvTnPlan { int splits, chunk; };
-static XvTnPlan xv_tn_plan(int M, int N, int R) {
+static XvTnPlan xv_tn_plan(int M, int N, int R, bool direct = false) {
     const int tiles = xv_cdiv(M, BM) * xv_cdiv(N, BN);
     const int ksteps = xv_cdiv(R, BK);
     XvTnPlan pl = {1, 0};
@@ -1311,12 +1311,16 @@ static XvTnPlan xv_tn_plan(int M, int N, int R) {
     // A short reduction over many tiles (the loss head's weight gradient: 232 tiles x 8 K-steps at 128 chunks) is not split: four splits of two
     // K-steps each wrote and re-read 60 MB of slabs beside the latency-bound chain of the segment layers (its d-out launch ran 45 instead of
     // 23 us); one workgroup per tile can store the result where it belongs (xv_engine.hip, loss_head_wgrad)
-    if (ksteps <= 16 && tiles >= 128) splits = 1;
+    // - only for the caller that asks for it (XvGemmTN::direct: its unsplit result is stored straight into the destination); a LAYER's
+    // weight gradient with many tiles and a short reduction (small-batch fine-tuning) keeps its splits - unsplit it would leave most of the
+    // chip idle
+    if (direct && ksteps <= 16 && tiles >= 128) splits = 1;
     pl.chunk = xv_cdiv(ksteps, splits) * BK;
     pl.splits = xv_cdiv(R, pl.chunk);
     return pl;
 }
 int xv_tn_splits(int M, int N, int R) { return xv_tn_plan(M, N, R).splits; }
+int xv_tn_splits_direct(int M, int N, int R) { return xv_tn_plan(M, N, R, true).splits; }
 
 int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     XV_REQUIRE(g.M % 4 == 0 && g.N % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0,
@@ -1345,8 +1349,8 @@ int xv_launch_gemm_tn(hipStream_t s, const XvGemmTN& g) {
     p.inv_rps = 1.0f / (float)p.rps;
     p.P = g.P; p.M = g.M; p.N = g.N; p.R = g.R;
     p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
-    const XvTnPlan pl = xv_tn_plan(g.M, g.N, g.R);
-    XV_REQUIRE(pl.splits == g.splits, "gemm_tn: splits must come from xv_tn_splits (%d vs %d)", pl.splits, g.splits);
+    const XvTnPlan pl = xv_tn_plan(g.M, g.N, g.R, g.direct != 0);
+    XV_REQUIRE(pl.splits == g.splits, "gemm_tn: splits must come from xv_tn_splits%s (%d vs %d)", g.direct ? "_direct" : "", pl.splits, g.splits);
     p.r_chunk = pl.chunk;
     p.ahead = p.r_chunk / BK >= XV_TN_AHEAD_MIN;      // (Appendix B, note 9)
     const int wgs = p.tiles_m * p.tiles_n * pl.splits;

@@ -4,7 +4,11 @@
 # Every (shape, variant) pair runs `bench.py --single-mode --no-cpu-baseline` once per round; one line per run: shape variant ms/step chunks/s.
 out=$1; rounds=$2; shapes=$3; shift 3
 R=${GRAFT_REPO_ROOT:-$PWD}
-one() { "$@" 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); r=d.get('roofline',{}); print(d['ms_per_step'], d['value'], 'dominant', r.get('avg_launch_ms'), r.get('frac'))"; }
+# stderr is kept: the library names an XV_* switch it does not know once ("ignoring unknown environment switch") and ignores it - a mistyped
+# A/B switch would then silently benchmark the default build, so such a run FAILS here instead of printing a number
+ERR=$(mktemp)
+one() { "$@" 2>$ERR | tail -1 > $ERR.out; if grep -q "ignoring unknown environment switch" $ERR; then echo "REFUSED: $(grep -m1 'ignoring unknown environment switch' $ERR)"; return 1; fi
+        cat $ERR.out | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); r=d.get('roofline',{}); print(d['ms_per_step'], d['value'], 'dominant', r.get('avg_launch_ms'), r.get('frac'))"; }
 IFS='|' read -ra SH <<< "$shapes"
 for i in $(seq 1 $rounds); do
   for sh in "${SH[@]}"; do
