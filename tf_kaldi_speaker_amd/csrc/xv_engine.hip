@@ -1756,6 +1756,11 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             rc = frame_backward(i, e->bufD);
             if (rc) return rc;
         }
+        if (e->segw_pending) {      // (no hand-over since stage 0 carried them: cannot happen with a frame layer below the pooling layer)
+            XV_CHECK_HIP(hipEventRecord(e->ev_dz, s));
+            rc = seg_wgrads_launch(e);
+            if (rc) return rc;
+        }
         if (e->eager.on && e->eager.applied < e->eager.ready) {
             // no hand-over in the last stage carried them (its weight gradients all ran on `s`: a three-layer stack): one of their own
             rc = chain(s, e->side, e->ev_dz);
