@@ -125,36 +125,42 @@ def cpu_baseline(seconds_budget=70.0):
     x = rs.randn(B, T, D).astype(np.float32)
     y = rs.randint(0, NSPK, B)
     O.train_step(V, {}, cfg, x[:8], y[:8], 0.01, 0)      # warm-up (BLAS thread pool, allocator)
-    counts = [1] if threadpool_limits is None else sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu)})
+    # rows: 1 thread (comparable to the reference's single_cpu mode), a few mid counts, and EVERY core of the host - three steps each
+    # (median) while the budget lasts; the 1-thread and all-core rows always get their three
+    counts = [1] if threadpool_limits is None else sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu), ncpu})
+    must = {1, ncpu}
     rows, t_start = [], time.time()
     import contextlib
-    for nt in counts:
-        if rows and time.time() - t_start + rows[-1]["seconds"] > seconds_budget:
-            break
+    step_no = [1]
+
+    def timed_steps(nt, n):
+        out = []
         ctx = threadpool_limits(limits=nt) if threadpool_limits is not None else contextlib.nullcontext()
         with ctx:
-            t0 = time.time()
-            O.train_step(V, {}, cfg, x, y, 0.01, 1)
-            dt = time.time() - t0
-        rows.append({"cores": int(nt), "value": round(B / dt, 2), "steps": 1, "seconds": round(dt, 2)})
+            for _ in range(n):
+                t0 = time.time()
+                O.train_step(V, {}, cfg, x, y, 0.01, step_no[0])
+                step_no[0] += 1
+                out.append(time.time() - t0)
+        return out
+    for nt in counts:
+        spent = time.time() - t_start
+        if nt not in must and rows and spent + 3 * rows[-1]["seconds"] > seconds_budget:
+            continue
+        ts = timed_steps(nt, 3 if (nt in must or spent < 0.6 * seconds_budget) else 1)
+        rows.append({"cores": int(nt), "value": round(B / float(np.median(ts)), 2), "steps": len(ts), "seconds": round(float(np.median(ts)), 2),
+                     "step_seconds": [round(t, 3) for t in ts]})
     best = max(rows, key=lambda r: r["value"])
-    # the headline row is not a single sample: more steps at the fastest thread count (at least three in all while the budget lasts, at most
-    # seven), `value` = the median step
-    times = [B / best["value"]]
-    ctx = threadpool_limits(limits=best["cores"]) if threadpool_limits is not None else contextlib.nullcontext()
-    with ctx:
-        while len(times) < 7 and (len(times) < 3 or time.time() - t_start + times[-1] < seconds_budget):
-            if time.time() - t_start + times[-1] > 2.0 * seconds_budget:
-                break
-            t0 = time.time()
-            O.train_step(V, {}, cfg, x, y, 0.01, 1 + len(times))
-            times.append(time.time() - t0)
+    # the headline row: more steps at the fastest thread count (at most seven in all), `value` = the median step
+    times = list(best["step_seconds"])
+    while len(times) < 7 and time.time() - t_start + times[-1] < seconds_budget:
+        times += timed_steps(best["cores"], 1)
     med = float(np.median(times))
     return {"value": round(B / med, 2), "unit": "chunks/s", "cores": best["cores"], "kind": "port", "host_cpus": ncpu,
             "steps": len(times), "step_seconds": [round(t, 3) for t in times],
             "sample": "oracle (NumPy/OpenBLAS fp32 port of the reference arithmetic, this repo - not TensorFlow) train_step on the benchmark "
-                      "batch (%d chunks x %d frames x %d-dim, %d speakers): one step per BLAS thread count (`rows`), then %d steps at the "
-                      "fastest count; `value` = the median step there" % (B, T, D, NSPK, len(times)),
+                      "batch (%d chunks x %d frames x %d-dim, %d speakers): three steps per BLAS thread count (`rows`: 1 thread, mid counts, every "
+                      "host core), then up to %d steps at the fastest count; `value` = the median step there" % (B, T, D, NSPK, len(times)),
             "rows": rows}
 
 
@@ -368,6 +374,30 @@ def visible_gpu_count():
         return None
 
 
+def rank_diagnostics(dev, local_rank):
+    """What a first multi-GPU run is read with, per rank: which device this rank really sits on (ordinal, PCI address, uuid), the RCCL
+    build torch carries, and the environment that decides how RCCL moves bytes between the ranks.  Never raises."""
+    out = {"local_rank": local_rank, "pid": os.getpid()}
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        out["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+        out["device_uuid"] = str(getattr(pr, "uuid", ""))
+        out["gcn_arch"] = getattr(pr, "gcnArchName", None)
+        out["compute_units"] = getattr(pr, "multi_processor_count", None)
+        out["hbm_gb"] = round(pr.total_memory / 2 ** 30, 1)
+    except Exception as exc:
+        out["device_properties_error"] = repr(exc)
+    try:
+        import torch.cuda.nccl as _nccl
+        out["rccl_version"] = ".".join(str(v) for v in _nccl.version())
+    except Exception as exc:
+        out["rccl_version"] = "unknown (%r)" % (exc,)
+    out["hip_version"] = getattr(torch.version, "hip", None)
+    out["env"] = {k: v for k, v in sorted(os.environ.items())
+                  if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_VISIBLE", "ROCR_VISIBLE", "CUDA_VISIBLE", "XV_")) or k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    return out
+
+
 def failure_line(n, error, **extra):
     """One JSON line for a run that produced no measurement, so that a broken multi-GPU launch still leaves a diagnosable record."""
     out = {"metric": "utterance-chunks/sec (%d-frame x %d-dim)" % (T, D), "value": None, "unit": "chunks/s", "n_gpus": n, "higher_is_better": True,
@@ -490,6 +520,7 @@ def main():
             mine = {"rank": rank, "backend": dist.get_backend(), "world_size": dist.get_world_size(), "device": torch.cuda.get_device_name(dev),
                     "device_index": dev_index, "data_seed": 1000 + rank, "loss": head["loss"], "trainable_checksum": head["trainable_checksum"],
                     "report": head["comm"]}
+            mine.update(rank_diagnostics(dev, local_rank))
             comm_all = [None] * world
             dist.all_gather_object(comm_all, mine)
         except Exception as exc:       # the report must never cost the bench line

@@ -321,6 +321,11 @@ int xv_margin_softmax_rows_ex(hipStream_t s, int kind, const float* logits, int 
                               const int32_t* labels, float m, float lambda, float* dlogits, float* dnorm, float* row_loss,
                               float* loss_out, float* xnorm, uint32_t* ticket);
 
+// The optimiser kernels (xv_sgd_update / xv_momentum_update / xv_adam_update with TF's Adam constants) with the choice of running as a filler:
+// no wave priority, few long workgroups - for a launch on a side stream beside GEMMs with a whole pass to finish in (xv_engine.hip eager_flush)
+int xv_update_launch(hipStream_t stream, int optimizer, float* p, const float* g, float* s0, float* s1, size_t count, float lr, float momentum,
+                     int nesterov, int t, float grad_scale, bool filler);
+
 // Activation behind a BatchNorm in the layer being processed (network_relu_type, tdnn.py:24-30): y > 0 ? y : slope[c] * y.
 // slope == nullptr: ReLU.  Set by the engine around a layer's calls (prelu: the layer's alpha variable, with dalpha = its gradient;
 // lrelu: a constant 0.2 vector); every entry point that takes a `relu` flag reads it (xv_elementwise.hip).

@@ -1986,14 +1986,15 @@ extern "C" int xv_sumsq(void* stream, const float* g, size_t count, float* out_a
     return 0;
 }
 
-__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, size_t count, float lr, float gs) {
-    XV_EW_PRIORITY();
+// (filler != 0: enqueued on a side stream with a whole backward pass to finish in - no wave priority, XV_EW_FILLER's rule)
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, size_t count, float lr, float gs, int filler) {
+    if (!filler) XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
         p[i] = p[i] - lr * (g[i] * gs);
 }
 __global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc, size_t count, float lr,
-                                float mom, int nesterov, float gs) {
-    XV_EW_PRIORITY();
+                                float mom, int nesterov, float gs, int filler) {
+    if (!filler) XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
         float gi = g[i] * gs;
         float a = mom * acc[i] + gi;
@@ -2002,8 +2003,8 @@ __global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__
     }
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t count, float lr_t, float b1, float b2, float eps, float gs) {
-    XV_EW_PRIORITY();
+                            size_t count, float lr_t, float b1, float b2, float eps, float gs, int filler) {
+    if (!filler) XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
         float gi = g[i] * gs;
         float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -2013,26 +2014,36 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
     }
 }
-extern "C" int xv_sgd_update(void* stream, float* p, const float* g, size_t count, float lr, float grad_scale) {
-    XV_REQUIRE(count > 0, "sgd_update: empty");
-    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for((long)count, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, count, lr, grad_scale);
+int xv_update_launch(hipStream_t stream, int optimizer, float* p, const float* g, float* s0, float* s1, size_t count, float lr, float momentum,
+                     int nesterov, int t, float grad_scale, bool filler) {
+    XV_REQUIRE(count > 0, "optimizer update: empty");
+    const dim3 grid(grid_for((long)count, 256, filler ? 1024 : 8192));      // (a filler in few, long workgroups: many short ones crawl beside a GEMM)
+    if (optimizer == 0) {
+        hipLaunchKernelGGL(sgd_kernel, grid, dim3(256), 0, stream, p, g, count, lr, grad_scale, filler ? 1 : 0);
+    } else if (optimizer == 1) {
+        hipLaunchKernelGGL(momentum_kernel, grid, dim3(256), 0, stream, p, g, s0, count, lr, momentum, nesterov, grad_scale, filler ? 1 : 0);
+    } else {
+        XV_REQUIRE(t >= 1, "adam_update: bad arguments");
+        const float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;      // tf.train.AdamOptimizer defaults (trainer.py:343)
+        const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
+        hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, stream, p, g, s0, s1, count, (float)lr_t, beta1, beta2, eps, grad_scale, filler ? 1 : 0);
+    }
     XV_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int xv_sgd_update(void* stream, float* p, const float* g, size_t count, float lr, float grad_scale) {
+    return xv_update_launch((hipStream_t)stream, 0, p, g, nullptr, nullptr, count, lr, 0.f, 0, 1, grad_scale, false);
+}
 extern "C" int xv_momentum_update(void* stream, float* p, const float* g, float* acc, size_t count, float lr, float momentum,
                                   int nesterov, float grad_scale) {
-    XV_REQUIRE(count > 0, "momentum_update: empty");
-    hipLaunchKernelGGL(momentum_kernel, dim3(grid_for((long)count, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, acc, count, lr,
-                       momentum, nesterov, grad_scale);
-    XV_LAUNCH_CHECK();
-    return 0;
+    return xv_update_launch((hipStream_t)stream, 1, p, g, acc, nullptr, count, lr, momentum, nesterov, 1, grad_scale, false);
 }
 extern "C" int xv_adam_update(void* stream, float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
                               float beta2, float eps, int t, float grad_scale) {
     XV_REQUIRE(count > 0 && t >= 1, "adam_update: bad arguments");
     double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for((long)count, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, count,
-                       (float)lr_t, beta1, beta2, eps, grad_scale);
+                       (float)lr_t, beta1, beta2, eps, grad_scale, 0);
     XV_LAUNCH_CHECK();
     return 0;
 }

@@ -1196,13 +1196,11 @@ float* ring_take(xv_engine* e, hipStream_t s) {
 
 // The optimiser step (trainer.py:332-346) on the float range [begin, end) of the trainable variables: the kernels are element-wise, so a
 // range at a time gives bit for bit what one launch over everything gives.
-int update_range(xv_engine* e, hipStream_t s, size_t begin, size_t end, float lr, float gs, int t) {
+int update_range(xv_engine* e, hipStream_t s, size_t begin, size_t end, float lr, float gs, int t, bool filler = false) {
     if (end <= begin) return 0;
     const xv_config& c = e->cfg;
-    const size_t n = end - begin;
-    if (c.optimizer == 0) return xv_sgd_update(s, e->V + begin, e->G + begin, n, lr, gs);
-    if (c.optimizer == 1) return xv_momentum_update(s, e->V + begin, e->G + begin, e->S + begin, n, lr, c.momentum, c.use_nesterov, gs);
-    return xv_adam_update(s, e->V + begin, e->G + begin, e->S + begin, e->S + e->n_train + begin, n, lr, 0.9f, 0.999f, 1e-8f, t, gs);
+    return xv_update_launch(s, c.optimizer, e->V + begin, e->G + begin, e->S ? e->S + begin : nullptr, e->S ? e->S + e->n_train + begin : nullptr,
+                            end - begin, lr, c.momentum, c.use_nesterov, t, gs, filler);
 }
 
 // Scheduled update (xv_engine_backward_update), called on the weight-gradient stream's side of a hand-over: that stream has just been made
@@ -1222,7 +1220,7 @@ int eager_flush(xv_engine* e) {
             hipStream_t q = e->side2;
             XV_CHECK_HIP(hipEventRecord(e->ev_upd, e->side));
             XV_CHECK_HIP(hipStreamWaitEvent(q, e->ev_upd, 0));
-            rc = update_range(e, q, e->stage_begin[0], e->stage_end[0], u.lr, u.gs, u.t);
+            rc = update_range(e, q, e->stage_begin[0], e->stage_end[0], u.lr, u.gs, u.t, true);      // (a filler, like the copies behind it)
             if (rc) return rc;
             rc = prep_layers(e, q, F, F + 2);
             if (rc) return rc;
