@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# $XV_LIB: an alternative build of the same C-ABI (tools/variant_bench*.sh A/B kernel variants on the GPU box); never a different backend
+# $XV_LIB: an alternative build of the same C-ABI (tools/variant.sh builds, tools/ab.sh / tools/probe.sh compare them on the GPU box); never a different backend
 LIB_PATH = os.environ.get("XV_LIB") or os.path.join(_HERE, "libxvector_hip.so")
 
 c_float_p = C.POINTER(C.c_float)

@@ -1,5 +1,5 @@
 // Diagnostics hooks of the fp32 GEMM kernels (xv_gemm.hip).  In the product build every hook is empty: no stamp executes, no buffer
-// exists.  -DXV_DIAG (tools/build_variants.sh builds such a library next to the product, tools/gemm_probe.cpp and tools/step_clock.py read it)
+// exists.  -DXV_DIAG (tools/variant.sh unit builds such a library next to the product, tools/gemm_probe.cpp and tools/step_clock.py read it)
 // compiles per-workgroup s_memtime / s_memrealtime stamps and the hardware placement of every workgroup of the NT kernels in:
 //   [wg][8] = {entry, loop start, loop end, exit, HW_ID | XCC_ID << 32, realtime at entry, realtime at exit, cycles wave 0 spent in the
 //   per-K-step wait + barrier (XV_DIAG >= 2)}

@@ -5,6 +5,8 @@
 // serial + wave shuffle / LDS combine.  No atomics on any path that feeds a gradient.
 #include <stdarg.h>
 
+#include <algorithm>
+
 #include "xv_common.h"
 #include "xv_epilogue.h"
 
@@ -1222,6 +1224,77 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dense_kernel(const float* __
     }
 }
 
+// The pooled pass in its affine form (plain ReLU or none; see bn_bwd_apply_dense_kernel) with a workgroup per (chunk, 256 channels, row range):
+// the chunk's pooled statistics, the seven per-channel vectors and the four coefficient vectors derived from them are set up ONCE for
+// ~T / (4 splits) rows per thread instead of once per eight (a strip kernel's workgroup moved 64 KB behind a two-level chain of ~16
+// dependent vector loads), there is no chunk boundary inside a workgroup, and a thread keeps two batches of eight 16-byte loads in flight
+// (the next batch is issued before the current one is computed and stored).  286 MB at S1, on the serial chain between the loss and the
+// first data-gradient GEMM.
+#define BPC_BATCH 8
+__global__ __launch_bounds__(256) void bn_bwd_apply_pooled_chunk_kernel(PoolGrad pg, const float* __restrict__ z, int n, const float* __restrict__ gamma,
+                                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                        const float* __restrict__ coef, int relu, float* __restrict__ dz, int ldz,
+                                                                        int rows_per /* rows of a chunk per workgroup (multiple of 4) */) {
+    XV_EW_PRIORITY();
+    const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int rl = threadIdx.x >> 6;
+    if (col >= n) return;
+    const int b = blockIdx.y, T = pg.t;
+    const int t_begin = blockIdx.z * rows_per, t_end = min(T, t_begin + rows_per);
+    if (t_begin >= T) return;
+    const f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
+    const f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
+    const f32x4 c1 = *(const f32x4*)(coef + col), c2 = *(const f32x4*)(coef + n + col);
+    const f32x4 g_is = *(const f32x4*)(gamma + col) * is;
+    const PoolCoef pc = pool_coef(pg, b, n, col);
+    // dz = on ? w (A z + B) + (C z + D) : C z + D   (bn_bwd_apply_dense_kernel, same expressions)
+    const f32x4 gc2 = g_is * is * c2;
+    const f32x4 C = -gc2, D = gc2 * mu - g_is * c1;
+    const f32x4 A = g_is * (pc.q * sc), B = g_is * (pc.dm + pc.q * (sh - pc.mean));
+    const float invT = 1.f / (float)T;
+    const long row0 = (long)b * T;
+    const float* __restrict__ zp = z + row0 * ldz + col;
+    float* __restrict__ dp = dz + row0 * ldz + col;
+    const float* __restrict__ wp = pg.w ? pg.w + row0 : nullptr;
+    const int t_last = t_end - 1;
+    auto load = [&](f32x4 (&v)[BPC_BATCH], float (&w)[BPC_BATCH], int t0) {
+#pragma unroll
+        for (int j = 0; j < BPC_BATCH; ++j) v[j] = *(const f32x4*)(zp + (long)min(t0 + 4 * j, t_last) * ldz);
+#pragma unroll
+        for (int j = 0; j < BPC_BATCH; ++j) w[j] = wp ? wp[min(t0 + 4 * j, t_last)] : invT;
+    };
+    auto proc = [&](const f32x4 (&v)[BPC_BATCH], const float (&w)[BPC_BATCH], int t0) {
+#pragma unroll
+        for (int j = 0; j < BPC_BATCH; ++j) {
+            const int t = t0 + 4 * j;
+            const f32x4 y = v[j] * sc + sh;
+            const f32x4 off = C * v[j] + D;
+            f32x4 on = w[j] * (A * v[j] + B) + off;
+            if (relu) {
+                on.x = y.x > 0.f ? on.x : off.x; on.y = y.y > 0.f ? on.y : off.y;
+                on.z = y.z > 0.f ? on.z : off.z; on.w = y.w > 0.f ? on.w : off.w;
+            }
+            if (t < t_end) *(f32x4*)(dp + (long)t * ldz) = on;
+        }
+    };
+    f32x4 va[BPC_BATCH], vb[BPC_BATCH];
+    float wa[BPC_BATCH], wb[BPC_BATCH];
+    int t0 = t_begin + rl;
+    constexpr int STEP = 4 * BPC_BATCH;
+    load(va, wa, t0);
+    while (true) {
+        if (t0 + STEP < t_end) load(vb, wb, t0 + STEP);
+        proc(va, wa, t0);
+        t0 += STEP;
+        if (t0 >= t_end) break;
+        if (t0 + STEP < t_end) load(va, wa, t0 + STEP);
+        proc(vb, wb, t0);
+        t0 += STEP;
+        if (t0 >= t_end) break;
+    }
+}
+
 // Same as bn_bwd_apply_kernel but dz is written as two fp16 planes [2][segs*(t+2pad)][ldd] scaled by the power of two
 // derived from *amax (xv_gemm16.hip); pad rows / columns are zero.
 // Thread = one 8-channel chunk (16 B per plane) x a strip of rows: the 7 per-channel parameter vectors are loaded
@@ -1418,7 +1491,15 @@ static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, co
         XV_LAUNCH_CHECK();
     }
     dim3 agrid(xv_cdiv(n / 4, 64), xv_cdiv(segs * (t + 2 * pad), BAF_ROWS));
-    if (pad == 0 && (!pooled || pg.t >= BAF_ROWS))
+    if (pooled && pad == 0 && !(relu && act.slope) && rows / pg.t <= 65535) {
+        // a workgroup per (chunk, 256 channels); chunks of few workgroups (a small batch) are cut into row ranges until ~3 workgroups per CU exist
+        const int nchunks = rows / pg.t, gx = xv_cdiv(n / 4, 64);
+        int rs = std::max(1, std::min(768 / std::max(1, gx * nchunks), pg.t / 32));
+        const int rows_per = (int)xv_align((size_t)xv_cdiv(pg.t, rs), 4);
+        rs = xv_cdiv(pg.t, rows_per);
+        hipLaunchKernelGGL(bn_bwd_apply_pooled_chunk_kernel, dim3(gx, nchunks, rs), dim3(256), 0, s, pg, z, n, gamma, mean, invstd, scale, shift,
+                           (const float*)coef, relu, dz_pad, ldz, rows_per);
+    } else if (pad == 0 && (!pooled || pg.t >= BAF_ROWS))
         hipLaunchKernelGGL(pooled ? bn_bwd_apply_dense_kernel<true> : bn_bwd_apply_dense_kernel<false>, agrid, dim3(256), 0, s, da, pg, z, rows, n, gamma,
                            mean, invstd, scale, shift, (const float*)coef, relu, dz_pad, relu ? act.slope : nullptr, ldz);
     else
@@ -1787,7 +1868,7 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
     auto on = [&](f32x4 a, float w) {
         wpp.x += (cnt_all || a.x > 0.f) ? w : 0.f; wpp.y += (cnt_all || a.y > 0.f) ? w : 0.f;
         wpp.z += (cnt_all || a.z > 0.f) ? w : 0.f; wpp.w += (cnt_all || a.w > 0.f) ? w : 0.f;
-        amx.x = fmaxf(amx.x, a.x); amx.y = fmaxf(amx.y, a.y); amx.z = fmaxf(amx.z, a.z); amx.w = fmaxf(amx.w, a.w);
+        if (amax_o) { amx.x = fmaxf(amx.x, a.x); amx.y = fmaxf(amx.y, a.y); amx.z = fmaxf(amx.z, a.z); amx.w = fmaxf(amx.w, a.w); }      // (split precision only)
     };
     float n0 = 0.f, n1 = 0.f;
     // frame weights: 1 (statistics pooling; n counts frames) or the attention weights of this chunk (n sums them); weighted incremental
@@ -1796,20 +1877,40 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
     // keep the exact quotient: there w / n must be exactly 1 on a lane's first frame, or a constant chunk no longer has a zero variance
     // (reference test_utils.py / pooling.py:160-162 clamp).
 #define XV_POOL_STEP2(mean, m2, n, v, w) { n += (w); const f32x4 d_ = (v) - mean; if (n > 0.f) mean += d_ * (wp ? (w) / n : __builtin_amdgcn_rcpf(n)); m2 += d_ * ((v) - mean) * (w); }
+    // batches of four frames per lane, two batches in flight: the NEXT batch's loads are issued before the current one is folded, so a lane
+    // always has 4-8 16-byte loads outstanding (the fold is ~45 vector instructions per 16 bytes: the first form loaded eight, waited, folded
+    // eight - its memory pipe idled while it computed; two batches of eight cost 204 VGPRs, i.e. a workgroup less per CU)
     int t = wave;
-    for (; t + 28 < T; t += 32) {
-        f32x4 v[8];
-        float w[8];
+    auto load4 = [&](f32x4 (&v)[4], float (&w)[4], int t0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(xp + (long)(t + 4 * u) * ld);
+        for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(xp + (long)(t0 + 4 * u) * ld);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = wp ? wp[t + 4 * u] : 1.f;
+        for (int u = 0; u < 4; ++u) w[u] = wp ? wp[t0 + 4 * u] : 1.f;
+    };
+    auto fold4 = [&](const f32x4 (&v)[4], const float (&w)[4]) {
 #pragma unroll
-        for (int u = 0; u < 8; u += 2) {
+        for (int u = 0; u < 4; u += 2) {
             const f32x4 a0 = act(v[u]), a1 = act(v[u + 1]);
             XV_POOL_STEP2(mean0, m20, n0, a0, w[u])
             XV_POOL_STEP2(mean1, m21, n1, a1, w[u + 1])
             if (wpos) { on(a0, w[u]); on(a1, w[u + 1]); }
+        }
+    };
+    if (t + 12 < T) {
+        f32x4 va[4], vb[4];
+        float wa[4], wb[4];
+        load4(va, wa, t);
+        while (true) {
+            const bool more_b = t + 16 + 12 < T;
+            if (more_b) load4(vb, wb, t + 16);
+            fold4(va, wa);
+            t += 16;
+            if (!more_b) break;
+            const bool more_a = t + 16 + 12 < T;
+            if (more_a) load4(va, wa, t + 16);
+            fold4(vb, wb);
+            t += 16;
+            if (!more_a) break;
         }
     }
     for (; t < T; t += 4) {

@@ -997,7 +997,8 @@ int engine_forward(xv_engine* e, void* stream, const float* features, int b, int
     {
         ActScope act(e, e->L[F - 1]);
         rc = xv_stat_pool_forward_bn_ex(s, e->L[F - 1].z, b, cur_t, e->P, e->L[F - 1].scale, e->L[F - 1].shift, 1, frame_w, e->pool,
-                                        training ? e->pool_wpos : nullptr, e->pool_amax, frames, t - cur_t, e->L[F - 1].ldz);
+                                        training ? e->pool_wpos : nullptr, e->f16 ? e->pool_amax : nullptr /* bounds |d a| for the dz planes' scale */,
+                                        frames, t - cur_t, e->L[F - 1].ldz);
     }
     if (rc) return rc;
     // segment-level layers: dense (+ BatchNorm + activation).  With <= XV_SEGMENT_MAX_ROWS chunks the GEMM, its split-K sum and the
@@ -1213,40 +1214,40 @@ int update_range(xv_engine* e, hipStream_t s, size_t begin, size_t end, float lr
 int eager_flush(xv_engine* e) {
     xv_engine::Eager& u = e->eager;
     const int F = e->F, lo = F >= 4 ? 2 : 1;
+    if (u.applied >= u.ready) return 0;
+    // [measured, round 6, same box] stages 1 and 2 IN LINE on the weight-gradient stream (at wave priority 3, in front of the next layer's
+    // weight-gradient GEMM): 50 + 102 us of that stream per S1 step for 12 + 22 MB of update traffic and the layers' copies - the stream
+    // that bounds the backward pass; the step was 0.6 % slower than backward + apply.  Everything goes to the loss head's stream as fillers.
+    hipStream_t q = e->side2;
+    XV_CHECK_HIP(hipEventRecord(e->ev_upd, e->side));
+    XV_CHECK_HIP(hipStreamWaitEvent(q, e->ev_upd, 0));
     while (u.applied < u.ready) {
         const int k = ++u.applied;
-        int rc;
+        int rc = update_range(e, q, e->stage_begin[k], e->stage_end[k], u.lr, u.gs, u.t, true);
+        if (rc) return rc;
         if (k == 0) {
-            hipStream_t q = e->side2;
-            XV_CHECK_HIP(hipEventRecord(e->ev_upd, e->side));
-            XV_CHECK_HIP(hipStreamWaitEvent(q, e->ev_upd, 0));
-            rc = update_range(e, q, e->stage_begin[0], e->stage_end[0], u.lr, u.gs, u.t, true);      // (a filler, like the copies behind it)
-            if (rc) return rc;
             rc = prep_layers(e, q, F, F + 2);
             if (rc) return rc;
             rc = prep_loss_head(e, q);
             if (rc) return rc;
-            XV_CHECK_HIP(hipEventRecord(e->ev_lw, q));      // (re-recorded: the join now waits for the loss head's weight gradient AND this)
-            e->lw_pending = true;
             e->prepped |= 3u << F;
             e->loss_prepped = e->N > 0;
         } else {
-            rc = update_range(e, e->side, e->stage_begin[k], e->stage_end[k], u.lr, u.gs, u.t);
-            if (rc) return rc;
             const int first = k == 1 ? F - 2 : lo, last = k == 1 ? F : F - 2;
             if (last > first) {
-                rc = prep_layers(e, e->side, first, last, true);
+                rc = prep_layers(e, q, first, last);
                 if (rc) return rc;
                 for (int i = first; i < last; ++i) e->prepped |= 1u << i;
             }
             if (k == 1 && e->att) {      // the key network's variables sit in this stage's slice (build_variables)
-                rc = prep_layers(e, e->side, e->K0(), e->K1() + 1, true);
+                rc = prep_layers(e, q, e->K0(), e->K1() + 1);
                 if (rc) return rc;
                 e->prepped |= 3u << e->K0();
             }
-            e->side_dirty = true;
         }
     }
+    XV_CHECK_HIP(hipEventRecord(e->ev_lw, q));      // (re-recorded: the join waits for the loss head's weight gradient AND everything enqueued here)
+    e->lw_pending = true;
     return 0;
 }
 

@@ -419,7 +419,7 @@ __device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (i
 // (Its context-window form of rounds 2-4 - the rows of one 16-channel chunk of x staged once for all taps - is gone: DESIGN.md Appendix B, note 4.)
 #define XV_NT_SK_WPC 3                       // workgroups per CU of the even schedule: one co-resident round of 768
 // Register budget: 128 VGPRs (4 waves per SIMD) although the launch is 3 workgroups per CU - the free fourth slot is worth more to the other
-// stream than the 7-23 spilled set-up registers cost (note 5; tools/build_variants.sh "sk168:-DXV_NT_SK_VGPRS=168 -DXV_NT_SK_OCC=3").
+// stream than the 7-23 spilled set-up registers cost (note 5; tools/variant.sh unit xv_gemm.hip "sk168:-DXV_NT_SK_VGPRS=168 -DXV_NT_SK_OCC=3").
 #ifndef XV_NT_SK_VGPRS
 #define XV_NT_SK_VGPRS 128
 #define XV_NT_SK_OCC XV_WGS_PER_CU

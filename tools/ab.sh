@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box, alternated in-step A/B of run-time switches (and, optionally, of another tree) on the GPU box:
-#   tools/ab_env.sh <out.txt> <rounds> "<shape args>|<shape args>..." "name1:ENV=a ENV2=b" "name2:" "tree:build_variants/r04_tree" ...
+#   tools/ab.sh <out.txt> <rounds> "<shape args>|<shape args>..." "name1:ENV=a ENV2=b" "name2:" "tree:build_variants/r04_tree" ...
 # Every (shape, variant) pair runs `bench.py --single-mode --no-cpu-baseline` once per round; one line per run: shape variant ms/step chunks/s.
 out=$1; rounds=$2; shapes=$3; shift 3
 R=${GRAFT_REPO_ROOT:-$PWD}

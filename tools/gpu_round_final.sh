@@ -29,7 +29,7 @@ for shape in "128 200" "64 300"; do set -- $shape
 done
 XV_PROBE_EXTRA=1 XV_PROBE_ONLY="att_key0 att_key1 ext_k3" timeout 300 tools/gemm_probe tf_kaldi_speaker_amd/libxvector_hip.so 128 200 5 > $O/gemm_probe_attention_extended.txt 2>&1
 XV_PROBE_EXTRA=1 XV_PROBE_ONLY="ext_k3 tdnn5" timeout 300 tools/gemm_probe tf_kaldi_speaker_amd/libxvector_hip.so 128 400 5 >> $O/gemm_probe_attention_extended.txt 2>&1
-# the clock inside the forward GEMM of a full S1 step (diagnostics build: tools/build_variants.sh xv_gemm.hip "diag:-DXV_DIAG=1")
+# the clock inside the forward GEMM of a full S1 step (diagnostics build: tools/variant.sh unit xv_gemm.hip "diag:-DXV_DIAG=1")
 if [ -f build_variants/diag/libxvector_hip.so ]; then
   XV_LIB=$GRAFT_REPO_ROOT/build_variants/diag/libxvector_hip.so XV_DIAG_M=24576 XV_DIAG_N=512 XV_DIAG_K=2560 timeout 300 python3 tools/step_clock.py 2>&1 | grep -v amdgpu.ids > $O/step_clock.txt
 fi

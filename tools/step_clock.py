@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The clock the chip holds INSIDE the forward GEMM of a full S1 training step on random data (DESIGN.md quoted both
 a GRBM_GUI_ACTIVE-derived 2.13 GHz under --pmc and 2.38 GHz from stamps of an isolated launch).  Needs a diagnostics build of the
-library (csrc/xv_diag.h; tools/build_variants.sh xv_gemm.hip "diag:-DXV_DIAG=1"):
+library (csrc/xv_diag.h; tools/variant.sh unit xv_gemm.hip "diag:-DXV_DIAG=1"):
 
     XV_LIB=build_variants/diag/libxvector_hip.so XV_DIAG_M=24576 XV_DIAG_N=512 XV_DIAG_K=2560 python3 tools/step_clock.py
 
