@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-/* 2: xv_config starts with struct_bytes (round 5).  3: xv_engine_backward_update, xv_engine_arena_bytes (round 6).  Bumped whenever xv_config's layout or an entry point's signature changes: a host
+/* 2: xv_config starts with struct_bytes (round 5).  3: xv_engine_arena_bytes (round 6).  Bumped whenever xv_config's layout or an entry point's signature changes: a host
  * built against another header must fail at load (xv_abi_version) or at xv_engine_create (struct_bytes), never read fields past the end
  * of a shorter struct. */
 #define XV_ABI_VERSION 3
@@ -479,14 +479,6 @@ int xv_engine_allreduce_wait(xv_engine* e, void* stream);
 int xv_engine_stage_grad_range(const xv_engine* e, int stage, size_t* begin, size_t* end);
 /* optimiser step on the bound buffers (after the gradient all-reduce). t = 1-based update count. */
 int xv_engine_apply(xv_engine* e, void* stream, float lr, float grad_scale, int t);
-/* xv_engine_backward(e, stream, -1) followed by xv_engine_apply(e, stream, lr, grad_scale, t) - the single-GPU train_op of
- * trainer.py:401-436, whose learning rate is known before the pass (a fed placeholder, trainer.py:326,507) - as ONE scheduled pass:
- * gradients and variables afterwards are bit for bit those of the two calls, but each backward stage's slice is updated, and its layers'
- * kernel-layout weight copies rebuilt, as soon as the slice is complete, on the engine's side streams beside the remaining data-gradient
- * GEMMs; only the first layers' slice is left for `stream` behind the join, and the next forward pass starts without side-stream weight
- * preparation or events.  The variables change DURING the pass: read pre-update values (xv_engine_loss_ptrs' regulariser, checkpoints)
- * before it, or use the two calls.  With split precision, concurrency off, a global-norm clip or XV_EAGER_UPDATE=0 it IS the two calls. */
-int xv_engine_backward_update(xv_engine* e, void* stream, float lr, float grad_scale, int t);
 /* bytes of device memory the engine's arena holds (activations, gradients' scratch, dz slots, workspaces) - diagnostics and tests */
 size_t xv_engine_arena_bytes(const xv_engine* e);
 /* scalars of the last step, device pointers to 1 float each: raw loss, regularisation loss */

@@ -3,13 +3,11 @@
  * by tests/test_gpu_c_abi.py, runs one full optimiser step (forward, loss, backward, apply) on caller-owned hipMalloc
  * buffers and writes raw loss, regularisation loss, the tdnn6_dense embedding and the updated variables back to a file.
  *
- *   engine_step <in.bin> <out.bin> feat_dim num_speakers loss_kind margin_m batch frames precision lr global_step [allreduce|update]
+ *   engine_step <in.bin> <out.bin> feat_dim num_speakers loss_kind margin_m batch frames precision lr global_step [allreduce]
  *
  * With the optional last argument the backward pass runs in its four stages and every finished gradient slice goes through
  * xv_engine_allreduce on a communication stream of the host's, over an RCCL communicator the host creates (one rank: the one GPU of the
  * test box; the call sequence is the one a multi-GPU host runs, and a sum over one rank must leave every bit where it was).
- * "update": backward and optimiser step as the one scheduled pass xv_engine_backward_update (losses and the embedding are read before it:
- * the variables change during the pass); it must leave the same variables as backward + apply, bit for bit.
  *
  * in.bin : float32 variables[variables_count] | float32 features[b*t*d] | int32 labels[b]
  * out.bin: float32 raw_loss | float32 reg_loss | int32 rows | int32 cols | float32 embedding[rows*cols] | float32 variables[...]
@@ -25,12 +23,11 @@
 #define XV_OK(call) do { if ((call) != 0) { fprintf(stderr, "%s: %s\n", #call, xv_last_error()); return 3; } } while (0)
 
 int main(int argc, char** argv) {
-    if (argc != 12 && !(argc == 13 && (strcmp(argv[12], "allreduce") == 0 || strcmp(argv[12], "update") == 0))) {
-        fprintf(stderr, "usage: %s in.bin out.bin feat_dim num_speakers loss_kind margin_m batch frames precision lr global_step [allreduce|update]\n", argv[0]);
+    if (argc != 12 && !(argc == 13 && strcmp(argv[12], "allreduce") == 0)) {
+        fprintf(stderr, "usage: %s in.bin out.bin feat_dim num_speakers loss_kind margin_m batch frames precision lr global_step [allreduce]\n", argv[0]);
         return 1;
     }
-    const int dp = argc == 13 && strcmp(argv[12], "allreduce") == 0;
-    const int scheduled = argc == 13 && strcmp(argv[12], "update") == 0;
+    const int dp = argc == 13;
     xv_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.struct_bytes = (int32_t)sizeof cfg;
@@ -95,7 +92,7 @@ int main(int argc, char** argv) {
             XV_OK(xv_engine_allreduce(e, cs, stage, comm));
         }
         XV_OK(xv_engine_allreduce_wait(e, s));
-    } else if (!scheduled) {
+    } else {
         XV_OK(xv_engine_backward(e, s, -1));
     }
     float *d_raw, *d_reg, *d_emb;
@@ -109,8 +106,7 @@ int main(int argc, char** argv) {
     HIP_OK(hipMemcpy(&reg, d_reg, sizeof(float), hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy2D(h_emb, (size_t)cols * sizeof(float), d_emb, (size_t)ld * sizeof(float), (size_t)cols * sizeof(float), (size_t)rows,
                        hipMemcpyDeviceToHost));
-    if (scheduled) XV_OK(xv_engine_backward_update(e, s, lr, 1.0f, 1));
-    else XV_OK(xv_engine_apply(e, s, lr, 1.0f, 1));
+    XV_OK(xv_engine_apply(e, s, lr, 1.0f, 1));
     HIP_OK(hipStreamSynchronize(s));
     HIP_OK(hipMemcpy(h_vars, d_vars, nv * sizeof(float), hipMemcpyDeviceToHost));
 

@@ -186,7 +186,6 @@ SIGNATURES = {
     "xv_engine_allreduce_wait": (_I, [_VP, _VP]),
     "xv_engine_stage_grad_range": (_I, [_VP, _I, C.POINTER(_SZ), C.POINTER(_SZ)]),
     "xv_engine_apply": (_I, [_VP, _VP, _F, _F, _I]),
-    "xv_engine_backward_update": (_I, [_VP, _VP, _F, _F, _I]),
     "xv_engine_arena_bytes": (_SZ, [_VP]),
     "xv_engine_loss_ptrs": (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),
     "xv_engine_endpoint": (_I, [_VP, C.c_char_p, C.POINTER(_VP), c_int32_p, c_int32_p, c_int32_p]),

@@ -50,8 +50,6 @@ struct XvEnv {
     int nt_sched;           // XV_NT_SCHED=dp|sk: force the schedule of the fp32 NT GEMM (0 = chosen per problem, 1 = dp, 2 = sk); diagnostics
     int dz_slots;           // XV_DZ_SLOTS=2: the two-slot dz ring in fp32 mode too (what an arena too large for a slot per layer gets; A/B and test switch)
     int conv_wr;            // XV_CONV_WR=4: 256-row tiles of the f16x3 context-window GEMM (kept parity-tested, off by default)
-    int seg_wgrad;          // XV_SEG_WGRAD=0|1|2 (default 1): hand-over of the two segment-level layers' weight gradients - one event record each (0), one for both after dz6 (1), none of their own: with the last frame layer's (2); A/B switch
-    int eager_update;       // XV_EAGER_UPDATE=0|1 (default 1): xv_engine_backward_update schedules the update per backward stage; 0 = backward, then apply (A/B switch)
 };
 const XvEnv* xv_env();
 
@@ -249,7 +247,7 @@ struct XvPrepJob {
 };
 #define XV_PREP_PAD 8            // not a weight: rows [O][C] of w copied into [O][c_pad] with zero pad columns (the features of a step, riding on the first layer's launch)
 #define XV_PREP_MAX_JOBS 32      // two layouts x (XV_MAX_FRAME_LAYERS + 2 segment + 2 attention-key layers)
-struct XvPrepJobs { int n, total_tiles; int prio; /* 1: not a filler (XV_EW_PRIORITY) */ XvPrepJob j[XV_PREP_MAX_JOBS]; };
+struct XvPrepJobs { int n, total_tiles; XvPrepJob j[XV_PREP_MAX_JOBS]; };
 #define XV_AMAX_MAX_JOBS 16
 struct XvAmaxJobs { int n; const float* x[XV_AMAX_MAX_JOBS]; size_t count[XV_AMAX_MAX_JOBS]; unsigned* out[XV_AMAX_MAX_JOBS]; };
 int xv_prep_add(XvPrepJobs& J, int type, const float* w, int k, int C, int O, int c_pad, int o_ld, void* dst, long plane, const unsigned* amax);
@@ -320,11 +318,6 @@ int xv_bn_relu_backward_pooled_ex(hipStream_t s, const float* pool_out, const fl
 int xv_margin_softmax_rows_ex(hipStream_t s, int kind, const float* logits, int rows, int n, int ldl, const float* x, int c,
                               const int32_t* labels, float m, float lambda, float* dlogits, float* dnorm, float* row_loss,
                               float* loss_out, float* xnorm, uint32_t* ticket);
-
-// The optimiser kernels (xv_sgd_update / xv_momentum_update / xv_adam_update with TF's Adam constants) with the choice of running as a filler:
-// no wave priority, few long workgroups - for a launch on a side stream beside GEMMs with a whole pass to finish in (xv_engine.hip eager_flush)
-int xv_update_launch(hipStream_t stream, int optimizer, float* p, const float* g, float* s0, float* s1, size_t count, float lr, float momentum,
-                     int nesterov, int t, float grad_scale, bool filler);
 
 // Activation behind a BatchNorm in the layer being processed (network_relu_type, tdnn.py:24-30): y > 0 ? y : slope[c] * y.
 // slope == nullptr: ReLU.  Set by the engine around a layer's calls (prelu: the layer's alpha variable, with dalpha = its gradient;

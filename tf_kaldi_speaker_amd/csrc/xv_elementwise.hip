@@ -36,7 +36,7 @@ XvEnvState xv_env_parse() {
     // program in the user's environment, which must not stop a training run.  A known switch with a value it does not understand still fails.
     static const char* known[] = {"XV_SEGMENT_FUSED", "XV_NT_SCHED", "XV_CONV_WR", "XV_PRECISION", "XV_LOADER", "XV_LOADER_PIN", "XV_SHARE_GPU",
                                   "XV_LIB", "XV_TUNE_TIMES", "XV_DATA_SCALE", "XV_B", "XV_PROBE_OPS", "XV_PROBE_ONLY", "XV_PROBE_PERIODS",
-                                  "XV_DIAG_M", "XV_DIAG_N", "XV_DIAG_K", "XV_DIAG_REPS", "XV_DIAG_B", "XV_PROBE_EXTRA", "XV_DZ_SLOTS", "XV_EAGER_UPDATE", "XV_SEG_WGRAD"};
+                                  "XV_DIAG_M", "XV_DIAG_N", "XV_DIAG_K", "XV_DIAG_REPS", "XV_DIAG_B", "XV_PROBE_EXTRA", "XV_DZ_SLOTS"};
     for (char** e = environ; e && *e; ++e) {
         if (strncmp(*e, "XV_", 3) != 0) continue;
         const char* eq = strchr(*e, '=');
@@ -56,7 +56,6 @@ XvEnvState xv_env_parse() {
         else fail("%s=%s: expected 0 or 1", name, v);
     };
     flag("XV_SEGMENT_FUSED", 1, &env.segment_fused);
-    flag("XV_EAGER_UPDATE", 1, &env.eager_update);
     env.nt_sched = 0;
     if (const char* v = getenv("XV_NT_SCHED")) {
         if (!strcmp(v, "dp")) env.nt_sched = 1;
@@ -67,11 +66,6 @@ XvEnvState xv_env_parse() {
     if (const char* v = getenv("XV_DZ_SLOTS")) {
         if (!strcmp(v, "2")) env.dz_slots = 2;
         else if (*v) fail("%s=%s: expected 2", "XV_DZ_SLOTS", v);
-    }
-    env.seg_wgrad = 1;
-    if (const char* v = getenv("XV_SEG_WGRAD")) {
-        if (!strcmp(v, "0") || !strcmp(v, "1") || !strcmp(v, "2")) env.seg_wgrad = v[0] - '0';
-        else if (*v) fail("%s=%s: expected 0, 1 or 2", "XV_SEG_WGRAD", v);
     }
     env.conv_wr = 0;
     if (const char* v = getenv("XV_CONV_WR")) {
@@ -271,7 +265,7 @@ extern "C" int xv_prep_weight_dgrad(void* stream, const float* kernel, int k, in
 // multi-job weight preparation (xv_common.h): one launch for every layout copy of every layer
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void weight_prep_multi_kernel(XvPrepJobs J) {
-    if (J.prio) XV_EW_PRIORITY();      // (a filler beside the forward GEMMs otherwise: XV_EW_FILLER)
+    XV_EW_FILLER();
     __shared__ float tile[32][33];
     int ji = 0;
 #pragma unroll 1
@@ -2087,15 +2081,14 @@ extern "C" int xv_sumsq(void* stream, const float* g, size_t count, float* out_a
     return 0;
 }
 
-// (filler != 0: enqueued on a side stream with a whole backward pass to finish in - no wave priority, XV_EW_FILLER's rule)
-__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, size_t count, float lr, float gs, int filler) {
-    if (!filler) XV_EW_PRIORITY();
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, size_t count, float lr, float gs) {
+    XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
         p[i] = p[i] - lr * (g[i] * gs);
 }
 __global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc, size_t count, float lr,
-                                float mom, int nesterov, float gs, int filler) {
-    if (!filler) XV_EW_PRIORITY();
+                                float mom, int nesterov, float gs) {
+    XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
         float gi = g[i] * gs;
         float a = mom * acc[i] + gi;
@@ -2104,8 +2097,8 @@ __global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__
     }
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t count, float lr_t, float b1, float b2, float eps, float gs, int filler) {
-    if (!filler) XV_EW_PRIORITY();
+                            size_t count, float lr_t, float b1, float b2, float eps, float gs) {
+    XV_EW_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
         float gi = g[i] * gs;
         float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -2115,36 +2108,26 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
     }
 }
-int xv_update_launch(hipStream_t stream, int optimizer, float* p, const float* g, float* s0, float* s1, size_t count, float lr, float momentum,
-                     int nesterov, int t, float grad_scale, bool filler) {
-    XV_REQUIRE(count > 0, "optimizer update: empty");
-    const dim3 grid(grid_for((long)count, 256, filler ? 1024 : 8192));      // (a filler in few, long workgroups: many short ones crawl beside a GEMM)
-    if (optimizer == 0) {
-        hipLaunchKernelGGL(sgd_kernel, grid, dim3(256), 0, stream, p, g, count, lr, grad_scale, filler ? 1 : 0);
-    } else if (optimizer == 1) {
-        hipLaunchKernelGGL(momentum_kernel, grid, dim3(256), 0, stream, p, g, s0, count, lr, momentum, nesterov, grad_scale, filler ? 1 : 0);
-    } else {
-        XV_REQUIRE(t >= 1, "adam_update: bad arguments");
-        const float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;      // tf.train.AdamOptimizer defaults (trainer.py:343)
-        const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
-        hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, stream, p, g, s0, s1, count, (float)lr_t, beta1, beta2, eps, grad_scale, filler ? 1 : 0);
-    }
+extern "C" int xv_sgd_update(void* stream, float* p, const float* g, size_t count, float lr, float grad_scale) {
+    XV_REQUIRE(count > 0, "sgd_update: empty");
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for((long)count, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, count, lr, grad_scale);
     XV_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int xv_sgd_update(void* stream, float* p, const float* g, size_t count, float lr, float grad_scale) {
-    return xv_update_launch((hipStream_t)stream, 0, p, g, nullptr, nullptr, count, lr, 0.f, 0, 1, grad_scale, false);
-}
 extern "C" int xv_momentum_update(void* stream, float* p, const float* g, float* acc, size_t count, float lr, float momentum,
                                   int nesterov, float grad_scale) {
-    return xv_update_launch((hipStream_t)stream, 1, p, g, acc, nullptr, count, lr, momentum, nesterov, 1, grad_scale, false);
+    XV_REQUIRE(count > 0, "momentum_update: empty");
+    hipLaunchKernelGGL(momentum_kernel, dim3(grid_for((long)count, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, acc, count, lr,
+                       momentum, nesterov, grad_scale);
+    XV_LAUNCH_CHECK();
+    return 0;
 }
 extern "C" int xv_adam_update(void* stream, float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
                               float beta2, float eps, int t, float grad_scale) {
     XV_REQUIRE(count > 0 && t >= 1, "adam_update: bad arguments");
     double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for((long)count, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, count,
-                       (float)lr_t, beta1, beta2, eps, grad_scale, 0);
+                       (float)lr_t, beta1, beta2, eps, grad_scale);
     XV_LAUNCH_CHECK();
     return 0;
 }

@@ -158,19 +158,6 @@ struct xv_engine {
     int with_margin = 1;
     hipStream_t last_stream = nullptr;
     size_t stage_begin[XV_BWD_STAGES], stage_end[XV_BWD_STAGES];
-    // Scheduled update (xv_engine_backward_update): the optimiser step and the kernel-layout weight copies of a backward stage's slice are
-    // enqueued as soon as that slice's gradients are complete - stage 0 (segment layers + loss head, 57 % of the parameters) on the loss
-    // head's stream, stages 1-2 on the weight-gradient stream right behind the hand-over wait of the next stage's first layer (the compute
-    // stream is inside that layer's data-gradient GEMM then), the last stage on the compute stream behind the join.  `prepped` says
-    // which layers' copies already match the updated variables when the next forward pass asks (ensure_weights).
-    struct Eager { bool on = false; float lr = 0.f, gs = 1.f; int t = 0; int ready = -1, applied = -1; } eager;
-    uint32_t prepped = 0;         // bit i: layer i's kernel-layout copies are up to date
-    bool loss_prepped = false;    // ... and the loss head's normalised copies
-    hipEvent_t ev_upd = nullptr;  // weight-gradient stream -> loss head's stream: stage 0 is complete
-    // the segment-level layers' weight gradients when they are handed over together (XvEnv::seg_wgrad): dz of tdnn(F+2) / tdnn(F+1), waiting
-    // for the hand-over of the last frame layer (mode 2)
-    const float* segw_dz7 = nullptr; const float* segw_dz6 = nullptr;
-    bool segw_pending = false;
     // scratch of the endpoints that are rebuilt on demand (xv_engine_endpoint: "<layer>_bn", "att_key1_relu"): a buffer of its own, allocated at
     // the first such request - every arena buffer wide enough holds live backward state (a dz slot per layer) between two passes
     float* ep_scratch = nullptr;
@@ -537,7 +524,7 @@ int alloc_buffers(xv_engine* e) {
     // Events between the engine's own streams order kernels of ONE device: no system-scope fence (cache write-back towards the host and
     // peers) when they are recorded.  Which events carry the system-scope release: ev_join (end of a pass / of a non-deferred stage), ev_stage[][],
     // ev_lw and ev_comm - everything a collective, whose bytes peer GPUs read, may be ordered behind.  Device scope only: ev_dz, the ring
-    // events, ev_prep, ev_lossprep, ev_upd (hand-overs between this engine's own kernels).
+    // events, ev_prep, ev_lossprep (hand-overs between this engine's own kernels).
     const unsigned local = hipEventDisableTiming | hipEventDisableSystemFence;
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_dz, local));
     for (int r = 0; r < 2; ++r)
@@ -547,7 +534,6 @@ int alloc_buffers(xv_engine* e) {
     // `s` next hands those bytes to PEER GPUs: it keeps the system-scope release (one packet per pass), like the stage / communication events
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_comm, hipEventDisableTiming));
-    XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_upd, local));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_prep, local));
     XV_CHECK_HIP(hipEventCreateWithFlags(&e->ev_lossprep, local));
     for (int k = 0; k < XV_BWD_STAGES; ++k)
@@ -570,9 +556,8 @@ int wait_lossprep(xv_engine* e, hipStream_t s) {
     return 0;
 }
 
-int prep_layers(xv_engine* e, hipStream_t s, int first, int last, bool prio = false) {
+int prep_layers(xv_engine* e, hipStream_t s, int first, int last) {
     XvPrepJobs J = {};
-    J.prio = prio ? 1 : 0;      // (in line on the weight-gradient stream, whose next GEMM waits for it: not a filler there)
     XvAmaxJobs A = {};
     for (int i = first; i < last; ++i) {
         Affine& a = e->L[i];
@@ -629,21 +614,6 @@ int prep_loss_head(xv_engine* e, hipStream_t s) {
 int ensure_weights(xv_engine* e, hipStream_t s, bool overlap = false) {
     if (!e->weights_dirty) return 0;
     int rc;
-    if (e->prepped || e->loss_prepped) {
-        // a scheduled update left only the last stage's layers (the first one or two): one launch on `s`, no side-stream half, no events
-        for (int i = 0; i < e->NL;) {
-            if ((e->prepped >> i) & 1u) { ++i; continue; }
-            int j = i;
-            while (j < e->NL && !((e->prepped >> j) & 1u)) ++j;
-            rc = prep_layers(e, s, i, j);
-            if (rc) return rc;
-            i = j;
-        }
-        if (!e->loss_prepped) { rc = prep_loss_head(e, s); if (rc) return rc; }
-        e->prepped = 0; e->loss_prepped = false;
-        e->weights_dirty = false;
-        return 0;
-    }
     if (overlap && e->concurrent && e->side) {
         rc = prep_layers(e, s, 0, 1);
         if (rc) return rc;
@@ -764,7 +734,6 @@ extern "C" void xv_engine_destroy(xv_engine* e) {
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->ev_comm) (void)hipEventDestroy(e->ev_comm);
     if (e->ev_prep) (void)hipEventDestroy(e->ev_prep);
-    if (e->ev_upd) (void)hipEventDestroy(e->ev_upd);
     if (e->ev_lossprep) (void)hipEventDestroy(e->ev_lossprep);
     for (int k = 0; k < XV_BWD_STAGES; ++k)
         for (int j = 0; j < 2; ++j) if (e->ev_stage[k][j]) (void)hipEventDestroy(e->ev_stage[k][j]);
@@ -798,7 +767,6 @@ extern "C" int xv_engine_bind(xv_engine* e, float* variables, float* grads, floa
     XV_REQUIRE(((uintptr_t)variables % 16) == 0 && ((uintptr_t)grads % 16) == 0, "engine_bind: buffers must be 16-byte aligned");
     e->V = variables; e->G = grads; e->S = opt_state;
     e->weights_dirty = true;
-    e->prepped = 0; e->loss_prepped = false;
     return 0;
 }
 
@@ -811,7 +779,6 @@ extern "C" int xv_engine_set_concurrency(xv_engine* e, int enabled) {
 extern "C" int xv_engine_invalidate_weights(xv_engine* e) {
     XV_REQUIRE(e, "null engine");
     e->weights_dirty = true;
-    e->prepped = 0; e->loss_prepped = false;
     return 0;
 }
 
@@ -1195,62 +1162,6 @@ float* ring_take(xv_engine* e, hipStream_t s) {
     return e->bufZ[zi];
 }
 
-// The optimiser step (trainer.py:332-346) on the float range [begin, end) of the trainable variables: the kernels are element-wise, so a
-// range at a time gives bit for bit what one launch over everything gives.
-int update_range(xv_engine* e, hipStream_t s, size_t begin, size_t end, float lr, float gs, int t, bool filler = false) {
-    if (end <= begin) return 0;
-    const xv_config& c = e->cfg;
-    return xv_update_launch(s, c.optimizer, e->V + begin, e->G + begin, e->S ? e->S + begin : nullptr, e->S ? e->S + e->n_train + begin : nullptr,
-                            end - begin, lr, c.momentum, c.use_nesterov, t, gs, filler);
-}
-
-// Scheduled update (xv_engine_backward_update), called on the weight-gradient stream's side of a hand-over: that stream has just been made
-// to wait for an event recorded on the compute stream BEHIND everything of stages <= eager.ready - their data gradients (which read the
-// variables of dense layers directly), their BatchNorm gradients - and, being in order, is itself behind their weight gradients.  So the
-// slices of those stages are complete and nothing reads their variables again in this pass: update them and rebuild their kernel-layout
-// copies for the next forward pass.  Stage 0 (the segment layers and the speaker matrix: most of the bytes, and a loss-head preparation that
-// takes 0.2 ms as a filler) goes to the loss head's stream, behind that stream's own weight gradient, where it has the whole backward
-// pass to finish; stages 1 and 2 are a few MB each and run here in line.
-int eager_flush(xv_engine* e) {
-    xv_engine::Eager& u = e->eager;
-    const int F = e->F, lo = F >= 4 ? 2 : 1;
-    if (u.applied >= u.ready) return 0;
-    // [measured, round 6, same box] stages 1 and 2 IN LINE on the weight-gradient stream (at wave priority 3, in front of the next layer's
-    // weight-gradient GEMM): 50 + 102 us of that stream per S1 step for 12 + 22 MB of update traffic and the layers' copies - the stream
-    // that bounds the backward pass; the step was 0.6 % slower than backward + apply.  Everything goes to the loss head's stream as fillers.
-    hipStream_t q = e->side2;
-    XV_CHECK_HIP(hipEventRecord(e->ev_upd, e->side));
-    XV_CHECK_HIP(hipStreamWaitEvent(q, e->ev_upd, 0));
-    while (u.applied < u.ready) {
-        const int k = ++u.applied;
-        int rc = update_range(e, q, e->stage_begin[k], e->stage_end[k], u.lr, u.gs, u.t, true);
-        if (rc) return rc;
-        if (k == 0) {
-            rc = prep_layers(e, q, F, F + 2);
-            if (rc) return rc;
-            rc = prep_loss_head(e, q);
-            if (rc) return rc;
-            e->prepped |= 3u << F;
-            e->loss_prepped = e->N > 0;
-        } else {
-            const int first = k == 1 ? F - 2 : lo, last = k == 1 ? F : F - 2;
-            if (last > first) {
-                rc = prep_layers(e, q, first, last);
-                if (rc) return rc;
-                for (int i = first; i < last; ++i) e->prepped |= 1u << i;
-            }
-            if (k == 1 && e->att) {      // the key network's variables sit in this stage's slice (build_variables)
-                rc = prep_layers(e, q, e->K0(), e->K1() + 1);
-                if (rc) return rc;
-                e->prepped |= 3u << e->K0();
-            }
-        }
-    }
-    XV_CHECK_HIP(hipEventRecord(e->ev_lw, q));      // (re-recorded: the join waits for the loss head's weight gradient AND everything enqueued here)
-    e->lw_pending = true;
-    return 0;
-}
-
 // dz of layer `a` (fp32 path) from the gradient w.r.t. its output: BN (+activation) backward, the activation alone, or da itself.
 // *ring: dz was written into the ring's current slot (ring_take) - the caller's weight gradient then owns the slot.
 int layer_dz(xv_engine* e, hipStream_t s, Affine& a, const float* da, int segs, int t_out, int pad, const float* act_out,
@@ -1303,27 +1214,7 @@ int layer_wgrad_on(xv_engine* e, hipStream_t q, void* wws, Affine& a, const floa
     return rc;
 }
 
-// Both segment-level layers' weight gradients on the loss head's stream, behind that stream's own weight gradient and ONE hand-over event
-// of the compute stream (recorded by the caller: ev_dz): they read dz7 / dz6, which sit in slots of their own (z_private) until the join.
-int seg_wgrads_launch(xv_engine* e) {
-    Affine &l6 = e->L[e->S0()], &l7 = e->L[e->S1()];
-    hipStream_t q = e->side2;
-    XV_CHECK_HIP(hipStreamWaitEvent(q, e->ev_dz, 0));
-    int rc = layer_wgrad_on(e, q, e->ws_side2, l7, l6.a, e->segw_dz7, e->B, 1, 0);
-    if (rc) return rc;
-    rc = layer_wgrad_on(e, q, e->ws_side2, l6, e->pool, e->segw_dz6, e->B, 1, 0);
-    if (rc) return rc;
-    XV_CHECK_HIP(hipEventRecord(e->ev_lw, q));      // (re-recorded: now behind the loss head's AND these weight gradients)
-    e->lw_pending = true;
-    e->segw_pending = false;
-    return 0;
-}
-int eager_flush(xv_engine* e);
-
 int layer_wgrad(xv_engine* e, hipStream_t s, Affine& a, const float* x, const float* dz, int segs, int t_in, int pad, bool ring) {
-    const int t_out = t_in - a.k + 1;
-    const int seg_pitch = t_out + 2 * pad;
-    (void)seg_pitch;
     xv_engine::ZRing& zr = e->zr[e->f16 ? 1 : 0];
     const int zi = zr.cur;
     const bool concurrent = e->concurrent && ring;   // dz aliasing the caller's buffer: keep everything in order
@@ -1333,14 +1224,6 @@ int layer_wgrad(xv_engine* e, hipStream_t s, Affine& a, const float* x, const fl
     if (concurrent) {
         rc = chain(s, e->side, e->ev_dz);
         if (rc) return rc;
-        if (e->segw_pending) {      // the segment layers' weight gradients ride on this hand-over (XvEnv::seg_wgrad == 2)
-            rc = seg_wgrads_launch(e);
-            if (rc) return rc;
-        }
-        if (e->eager.on && e->eager.applied < e->eager.ready) {      // the stages above this layer's are complete: see eager_flush
-            rc = eager_flush(e);
-            if (rc) return rc;
-        }
     }
     // [measured, round 4, same box, variant builds] the LAST weight-gradient launches of the side stream (tdnn2's; tdnn2-3's; all four) as 768
     // rectangles instead of a full round - so that the BatchNorm backward of tdnn1, which waits 250-300 us for slots beside tdnn2's weight
@@ -1636,20 +1519,11 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
                 rc = layer_dz(e, s, l7, d, b, 1, 0, e->h7, &dz7, &ring7);
                 if (rc) return rc;
             }
-            // The two segment layers' weight gradients: each handed to the weight-gradient stream behind its own dz (seg_wgrad 0: two event
-            // records on the compute stream inside the latency-bound chain), or both together to the loss head's stream - behind ONE record
-            // after dz6 (1), or on the record the last frame layer's hand-over makes anyway (2: none of their own; single-pass backward only).
-            // Needs a dz slot per layer: the slots are handed out here, the weight gradients launched later.
-            const XvEnv* envw = xv_env();
-            if (!envw) return 2;
-            const int segw = (e->z_private && e->concurrent && ring7 && e->side2) ? ((defer || stage != -1) && envw->seg_wgrad == 2 ? 1 : envw->seg_wgrad) : 0;
-            xv_engine::ZRing& zr0 = e->zr[0];
-            if (segw == 0) {
-                rc = layer_wgrad(e, s, l7, l6.a, dz7, b, 1, 0, ring7);
-                if (rc) return rc;
-            } else {
-                zr0.cur = (zr0.cur + 1) % zr0.n; ++e->z_taken; e->side_dirty = true;      // dz7's slot is taken
-            }
+            // [measured, round 6, profiles/r06_scheduled_update.txt] both segment layers' weight gradients behind ONE event record (after dz6) on the
+            // loss head's stream instead of a record each: S1 +0.3 ... +0.5 %, 64 x U +0.2 %; with no record of their own (launched with the last
+            // frame layer's hand-over) +0.8 % / +0.4 % - the packets on the compute stream are not what this chain costs
+            rc = layer_wgrad(e, s, l7, l6.a, dz7, b, 1, 0, ring7);
+            if (rc) return rc;
             // d a6 = dz7 . W7^T and tdnn6's BatchNorm (+ activation) backward in one launch -> dz6
             float* dz6 = ring_take(e, s);
             XV_REQUIRE(dz6, "engine_backward: waiting for a dz slot failed");
@@ -1667,19 +1541,8 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
                 rc = xv_launch_skinny(s, g);
                 if (rc) return rc;
             }
-            if (segw == 0) {
-                rc = layer_wgrad(e, s, l6, e->pool, dz6, b, 1, 0, true);
-                if (rc) return rc;
-            } else {
-                zr0.cur = (zr0.cur + 1) % zr0.n; ++e->z_taken;
-                e->segw_dz7 = dz7; e->segw_dz6 = dz6;
-                e->segw_pending = true;
-                if (segw == 1) {
-                    XV_CHECK_HIP(hipEventRecord(e->ev_dz, s));
-                    rc = seg_wgrads_launch(e);
-                    if (rc) return rc;
-                }
-            }
+            rc = layer_wgrad(e, s, l6, e->pool, dz6, b, 1, 0, true);
+            if (rc) return rc;
             // d pool = dz6 . W6^T (into d_small0); the pooling backward itself is evaluated inside the last frame layer's BN backward
             // (stage 1) from (pool, d pool): its d a is never written
             {
@@ -1692,7 +1555,6 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             }
         }
         if (stage == 0) { rc = end_stage(e, s, 0, defer); if (rc) return rc; }
-        e->eager.ready = 0;
     }
     const int F = e->F;
     const int Tp = e->Tl[F];          // pooled frames
@@ -1740,7 +1602,6 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
         rc = frame_backward(F - 2, e->bufD);
         if (rc) return rc;
         if (stage == 1) { rc = end_stage(e, s, 1, defer); if (rc) return rc; }
-        e->eager.ready = 1;
     }
     if (stage == -1 || stage == 2) {
         for (int i = F - 3; i >= lo; --i) {
@@ -1748,65 +1609,18 @@ int engine_backward(xv_engine* e, void* stream, int stage, bool defer) {
             if (rc) return rc;
         }
         if (stage == 2) { rc = end_stage(e, s, 2, defer); if (rc) return rc; }
-        e->eager.ready = 2;
     }
     if (stage == -1 || stage == 3) {
         for (int i = lo - 1; i >= 0; --i) {
             rc = frame_backward(i, e->bufD);
             if (rc) return rc;
         }
-        if (e->segw_pending) {      // (no hand-over since stage 0 carried them: cannot happen with a frame layer below the pooling layer)
-            XV_CHECK_HIP(hipEventRecord(e->ev_dz, s));
-            rc = seg_wgrads_launch(e);
-            if (rc) return rc;
-        }
-        if (e->eager.on && e->eager.applied < e->eager.ready) {
-            // no hand-over in the last stage carried them (its weight gradients all ran on `s`: a three-layer stack): one of their own
-            rc = chain(s, e->side, e->ev_dz);
-            if (rc) return rc;
-            rc = eager_flush(e);
-            if (rc) return rc;
-        }
         rc = end_stage(e, s, XV_BWD_STAGES - 1, defer);       // end of the backward pass: every gradient is visible to `stream`
         if (rc) return rc;
-        if (e->eager.on) {      // the last stage's slice (the first one or two layers) behind the join; their copies are made by the next forward
-            rc = update_range(e, s, e->stage_begin[XV_BWD_STAGES - 1], e->stage_end[XV_BWD_STAGES - 1], e->eager.lr, e->eager.gs, e->eager.t);
-            if (rc) return rc;
-            e->weights_dirty = true;
-            e->reg_valid = false;
-        }
     }
     return 0;
 }
 }  // namespace
-
-// xv_engine_backward(e, stream, -1) + xv_engine_apply(e, stream, lr, grad_scale, t) as ONE scheduled pass (include/xvector_hip.h): same
-// gradients, same variables afterwards, bit for bit.  What does not fit the schedule runs the two calls as they are: split precision (its
-// weight copies need the tensors' max |w| first), everything on one stream, a global-norm clip (needs every gradient before any update).
-extern "C" int xv_engine_backward_update(xv_engine* e, void* stream, float lr, float grad_scale, int t) {
-    XV_REQUIRE(e && e->V && e->G, "engine_backward_update: buffers not bound");
-    XV_REQUIRE(e->cfg.optimizer == 0 || e->S, "engine_backward_update: optimiser state buffer not bound");
-    const XvEnv* env = xv_env();
-    if (!env) return 2;
-    const bool scheduled = env->eager_update && !e->f16 && e->concurrent && e->side && e->side2 && e->cfg.clip_gradient_norm <= 0.f && e->NL < 32;
-    int rc;
-    if (!scheduled) {
-        rc = engine_backward(e, stream, -1, false);
-        if (rc) return rc;
-        return xv_engine_apply(e, stream, lr, grad_scale, t);
-    }
-    hipStream_t s = (hipStream_t)stream;
-    rc = wait_prep(e, s);           // (no-ops after a training forward + loss_forward: the update rewrites what those side-stream halves read)
-    if (rc) return rc;
-    rc = wait_lossprep(e, s);
-    if (rc) return rc;
-    e->prepped = 0; e->loss_prepped = false;
-    e->eager.on = true; e->eager.lr = lr; e->eager.gs = grad_scale; e->eager.t = t; e->eager.ready = -1; e->eager.applied = -1;
-    rc = engine_backward(e, stream, -1, false);
-    e->eager.on = false;
-    if (rc) { e->prepped = 0; e->loss_prepped = false; e->weights_dirty = true; }
-    return rc;
-}
 
 // ---- gradient exchange for hosts without torch.distributed (the Python host runs the same collective through
 // torch.distributed in parallel.py).  RCCL is resolved at first use from the process - the host that created the communicator has it
@@ -1900,7 +1714,6 @@ extern "C" int xv_engine_apply(xv_engine* e, void* stream, float lr, float grad_
     else if (c.optimizer == 1) rc = xv_momentum_update(s, e->V, e->G, e->S, e->n_train, lr, c.momentum, c.use_nesterov, grad_scale);
     else rc = xv_adam_update(s, e->V, e->G, e->S, e->S + e->n_train, e->n_train, lr, 0.9f, 0.999f, 1e-8f, t, grad_scale);
     e->weights_dirty = true;
-    e->prepped = 0; e->loss_prepped = false;
     e->reg_valid = false;
     return rc;
 }

@@ -311,13 +311,6 @@ class Engine(object):
         _lib.check(self.lib.xv_engine_apply(self.h, _stream(), float(lr), float(grad_scale), int(self.update_count)),
                    "xv_engine_apply")
 
-    def backward_update(self, lr, grad_scale=1.0):
-        """backward(-1) + apply(lr) as one scheduled pass (xv_engine_backward_update): bit-identical variables and gradients, the update
-        and the next forward's weight copies enqueued per backward stage beside the remaining data-gradient GEMMs."""
-        self.update_count += 1
-        _lib.check(self.lib.xv_engine_backward_update(self.h, _stream(), float(lr), float(grad_scale), int(self.update_count)),
-                   "xv_engine_backward_update")
-
     @property
     def arena_bytes(self):
         return int(self.lib.xv_engine_arena_bytes(self.h))
@@ -386,13 +379,6 @@ class Engine(object):
             for (b, e), v in zip(frozen_stats, keep):
                 self.variables[b:e].copy_(v)
         self.loss(labels, global_step, True)
-        frozen = getattr(self, "_frozen_grads", None) or ()
-        if allreduce is None and not frozen and not fetch_losses:
-            # the single-GPU step whose learning rate is known up front (a fed placeholder, trainer.py:326,507): the engine schedules the
-            # update and the next forward's weight copies per backward stage.  Logging steps (losses on the pre-update weights), frozen
-            # variables and data parallelism take the two calls below
-            self.backward_update(lr)
-            return None
         if allreduce is None:
             self.backward(-1)
             grad_scale = 1.0
@@ -405,6 +391,7 @@ class Engine(object):
                 allreduce.mark_compute_done()
             allreduce.wait()
             grad_scale = allreduce.grad_scale
+        frozen = getattr(self, "_frozen_grads", None) or ()
         saved = []
         for b, e in frozen:
             self.grads[b:e].zero_()
