@@ -228,7 +228,7 @@ def test_no_shuffle_starts_at_frame_zero_and_few_speakers_are_duplicated(nl, dat
 
 
 def test_eight_concurrent_loaders_scale_with_the_host(tmp_path):
-    """One native loader per rank, as an 8-GPU job runs them (tools/loader_scale.py): the instances share nothing but the page
+    """One native loader per rank, as an 8-GPU job runs them (tools/bench_host.py loader_scale): the instances share nothing but the page
     cache, so 8 single-threaded loaders in 8 processes must deliver close to 8x one of them when the host has the cores (no
     global lock, no shared queue) - the property the >= 6x 1 -> 8 GPU scaling target rests on.  The absolute
     figure against the per-GPU step rate is printed by the tool on the GPU box's host (profiles/)."""

@@ -11,7 +11,7 @@
 // matters stays a normal fp16.  The max is produced by whoever writes the tensor (exact output range of
 // BN+ReLU from the GEMM epilogue's column min/max; a bound for the BN backward; a reduction for inputs and
 // weights) and travels as the uint bits of a float in device memory - no host round trip.
-// Measured on MI355X (tests/test_gpu_ops_f16x3.py, tools/gemm16_bench.py): max error vs float64 5e-7..8e-7 of the output scale (fp32-input MFMA:
+// Measured on MI355X (tests/test_gpu_ops_f16x3.py, tools/bench_kernel.py gemm16): max error vs float64 5e-7..8e-7 of the output scale (fp32-input MFMA:
 // 1.7e-7), 2.6-3.0x the speed of the fp32-input MFMA kernels of xv_gemm.hip.
 //
 // Plane layout: [2][rows][ld] 16-bit, channel axis contiguous, ld a multiple of 8 (16-byte chunks), zero padded.

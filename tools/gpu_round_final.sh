@@ -6,18 +6,18 @@ cd $GRAFT_REPO_ROOT
 tools/profile_round.sh $tag 2>&1 | tail -12
 O=$GRAFT_REPO_ROOT/gpurun_out/profiles_$tag
 export TMPDIR=/tmp
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/ew -- python3 $GRAFT_REPO_ROOT/tools/elementwise_bench.py > $O/ew.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/ew -- python3 $GRAFT_REPO_ROOT/tools/bench_kernel.py elementwise > $O/ew.log 2>&1)
 python3 tools/elementwise_summary.py $(find $O/ew -name "*kernel_trace.csv" | head -1) > $O/elementwise.json; rm -rf $O/ew $O/ew.log
-timeout 900 python3 tools/pool_bench.py 2>&1 | grep -v amdgpu.ids > $O/pool_bench.txt
-timeout 900 python3 tools/segment_bench.py 2>&1 | grep -v amdgpu.ids > $O/segment_bench.txt
-timeout 900 python3 tools/e2e_ab.py --rounds 2 2>&1 | grep -v amdgpu.ids > $O/e2e_ab.txt
-timeout 900 python3 tools/extract_bench.py 2>&1 | grep -v amdgpu.ids > $O/extract_bench.txt; timeout 900 python3 tools/extract_driver_bench.py 2>&1 | grep -v amdgpu.ids >> $O/extract_bench.txt; tail -4 $O/extract_bench.txt
+timeout 900 python3 tools/bench_kernel.py pool 2>&1 | grep -v amdgpu.ids > $O/pool_bench.txt
+timeout 900 python3 tools/bench_kernel.py segment 2>&1 | grep -v amdgpu.ids > $O/segment_bench.txt
+timeout 900 python3 tools/bench_host.py e2e_ab --rounds 2 2>&1 | grep -v amdgpu.ids > $O/e2e_ab.txt
+timeout 900 python3 tools/bench_host.py extract 2>&1 | grep -v amdgpu.ids > $O/extract_bench.txt; timeout 900 python3 tools/bench_host.py extract_driver 2>&1 | grep -v amdgpu.ids >> $O/extract_bench.txt; tail -4 $O/extract_bench.txt
 timeout 900 python3 bench.py --extended --frames 400 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_extended.json
 python3 tools/bench_summary.py $O/bench_extended.json | grep -E "^f32|^f16x3"
 timeout 900 python3 tools/shape_sweep.py --precision f32 2>/dev/null > $O/shapes_f32.json
 timeout 900 python3 tools/shape_sweep.py --precision f16x3 2>/dev/null > $O/shapes_f16x3.json
-timeout 900 python3 tools/loader_scale.py --batches 400 --need 22800 2>/dev/null | tail -1 > $O/loader_scale.json
-timeout 900 python3 tools/trainer_bench.py 400 2>&1 | grep -v amdgpu.ids | tail -3 > $O/trainer_bench.txt
+timeout 900 python3 tools/bench_host.py loader_scale --batches 400 --need 22800 2>/dev/null | tail -1 > $O/loader_scale.json
+timeout 900 python3 tools/bench_host.py trainer 400 2>&1 | grep -v amdgpu.ids | tail -3 > $O/trainer_bench.txt
 tools/step_timeline.sh $O/s3_64x300 -- --chunks 64 --frames 300; rm -f $O/s3_64x300.log $O/s3_64x300.json
 tools/step_timeline.sh $O/s4 -- --attention; rm -f $O/s4.log $O/s4.json
 tools/step_timeline.sh $O/s5 -- --extended --frames 400; rm -f $O/s5.log $O/s5.json

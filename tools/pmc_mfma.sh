@@ -7,11 +7,11 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/$out
 export TMPDIR=/tmp
 CNT="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
-for prog in gemm_bench gemm16_bench; do
+for prog in gemm gemm16; do
   for scale in 1 0; do
-    tag=${prog}_x${scale}
+    tag=${prog}_bench_x${scale}
     export XV_DATA_SCALE=$scale
-    (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $R/$out/$tag -- python3 $R/tools/$prog.py > $R/$out/$tag.log 2>&1)
+    (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $R/$out/$tag -- python3 $R/tools/bench_kernel.py $prog > $R/$out/$tag.log 2>&1)
   done
 done
 unset XV_DATA_SCALE

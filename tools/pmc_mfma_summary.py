@@ -5,8 +5,8 @@ import collections, csv, glob, json, os, sys
 
 root = sys.argv[1]
 out = {"method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 "
-                 "SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace, one pass per program (tools/gemm_bench.py = fp32-input MFMA kernels, "
-                 "tools/gemm16_bench.py = f16x3 kernels; S1 layer shapes) and operand fill (XV_DATA_SCALE=1 random normal, 0 all-zero); "
+                 "SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace, one pass per program (tools/bench_kernel.py gemm = fp32-input MFMA kernels, "
+                 "bench_kernel.py gemm16 = f16x3 kernels; S1 layer shapes) and operand fill (XV_DATA_SCALE=1 random normal, 0 all-zero); "
                  "values are means over the dispatches of each kernel; clock_ghz = GRBM_GUI_ACTIVE / 8 / duration (sum over the 8 XCDs, "
                  "reads high on dispatches < 0.3 ms per the guide); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (256 CUs x 4 SIMDs x "
                  "GRBM_GUI_ACTIVE / 8)", "runs": {}}
