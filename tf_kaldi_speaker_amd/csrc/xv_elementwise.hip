@@ -1218,24 +1218,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dense_kernel(const float* __
     }
 }
 
-// The pooled pass in its affine form (plain ReLU or none; see bn_bwd_apply_dense_kernel) with a workgroup per (chunk, 256 channels, row range):
-// the chunk's pooled statistics, the seven per-channel vectors and the four coefficient vectors derived from them are set up ONCE for
-// ~T / (4 splits) rows per thread instead of once per eight (a strip kernel's workgroup moved 64 KB behind a two-level chain of ~16
-// dependent vector loads), there is no chunk boundary inside a workgroup, and a thread keeps two batches of eight 16-byte loads in flight
-// (the next batch is issued before the current one is computed and stored).  286 MB at S1, on the serial chain between the loss and the
-// first data-gradient GEMM.
-#define BPC_BATCH 8
-__global__ __launch_bounds__(256) void bn_bwd_apply_pooled_chunk_kernel(PoolGrad pg, const float* __restrict__ z, int n, const float* __restrict__ gamma,
+// The pooled pass in its affine form (plain ReLU or none; see bn_bwd_apply_dense_kernel) with a workgroup per (chunk, row range) that covers
+// WHOLE rows: thread q owns channel quad q of every row of its range, so a workgroup streams consecutive bytes (a row after a row) as torch's
+// flat element-wise kernel does - that kernel moves the same 286 MB at 6.5 TB/s, the strip forms (64 quads x row lanes: 1 KB pieces at a
+// 6 KB stride per workgroup) at 5.0.  The chunk's pooled statistics, the seven per-channel vectors and the four coefficient vectors derived
+// from them are set up ONCE per thread for ~T / splits rows, there is no chunk boundary inside a workgroup, and a thread keeps two batches
+// of BPC_BATCH 16-byte loads in flight.  Block = nq (n / 4) threads rounded up to whole waves (n <= 4 096 channels).  286 MB at S1, on the
+// serial chain between the loss and the first data-gradient GEMM.
+#define BPC_BATCH 4
+__global__ __launch_bounds__(1024) void bn_bwd_apply_pooled_rows_kernel(PoolGrad pg, const float* __restrict__ z, int n, const float* __restrict__ gamma,
                                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                                         const float* __restrict__ coef, int relu, float* __restrict__ dz, int ldz,
-                                                                        int rows_per /* rows of a chunk per workgroup (multiple of 4) */) {
+                                                                        int rows_per /* rows of a chunk per workgroup */) {
     XV_EW_PRIORITY();
-    const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int rl = threadIdx.x >> 6;
+    const int col = threadIdx.x * 4;
     if (col >= n) return;
-    const int b = blockIdx.y, T = pg.t;
-    const int t_begin = blockIdx.z * rows_per, t_end = min(T, t_begin + rows_per);
+    const int b = blockIdx.x, T = pg.t;
+    const int t_begin = blockIdx.y * rows_per, t_end = min(T, t_begin + rows_per);
     if (t_begin >= T) return;
     const f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
     const f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
@@ -1254,14 +1254,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pooled_chunk_kernel(PoolGrad
     const int t_last = t_end - 1;
     auto load = [&](f32x4 (&v)[BPC_BATCH], float (&w)[BPC_BATCH], int t0) {
 #pragma unroll
-        for (int j = 0; j < BPC_BATCH; ++j) v[j] = *(const f32x4*)(zp + (long)min(t0 + 4 * j, t_last) * ldz);
+        for (int j = 0; j < BPC_BATCH; ++j) v[j] = *(const f32x4*)(zp + (long)min(t0 + j, t_last) * ldz);
 #pragma unroll
-        for (int j = 0; j < BPC_BATCH; ++j) w[j] = wp ? wp[min(t0 + 4 * j, t_last)] : invT;
+        for (int j = 0; j < BPC_BATCH; ++j) w[j] = wp ? wp[min(t0 + j, t_last)] : invT;
     };
     auto proc = [&](const f32x4 (&v)[BPC_BATCH], const float (&w)[BPC_BATCH], int t0) {
 #pragma unroll
         for (int j = 0; j < BPC_BATCH; ++j) {
-            const int t = t0 + 4 * j;
+            const int t = t0 + j;
             const f32x4 y = v[j] * sc + sh;
             const f32x4 off = C * v[j] + D;
             f32x4 on = w[j] * (A * v[j] + B) + off;
@@ -1274,17 +1274,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pooled_chunk_kernel(PoolGrad
     };
     f32x4 va[BPC_BATCH], vb[BPC_BATCH];
     float wa[BPC_BATCH], wb[BPC_BATCH];
-    int t0 = t_begin + rl;
-    constexpr int STEP = 4 * BPC_BATCH;
+    int t0 = t_begin;
     load(va, wa, t0);
     while (true) {
-        if (t0 + STEP < t_end) load(vb, wb, t0 + STEP);
+        if (t0 + BPC_BATCH < t_end) load(vb, wb, t0 + BPC_BATCH);
         proc(va, wa, t0);
-        t0 += STEP;
+        t0 += BPC_BATCH;
         if (t0 >= t_end) break;
-        if (t0 + STEP < t_end) load(va, wa, t0 + STEP);
+        if (t0 + BPC_BATCH < t_end) load(va, wa, t0 + BPC_BATCH);
         proc(vb, wb, t0);
-        t0 += STEP;
+        t0 += BPC_BATCH;
         if (t0 >= t_end) break;
     }
 }
@@ -1485,13 +1484,13 @@ static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, co
         XV_LAUNCH_CHECK();
     }
     dim3 agrid(xv_cdiv(n / 4, 64), xv_cdiv(segs * (t + 2 * pad), BAF_ROWS));
-    if (pooled && pad == 0 && !(relu && act.slope) && rows / pg.t <= 65535) {
-        // a workgroup per (chunk, 256 channels); chunks of few workgroups (a small batch) are cut into row ranges until ~3 workgroups per CU exist
-        const int nchunks = rows / pg.t, gx = xv_cdiv(n / 4, 64);
-        int rs = std::max(1, std::min(768 / std::max(1, gx * nchunks), pg.t / 32));
-        const int rows_per = (int)xv_align((size_t)xv_cdiv(pg.t, rs), 4);
+    if (pooled && pad == 0 && !(relu && act.slope) && n <= 4096) {
+        // a workgroup per (chunk, row range), whole rows; the ranges are cut so that ~4 096 waves exist (16 per CU: 128 KB of loads in flight each) while a range keeps >= 16 rows
+        const int nchunks = rows / pg.t, waves = xv_cdiv(n / 4, 64);
+        int rs = std::max(1, std::min(4096 / std::max(1, waves * nchunks), pg.t / 16));
+        const int rows_per = xv_cdiv(pg.t, rs);
         rs = xv_cdiv(pg.t, rows_per);
-        hipLaunchKernelGGL(bn_bwd_apply_pooled_chunk_kernel, dim3(gx, nchunks, rs), dim3(256), 0, s, pg, z, n, gamma, mean, invstd, scale, shift,
+        hipLaunchKernelGGL(bn_bwd_apply_pooled_rows_kernel, dim3(nchunks, rs), dim3(waves * 64), 0, s, pg, z, n, gamma, mean, invstd, scale, shift,
                            (const float*)coef, relu, dz_pad, ldz, rows_per);
     } else if (pad == 0 && (!pooled || pg.t >= BAF_ROWS))
         hipLaunchKernelGGL(pooled ? bn_bwd_apply_dense_kernel<true> : bn_bwd_apply_dense_kernel<false>, agrid, dim3(256), 0, s, da, pg, z, rows, n, gamma,

@@ -65,7 +65,6 @@ struct NTArgs {
     float* slab;                // [(tiles - n_whole) * shares][128 * 128]: partial tiles in lane order
     unsigned* tickets;          // one per tile, zero between launches
     int row_store;              // epilogue through LDS with 16-byte row stores (nt_store_tile_rows): C / ldc 16-byte aligned, N % 4 == 0
-    int stagger;                // > 0 (experiment build, XV_NT_STAGGER): the first round's workgroups start stagger x s_sleep(127) x their slot late
 };
 
 // Out-of-range rows / k read this 16-byte zero page instead of being masked after the load: the
@@ -223,15 +222,6 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) __attribute__((amdgpu_num_vgpr(
     XV_STAMP_ENTRY(p.stamp_half);
     unsigned long long stall = 0;
     (void)stall;
-#ifdef XV_NT_STAGGER
-    // Experiment: a multi-round launch of short tiles (tdnn5's forward: 2 232 tiles of 32 K-steps) runs its rounds in lockstep - the four
-    // workgroups of a CU start together, finish together, and their prologues / epilogues (~13 of ~110 us) never overlap another workgroup's
-    // K loop.  The first round's workgroups start a quarter tile apart by their wave slot; later rounds inherit the offsets.
-    if (p.stagger > 0 && (int)blockIdx.x < XV_RESIDENT_WGS) {
-        const int slot = xv_wave_slot() & 3;
-        for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 
     // whole tiles first: the hardware places them first (n_whole is a multiple of 256 - the same number on every CU of an empty chip), the
     // short share blocks behind them are dealt into whatever slots are free
@@ -817,10 +807,6 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
     p.tiles_m = xv_cdiv(g.M, BM); p.tiles_n = xv_cdiv(g.N, BN);
     p.bias = g.bias; p.part_sum = nullptr; p.part_m2 = nullptr;
     p.n_whole = 0; p.shares = 0; p.slab = nullptr; p.tickets = nullptr;
-    p.stagger = 0;
-#ifdef XV_NT_STAGGER
-    if (xv_cdiv(g.M, BM) * xv_cdiv(g.N, BN) >= 2 * XV_RESIDENT_WGS && xv_cdiv(g.K, BK) <= 64) p.stagger = XV_NT_STAGGER;
-#endif
 #ifdef XV_NT_NO_ROWS      // (A/B build constant: the four-byte-store epilogue everywhere)
     p.row_store = 0;
 #else
