@@ -1218,76 +1218,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_dense_kernel(const float* __
     }
 }
 
-// The pooled pass in its affine form (plain ReLU or none; see bn_bwd_apply_dense_kernel) with a workgroup per (chunk, row range) that covers
-// WHOLE rows: thread q owns channel quad q of every row of its range, so a workgroup streams consecutive bytes (a row after a row) as torch's
-// flat element-wise kernel does - that kernel moves the same 286 MB at 6.5 TB/s, the strip forms (64 quads x row lanes: 1 KB pieces at a
-// 6 KB stride per workgroup) at 5.0.  The chunk's pooled statistics, the seven per-channel vectors and the four coefficient vectors derived
-// from them are set up ONCE per thread for ~T / splits rows, there is no chunk boundary inside a workgroup, and a thread keeps two batches
-// of BPC_BATCH 16-byte loads in flight.  Block = nq (n / 4) threads rounded up to whole waves (n <= 4 096 channels).  286 MB at S1, on the
-// serial chain between the loss and the first data-gradient GEMM.
-#define BPC_BATCH 4
-__global__ __launch_bounds__(1024) void bn_bwd_apply_pooled_rows_kernel(PoolGrad pg, const float* __restrict__ z, int n, const float* __restrict__ gamma,
-                                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                        const float* __restrict__ coef, int relu, float* __restrict__ dz, int ldz,
-                                                                        int rows_per /* rows of a chunk per workgroup */) {
-    XV_EW_PRIORITY();
-    const int col = threadIdx.x * 4;
-    if (col >= n) return;
-    const int b = blockIdx.x, T = pg.t;
-    const int t_begin = blockIdx.y * rows_per, t_end = min(T, t_begin + rows_per);
-    if (t_begin >= T) return;
-    const f32x4 mu = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
-    const f32x4 sc = *(const f32x4*)(scale + col), sh = *(const f32x4*)(shift + col);
-    const f32x4 c1 = *(const f32x4*)(coef + col), c2 = *(const f32x4*)(coef + n + col);
-    const f32x4 g_is = *(const f32x4*)(gamma + col) * is;
-    const PoolCoef pc = pool_coef(pg, b, n, col);
-    // dz = on ? w (A z + B) + (C z + D) : C z + D   (bn_bwd_apply_dense_kernel, same expressions)
-    const f32x4 gc2 = g_is * is * c2;
-    const f32x4 C = -gc2, D = gc2 * mu - g_is * c1;
-    const f32x4 A = g_is * (pc.q * sc), B = g_is * (pc.dm + pc.q * (sh - pc.mean));
-    const float invT = 1.f / (float)T;
-    const long row0 = (long)b * T;
-    const float* __restrict__ zp = z + row0 * ldz + col;
-    float* __restrict__ dp = dz + row0 * ldz + col;
-    const float* __restrict__ wp = pg.w ? pg.w + row0 : nullptr;
-    const int t_last = t_end - 1;
-    auto load = [&](f32x4 (&v)[BPC_BATCH], float (&w)[BPC_BATCH], int t0) {
-#pragma unroll
-        for (int j = 0; j < BPC_BATCH; ++j) v[j] = *(const f32x4*)(zp + (long)min(t0 + j, t_last) * ldz);
-#pragma unroll
-        for (int j = 0; j < BPC_BATCH; ++j) w[j] = wp ? wp[min(t0 + j, t_last)] : invT;
-    };
-    auto proc = [&](const f32x4 (&v)[BPC_BATCH], const float (&w)[BPC_BATCH], int t0) {
-#pragma unroll
-        for (int j = 0; j < BPC_BATCH; ++j) {
-            const int t = t0 + j;
-            const f32x4 y = v[j] * sc + sh;
-            const f32x4 off = C * v[j] + D;
-            f32x4 on = w[j] * (A * v[j] + B) + off;
-            if (relu) {
-                on.x = y.x > 0.f ? on.x : off.x; on.y = y.y > 0.f ? on.y : off.y;
-                on.z = y.z > 0.f ? on.z : off.z; on.w = y.w > 0.f ? on.w : off.w;
-            }
-            if (t < t_end) *(f32x4*)(dp + (long)t * ldz) = on;
-        }
-    };
-    f32x4 va[BPC_BATCH], vb[BPC_BATCH];
-    float wa[BPC_BATCH], wb[BPC_BATCH];
-    int t0 = t_begin;
-    load(va, wa, t0);
-    while (true) {
-        if (t0 + BPC_BATCH < t_end) load(vb, wb, t0 + BPC_BATCH);
-        proc(va, wa, t0);
-        t0 += BPC_BATCH;
-        if (t0 >= t_end) break;
-        if (t0 + BPC_BATCH < t_end) load(va, wa, t0 + BPC_BATCH);
-        proc(vb, wb, t0);
-        t0 += BPC_BATCH;
-        if (t0 >= t_end) break;
-    }
-}
-
 // Same as bn_bwd_apply_kernel but dz is written as two fp16 planes [2][segs*(t+2pad)][ldd] scaled by the power of two
 // derived from *amax (xv_gemm16.hip); pad rows / columns are zero.
 // Thread = one 8-channel chunk (16 B per plane) x a strip of rows: the 7 per-channel parameter vectors are loaded
@@ -1484,15 +1414,10 @@ static int bn_relu_backward_impl(hipStream_t s, const float* da, PoolGrad pg, co
         XV_LAUNCH_CHECK();
     }
     dim3 agrid(xv_cdiv(n / 4, 64), xv_cdiv(segs * (t + 2 * pad), BAF_ROWS));
-    if (pooled && pad == 0 && !(relu && act.slope) && n <= 4096) {
-        // a workgroup per (chunk, row range), whole rows; the ranges are cut so that ~4 096 waves exist (16 per CU: 128 KB of loads in flight each) while a range keeps >= 16 rows
-        const int nchunks = rows / pg.t, waves = xv_cdiv(n / 4, 64);
-        int rs = std::max(1, std::min(4096 / std::max(1, waves * nchunks), pg.t / 16));
-        const int rows_per = xv_cdiv(pg.t, rs);
-        rs = xv_cdiv(pg.t, rows_per);
-        hipLaunchKernelGGL(bn_bwd_apply_pooled_rows_kernel, dim3(nchunks, rs), dim3(waves * 64), 0, s, pg, z, n, gamma, mean, invstd, scale, shift,
-                           (const float*)coef, relu, dz_pad, ldz, rows_per);
-    } else if (pad == 0 && (!pooled || pg.t >= BAF_ROWS))
+    // [measured, round 6, profiles/r06_pooled_kernels.txt] two other forms of the pooled pass were built and dropped: a workgroup per (chunk, 256
+    // channels) with the parameters set up once and two batches of eight loads in flight (78 us for statistics + apply alone, as this strip form),
+    // and whole-row workgroups that stream consecutive bytes as torch's flat element-wise kernel does (82 us)
+    if (pad == 0 && (!pooled || pg.t >= BAF_ROWS))
         hipLaunchKernelGGL(pooled ? bn_bwd_apply_dense_kernel<true> : bn_bwd_apply_dense_kernel<false>, agrid, dim3(256), 0, s, da, pg, z, rows, n, gamma,
                            mean, invstd, scale, shift, (const float*)coef, relu, dz_pad, relu ? act.slope : nullptr, ldz);
     else
@@ -1870,40 +1795,22 @@ __global__ __launch_bounds__(256) void stat_pool_fwd_kernel(const float* __restr
     // keep the exact quotient: there w / n must be exactly 1 on a lane's first frame, or a constant chunk no longer has a zero variance
     // (reference test_utils.py / pooling.py:160-162 clamp).
 #define XV_POOL_STEP2(mean, m2, n, v, w) { n += (w); const f32x4 d_ = (v) - mean; if (n > 0.f) mean += d_ * (wp ? (w) / n : __builtin_amdgcn_rcpf(n)); m2 += d_ * ((v) - mean) * (w); }
-    // batches of four frames per lane, two batches in flight: the NEXT batch's loads are issued before the current one is folded, so a lane
-    // always has 4-8 16-byte loads outstanding (the fold is ~45 vector instructions per 16 bytes: the first form loaded eight, waited, folded
-    // eight - its memory pipe idled while it computed; two batches of eight cost 204 VGPRs, i.e. a workgroup less per CU)
+    // [measured, round 6] two batches of four loads in flight (the next batch issued before the current one is folded): 26.4 us alone against
+    // 26.5 for this form; two batches of eight need 204 VGPRs (a workgroup less per CU)
     int t = wave;
-    auto load4 = [&](f32x4 (&v)[4], float (&w)[4], int t0) {
+    for (; t + 28 < T; t += 32) {
+        f32x4 v[8];
+        float w[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(xp + (long)(t0 + 4 * u) * ld);
+        for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(xp + (long)(t + 4 * u) * ld);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = wp ? wp[t0 + 4 * u] : 1.f;
-    };
-    auto fold4 = [&](const f32x4 (&v)[4], const float (&w)[4]) {
+        for (int u = 0; u < 8; ++u) w[u] = wp ? wp[t + 4 * u] : 1.f;
 #pragma unroll
-        for (int u = 0; u < 4; u += 2) {
+        for (int u = 0; u < 8; u += 2) {
             const f32x4 a0 = act(v[u]), a1 = act(v[u + 1]);
             XV_POOL_STEP2(mean0, m20, n0, a0, w[u])
             XV_POOL_STEP2(mean1, m21, n1, a1, w[u + 1])
             if (wpos) { on(a0, w[u]); on(a1, w[u + 1]); }
-        }
-    };
-    if (t + 12 < T) {
-        f32x4 va[4], vb[4];
-        float wa[4], wb[4];
-        load4(va, wa, t);
-        while (true) {
-            const bool more_b = t + 16 + 12 < T;
-            if (more_b) load4(vb, wb, t + 16);
-            fold4(va, wa);
-            t += 16;
-            if (!more_b) break;
-            const bool more_a = t + 16 + 12 < T;
-            if (more_a) load4(va, wa, t + 16);
-            fold4(vb, wb);
-            t += 16;
-            if (!more_a) break;
         }
     }
     for (; t < T; t += 4) {

@@ -435,8 +435,9 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int w = xcd_swizzle(blockIdx.x, gridDim.x);
-    const long u_end = (long)(w + 1) * q.total / q.P;
-    long u = (long)w * q.total / q.P;
+    // (unit indices fit 32 bits - the launcher checks total < 2^31 -; as 64-bit scalars they were five register pairs live across the whole run)
+    const int u_end = (int)((long)(w + 1) * q.total / q.P);
+    int u = (int)((long)w * q.total / q.P);
     const int first_tile = (int)(u / q.nk);
     XV_STAMP_ENTRY(p.stamp_half);
     bool first_seg = true;
@@ -458,17 +459,17 @@ __global__ __launch_bounds__(256, XV_NT_SK_OCC) __attribute__((amdgpu_num_vgpr(X
     // an XCD at any moment are the same few for all its workgroups, as in a one-workgroup-per-tile launch.  In run order the workgroups of
     // an XCD sit at all K offsets at once, their weight slices do not fit the L2 together and are re-fetched from the Infinity Cache
     // (1.45 -> 0.16 GB past the L2 per launch, same time: DESIGN.md Appendix B, note 6.)
-    const long u_begin = u;
-    const long u_mid = (u / q.nk + 1) * q.nk;                  // end of the first tile of the run
+    const int u_begin = u;
+    const int u_mid = (u / q.nk + 1) * q.nk;                   // end of the first tile of the run
     const bool wrap_first = u % q.nk != 0 && u_mid < u_end && u_end - u_mid <= q.nk;
     for (int pass = 0; pass < 2; ++pass) {
-    long u_stop = u_end;
+    int u_stop = u_end;
     if (wrap_first) { u = pass == 0 ? u_mid : u_begin; u_stop = pass == 0 ? u_end : u_mid; }
     else if (pass == 1) break;
     while (u < u_stop) {
         const int tile = (int)(u / q.nk);
-        const int kt0 = (int)(u - (long)tile * q.nk);
-        const int kt1 = (int)min((long)q.nk, kt0 + (u_stop - u));
+        const int kt0 = u - tile * q.nk;
+        const int kt1 = min(q.nk, kt0 + (u_stop - u));
         const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -822,6 +823,7 @@ int xv_launch_gemm_nt(hipStream_t s, const XvGemmNT& g) {
         NTSKArgs q;
         q.nk = ksteps;
         q.total = (long)tiles * ksteps;
+        XV_REQUIRE(q.total < (1L << 31), "gemm_nt: %d tiles x %d K-steps exceed the evenly scheduled kernel's 32-bit unit index", tiles, ksteps);
         q.P = pl.p_sk;
         const bool shared_tiles = q.total % q.P != 0 || (q.total / q.P) % ksteps != 0;
         p.C = g.C; p.ldc = g.ldc; p.c_split_stride = 0; p.k_chunk = ksteps * BK;

@@ -21,7 +21,7 @@ def nbytes(name, n):
     if "stat_pool_fwd" in name: return t
     if "bn_bwd_reduce_pooled_kernel" in name: return t
     if name.startswith("bn_bwd_reduce_kernel") or "bn_bwd_reduce_kernel<false>" in name: return 2 * t
-    if "bn_bwd_apply_dense_kernel<true>" in name or "bn_bwd_apply_pooled_chunk_kernel" in name: return 2 * t      # pooled upstream gradient: z in, dz out
+    if "bn_bwd_apply_dense_kernel<true>" in name: return 2 * t      # pooled upstream gradient: z in, dz out
     if "bn_bwd_apply_dense_kernel<false>" in name: return 3 * t     # da, z in, dz out (no padding rows)
     if "bn_bwd_apply_kernel<true>" in name or "bn_bwd_apply_split_kernel<true>" in name: return 2 * t
     if "bn_bwd_apply_kernel<false>" in name or "bn_bwd_apply_split_kernel<false>" in name: return 3 * t * (1 + 8.0 / T / 3)
@@ -46,7 +46,7 @@ for name, gx, gy, n, us, b in sorted(out, key=lambda v: v[0]):
     # two candidate widths per (name, grid): keep 1500 for the larger grid of a name, 512 for the smaller
     grids = sorted({(int(a[1] or 0) * max(int(a[2] or 1), 1)) for a in out if a[0] == name})
     g = int(gx or 0) * max(int(gy or 1), 1)
-    width = 1500 if (len(grids) > 1 and g == grids[-1]) or ("kernel<true>" in name or "stat_pool" in name or "reduce_pooled" in name or "pooled_chunk" in name) else 512
+    width = 1500 if (len(grids) > 1 and g == grids[-1]) or ("kernel<true>" in name or "stat_pool" in name or "reduce_pooled" in name) else 512
     if name.startswith("sgd_kernel"):
         width = 0
     if n != (width or 512) or (name, gx, gy) in seen:
