@@ -249,10 +249,13 @@ def activation_summaries(endpoints):
 
 
 def remove_params_prefix(params, prefix):
-    for k in list(params.dict.keys()):
-        if k.startswith(prefix + "_"):
-            params.dict[k[len(prefix) + 1:]] = params.dict[k]
-    return params
+    """A NEW ParamsPlain with `<prefix>_` cut off the keys that carry it and every other key as it was (reference utils.py:349-358; the
+    argument is left untouched, a prefixed key replaces an unprefixed one of the same name when it comes later in the dict)."""
+    out = ParamsPlain()
+    cut = prefix + "_"
+    for k, v in params.dict.items():
+        out.dict[k[len(cut):] if k[:len(cut)] == cut else k] = v
+    return out
 
 
 def add_dict_prefix(d, prefix):
