@@ -100,6 +100,23 @@ for (nspk, nutt, seed) in ((4, 5, 7), (2, 3, 0), (8, 5, 11), (10, 6, 3), (3, 1, 
     finally:
         sys.argv = argv
     out["sample_validset"].append({"num_spks": nspk, "num_utts": nutt, "seed": seed, "spk2utt": spk2utt, "stdout": buf.getvalue()})
+# dataset/data_loader.py:get_speaker_info (:14-55; the module imports tensorflow for its logging only): its source, with the one Python 2 idiom it
+# holds (`line.decode()` on a str read in text mode) taken out at run time, on a small data directory of text files
+dsrc = open("/root/reference/dataset/data_loader.py").read()
+for node in ast.parse(dsrc).body:
+    if isinstance(node, ast.FunctionDef) and node.name == "get_speaker_info":
+        seg = ast.get_source_segment(dsrc, node)
+        assert seg.count("line.decode().split(' ')") == 1
+        exec(compile(seg.replace("line.decode().split(' ')", "line.split(' ')"), "<get_speaker_info of dataset/data_loader.py>", "exec"), ns)
+files = {"spklist": "spkA 0\nspkB 1\nspkC 2\nspkD 3\n",      # spkD: in the list, not in this directory (a validation set holds a subset)
+         "spk2utt": "spkB spkB-u0 spkB-u1\nspkA spkA-u0\nspkC spkC-u0 spkC-u1 spkC-u2\n",
+         "feats.scp": "".join("%s /data/feats.%d.ark:%d\n" % (u, i % 2, 17 + 1000 * i) for i, u in enumerate(["spkA-u0", "spkB-u0", "spkB-u1", "spkC-u0", "spkC-u1", "spkC-u2"])),
+         "utt2num_frames": "".join("%s %d\n" % (u, 300 + 10 * i) for i, u in enumerate(["spkA-u0", "spkB-u0", "spkB-u1", "spkC-u0", "spkC-u1", "spkC-u2"]))}
+tmp3 = tempfile.mkdtemp(prefix="xv_host_golden_")
+for name, text in files.items():
+    open(os.path.join(tmp3, name), "w").write(text)
+s2f, f2s, s2i = ns["get_speaker_info"](tmp3, os.path.join(tmp3, "spklist"))
+out["speaker_info"] = {"files": files, "spk2features": {str(k): v for k, v in s2f.items()}, "features2spk": f2s, "spk2index": s2i}
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_golden.npz")
 arrays["eer"] = np.array(arrays_eer)
 arrays["text_cases"] = np.array(json.dumps(out))

@@ -519,3 +519,18 @@ def test_sample_validset_script_draws_what_the_reference_script_draws(tmp_path):
         with redirect_stdout(buf):
             main([str(c["num_spks"]), str(c["num_utts"]), str(p), "--seed", str(c["seed"])])
         assert buf.getvalue() == c["stdout"], c
+
+
+def test_get_speaker_info_matches_the_reference_function(tmp_path):
+    """dataset/data_loader.py:get_speaker_info against the reference's function (:14-55, source executed by tests/golden/make_host_golden.py) on
+    a directory whose spklist names a speaker the directory does not hold (a validation subset).  The reference keeps feats.scp's line end
+    inside every "utt path:offset" string (its reader strips it later); here the strings are clean - compared modulo that newline."""
+    from tf_kaldi_speaker_amd.dataset.data_loader import get_speaker_info
+    _, cases = _host_golden()
+    c = cases["speaker_info"]
+    for name, text in c["files"].items():
+        (tmp_path / name).write_text(text)
+    s2f, f2s, s2i = get_speaker_info(str(tmp_path), str(tmp_path / "spklist"))
+    assert s2i == c["spk2index"]
+    assert {str(k): v for k, v in s2f.items()} == {k: [x.rstrip("\n") for x in v] for k, v in c["spk2features"].items()}
+    assert f2s == {k.rstrip("\n"): v for k, v in c["features2spk"].items()}
