@@ -235,11 +235,11 @@ def test_eight_concurrent_loaders_scale_with_the_host(tmp_path):
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
-    import loader_scale
+    import bench_host
     root, spklist, _ = make_data_dir(str(tmp_path / "d"), num_spk=40, utts_per_spk=4, dim=30, min_frames=450, max_frames=600, seed=3)
     cores = os.cpu_count() or 1
     procs = min(8, cores)
-    one = loader_scale.run(1, 1, 150, chunks=32, root=root, spklist=spklist)
-    many = loader_scale.run(procs, 1, 150, chunks=32, root=root, spklist=spklist)
+    one = bench_host.loader_scale_run(1, 1, 150, chunks=32, root=root, spklist=spklist)
+    many = bench_host.loader_scale_run(procs, 1, 150, chunks=32, root=root, spklist=spklist)
     print("one loader %.0f chunks/s, %d loaders %.0f chunks/s aggregate" % (one["aggregate_chunks_per_s"], procs, many["aggregate_chunks_per_s"]))
     assert many["aggregate_chunks_per_s"] >= 0.35 * procs * one["aggregate_chunks_per_s"], (one, many)

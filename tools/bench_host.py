@@ -92,9 +92,11 @@ def _scale_worker(rank, root, spklist, threads, batches, chunks, start_evt, q):
     q.put(("done", rank, n, dt))
 
 
-def loader_scale_run(procs, threads, batches, chunks=128):
+def loader_scale_run(procs, threads, batches, chunks=128, root=None, spklist=None):
+    """(also called by tests/test_native_loader.py on its own small directory)"""
     import multiprocessing as mp
-    root, spklist = synthetic_dir("xv_loader_scale_", num_spk=max(chunks, 100), utts_per_spk=6)
+    if root is None:
+        root, spklist = synthetic_dir("xv_loader_scale_", num_spk=max(chunks, 100), utts_per_spk=6)
     ctx = mp.get_context("spawn")
     q, start_evt = ctx.Queue(), ctx.Event()
     ps = [ctx.Process(target=_scale_worker, args=(r, root, spklist, threads, batches, chunks, start_evt, q)) for r in range(procs)]
