@@ -103,3 +103,18 @@ def test_visible_gpu_count_reads_the_environment_first(monkeypatch):
     monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
     n = bench.visible_gpu_count()
     assert n is None or n >= 0
+
+
+def test_bench_rank_diagnostics_never_raise():
+    """bench.py's per-rank report for a first multi-GPU run (device ordinal / PCI address / RCCL build / environment) is assembled without a
+    GPU too - it must never cost the bench line."""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import bench
+    d = bench.rank_diagnostics(torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu"), 3)
+    assert d["local_rank"] == 3 and "rccl_version" in d and isinstance(d["env"], dict)
+    assert ("pci_bus_id" in d) == torch.cuda.is_available() or "device_properties_error" in d
+    json.dumps(d)
