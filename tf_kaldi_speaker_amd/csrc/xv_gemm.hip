@@ -1127,7 +1127,9 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p
 #define TNW_M 160
 #define TNW_A_PIECES (BK * TNW_M / 256)      // 1 KB pieces per stage: 10
 #define TNW_B_PIECES (BK * BN / 256)         // 8
+#ifndef TNW_WGS
 #define TNW_WGS 512                         // (768 / 1 024 workgroups were slower: Appendix B, note 8)
+#endif
 __global__ __launch_bounds__(256, 2) void xv_gemm_tn160_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (TNW_M + BN)];      // [slot][A [16][160] | B [16][128]]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1317,6 +1319,12 @@ static XvTnPlan xv_tn_plan(int M, int N, int R, bool direct = false) {
     // weight gradient with many tiles and a short reduction (small-batch fine-tuning) keeps its splits - unsplit it would leave most of the
     // chip idle
     if (direct && ksteps <= 16 && tiles >= 128) splits = 1;
+    // A layer with few tiles (a 512 x 512 dense layer: 16) gets ONE workgroup per CU, not a co-resident round of four: 16 tiles x 16 splits =
+    // 256 workgroups.  [measured, round 6, same box, alternated, profiles/r06_tn_few_tiles.txt] against 64 splits (1 024 workgroups, 67 MB of
+    // slabs for a 1 MB gradient): S1 -0.4 ... -0.7 %, 64 x U{200..400} -0.1 ... -0.4 %, S2 -0.4 %, S4 -0.4 %, S5 -0.1 ... -0.4 %; alone the
+    // layer's weight gradient 111.7 -> 108.4 us.  8 / 12 / 20 / 24 splits are slower than 16 (256 workgroups = the same load on every CU);
+    // the same cap on the 48-tile layers (tdnn5: 21 -> 16 splits = 768 workgroups) is neutral, on the 80 / 112-tile layers harmful.
+    if (tiles <= 16) splits = std::min(splits, std::max(1, 256 / tiles));
     pl.chunk = xv_cdiv(ksteps, splits) * BK;
     pl.splits = xv_cdiv(R, pl.chunk);
     return pl;

@@ -11,7 +11,7 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 def first_forward(after):
     for i in range(after, len(rows)):
         n = rows[i]["Kernel_Name"]
-        if ("xv_gemm_nt" in n and "<true" in n) or "xv_gemm16_nt_kernel<true" in n:
+        if ("xv_gemm_nt" in n and "<true" in n) or "xv_gemm16_nt_kernel<true" in n or "xv_gemm16_nt_conv_kernel<1" in n:      # (forward = the launches with BatchNorm statistics)
             return i
     return len(rows) - 1
 
