@@ -417,7 +417,7 @@ struct NTSKArgs {
 __device__ __forceinline__ int ntsk_owner(long u, int P, long total) { return (int)((((u + 1) * P) - 1) / total); }
 
 // (Its context-window form of rounds 2-4 - the rows of one 16-channel chunk of x staged once for all taps - is gone: DESIGN.md Appendix B, note 4.)
-#define XV_NT_SK_WPC 3                       // workgroups per CU of the even schedule: one co-resident round of 768
+#define XV_NT_SK_WPC 3                       // workgroups per CU of the even schedule: one co-resident round of 768 (2 / 4 per CU: S1 +0.5 %, round 6)
 // Register budget: 128 VGPRs (4 waves per SIMD) although the launch is 3 workgroups per CU - the free fourth slot is worth more to the other
 // stream than the 7-23 spilled set-up registers cost (note 5; tools/variant.sh unit xv_gemm.hip "sk168:-DXV_NT_SK_VGPRS=168 -DXV_NT_SK_OCC=3").
 #ifndef XV_NT_SK_VGPRS
@@ -1127,9 +1127,7 @@ __global__ __launch_bounds__(256, XV_WGS_PER_CU) void xv_gemm_tn_kernel(TNArgs p
 #define TNW_M 160
 #define TNW_A_PIECES (BK * TNW_M / 256)      // 1 KB pieces per stage: 10
 #define TNW_B_PIECES (BK * BN / 256)         // 8
-#ifndef TNW_WGS
-#define TNW_WGS 512                         // (768 / 1 024 workgroups were slower: Appendix B, note 8)
-#endif
+#define TNW_WGS 512                         // (768 / 1 024 workgroups were slower alone: Appendix B, note 8; 256 / 384 no different in the step: round 6)
 __global__ __launch_bounds__(256, 2) void xv_gemm_tn160_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (TNW_M + BN)];      // [slot][A [16][160] | B [16][128]]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1472,7 +1470,7 @@ int xv_launch_wgrad_reduce(hipStream_t s, const float* P, int splits, int k, int
     const int rows = k * C, gx = xv_cdiv(n_out / 4, 64);
     const bool zsplit = splits >= 32 && (long)rows * gx < 1024;
     const int row_blocks = zsplit ? rows : xv_cdiv(rows, 4);
-    const dim3 grid(gx, std::min(row_blocks, std::max(1, 2048 / gx)));
+    const dim3 grid(gx, std::min(row_blocks, std::max(1, 2048 / gx)));      // (256 ... 4 096: no difference in the step, profiles/r06_tn_few_tiles.txt)
     if (zsplit)
         hipLaunchKernelGGL(xv_wgrad_reduce_kernel<true>, grid, dim3(256), 0, s, P, splits, (long)k * c_pad * n_in, rows, C, c_pad, n_in, n_out / 4, w,
                            ldw, l2, out, ldo);
