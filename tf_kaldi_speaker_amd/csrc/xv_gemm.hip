@@ -762,6 +762,12 @@ static XvNtPlan xv_nt_plan(int M, int N, int K, bool stats, bool co_running, boo
     const long t_sk = (total / p_sk) * xv_cdiv(p_sk, 256) + (15 * 16 / BK) * std::min<long>(XV_NT_SK_WPC, xv_cdiv(p_sk, 256));
     const long t_dp = tiles <= XV_RESIDENT_WGS ? (long)xv_cdiv(tiles, 256) * ksteps : total / 256 + ksteps / 2;
     bool sk = forced ? forced == 2 : t_sk + t_sk / 32 < t_dp;
+    // Beside the weight-gradient stream (the data gradients) a launch with at least two whole tiles per CU is dealt one workgroup per tile: its
+    // workgroups are never all resident at once there anyway (the other stream's kernel holds slots), so a partial last round is not the
+    // cost `t_dp` prices, while the even schedule's slower K loop and hand-overs are.  [measured, round 6, same box, 6 alternated rounds,
+    // profiles/r06_nt_co_running.txt] S1 (tdnn2's data gradient: 784 tiles, until now on the even schedule) -0.25 ... -0.4 %, S4 -0.4 %,
+    // 64 x U{200..400} / S2 / S5 +-0.1 %; for every tile count -0.4 / -0.1 / +0.2 %, from three whole tiles per CU -0.3 / -0.3 / +0.1 %.
+    if (!forced && co_running && tiles >= 512) sk = false;
     const int shares = forced || !have_ws || tiles > XV_TN_MAX_TILES ? 0 : xv_nt_shares(tiles, ksteps, stats, co_running, ws_bytes);
     if (shares) sk = false;
     const bool few = !stats && tiles < 192 && ksteps >= 8 && !forced;
