@@ -768,7 +768,11 @@ static XvNtPlan xv_nt_plan(int M, int N, int K, bool stats, bool co_running, boo
     // profiles/r06_nt_co_running.txt] S1 (tdnn2's data gradient: 784 tiles, until now on the even schedule) -0.25 ... -0.4 %, S4 -0.4 %,
     // 64 x U{200..400} / S2 / S5 +-0.1 %; for every tile count -0.4 / -0.1 / +0.2 %, from three whole tiles per CU -0.3 / -0.3 / +0.1 %.
     if (!forced && co_running && tiles >= 512) sk = false;
-    const int shares = forced || !have_ws || tiles > XV_TN_MAX_TILES ? 0 : xv_nt_shares(tiles, ksteps, stats, co_running, ws_bytes);
+    // ... and "whole tiles + shares" there only for long tiles (>= 100 K-steps): a share's hand-over (slab store, ticket, the last share sums the
+    // others) is ~10 K-steps of latency whatever the tile's length, and beside the other stream's GEMM the partial round it avoids costs little.
+    // [measured, round 6, same box, 4 alternated rounds, profiles/r06_nt_co_running.txt] S5 (ten layers of 32 / 96 K-step tiles at 128 x 400)
+    // -1.0 %, every other shape within +-0.2 %; no shares at all beside the stream: S5 -1.2 %, 64 x U{200..400} +0.7 %, S2 +0.3 %.
+    const int shares = forced || !have_ws || tiles > XV_TN_MAX_TILES || (co_running && ksteps < 100) ? 0 : xv_nt_shares(tiles, ksteps, stats, co_running, ws_bytes);
     if (shares) sk = false;
     const bool few = !stats && tiles < 192 && ksteps >= 8 && !forced;
     if (!few && sk) {
