@@ -3,7 +3,7 @@
 sub-command per question (they used to be eight scripts); every one builds its own synthetic Kaldi directory / archive under $TMPDIR.
 
   python tools/bench_host.py loader [workers=4] [batches=40]    native C++ loader threads vs batches planned in Python + native codec on a thread pool
-  python tools/bench_host.py loader_scale [--procs 8] [--threads 8] [--batches 60] [--need 21500]
+  python tools/bench_host.py loader_scale [--procs 8] [--threads 8] [--batches 60] [--need 25800]
                                                                 N loader processes at once (one per rank of an N-GPU job): aggregate chunks/s as JSON
   python tools/bench_host.py e2e [steps=60] [threads=8]         native loader -> pinned -> async H2D -> training steps, against resident batches
                                                                 (XV_LOADER=gpu_decode: 'CM ' bytes over PCIe, decoded on the GPU)
@@ -124,7 +124,7 @@ def cmd_loader_scale(argv):
     ap.add_argument("--procs", type=int, default=8)
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--batches", type=int, default=60)
-    ap.add_argument("--need", type=float, default=21500.0, help="per-GPU step rate in chunks/s the loaders have to out-run (bench.py `value`)")
+    ap.add_argument("--need", type=float, default=25800.0, help="per-GPU step rate in chunks/s the loaders have to out-run (bench.py `value`)")
     a = ap.parse_args(argv)
     one = loader_scale_run(1, a.threads, a.batches)
     many = loader_scale_run(a.procs, a.threads, a.batches)

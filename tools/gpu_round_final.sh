@@ -16,7 +16,7 @@ timeout 900 python3 bench.py --extended --frames 400 --steps 20 --warmup 5 --no-
 python3 tools/bench_summary.py $O/bench_extended.json | grep -E "^f32|^f16x3"
 timeout 900 python3 tools/shape_sweep.py --precision f32 2>/dev/null > $O/shapes_f32.json
 timeout 900 python3 tools/shape_sweep.py --precision f16x3 2>/dev/null > $O/shapes_f16x3.json
-timeout 900 python3 tools/bench_host.py loader_scale --batches 400 --need 22800 2>/dev/null | tail -1 > $O/loader_scale.json
+timeout 900 python3 tools/bench_host.py loader_scale --batches 400 --need 25800 2>/dev/null | tail -1 > $O/loader_scale.json
 timeout 900 python3 tools/bench_host.py trainer 400 2>&1 | grep -v amdgpu.ids | tail -3 > $O/trainer_bench.txt
 tools/step_timeline.sh $O/s3_64x300 -- --chunks 64 --frames 300; rm -f $O/s3_64x300.log $O/s3_64x300.json
 tools/step_timeline.sh $O/s4 -- --attention; rm -f $O/s4.log $O/s4.json
