@@ -107,12 +107,30 @@ def step_bytes(b, t, d, n, layers=REFERENCE_LAYERS):
     return 5.0 * S + 2.0 * 4.0 * b * t * d + 5.0 * P
 
 
+def cgroup_cpus():
+    """CPUs' worth of run time this process's cgroup may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited.  os.cpu_count()
+    and the affinity mask do not show it: the round-6 GPU boxes report 256 CPUs and run under a 16-CPU quota, and every host-side figure
+    (this baseline's best thread count, the loaders' aggregate rate) is a figure for THAT many cores."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else round(int(quota) / float(period), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+            quota, period = int(f.read()), int(g.read())
+        return None if quota <= 0 else round(quota / float(period), 2)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(seconds_budget=70.0):
     """The oracle (a NumPy port of the reference arithmetic, NOT TensorFlow) on the host cores: ONE fp32 train_step of the
     full S1 batch (128 chunks x 200 frames, 7351 speakers) per BLAS thread count - 1 thread (comparable to the reference's
-    single_cpu mode, trainer.py:46-50), then 8 / 16 / 32 threads as far as the box has them and the budget allows (the port is
-    dominated by NumPy element-wise passes and OpenBLAS on every core of a large host is slower than on a few, so "all
-    cores" is not the best row).  `value` is the fastest row, `cores` the threads it used."""
+    single_cpu mode, trainer.py:46-50), then 8 / 16 / 32 threads, the cgroup's CPU quota and every core the host reports, as far as
+    the budget allows ("every core" is not the best row: the process may only use `cgroup_cpus` of them at a time, more threads than
+    that are throttled, and the port is part NumPy element-wise passes).  `value` is the fastest row, `cores` the threads it used."""
     from oracle import xvector_oracle as O
     try:
         from threadpoolctl import threadpool_limits
@@ -127,7 +145,9 @@ def cpu_baseline(seconds_budget=70.0):
     O.train_step(V, {}, cfg, x[:8], y[:8], 0.01, 0)      # warm-up (BLAS thread pool, allocator)
     # rows: 1 thread (comparable to the reference's single_cpu mode), a few mid counts, and EVERY core of the host - three steps each
     # (median) while the budget lasts; the 1-thread and all-core rows always get their three
-    counts = [1] if threadpool_limits is None else sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu), ncpu})
+    quota = cgroup_cpus()
+    counts = [1] if threadpool_limits is None else sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu), ncpu} |
+                                                          ({max(1, min(int(quota), ncpu))} if quota else set()))
     must = {1, ncpu}
     rows, t_start = [], time.time()
     import contextlib
@@ -156,7 +176,7 @@ def cpu_baseline(seconds_budget=70.0):
     while len(times) < 7 and time.time() - t_start + times[-1] < seconds_budget:
         times += timed_steps(best["cores"], 1)
     med = float(np.median(times))
-    return {"value": round(B / med, 2), "unit": "chunks/s", "cores": best["cores"], "kind": "port", "host_cpus": ncpu,
+    return {"value": round(B / med, 2), "unit": "chunks/s", "cores": best["cores"], "kind": "port", "host_cpus": ncpu, "cgroup_cpus": quota,
             "steps": len(times), "step_seconds": [round(t, 3) for t in times],
             "sample": "oracle (NumPy/OpenBLAS fp32 port of the reference arithmetic, this repo - not TensorFlow) train_step on the benchmark "
                       "batch (%d chunks x %d frames x %d-dim, %d speakers): three steps per BLAS thread count (`rows`: 1 thread, mid counts, every "

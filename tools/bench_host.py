@@ -130,6 +130,11 @@ def cmd_loader_scale(argv):
     many = loader_scale_run(a.procs, a.threads, a.batches)
     many["single_proc_chunks_per_s"] = one["aggregate_chunks_per_s"]
     many["needed_chunks_per_s"] = a.procs * a.need
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import cgroup_cpus
+    many["cgroup_cpus"] = cgroup_cpus()      # the aggregate is a figure for this many cores, whatever host_cpus says
+    if many["cgroup_cpus"]:
+        many["chunks_per_s_per_cpu"] = round(many["aggregate_chunks_per_s"] / min(many["cgroup_cpus"], a.procs * (a.threads + 1)), 1)
     many["headroom"] = round(many["aggregate_chunks_per_s"] / many["needed_chunks_per_s"], 2)
     print(json.dumps(many))
 
