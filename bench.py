@@ -125,6 +125,16 @@ def cgroup_cpus():
         return None
 
 
+def cgroup_throttle():
+    """(periods in which this cgroup ran out of CPU quota, microseconds its threads were held) so far, or None."""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as f:
+            st = dict(line.split()[:2] for line in f if line.strip())
+        return int(st["nr_throttled"]), int(st["throttled_usec"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(seconds_budget=70.0):
     """The oracle (a NumPy port of the reference arithmetic, NOT TensorFlow) on the host cores: ONE fp32 train_step of the
     full S1 batch (128 chunks x 200 frames, 7351 speakers) per BLAS thread count - 1 thread (comparable to the reference's
@@ -280,11 +290,21 @@ def run_mode(precision, args, dev, rank, world, dist, chunks, t_lo, t_hi, h2d=Fa
         _lib.check(lib.xv_profile_begin_kinds(int(args.steps * launches_per_step), 1 << dom), "xv_profile_begin_kinds")
     if allreduce is not None:
         allreduce.reset_timing()
+    cpu0 = time.process_time()                    # every thread of this process (HIP / RCCL helper threads included)
+    thr0 = cgroup_throttle()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(step0 + i)
+    t_enq = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
+    # host side of the timed region: CPUs this rank kept busy (the wait in fence() spins) and the share of the region its thread spent
+    # enqueueing - on a box whose cgroup allows fewer CPUs than N ranks burn, the ranks get throttled and the GPU path is not what is measured
+    res["host"] = {"cpus_busy": round((time.process_time() - cpu0) / max(elapsed, 1e-9), 2), "enqueue_frac": round(t_enq / max(elapsed, 1e-9), 3),
+                   "cgroup_cpus": cgroup_cpus(), "os_cpus": os.cpu_count()}
+    thr1 = cgroup_throttle()
+    if thr0 is not None and thr1 is not None:     # (cgroup-wide: every rank of the job counts into the same figures)
+        res["host"].update(throttled_periods=thr1[0] - thr0[0], throttled_thread_ms=round((thr1[1] - thr0[1]) / 1e3, 1))
     if not light:
         res["timed"] = _profile_table(lib, _lib, "timed")
     if dist is not None:
@@ -539,7 +559,7 @@ def main():
         try:
             mine = {"rank": rank, "backend": dist.get_backend(), "world_size": dist.get_world_size(), "device": torch.cuda.get_device_name(dev),
                     "device_index": dev_index, "data_seed": 1000 + rank, "loss": head["loss"], "trainable_checksum": head["trainable_checksum"],
-                    "report": head["comm"]}
+                    "report": head["comm"], "host": head["host"]}
             mine.update(rank_diagnostics(dev, local_rank))
             comm_all = [None] * world
             dist.all_gather_object(comm_all, mine)
@@ -580,6 +600,7 @@ def main():
             "kernels_note": "per-kind figures come from an untimed 3-step probe pass with every GEMM launch bracketed by HIP events; "
                             "the timed region brackets only the dominant kind (`roofline`), which keeps the events' queue time out of `value`",
             "loss": hs["loss"],
+            "host": head["host"],
         }
         if other is not None:
             os_ = summarize(other, args, world, chunks)
